@@ -1,0 +1,54 @@
+"""Golden-case table shared by `oracle/make_golden.py` (generator, build
+container only) and the tests (consumers, anywhere).  TEST INFRASTRUCTURE ONLY.
+
+A case is fully determined by (config name + overrides, seeds): inputs are
+rebuilt with `tdmpc2_amd.synth`; only the reference's OUTPUTS are stored in
+`tests/golden/<case>.npz`.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from tdmpc2_amd import synth
+from tdmpc2_amd.config import get_discount, named_config, planner_iterations
+
+CASES = {
+    # name: (config, overrides, n_envs, eval_mode, head_std)
+    "tiny": ("tiny", {}, 3, False, 0.06),
+    "tiny_eval": ("tiny", {}, 2, True, 0.06),
+    "tiny_mt": ("tiny", dict(task="mt30", model_size=None), 3, False, 0.06),
+    "c1": ("c1", {}, 2, False, 0.06),
+    "c1_wide": ("c1", {}, 1, False, 0.1),
+    "c2": ("c2", {}, 2, False, 0.06),
+    "mt5": ("mt5", {}, 2, False, 0.06),
+}
+
+
+def build_case(name: str):
+    cfg_name, overrides, E, eval_mode, head_std = CASES[name]
+    cfg = named_config(cfg_name, **overrides)
+    if cfg.multitask and name == "tiny_mt":
+        # heterogeneous action dims / episode lengths to exercise masks and per-task discounts
+        n = len(cfg.tasks)
+        cfg.action_dims = [cfg.action_dim - (i % 3) for i in range(n)]
+        cfg.episode_lengths = [500 if i % 2 == 0 else 100 for i in range(n)]
+    if cfg.multitask and name == "mt5":
+        n = len(cfg.tasks)
+        cfg.action_dims = [cfg.action_dim - (i % 4) for i in range(n)]
+        cfg.episode_lengths = [500 if i % 2 == 0 else 1000 for i in range(n)]
+    I = planner_iterations(cfg)
+    sd = synth.make_state_dict(cfg, seed=0, head_std=head_std)
+    z0 = synth.make_latents(cfg, E, seed=1)
+    tape = synth.make_noise_tape(cfg, E, I, seed=2)
+    prev = np.random.default_rng(5).uniform(-0.5, 0.5, (E, cfg.horizon, cfg.action_dim)).astype(np.float32)
+    t0 = np.array([(e % 2 == 0) for e in range(E)])
+    if cfg.multitask:
+        tasks = [(7 * e + 3) % len(cfg.tasks) for e in range(E)]
+        disc_t = torch.tensor([get_discount(cfg, L) for L in cfg.episode_lengths])  # tdmpc2.py:35-37
+        discounts = [disc_t[t] for t in tasks]
+    else:
+        tasks = None
+        discounts = [get_discount(cfg, cfg.episode_length)] * E
+    return dict(cfg=cfg, iterations=I, sd=sd, z0=z0, tape=tape, prev_mean=prev, t0=t0, tasks=tasks,
+                discounts=discounts, eval_mode=eval_mode, n_envs=E)

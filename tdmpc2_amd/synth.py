@@ -1,0 +1,135 @@
+"""Deterministic synthetic planner inputs (weights, latents, noise tapes).
+
+Everything is drawn from ``numpy.random.default_rng(seed)`` in a fixed order, so
+the container that generates golden fixtures and the GPU box that replays them
+build bit-identical inputs from a seed alone (weights are ~20 MB for the 5M
+model: too large to commit, cheap to regenerate).
+
+Weight shapes follow the reference's module constructors
+(tdmpc2/common/world_model.py:20-36, tdmpc2/common/layers.py:121-164) and are
+returned as a state dict in the reference's checkpoint key layout
+(SURVEY.md section 8(a) row 16).  Unlike the reference's fresh init
+(common/init.py:14-17 zeroes the reward/Q output layers, which makes every
+trajectory value 0 and top-k degenerate) the output layers are non-zero.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+
+from .config import Config
+
+
+def _linear(rng, out_f, in_f, w_std=0.02, b_std=0.02):
+    w = (rng.standard_normal((out_f, in_f)) * w_std).astype(np.float32)
+    b = (rng.standard_normal((out_f,)) * b_std).astype(np.float32)
+    return w, b
+
+
+def _ln(rng, n):
+    g = (1.0 + 0.1 * rng.standard_normal((n,))).astype(np.float32)
+    b = (0.1 * rng.standard_normal((n,))).astype(np.float32)
+    return g, b
+
+
+def _mlp(rng, sd, prefix, in_dim, hidden, out_dim, last_ln, out_std=0.02, stack=None):
+    """Fill `sd` with one reference `layers.mlp` worth of parameters.
+
+    stack=None -> plain keys '<prefix>.<i>.weight'; stack=n -> leading ensemble
+    dim n (keys '<prefix>.<i>.weight' hold [n, out, in]).
+    """
+    dims = [in_dim] + list(hidden) + [out_dim]
+    for i in range(len(dims) - 1):
+        last = i == len(dims) - 2
+        std = out_std if last else 0.02
+
+        def one():
+            w, b = _linear(rng, dims[i + 1], dims[i], w_std=std)
+            ent = {"weight": w, "bias": b}
+            if (not last) or last_ln:
+                g, bb = _ln(rng, dims[i + 1])
+                ent["ln.weight"], ent["ln.bias"] = g, bb
+            return ent
+
+        if stack is None:
+            ent = one()
+        else:
+            ents = [one() for _ in range(stack)]
+            ent = {k: np.stack([e[k] for e in ents], 0) for k in ents[0]}
+        for k, v in ent.items():
+            sd[f"{prefix}.{i}.{k}"] = v
+
+
+def make_state_dict(cfg: Config, seed: int = 0, head_std: float = 0.06) -> Dict[str, np.ndarray]:
+    """Synthetic WorldModel state dict (new-format keys, numpy float32)."""
+    rng = np.random.default_rng(seed)
+    sd: Dict[str, np.ndarray] = {}
+    L, M, A, T = cfg.latent_dim, cfg.mlp_dim, cfg.action_dim, cfg.task_dim
+    if cfg.multitask:
+        n_tasks = len(cfg.tasks)
+        # a few rows with norm > 1 so the max_norm=1 renorm path (world_model.py:21) is exercised
+        emb = rng.uniform(-0.02, 0.02, size=(n_tasks, T)).astype(np.float32)
+        emb[::3] *= 12.0
+        sd["_task_emb.weight"] = emb
+        masks = np.zeros((n_tasks, A), np.float32)
+        for i in range(n_tasks):
+            masks[i, : cfg.action_dims[i]] = 1.0
+        sd["_action_masks"] = masks
+    obs_dim = cfg.obs_shape["state"][0]
+    _mlp(rng, sd, "_encoder.state", obs_dim + T, max(cfg.num_enc_layers - 1, 1) * [cfg.enc_dim], L, last_ln=True)
+    _mlp(rng, sd, "_dynamics", L + A + T, 2 * [M], L, last_ln=True)
+    _mlp(rng, sd, "_reward", L + A + T, 2 * [M], max(cfg.num_bins, 1), last_ln=False, out_std=head_std)
+    if cfg.episodic:
+        _mlp(rng, sd, "_termination", L + T, 2 * [M], 1, last_ln=False, out_std=head_std)
+    _mlp(rng, sd, "_pi", L + T, 2 * [M], 2 * A, last_ln=False, out_std=0.05)
+    _mlp(rng, sd, "_Qs.params", L + A + T, 2 * [M], max(cfg.num_bins, 1), last_ln=False, out_std=head_std,
+         stack=cfg.num_q)
+    sd["log_std_min"] = np.asarray(cfg.log_std_min, np.float32)
+    sd["log_std_dif"] = np.asarray(np.float32(cfg.log_std_max) - np.float32(cfg.log_std_min), np.float32)
+    return sd
+
+
+def simnorm_np(x: np.ndarray, g: int) -> np.ndarray:
+    shp = x.shape
+    x = x.reshape(*shp[:-1], -1, g).astype(np.float64)
+    x = np.exp(x - x.max(-1, keepdims=True))
+    x = x / x.sum(-1, keepdims=True)
+    return x.reshape(shp).astype(np.float32)
+
+
+def make_latents(cfg: Config, n_envs: int, seed: int = 1) -> np.ndarray:
+    """z0 = SimNorm(randn[E, L]): what `encode` emits."""
+    rng = np.random.default_rng(seed)
+    return simnorm_np(rng.standard_normal((n_envs, cfg.latent_dim)).astype(np.float32), cfg.simnorm_dim)
+
+
+def make_obs(cfg: Config, n_envs: int, seed: int = 3) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((n_envs, cfg.obs_shape["state"][0])).astype(np.float32)
+
+
+def make_noise_tape(cfg: Config, n_envs: int, iterations: int, seed: int = 2) -> Dict[str, np.ndarray]:
+    """One noise tape per env, shaped like the reference's six RNG draw sites
+    (SURVEY.md section 3.2):
+
+    pi_traj_eps [E,H,P,A]   world_model.py:156 via tdmpc2.py:158,160
+    sample_eps  [E,I,H,N-P,A] tdmpc2.py:176
+    pi_eps      [E,I,N,A]   world_model.py:156 via tdmpc2.py:135
+    qidx        [E,I,2]     world_model.py:212  (randperm(nq)[:2])
+    gumbel_exp  [E,K]       math.py:90          (Exp(1) draws)
+    final_eps   [E,A]       tdmpc2.py:204
+    """
+    rng = np.random.default_rng(seed)
+    H, N, P, A, K = cfg.horizon, cfg.num_samples, cfg.num_pi_trajs, cfg.action_dim, cfg.num_elites
+    E, I = n_envs, iterations
+    f32 = np.float32
+    tape = {
+        "pi_traj_eps": rng.standard_normal((E, H, P, A)).astype(f32),
+        "sample_eps": rng.standard_normal((E, I, H, N - P, A)).astype(f32),
+        "pi_eps": rng.standard_normal((E, I, N, A)).astype(f32),
+        "qidx": np.stack([np.stack([rng.permutation(cfg.num_q)[:2] for _ in range(I)]) for _ in range(E)]).astype(np.int32),
+        "gumbel_exp": rng.exponential(size=(E, K)).astype(f32),
+        "final_eps": rng.standard_normal((E, A)).astype(f32),
+    }
+    return tape
