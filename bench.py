@@ -1,0 +1,235 @@
+"""plan() calls/sec on MI355X — BASELINE.json's metric.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--config c2] [--iterations 6]
+
+A "step" is one pass of the hot path over one batch of synthetic input: E independent plans
+(synthetic SimNorm latents, random-init weights of the named architecture, in-kernel Philox noise —
+everything of TDMPC2._plan after encode()).  Inputs are resident in HBM before the timed region.
+For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL); environments are sharded,
+E per GPU (weak scaling), no collective in the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from tdmpc2_amd import synth  # noqa: E402
+from tdmpc2_amd.config import get_discount, named_config  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def per_row_macs(cfg):
+    L, M, A, T, B = cfg.latent_dim, cfg.mlp_dim, cfg.action_dim, cfg.task_dim, cfg.num_bins
+    dyn = (L + A + T) * M + M * M + M * L
+    rew = (L + A + T) * M + M * M + M * B
+    pi = (L + T) * M + M * M + 2 * A * M
+    return dyn, rew, pi
+
+
+def flops_rollout_launch(cfg, n_envs):
+    """As-written FLOPs of one CEM iteration's _estimate_value for n_envs plans:
+    all num_q Q heads counted, elementwise work excluded."""
+    dyn, rew, pi = per_row_macs(cfg)
+    return n_envs * 2 * cfg.num_samples * (cfg.horizon * (rew + dyn) + pi + cfg.num_q * rew)
+
+
+def flops_plan(cfg, iterations):
+    dyn, rew, pi = per_row_macs(cfg)
+    pitraj = cfg.num_pi_trajs * (cfg.horizon * pi + (cfg.horizon - 1) * dyn)
+    return 2 * pitraj + iterations * flops_rollout_launch(cfg, 1)
+
+
+def disc_pow_rows(cfg, n_envs, device):
+    g = get_discount(cfg, cfg.episode_length)
+    d, vals = 1, []
+    for _ in range(cfg.horizon + 1):
+        vals.append(float(d))
+        d = d * g
+    return torch.tensor(vals, dtype=torch.float32, device=device).repeat(n_envs, 1).contiguous()
+
+
+def cpu_baseline(cfg, iterations, sd_np, budget_s=12.0):
+    """The oracle (= the reference's planner math as plain torch CPU ops) timed on this box's host cores
+    on a bounded sample of the same workload.  Test infrastructure used as a reported baseline only."""
+    from oracle import planner_oracle as po
+
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    model = po.OracleModel(cfg, {k: torch.as_tensor(v) for k, v in sd_np.items()})
+    z0 = synth.make_latents(cfg, 1, seed=1)
+    tape = po.env_tape(synth.make_noise_tape(cfg, 1, iterations, seed=2), 0)
+    disc = get_discount(cfg, cfg.episode_length)
+    prev = torch.zeros(cfg.horizon, cfg.action_dim)
+
+    def one(t0):
+        nonlocal prev
+        a, prev, _ = po.plan(model, z0=torch.as_tensor(z0), tape=tape, prev_mean=prev, t0=t0, eval_mode=False,
+                             task=None, discount=disc, iterations=iterations)
+
+    with torch.no_grad():
+        one(True)  # warm-up
+        n, t_start = 0, time.perf_counter()
+        while True:
+            one(False)
+            n += 1
+            el = time.perf_counter() - t_start
+            if (el >= budget_s and n >= 3) or n >= 64:
+                break
+    return {"value": round(n / el, 3), "unit": "plans/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{n} sequential plan() calls of the same workload (1 env, recorded noise tape) after 1 warm-up, "
+                      f"{el:.1f} s wall, torch {torch.__version__} CPU fp32",
+            "ms_per_plan": round(1e3 * el / n, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=256, help="independent environments planned per GPU per step")
+    ap.add_argument("--config", default="c2", help="c1 cheetah-run 5M | c2 dog-run 5M (BASELINE configs[1])")
+    ap.add_argument("--iterations", type=int, default=6, help="CEM iterations (the metric is quoted at 6)")
+    ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the planner has no CPU path")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from tdmpc2_amd.dist import broadcast_state_dict
+    from tdmpc2_amd.native import NativePlanner
+
+    cfg = named_config(args.config)
+    I, E, K, W = args.iterations, args.envs, args.steps, args.warmup
+    sd_np = synth.make_state_dict(cfg, seed=0)
+    # weights: rank 0's copy is broadcast over RCCL (one bucketed collective), outside the timed region
+    sd = {k: (torch.as_tensor(v).to(device) if rank == 0 else torch.zeros(v.shape, dtype=torch.float32, device=device))
+          for k, v in sd_np.items()}
+    broadcast_state_dict(sd, src=0)
+    planner = NativePlanner(cfg, I, device, max_envs=E)
+    planner.bind_state_dict(sd)
+
+    z0 = torch.as_tensor(synth.make_latents(cfg, E, seed=1000 + rank)).to(device)
+    disc = disc_pow_rows(cfg, E, device)
+    prev = torch.zeros(E, cfg.horizon, cfg.action_dim, device=device)
+    cold = torch.ones(E, dtype=torch.uint8, device=device)
+    warm = torch.zeros(E, dtype=torch.uint8, device=device)
+    out = torch.empty(E, cfg.action_dim, device=device)
+
+    def step(i, flags):
+        planner.plan(z0, disc, prev, flags, eval_mode=False, tape=None, seed=(rank << 32) + i, out=out)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    step(0, cold)
+    for i in range(W):
+        step(1 + i, warm)
+    planner.set_profiling(K * I)
+    fence()
+    t_start = time.perf_counter()
+    for i in range(K):
+        step(100 + i, warm)
+    fence()
+    elapsed = time.perf_counter() - t_start
+    roll_ms, roll_n = planner.profile_read()
+    planner.set_profiling(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all()
+
+    extra = {}
+    if rank == 0:
+        # single-environment latency (the reference's E = 1 semantics), reported beside the throughput
+        one = NativePlanner(cfg, I, device, max_envs=1)
+        one.bind_state_dict(sd)
+        z1, d1 = z0[:1].contiguous(), disc[:1].contiguous()
+        p1 = torch.zeros(1, cfg.horizon, cfg.action_dim, device=device)
+        o1 = torch.empty(1, cfg.action_dim, device=device)
+        for i in range(2):
+            one.plan(z1, d1, p1, warm[:1], seed=i, out=o1)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        for i in range(5):
+            one.plan(z1, d1, p1, warm[:1], seed=10 + i, out=o1)
+        torch.cuda.synchronize(device)
+        extra["latency_ms_single_env"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    plans = world * E * K
+    value = plans / elapsed
+    launch_s = (roll_ms / 1e3) / max(roll_n, 1)
+    achieved = flops_rollout_launch(cfg, E) / launch_s / 1e12
+    line = {
+        "metric": "plan() calls/sec (H=3, 512 samples, 6 iters)",
+        "value": round(value, 2),
+        "unit": "plans/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": round(1e3 * elapsed / K, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"{args.config}: {cfg.task} 5M-class world model (L{cfg.latent_dim} M{cfg.mlp_dim} A{cfg.action_dim} "
+                        f"nq{cfg.num_q}), plan() H={cfg.horizon} N={cfg.num_samples} K={cfg.num_elites} "
+                        f"P={cfg.num_pi_trajs} I={I}, {E} independent envs per GPU per step, random-init weights, "
+                        f"SimNorm latents, in-kernel Philox noise",
+            "envs_per_gpu": E, "iterations": I, "parallelism": f"env-sharded x{world}",
+            "gflop_per_plan_as_written": round(flops_plan(cfg, I) / 1e9, 3),
+        },
+        "roofline": {
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": "k_rollout", "launches_timed": roll_n, "avg_launch_ms": round(1e3 * launch_s, 4),
+            "note": "achieved = as-written FLOPs of one CEM iteration (all num_q Q heads, SURVEY 8(d)) x envs / "
+                    "mean k_rollout duration (HIP events on the launch stream); the kernel executes fewer "
+                    "(2 of num_q heads, shared z0 product at t=0); peak = fp32-input MFMA (exact fp32)",
+        },
+        "plan_tflops_as_written": round(value * flops_plan(cfg, I) / 1e12, 2),
+        "extra": extra,
+    }
+    if world == 1 and not args.skip_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(cfg, I, sd_np, args.cpu_budget)
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

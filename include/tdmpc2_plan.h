@@ -1,0 +1,167 @@
+/*
+ * tdmpc2_plan.h — C ABI of the MI355X-native TD-MPC2 MPPI/CEM planner.
+ *
+ * The reference (nicklashansen/tdmpc2) is pure Python and has no FFI layer; its
+ * boundary for this path is the method pair
+ *     TDMPC2.act(obs, t0, eval_mode, task)        tdmpc2/tdmpc2.py:97-120
+ *     TDMPC2.plan -> _plan(obs, t0, eval_mode, task)  tdmpc2/tdmpc2.py:45-55,138-206
+ * The entry points below are what a ctypes binding of that path needs (the
+ * reference-side stub is shown in INTEGRATION.md).  They replace, one for one:
+ *
+ *   tdmpc2_plan_create        <- TDMPC2.__init__ planner state         tdmpc2/tdmpc2.py:17-43
+ *   tdmpc2_plan_bind_weights  <- WorldModel parameters / load_state_dict tdmpc2/common/world_model.py:20-36,
+ *                                                                       tdmpc2/tdmpc2.py:81-95
+ *   tdmpc2_plan_run           <- TDMPC2._plan after encode()            tdmpc2/tdmpc2.py:154-206
+ *   tdmpc2_plan_estimate_value<- TDMPC2._estimate_value                 tdmpc2/tdmpc2.py:122-136
+ *   tdmpc2_plan_refit         <- the elite select + refit block         tdmpc2/tdmpc2.py:184-197
+ *
+ * Conventions
+ *   - plain C types only; every tensor is a DEVICE pointer to fp32 (or int32 /
+ *     uint8 where stated), densely packed, last index fastest.
+ *   - the caller owns every buffer it passes; the library owns only what it
+ *     allocates in create/bind and frees in destroy.  `run` allocates nothing.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *     a handle is not re-entrant.  Return value 0 = ok, otherwise an error code
+ *     (no C++ exception crosses the ABI); `tdmpc2_last_error()` has the text.
+ *   - E = number of independent environments planned in one call (the reference
+ *     is E = 1: tdmpc2/tdmpc2.py:111,163).  H horizon, N num_samples,
+ *     K num_elites, P num_pi_trajs, I iterations, A action_dim, L latent_dim,
+ *     M mlp_dim, T task_dim, B num_bins, nq num_q.
+ */
+#ifndef TDMPC2_PLAN_H
+#define TDMPC2_PLAN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDMPC2_PLAN_ABI_VERSION 1
+
+typedef struct tdmpc2_plan tdmpc2_plan_t;
+
+/* Planner constants; field names follow the reference config
+ * (tdmpc2/config.yaml:33-64).  `iterations` is the value AFTER the reference's
+ * "+2 if action_dim >= 20" adjustment (tdmpc2/tdmpc2.py:34) — the host applies it. */
+typedef struct tdmpc2_plan_cfg {
+    int32_t horizon, num_samples, num_elites, num_pi_trajs, iterations;
+    int32_t action_dim, latent_dim, mlp_dim, task_dim, num_bins, num_q, simnorm_dim;
+    float vmin, vmax, min_std, max_std, temperature;
+    float log_std_min, log_std_dif;   /* WorldModel buffers, world_model.py:34-35 */
+    int32_t multitask, episodic;
+    int32_t max_envs;                 /* workspace is sized for this many concurrent plans */
+    int32_t device;                   /* HIP device ordinal */
+} tdmpc2_plan_cfg;
+
+enum tdmpc2_net {
+    TDMPC2_NET_DYNAMICS = 0,    /* WorldModel._dynamics     world_model.py:26 */
+    TDMPC2_NET_REWARD = 1,      /* WorldModel._reward       world_model.py:27 */
+    TDMPC2_NET_PI = 2,          /* WorldModel._pi           world_model.py:29 */
+    TDMPC2_NET_Q = 3,           /* WorldModel._Qs (stacked) world_model.py:30 */
+    TDMPC2_NET_TERMINATION = 4  /* WorldModel._termination  world_model.py:28 */
+};
+
+enum tdmpc2_status {
+    TDMPC2_OK = 0,
+    TDMPC2_ERR_INVALID = 1,      /* bad argument */
+    TDMPC2_ERR_UNSUPPORTED = 2,  /* configuration outside what the kernels are built for */
+    TDMPC2_ERR_HIP = 3,          /* a HIP runtime call failed */
+    TDMPC2_ERR_STATE = 4         /* e.g. run before all weights are bound */
+};
+
+/* The reference's six RNG draw sites as input tensors.
+ * Passing a tape makes a plan a pure function of its inputs (parity runs);
+ * passing NULL selects the in-kernel Philox4x32-10 generator (fast mode). */
+typedef struct tdmpc2_noise {
+    const float *pi_traj_eps;  /* [E,H,P,A]      randn_like, world_model.py:156 via tdmpc2.py:158,160 */
+    const float *sample_eps;   /* [E,I,H,N-P,A]  randn,      tdmpc2.py:176 */
+    const float *pi_eps;       /* [E,I,N,A]      randn_like, world_model.py:156 via tdmpc2.py:135 */
+    const int32_t *qidx;       /* [E,I,2]        randperm(nq)[:2], world_model.py:212 */
+    const float *gumbel_exp;   /* [E,K]          exponential_(), math.py:90 */
+    const float *final_eps;    /* [E,A]          randn, tdmpc2.py:204 (unused when eval_mode) */
+} tdmpc2_noise;
+
+/* Optional stage-wise outputs (any pointer may be NULL). */
+typedef struct tdmpc2_debug {
+    float *value;       /* [E,I,N]   value after nan_to_num, tdmpc2.py:184 */
+    int32_t *elite_idx; /* [E,I,K]   topk indices (value desc, index asc on ties), tdmpc2.py:185 */
+    float *score;       /* [E,I,K]   normalised elite scores, tdmpc2.py:190-191 */
+    float *mean;        /* [E,I,H,A] tdmpc2.py:192,196 */
+    float *std;         /* [E,I,H,A] tdmpc2.py:193-194,197 */
+    float *actions;     /* [E,I,H,N,A] sampled actions of every iteration, tdmpc2.py:176-181 */
+} tdmpc2_debug;
+
+int tdmpc2_plan_abi_version(void);
+const char *tdmpc2_last_error(void);
+
+/* Allocate a planner for `cfg` on cfg->device.  TDMPC2_ERR_UNSUPPORTED if the
+ * configuration is outside the compiled kernels' envelope. */
+int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out);
+void tdmpc2_plan_destroy(tdmpc2_plan_t *h);
+
+/* Bytes of device memory held by the handle (packed weights + workspace). */
+uint64_t tdmpc2_plan_device_bytes(const tdmpc2_plan_t *h);
+
+/* Hand one layer of one network to the planner.  Pointers are device fp32 in
+ * the checkpoint's own layout (nn.Linear: W[out,in] row-major, b[out];
+ * LayerNorm ln_g/ln_b[out], NULL for the plain output layers).  For
+ * TDMPC2_NET_Q every tensor carries the leading ensemble dim num_q
+ * ("_Qs.params.<layer>.<name>", tdmpc2/common/layers.py:167-199).  The first
+ * layer's input columns are ordered [z | task_emb | action]
+ * (world_model.py:118-120).  The library re-packs into its own MFMA fragment
+ * layout; the source buffers may be freed after the stream reaches this call. */
+int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *W, const float *b,
+                             const float *ln_g, const float *ln_b, int out_features, int in_features,
+                             void *stream);
+
+/* One plan per environment: everything of TDMPC2._plan after encode().
+ *   z0         [E,L]     latent from WorldModel.encode (tdmpc2.py:153)
+ *   task_emb   [E,T]     looked-up (max_norm-renormalised) task embedding rows, NULL if !multitask
+ *   act_mask   [E,A]     WorldModel._action_masks[task], NULL if !multitask
+ *   disc_pow   [E,H+1]   discount^0..discount^H exactly as tdmpc2.py:126,130-132 accumulates them
+ *   prev_mean  [E,H,A]   in: TDMPC2._prev_mean, out: new mean (tdmpc2.py:166-167,205)
+ *   t0         [E] u8    first step of an episode (no warm start)
+ *   eval_mode            0: add std*noise to the chosen action (tdmpc2.py:203-204)
+ *   tape                 NULL -> Philox(seed); `seed` is ignored when a tape is given
+ *   action     [E,A]     out: the clamped action (tdmpc2.py:206) */
+int tdmpc2_plan_run(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *task_emb,
+                    const float *act_mask, const float *disc_pow, float *prev_mean, const uint8_t *t0,
+                    int eval_mode, const tdmpc2_noise *tape, uint64_t seed, float *action,
+                    const tdmpc2_debug *dbg, void *stream);
+
+/* TDMPC2._estimate_value on given action sequences (stage-wise parity).
+ *   actions [E,H,N,A], pi_eps [E,N,A], qidx [E,2] -> value [E,N] (before nan_to_num). */
+int tdmpc2_plan_estimate_value(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *task_emb,
+                               const float *act_mask, const float *disc_pow, const float *actions,
+                               const float *pi_eps, const int32_t *qidx, float *value, void *stream);
+
+/* The same, additionally dumping the activation tile after every fused phase (layer-level parity:
+ * each fused stage is checked against its unfused counterpart at its own scale).
+ *   trace_tiles   [E*N/64, 5H+7, 64, L]  per 64-row tile, in execution order: for t < H {reward h1, reward h2,
+ *                 dynamics h1, dynamics h2, z_{t+1}}, then {pi h1, pi h2, z_H, Q_a h1, Q_a h2, Q_b h1, Q_b h2}
+ *   trace_scalars [E, N, H+2+A]          r_0..r_{H-1}, Q_a, Q_b, a_H[A]
+ * Either may be NULL. */
+int tdmpc2_plan_estimate_value_trace(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *task_emb,
+                                     const float *act_mask, const float *disc_pow, const float *actions,
+                                     const float *pi_eps, const int32_t *qidx, float *value,
+                                     float *trace_tiles, float *trace_scalars, void *stream);
+
+/* Elite select + refit on given values (stage-wise parity).
+ *   value [E,N] in/out (nan_to_num applied), actions [E,H,N,A], act_mask [E,A]|NULL
+ *   -> mean,std [E,H,A]; score [E,K]; elite_idx [E,K] (outputs may be NULL). */
+int tdmpc2_plan_refit(tdmpc2_plan_t *h, int n_envs, float *value, const float *actions,
+                      const float *act_mask, float *mean, float *std, float *score,
+                      int32_t *elite_idx, void *stream);
+
+/* Live timing of the dominant (rollout) kernel: after set_profiling(h, n > 0) every rollout launch
+ * is bracketed by HIP events recorded on the caller's stream (up to n launches are kept; n = 0 turns
+ * it off).  profile_read synchronises those events, returns their summed duration and the number of
+ * launches measured, and rewinds the buffer. */
+int tdmpc2_plan_set_profiling(tdmpc2_plan_t *h, int max_launches);
+int tdmpc2_plan_profile_read(tdmpc2_plan_t *h, float *rollout_ms_total, int *rollout_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDMPC2_PLAN_H */

@@ -287,3 +287,48 @@ def plan_batch(model: OracleModel, z0, tape, prev_mean, t0, eval_mode, tasks, di
         stages.append(st)
     st = {k: torch.stack([s[k] for s in stages]) for k in stages[0]}
     return torch.stack(acts), torch.stack(means), st
+
+
+# --------------------------------------------------------------------------- layer-level trace
+def _mlp_hidden(sd, prefix, x):
+    """The two NormedLinear(Mish) hidden activations of a reference `mlp` (layers.py:121-133)."""
+    hs = []
+    for i in (0, 1):
+        x = normed_linear(x, sd[f"{prefix}.{i}.weight"], sd[f"{prefix}.{i}.bias"], sd[f"{prefix}.{i}.ln.weight"],
+                          sd[f"{prefix}.{i}.ln.bias"], F.mish)
+        hs.append(x)
+    return hs
+
+
+def trace_estimate_value(model: OracleModel, z, actions, task, discount, pi_eps, qidx):
+    """_estimate_value (tdmpc2/tdmpc2.py:122-136) with every intermediate the fused kernel can dump
+    (tdmpc2_plan_estimate_value_trace).  Returns (value [N], tiles [5H+7, N, L], scalars [N, H+2+A])."""
+    cfg, sd = model.cfg, model.sd
+    H = cfg.horizon
+    tiles, rs = [], []
+    G, disc = 0, 1
+    emb = (lambda x: model.task_emb(x, task)) if cfg.multitask else (lambda x: x)
+    for t in range(H):
+        x = torch.cat([emb(z), actions[t]], dim=-1)
+        rh = _mlp_hidden(sd, "_reward", x)
+        r = two_hot_inv(F.linear(rh[1], sd["_reward.2.weight"], sd["_reward.2.bias"]), cfg)
+        dh = _mlp_hidden(sd, "_dynamics", x)
+        z = normed_linear(dh[1], sd["_dynamics.2.weight"], sd["_dynamics.2.bias"], sd["_dynamics.2.ln.weight"],
+                          sd["_dynamics.2.ln.bias"], lambda u: simnorm(u, cfg.simnorm_dim))
+        tiles += [rh[0], rh[1], dh[0], dh[1], z]
+        rs.append(r)
+        G = G + disc * r
+        disc = disc * discount
+    ph = _mlp_hidden(sd, "_pi", emb(z))
+    a = model.pi(z, task, pi_eps)
+    x = torch.cat([emb(z), a], dim=-1)
+    qh, qv = [], []
+    for q in qidx.tolist():
+        hsd = {k.replace("_Qs.params", "_q"): v[q] for k, v in sd.items() if k.startswith("_Qs.params.")}
+        hh = _mlp_hidden(hsd, "_q", x)
+        qh += hh
+        qv.append(two_hot_inv(F.linear(hh[1], hsd["_q.2.weight"], hsd["_q.2.bias"]), cfg))
+    tiles += [ph[0], ph[1], z] + qh
+    value = G + disc * ((qv[0] + qv[1]) / 2)
+    scalars = torch.cat(rs + qv + [a], dim=-1)
+    return value.squeeze(1), torch.stack(tiles), scalars

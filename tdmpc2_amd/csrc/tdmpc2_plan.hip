@@ -1,0 +1,1324 @@
+// MI355X (gfx950 / CDNA4) native TD-MPC2 MPPI/CEM planner.
+//
+// What this file implements (reference: nicklashansen/tdmpc2, paths relative to its root):
+//   TDMPC2._plan after encode()            tdmpc2/tdmpc2.py:154-206
+//   TDMPC2._estimate_value                 tdmpc2/tdmpc2.py:122-136
+//   WorldModel.next / reward / pi / Q      tdmpc2/common/world_model.py:114-216
+//   NormedLinear / SimNorm                 tdmpc2/common/layers.py:74-118
+//   two_hot_inv / symexp / log_std / gumbel_softmax_sample   tdmpc2/common/math.py
+//
+// Design (see DESIGN.md for the full account):
+//   * One persistent "rollout" workgroup owns 64 sample rows of one plan for a
+//     whole CEM iteration: the H-step latent rollout (reward + dynamics MLPs),
+//     the policy prior and the two selected Q heads.  Activations never leave
+//     the CU: the current layer's input [64 x 512(+A)] fp32 lives in LDS, the
+//     layer's output accumulates in MFMA accumulators (v_mfma_f32_32x32x2_f32,
+//     exact fp32), LayerNorm/Mish/SimNorm/two-hot run on the tile in place.
+//   * Weights are re-packed once (bind) into MFMA B-fragment order so that a
+//     wave's global_load_dwordx4 reads 1 KiB contiguous; each workgroup streams
+//     every layer exactly once per use (32 FLOP per weight byte), from L2/MALL.
+//   * Reward and dynamics share their first-layer input, so both first layers
+//     are computed in one pass over the LDS tile (two accumulator sets); the
+//     same trick is used for the two Q heads.  At t = 0 every row shares z0, so
+//     the z-part of both first layers is computed once per plan (setup kernel)
+//     and only the action columns are contracted per row.
+//   * One small workgroup per plan does nan_to_num + top-k + score + mean/std
+//     refit (+ the final Gumbel pick) between rollout launches.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/tdmpc2_plan.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int ROWS = 64;        // sample rows per rollout workgroup
+constexpr int NTHREADS = 512;   // 8 wavefronts
+constexpr int WIDTH = 512;      // latent_dim == mlp_dim of the fused size class
+constexpr int ZKB = WIDTH / 8;  // k-blocks (of 8) covering the latent columns
+constexpr int MAXQ = 8;
+constexpr int MAXH = 8;
+constexpr float LN_EPS = 1e-5f;
+
+// ---------------------------------------------------------------- device-side descriptors
+struct LayerW {
+    const float *wp;    // packed [CT][KB][64 lanes][4]
+    const float *bias;  // [CT*32] zero padded
+    const float *g;     // LayerNorm weight [out] (null for plain output layers)
+    const float *b;     // LayerNorm bias   [out]
+    int KB;             // k-blocks in the packed matrix
+    int CT;             // column tiles (of 32 output features)
+};
+struct NetW {
+    LayerW l[3];
+};
+
+struct RolloutParams {
+    int E, N, H, A, Apad, P, stride, tiles, nq, num_bins, multitask, given_actions, iter, iters_total;
+    int nnets;  // vectors per plan in `beff`
+    float log_std_min, log_std_dif;
+    NetW dyn, rew, pi;
+    NetW q[MAXQ];
+    const float *bins;
+    const float *z0;        // [E,L]
+    const float *beff;      // [E,nnets,WIDTH] effective first-layer biases (multitask) or null
+    const float *cvec;      // [E,2,WIDTH]: z0-part (+bias) of reward / dynamics layer 1
+    const float *act_mask;  // [E,A] or null
+    const float *disc_pow;  // [E,H+1]
+    const float *mean;      // [E,H,A]
+    const float *std;       // [E,H,A]
+    const float *sample_eps;  // tape slice for this iteration: env stride given below
+    long sample_eps_estride;
+    const float *pi_eps;
+    long pi_eps_estride;
+    const int *qidx;
+    long qidx_estride;
+    unsigned long long seed;
+    unsigned int call;
+    float *actions;   // [E,H,N,A]
+    float *value;     // [E,N]
+    float *zscratch;  // [E*tiles,64,WIDTH]
+    float *trace_tiles;    // optional [E*tiles, 5H+7, 64, WIDTH] activations after each phase
+    float *trace_scalars;  // optional [E, N, H+2+A]: r_0..r_{H-1}, Q_a, Q_b, a_H[A]
+};
+
+// net slots inside `beff`
+enum { BE_DYN = 0, BE_REW = 1, BE_PI = 2, BE_Q0 = 3 };
+
+// ---------------------------------------------------------------- small math
+__device__ __forceinline__ float mish_f(float x) {
+    // x * tanh(softplus(x)) == x * n / (n + 2),  n = e^x (e^x + 2); no cancellation for x << 0.
+    // reference: nn.Mish in NormedLinear, tdmpc2/common/layers.py:103
+    if (x > 20.f) return x;
+    const float e = expf(x);
+    const float n = e * (e + 2.f);
+    return x * (n / (n + 2.f));
+}
+
+__device__ __forceinline__ float symexp_f(float x) {
+    // tdmpc2/common/math.py:50-55: sign(x) * (exp(|x|) - 1)
+    const float m = expf(fabsf(x)) - 1.f;
+    return x > 0.f ? m : (x < 0.f ? -m : 0.f);
+}
+
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {  // sum over aligned groups of W lanes
+#pragma unroll
+    for (int m = 1; m < W; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+template <int W>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int m = 1; m < W; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+
+// ---------------------------------------------------------------- Philox4x32-10 (fast mode RNG)
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+enum { SITE_PITRAJ = 1, SITE_SAMPLE = 2, SITE_PI = 3, SITE_QIDX = 4, SITE_GUMBEL = 5, SITE_FINAL = 6 };
+
+__device__ __forceinline__ uint4 rng_raw(unsigned long long seed, unsigned call, int site, int iter, int env,
+                                         unsigned idx) {
+    return philox4x32_10(make_uint4(idx, (unsigned)(site | (iter << 8)), (unsigned)env, call),
+                         make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+}
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ float rng_normal(unsigned long long seed, unsigned call, int site, int iter, int env,
+                                            unsigned idx) {
+    const uint4 r = rng_raw(seed, call, site, iter, env, idx);
+    const float u1 = u01(r.x), u2 = u01(r.y);
+    return sqrtf(-2.f * logf(u1)) * cospif(2.f * u2);
+}
+__device__ __forceinline__ float rng_exponential(unsigned long long seed, unsigned call, int site, int iter,
+                                                 int env, unsigned idx) {
+    return -logf(u01(rng_raw(seed, call, site, iter, env, idx).x));
+}
+
+// ---------------------------------------------------------------- MFMA contraction loops
+// Per workgroup: A operand = activations act[64][stride] in LDS (k contiguous), B operand = packed
+// weights.  v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].
+// One 16-byte read per operand feeds 4 MFMAs: lane (i,h) holds k = kb*8 + 4h + r for r = 0..3, i.e.
+// MFMA r contracts the pair {kb*8 + r, kb*8 + 4 + r}; the same permutation on both operands.
+// Wave w of 8 owns output columns [64w, 64w+64) for both 32-row tiles: acc[set][row tile][col tile].
+template <int NS>
+__device__ __forceinline__ void kloop_full(const float *act, int stride, const float *const (&wp)[NS], const int (&KB)[NS],
+                                           int kb0, int kb1, int wave, int lane, f32x16 (&acc)[NS][2][2]) {
+    const int i = lane & 31, h = lane >> 5;
+    const float *a0p = act + i * stride + 4 * h;
+    const float *a1p = a0p + 32 * stride;
+    const f32x4 *w[NS][2];
+    f32x4 bn[NS][2];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            w[s][c] = reinterpret_cast<const f32x4 *>(wp[s]) + (size_t)(2 * wave + c) * KB[s] * 64 + lane;
+            bn[s][c] = w[s][c][(size_t)kb0 * 64];
+        }
+#pragma unroll 2
+    for (int kb = kb0; kb < kb1; ++kb) {
+        f32x4 b[NS][2];
+        const int kn = (kb + 1 < kb1) ? kb + 1 : kb;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                b[s][c] = bn[s][c];
+                bn[s][c] = w[s][c][(size_t)kn * 64];
+            }
+        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p + kb * 8);
+        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(a1p + kb * 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                acc[s][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b[s][0][r], acc[s][0][0], 0, 0, 0);
+                acc[s][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b[s][1][r], acc[s][0][1], 0, 0, 0);
+                acc[s][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b[s][0][r], acc[s][1][0], 0, 0, 0);
+                acc[s][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b[s][1][r], acc[s][1][1], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// One 32x32 output tile (row tile rt, column tile ct) — the narrow output layers (two-hot / pi heads).
+__device__ __forceinline__ void kloop_tile(const float *act, int stride, const float *wp, int KB, int ct, int rt,
+                                           int kb0, int kb1, int lane, f32x16 &acc) {
+    const int i = lane & 31, h = lane >> 5;
+    const float *ap = act + (rt * 32 + i) * stride + 4 * h;
+    const f32x4 *w = reinterpret_cast<const f32x4 *>(wp) + (size_t)ct * KB * 64 + lane;
+    f32x4 bn = w[(size_t)kb0 * 64];
+#pragma unroll 2
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const f32x4 b = bn;
+        const int kn = (kb + 1 < kb1) ? kb + 1 : kb;
+        bn = w[(size_t)kn * 64];
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(ap + kb * 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void zero4(f32x16 (&a)[2][2]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a[r][c][e] = 0.f;
+}
+
+// C/D fragment of a 32x32 tile: lane l holds column (l & 31), rows (reg&3) + 8*(reg>>2) + 4*(l>>5).
+__device__ __forceinline__ void store_full(float *act, int stride, const f32x16 (&acc)[2][2], const float *bias,
+                                           int wave, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int col = (2 * wave + c) * 32 + j;
+        const float bv = bias[col];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                act[row * stride + col] = acc[rt][c][reg] + bv;
+            }
+    }
+}
+__device__ __forceinline__ void store_tile(float *act, int stride, const f32x16 &acc, const float *bias, int ct,
+                                           int rt, int lane) {
+    const int j = lane & 31, h = lane >> 5;
+    const int col = ct * 32 + j;
+    const float bv = bias[col];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        act[row * stride + col] = acc[reg] + bv;
+    }
+}
+
+// ---------------------------------------------------------------- row-wise epilogues (in place, in LDS)
+// Thread t owns row (t >> 3) and the sixteen 4-column chunks {part + 8q}, part = t & 7: the 8 owners
+// of a row are 8 adjacent lanes.  LayerNorm = biased variance, eps 1e-5 (nn.LayerNorm defaults,
+// tdmpc2/common/layers.py:101); ACT 0 = Mish, 1 = SimNorm over groups of 8 (layers.py:84-88).
+template <int ACT>
+__device__ __forceinline__ void ln_act_rows(float *act, int stride, const float *g, const float *b, int tid,
+                                            float *gcopy /* optional [64][WIDTH] global copy of the result */) {
+    const int row = tid >> 3, part = tid & 7;
+    float *rp = act + row * stride + 4 * part;
+    // three passes over the row slice in LDS (cheap) instead of 64 live registers per thread
+    float s = 0.f;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(rp + 32 * q);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float mean = group_sum<8>(s) * (1.0f / WIDTH);
+    float ss = 0.f;
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(rp + 32 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[e] - mean;
+            ss += d * d;
+        }
+    }
+    const float var = group_sum<8>(ss) * (1.0f / WIDTH);
+    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+#pragma unroll 2
+    for (int q = 0; q < 16; ++q) {
+        const int col = 4 * part + 32 * q;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(rp + 32 * q);
+        const f32x4 gg = *reinterpret_cast<const f32x4 *>(g + col);
+        const f32x4 bb = *reinterpret_cast<const f32x4 *>(b + col);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (v[e] - mean) * rstd * gg[e] + bb[e];
+        if (ACT == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = mish_f(y[e]);
+        } else {
+            // group of 8 columns = this lane's chunk + the chunk of lane (part ^ 1)
+            float m = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
+            m = fmaxf(m, __shfl_xor(m, 1));
+            float es = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = expf(y[e] - m);
+                es += y[e];
+            }
+            es += __shfl_xor(es, 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = y[e] / es;
+        }
+        *reinterpret_cast<f32x4 *>(rp + 32 * q) = y;
+        if (gcopy) *reinterpret_cast<f32x4 *>(gcopy + row * WIDTH + col) = y;
+    }
+}
+
+// two_hot_inv (tdmpc2/common/math.py:74-83) on logits in act[row][0..num_bins): softmax, expectation over
+// the bin centres, symexp.  Result valid in every thread of the row's 8-lane group.
+__device__ __forceinline__ float twohot_rows(const float *act, int stride, const float *bins, int num_bins, int tid) {
+    const int row = tid >> 3, part = tid & 7;
+    const float *rp = act + row * stride;
+    float v[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int j = part + 8 * q;
+        v[q] = (j < num_bins) ? rp[j] : -INFINITY;
+        m = fmaxf(m, v[q]);
+    }
+    m = group_max<8>(m);
+    float es = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int j = part + 8 * q;
+        v[q] = (j < num_bins) ? expf(v[q] - m) : 0.f;
+        es += v[q];
+    }
+    es = group_sum<8>(es);
+    float x = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int j = part + 8 * q;
+        if (j < num_bins) x += (v[q] / es) * bins[j];
+    }
+    x = group_sum<8>(x);
+    return symexp_f(x);
+}
+
+// ---------------------------------------------------------------- composite phases
+struct Ctx {
+    float *act;
+    int stride, tid, wave, lane;
+};
+
+// out = ACT(LayerNorm(W x + bias)) for a WIDTH-wide layer; input and output in ctx.act.
+template <int ACT>
+__device__ __forceinline__ void layer_full(const Ctx &c, const LayerW &ly, const float *bias, int kb0, int kb1,
+                                           float *gcopy = nullptr) {
+    f32x16 acc[1][2][2];
+    zero4(acc[0]);
+    const float *const wp[1] = {ly.wp};
+    const int KB[1] = {ly.KB};
+    kloop_full<1>(c.act, c.stride, wp, KB, kb0, kb1, c.wave, c.lane, acc);
+    __syncthreads();
+    store_full(c.act, c.stride, acc[0], bias, c.wave, c.lane);
+    __syncthreads();
+    ln_act_rows<ACT>(c.act, c.stride, ly.g, ly.b, c.tid, gcopy);
+    __syncthreads();
+}
+
+// Two-hot output layer: logits -> scalar per row (returned to every thread of the row group).
+__device__ __forceinline__ float head_twohot(const Ctx &c, const LayerW &ly, const float *bins, int num_bins) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int rt = c.wave & 1, ct = c.wave >> 1;
+    if (ct < ly.CT) kloop_tile(c.act, c.stride, ly.wp, ly.KB, ct, rt, 0, ZKB, c.lane, acc);
+    __syncthreads();
+    if (ct < ly.CT) store_tile(c.act, c.stride, acc, ly.bias, ct, rt, c.lane);
+    __syncthreads();
+    const float r = twohot_rows(c.act, c.stride, bins, num_bins, c.tid);
+    __syncthreads();
+    return r;
+}
+
+// Policy prior output layer + squashed Gaussian sample (tdmpc2/common/world_model.py:152-173).
+// eps(row, a) supplies the randn_like draw.  Writes the action into act[row][WIDTH + a] and, if
+// `gdst` is given, into gdst[row * A + a] for rows < nvalid.
+template <typename EpsFn>
+__device__ __forceinline__ void head_pi(const Ctx &c, const LayerW &ly, int A, int Apad, float lsmin, float lsdif,
+                                        const float *mask, EpsFn eps, float *gdst, int nvalid) {
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int rt = c.wave & 1, ct = c.wave >> 1;
+    if (ct < ly.CT) kloop_tile(c.act, c.stride, ly.wp, ly.KB, ct, rt, 0, ZKB, c.lane, acc);
+    __syncthreads();
+    if (ct < ly.CT) store_tile(c.act, c.stride, acc, ly.bias, ct, rt, c.lane);
+    __syncthreads();
+    const int row = c.tid >> 3, part = c.tid & 7;
+    float *rp = c.act + row * c.stride;
+    for (int a = part; a < Apad; a += 8) {
+        float out = 0.f;
+        if (a < A) {
+            float mu = rp[a];
+            float ls = lsmin + 0.5f * lsdif * (tanhf(rp[A + a]) + 1.f);  // math.log_std, math.py:12-13
+            float e = eps(row, a);
+            if (mask) {
+                const float mk = mask[a];
+                mu *= mk;
+                ls *= mk;
+                e *= mk;
+            }
+            out = tanhf(mu + e * expf(ls));  // reparameterisation + squash, world_model.py:173-174
+            if (gdst && row < nvalid) gdst[row * A + a] = out;
+        }
+        rp[WIDTH + a] = out;
+    }
+    __syncthreads();
+}
+
+// Copy a [64][WIDTH] tile between LDS rows and a dense global buffer.
+__device__ __forceinline__ void tile_from_global(const Ctx &c, const float *src) {
+    for (int idx = c.tid; idx < ROWS * (WIDTH / 4); idx += NTHREADS) {
+        const int row = idx / (WIDTH / 4), c4 = idx % (WIDTH / 4);
+        *reinterpret_cast<f32x4 *>(c.act + row * c.stride + 4 * c4) =
+            *reinterpret_cast<const f32x4 *>(src + row * WIDTH + 4 * c4);
+    }
+}
+__device__ __forceinline__ void tile_broadcast_row(const Ctx &c, const float *src_row) {
+    for (int idx = c.tid; idx < ROWS * (WIDTH / 4); idx += NTHREADS) {
+        const int row = idx / (WIDTH / 4), c4 = idx % (WIDTH / 4);
+        *reinterpret_cast<f32x4 *>(c.act + row * c.stride + 4 * c4) =
+            *reinterpret_cast<const f32x4 *>(src_row + 4 * c4);
+    }
+}
+
+__device__ __forceinline__ void dump_tile(const Ctx &c, float *trace, int nslot, int slot) {
+    if (!trace) return;
+    float *dst = trace + ((size_t)blockIdx.x * nslot + slot) * ROWS * WIDTH;
+    for (int idx = c.tid; idx < ROWS * (WIDTH / 4); idx += NTHREADS) {
+        const int row = idx / (WIDTH / 4), c4 = idx % (WIDTH / 4);
+        *reinterpret_cast<f32x4 *>(dst + row * WIDTH + 4 * c4) =
+            *reinterpret_cast<const f32x4 *>(c.act + row * c.stride + 4 * c4);
+    }
+}
+
+// ================================================================ kernel: per-plan setup
+// grid = E.  (1) effective first-layer biases b + W[:, L:L+T] . task_emb (multitask);
+// (2) cvec = z0-part (+ bias) of the reward / dynamics first layers (all rows share z0 at t = 0,
+//     tdmpc2/tdmpc2.py:163); (3) mean / std initialisation and warm start (tdmpc2.py:164-167).
+struct SetupParams {
+    int E, H, A, T, multitask, nq, nnets, stride;
+    float max_std;
+    NetW dyn, rew, pi;
+    NetW q[MAXQ];
+    const float *wemb[3 + MAXQ];  // [out=WIDTH][T] task-embedding columns of each first layer
+    const float *z0, *task_emb, *prev_mean;
+    const unsigned char *t0;
+    float *beff, *cvec, *mean, *std;
+};
+
+__global__ __launch_bounds__(NTHREADS, 2) void k_setup(SetupParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    Ctx c{smem, p.stride, tid, tid >> 6, tid & 63};
+    if (p.multitask) {
+        // one thread per output column, one dot product of length T per net
+        const float *emb = p.task_emb + (size_t)e * p.T;
+        for (int net = 0; net < p.nnets; ++net) {
+            const LayerW &l1 = net == BE_DYN ? p.dyn.l[0] : net == BE_REW ? p.rew.l[0] : net == BE_PI ? p.pi.l[0]
+                                                                                                    : p.q[net - BE_Q0].l[0];
+            const float *w = p.wemb[net] + (size_t)tid * p.T;
+            float s = 0.f;
+            for (int k = 0; k < p.T; ++k) s = fmaf(w[k], emb[k], s);
+            p.beff[((size_t)e * p.nnets + net) * WIDTH + tid] = l1.bias[tid] + s;
+        }
+    }
+    for (int idx = tid; idx < p.H * p.A; idx += NTHREADS) {
+        const int t = idx / p.A;
+        float m = 0.f;
+        if (!p.t0[e] && t < p.H - 1) m = p.prev_mean[(size_t)e * p.H * p.A + idx + p.A];
+        p.mean[(size_t)e * p.H * p.A + idx] = m;
+        p.std[(size_t)e * p.H * p.A + idx] = p.max_std;
+    }
+    tile_broadcast_row(c, p.z0 + (size_t)e * WIDTH);
+    __syncthreads();  // also orders the beff stores above for this block's later reads
+    f32x16 acc[2][2][2];
+    zero4(acc[0]);
+    zero4(acc[1]);
+    const float *const wp[2] = {p.rew.l[0].wp, p.dyn.l[0].wp};
+    const int KB[2] = {p.rew.l[0].KB, p.dyn.l[0].KB};
+    kloop_full<2>(c.act, c.stride, wp, KB, 0, ZKB, c.wave, c.lane, acc);
+    const float *b_rew = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_REW) * WIDTH : p.rew.l[0].bias;
+    const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
+    // row 0 of the tile lives in lanes with (lane >> 5) == 0, register 0 of row tile 0
+    if ((c.lane >> 5) == 0) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int col = (2 * c.wave + ct) * 32 + (c.lane & 31);
+            p.cvec[((size_t)e * 2 + 0) * WIDTH + col] = acc[0][0][ct][0] + b_rew[col];
+            p.cvec[((size_t)e * 2 + 1) * WIDTH + col] = acc[1][0][ct][0] + b_dyn[col];
+        }
+    }
+}
+
+// ================================================================ kernel: policy-prior trajectories
+// grid = E (rows < P of one tile are meaningful).  tdmpc2/tdmpc2.py:154-160.
+struct PiTrajParams {
+    int E, N, H, A, Apad, P, stride, multitask, nnets;
+    float log_std_min, log_std_dif;
+    NetW dyn, pi;
+    const float *z0, *beff, *act_mask;
+    const float *pi_traj_eps;  // [E,H,P,A] or null
+    unsigned long long seed;
+    unsigned int call;
+    float *actions;   // [E,H,N,A]
+    float *zscratch;  // [E,64,WIDTH] (tile 0 of each plan)
+    long zscratch_estride;
+};
+
+__global__ __launch_bounds__(NTHREADS, 2) void k_pitraj(PiTrajParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int e = blockIdx.x, tid = threadIdx.x;
+    Ctx c{smem, p.stride, tid, tid >> 6, tid & 63};
+    const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
+    const float *b_pi = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_PI) * WIDTH : p.pi.l[0].bias;
+    const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
+    float *zs = p.zscratch + (size_t)e * p.zscratch_estride;
+    const int KBA = ZKB + p.Apad / 8;
+    tile_broadcast_row(c, p.z0 + (size_t)e * WIDTH);
+    for (int idx = tid; idx < ROWS * WIDTH / 4; idx += NTHREADS)
+        *reinterpret_cast<f32x4 *>(zs + 4 * idx) =
+            *reinterpret_cast<const f32x4 *>(p.z0 + (size_t)e * WIDTH + 4 * (idx % (WIDTH / 4)));
+    __syncthreads();
+    for (int t = 0; t < p.H; ++t) {
+        // a_t = pi(z)
+        layer_full<0>(c, p.pi.l[0], b_pi, 0, ZKB);
+        layer_full<0>(c, p.pi.l[1], p.pi.l[1].bias, 0, ZKB);
+        const float *tape = p.pi_traj_eps ? p.pi_traj_eps + ((size_t)e * p.H + t) * p.P * p.A : nullptr;
+        auto eps = [&](int row, int a) -> float {
+            if (row >= p.P) return 0.f;
+            if (tape) return tape[row * p.A + a];
+            return rng_normal(p.seed, p.call, SITE_PITRAJ, t, e, (unsigned)(row * p.A + a));
+        };
+        head_pi(c, p.pi.l[2], p.A, p.Apad, p.log_std_min, p.log_std_dif, mask, eps,
+                p.actions + ((size_t)e * p.H + t) * p.N * p.A, p.P);
+        if (t == p.H - 1) break;
+        // z = next(z, a_t)
+        tile_from_global(c, zs);
+        __syncthreads();
+        layer_full<0>(c, p.dyn.l[0], b_dyn, 0, KBA);
+        layer_full<0>(c, p.dyn.l[1], p.dyn.l[1].bias, 0, ZKB);
+        layer_full<1>(c, p.dyn.l[2], p.dyn.l[2].bias, 0, ZKB, zs);
+    }
+}
+
+// ================================================================ kernel: one CEM iteration's rollouts
+// grid = E * N/64.  tdmpc2/tdmpc2.py:176-184 (sampling + _estimate_value).
+__global__ __launch_bounds__(NTHREADS, 2) void k_rollout(RolloutParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int e = blockIdx.x / p.tiles, tile = blockIdx.x % p.tiles;
+    const int tid = threadIdx.x;
+    Ctx c{smem, p.stride, tid, tid >> 6, tid & 63};
+    float *sm_mean = smem + ROWS * p.stride;  // [H*A]
+    float *sm_std = sm_mean + p.H * p.A;
+    const int row0 = tile * ROWS;
+    const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
+    const float *disc = p.disc_pow + (size_t)e * (p.H + 1);
+    const int KBA = ZKB + p.Apad / 8;
+    float *zs = p.zscratch + (size_t)blockIdx.x * ROWS * WIDTH;
+    const int NSLOT = 5 * p.H + 7;
+    float *tsc = p.trace_scalars ? p.trace_scalars + ((size_t)e * p.N + row0 + (tid >> 3)) * (p.H + 2 + p.A) : nullptr;
+
+    for (int idx = tid; idx < p.H * p.A; idx += NTHREADS) {
+        sm_mean[idx] = p.mean[(size_t)e * p.H * p.A + idx];
+        sm_std[idx] = p.std[(size_t)e * p.H * p.A + idx];
+    }
+    int q0, q1;
+    if (p.qidx) {
+        q0 = p.qidx[(size_t)e * p.qidx_estride + 0];
+        q1 = p.qidx[(size_t)e * p.qidx_estride + 1];
+    } else {  // two distinct heads, uniform over ordered pairs (randperm(nq)[:2], world_model.py:212)
+        const uint4 r = rng_raw(p.seed, p.call, SITE_QIDX, p.iter, e, 0);
+        q0 = (int)(r.x % (unsigned)p.nq);
+        q1 = (int)(r.y % (unsigned)(p.nq - 1));
+        if (q1 >= q0) ++q1;
+    }
+    const float *b_rew = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_REW) * WIDTH : p.rew.l[0].bias;
+    const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
+    const float *b_pi = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_PI) * WIDTH : p.pi.l[0].bias;
+    const float *b_q0 = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_Q0 + q0) * WIDTH : p.q[q0].l[0].bias;
+    const float *b_q1 = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_Q0 + q1) * WIDTH : p.q[q1].l[0].bias;
+    __syncthreads();
+
+    float G = 0.f;
+    for (int t = 0; t < p.H; ++t) {
+        // ---- actions of step t for this tile's rows (tdmpc2.py:176-181) -> LDS columns [WIDTH, WIDTH+Apad)
+        {
+            float *ag = p.actions + ((size_t)e * p.H + t) * p.N * p.A;
+            for (int idx = tid; idx < ROWS * p.Apad; idx += NTHREADS) {
+                const int row = idx / p.Apad, a = idx % p.Apad;
+                const int n = row0 + row;
+                float v = 0.f;
+                if (a < p.A) {
+                    if (p.given_actions || n < p.P) {
+                        v = ag[(size_t)n * p.A + a];
+                    } else {
+                        float r;
+                        const unsigned ridx = (unsigned)(((size_t)t * (p.N - p.P) + (n - p.P)) * p.A + a);
+                        if (p.sample_eps)
+                            r = p.sample_eps[(size_t)e * p.sample_eps_estride + ridx];
+                        else
+                            r = rng_normal(p.seed, p.call, SITE_SAMPLE, p.iter, e, ridx);
+                        v = sm_mean[t * p.A + a] + sm_std[t * p.A + a] * r;
+                        v = fminf(fmaxf(v, -1.f), 1.f);
+                    }
+                    if (mask && !p.given_actions) v *= mask[a];
+                    if (!p.given_actions) ag[(size_t)n * p.A + a] = v;
+                }
+                c.act[row * c.stride + WIDTH + a] = v;
+            }
+        }
+        __syncthreads();
+        // ---- first layers of reward and dynamics in one pass over [z_t | a_t]
+        f32x16 acc[2][2][2];
+        zero4(acc[0]);
+        zero4(acc[1]);
+        {
+            const float *const wp[2] = {p.rew.l[0].wp, p.dyn.l[0].wp};
+            const int KB[2] = {p.rew.l[0].KB, p.dyn.l[0].KB};
+            // t = 0: every row shares z0 -> z-part precomputed per plan in cvec, contract actions only
+            kloop_full<2>(c.act, c.stride, wp, KB, t == 0 ? ZKB : 0, KBA, c.wave, c.lane, acc);
+        }
+        __syncthreads();
+        store_full(c.act, c.stride, acc[0], t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew, c.wave, c.lane);
+        __syncthreads();
+        ln_act_rows<0>(c.act, c.stride, p.rew.l[0].g, p.rew.l[0].b, tid, nullptr);
+        __syncthreads();
+        dump_tile(c, p.trace_tiles, NSLOT, 5 * t + 0);
+        // ---- reward: layer 2, two-hot head
+        layer_full<0>(c, p.rew.l[1], p.rew.l[1].bias, 0, ZKB);
+        dump_tile(c, p.trace_tiles, NSLOT, 5 * t + 1);
+        const float r = head_twohot(c, p.rew.l[2], p.bins, p.num_bins);
+        if (tsc && (tid & 7) == 0) tsc[t] = r;
+        G += disc[t] * r;  // G + discount * (1 - termination) * reward, termination == 0 (tdmpc2.py:130)
+        // ---- dynamics: release the held first layer, layers 2 and 3 (SimNorm)
+        store_full(c.act, c.stride, acc[1], t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn, c.wave, c.lane);
+        __syncthreads();
+        ln_act_rows<0>(c.act, c.stride, p.dyn.l[0].g, p.dyn.l[0].b, tid, nullptr);
+        __syncthreads();
+        dump_tile(c, p.trace_tiles, NSLOT, 5 * t + 2);
+        layer_full<0>(c, p.dyn.l[1], p.dyn.l[1].bias, 0, ZKB);
+        dump_tile(c, p.trace_tiles, NSLOT, 5 * t + 3);
+        layer_full<1>(c, p.dyn.l[2], p.dyn.l[2].bias, 0, ZKB, t == p.H - 1 ? zs : nullptr);
+        dump_tile(c, p.trace_tiles, NSLOT, 5 * t + 4);
+    }
+    // ---- a_H = pi(z_H) (tdmpc2.py:135); z_H was also saved to zs
+    layer_full<0>(c, p.pi.l[0], b_pi, 0, ZKB);
+    dump_tile(c, p.trace_tiles, NSLOT, 5 * p.H + 0);
+    layer_full<0>(c, p.pi.l[1], p.pi.l[1].bias, 0, ZKB);
+    dump_tile(c, p.trace_tiles, NSLOT, 5 * p.H + 1);
+    {
+        auto eps = [&](int row, int a) -> float {
+            const unsigned ridx = (unsigned)((size_t)(row0 + row) * p.A + a);
+            if (p.pi_eps) return p.pi_eps[(size_t)e * p.pi_eps_estride + ridx];
+            return rng_normal(p.seed, p.call, SITE_PI, p.iter, e, ridx);
+        };
+        head_pi(c, p.pi.l[2], p.A, p.Apad, p.log_std_min, p.log_std_dif, mask, eps, nullptr, 0);
+    }
+    tile_from_global(c, zs);
+    __syncthreads();
+    dump_tile(c, p.trace_tiles, NSLOT, 5 * p.H + 2);
+    if (tsc) {
+        const int row = tid >> 3;
+        for (int a = tid & 7; a < p.A; a += 8) tsc[p.H + 2 + a] = c.act[row * c.stride + WIDTH + a];
+    }
+    // ---- Q(z_H, a_H): the two selected heads, first layers in one pass (world_model.py:186-216)
+    f32x16 acc[2][2][2];
+    zero4(acc[0]);
+    zero4(acc[1]);
+    {
+        const float *const wp[2] = {p.q[q0].l[0].wp, p.q[q1].l[0].wp};
+        const int KB[2] = {p.q[q0].l[0].KB, p.q[q1].l[0].KB};
+        kloop_full<2>(c.act, c.stride, wp, KB, 0, KBA, c.wave, c.lane, acc);
+    }
+    __syncthreads();
+    store_full(c.act, c.stride, acc[0], b_q0, c.wave, c.lane);
+    __syncthreads();
+    ln_act_rows<0>(c.act, c.stride, p.q[q0].l[0].g, p.q[q0].l[0].b, tid, nullptr);
+    __syncthreads();
+    dump_tile(c, p.trace_tiles, NSLOT, 5 * p.H + 3);
+    layer_full<0>(c, p.q[q0].l[1], p.q[q0].l[1].bias, 0, ZKB);
+    dump_tile(c, p.trace_tiles, NSLOT, 5 * p.H + 4);
+    const float qa = head_twohot(c, p.q[q0].l[2], p.bins, p.num_bins);
+    store_full(c.act, c.stride, acc[1], b_q1, c.wave, c.lane);
+    __syncthreads();
+    ln_act_rows<0>(c.act, c.stride, p.q[q1].l[0].g, p.q[q1].l[0].b, tid, nullptr);
+    __syncthreads();
+    dump_tile(c, p.trace_tiles, NSLOT, 5 * p.H + 5);
+    layer_full<0>(c, p.q[q1].l[1], p.q[q1].l[1].bias, 0, ZKB);
+    dump_tile(c, p.trace_tiles, NSLOT, 5 * p.H + 6);
+    const float qb = head_twohot(c, p.q[q1].l[2], p.bins, p.num_bins);
+    if (tsc && (tid & 7) == 0) {
+        tsc[p.H] = qa;
+        tsc[p.H + 1] = qb;
+    }
+    // G + discount * (1 - termination) * Q.sum(0) / 2   (tdmpc2.py:136, world_model.py:216)
+    if ((tid & 7) == 0) p.value[(size_t)e * p.N + row0 + (tid >> 3)] = G + disc[p.H] * ((qa + qb) / 2.f);
+}
+
+// ================================================================ kernel: elite select + refit
+// grid = E, block = N threads.  tdmpc2/tdmpc2.py:184-206.
+struct RefitParams {
+    int E, N, H, A, K, iter, last, eval_mode;
+    float temperature, min_std, max_std;
+    float *value;          // [E,N] in/out (nan_to_num)
+    const float *actions;  // [E,H,N,A]
+    const float *act_mask; // [E,A] or null
+    float *mean, *std;     // [E,H,A] out
+    float *score;          // [E,K] out (may be null)
+    int *elite_idx;        // [E,K] out (may be null)
+    // last iteration only
+    const float *gumbel_exp;  // [E,K] or null -> Philox
+    const float *final_eps;   // [E,A] or null -> Philox
+    unsigned long long seed;
+    unsigned int call;
+    float *prev_mean;  // [E,H,A]
+    float *action;     // [E,A]
+    // debug copies (per iteration slices already offset by the host; env stride given)
+    float *dbg_value; long dbg_value_es;
+    int *dbg_idx; long dbg_idx_es;
+    float *dbg_score; long dbg_score_es;
+    float *dbg_mean; long dbg_mean_es;
+    float *dbg_std; long dbg_std_es;
+};
+
+__global__ void k_refit(RefitParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *sv = smem;                           // [N]
+    float *ev = sv + p.N;                       // [K]
+    float *sc = ev + p.K;                       // [K]
+    int *ei = reinterpret_cast<int *>(sc + p.K);  // [K]
+    float *smean = reinterpret_cast<float *>(ei + p.K);  // [H*A]
+    float *sstd = smean + p.H * p.A;                     // [H*A]
+    __shared__ float s_sum, s_ssum;
+    __shared__ int s_pick;
+    const int e = blockIdx.x, tid = threadIdx.x;
+    // value.nan_to_num(0): nan -> 0, +-inf -> +-FLT_MAX (tdmpc2.py:184)
+    float v = p.value[(size_t)e * p.N + tid];
+    if (v != v) v = 0.f;
+    else if (v == INFINITY) v = 3.402823466e+38f;
+    else if (v == -INFINITY) v = -3.402823466e+38f;
+    p.value[(size_t)e * p.N + tid] = v;
+    if (p.dbg_value) p.dbg_value[(size_t)e * p.dbg_value_es + tid] = v;
+    sv[tid] = v;
+    __syncthreads();
+    // rank = position in (value desc, index asc) order; torch.topk(..., sorted=True) (tdmpc2.py:185)
+    int rank = 0;
+    for (int j = 0; j < p.N; ++j) {
+        const float u = sv[j];
+        rank += (u > v) || (u == v && j < tid);
+    }
+    if (rank < p.K) {
+        ei[rank] = tid;
+        ev[rank] = v;
+    }
+    __syncthreads();
+    if (tid < p.K) sc[tid] = expf(p.temperature * (ev[tid] - ev[0]));  // max(elite_value) == ev[0]
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int k = 0; k < p.K; ++k) s += sc[k];
+        s_sum = s;
+    }
+    __syncthreads();
+    if (tid < p.K) sc[tid] = sc[tid] / s_sum;  // score / score.sum(0)  (tdmpc2.py:191)
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int k = 0; k < p.K; ++k) s += sc[k];
+        s_ssum = s + 1e-9f;  // score.sum(0) + 1e-9 (tdmpc2.py:192-193)
+    }
+    __syncthreads();
+    const float *acts = p.actions + (size_t)e * p.H * p.N * p.A;
+    for (int idx = tid; idx < p.H * p.A; idx += blockDim.x) {
+        const int t = idx / p.A, a = idx % p.A;
+        const float *at = acts + (size_t)t * p.N * p.A + a;
+        float m = 0.f;
+        for (int k = 0; k < p.K; ++k) m += sc[k] * at[(size_t)ei[k] * p.A];
+        m = m / s_ssum;
+        float s2 = 0.f;
+        for (int k = 0; k < p.K; ++k) {
+            const float d = at[(size_t)ei[k] * p.A] - m;
+            s2 += sc[k] * (d * d);
+        }
+        float sd = sqrtf(s2 / s_ssum);
+        sd = fminf(fmaxf(sd, p.min_std), p.max_std);
+        if (p.act_mask) {
+            const float mk = p.act_mask[(size_t)e * p.A + a];
+            m *= mk;
+            sd *= mk;
+        }
+        smean[idx] = m;
+        sstd[idx] = sd;
+        p.mean[(size_t)e * p.H * p.A + idx] = m;
+        p.std[(size_t)e * p.H * p.A + idx] = sd;
+        if (p.dbg_mean) p.dbg_mean[(size_t)e * p.dbg_mean_es + idx] = m;
+        if (p.dbg_std) p.dbg_std[(size_t)e * p.dbg_std_es + idx] = sd;
+    }
+    if (tid < p.K) {
+        if (p.score) p.score[(size_t)e * p.K + tid] = sc[tid];
+        if (p.elite_idx) p.elite_idx[(size_t)e * p.K + tid] = ei[tid];
+        if (p.dbg_score) p.dbg_score[(size_t)e * p.dbg_score_es + tid] = sc[tid];
+        if (p.dbg_idx) p.dbg_idx[(size_t)e * p.dbg_idx_es + tid] = ei[tid];
+    }
+    if (!p.last) return;
+    __syncthreads();
+    // gumbel_softmax_sample(score) (tdmpc2/common/math.py:86-94): argmax softmax(log p - log Exp(1))
+    if (tid == 0) {
+        float gmax = -INFINITY;
+        for (int k = 0; k < p.K; ++k) {
+            const float ex = p.gumbel_exp ? p.gumbel_exp[(size_t)e * p.K + k]
+                                          : rng_exponential(p.seed, p.call, SITE_GUMBEL, 0, e, (unsigned)k);
+            const float gk = logf(sc[k]) + (-logf(ex));
+            ev[k] = gk;
+            gmax = fmaxf(gmax, gk);
+        }
+        float s = 0.f;
+        for (int k = 0; k < p.K; ++k) {
+            ev[k] = expf(ev[k] - gmax);
+            s += ev[k];
+        }
+        int best = 0;
+        float bv = -1.f;
+        for (int k = 0; k < p.K; ++k) {
+            const float y = ev[k] / s;
+            if (y > bv) {
+                bv = y;
+                best = k;
+            }
+        }
+        s_pick = ei[best];
+    }
+    __syncthreads();
+    for (int a = tid; a < p.A; a += blockDim.x) {
+        float x = acts[(size_t)s_pick * p.A + a];  // elite_actions[0, rand_idx]
+        if (!p.eval_mode) {
+            const float n = p.final_eps ? p.final_eps[(size_t)e * p.A + a]
+                                        : rng_normal(p.seed, p.call, SITE_FINAL, 0, e, (unsigned)a);
+            x = x + sstd[a] * n;  // a + std[0] * randn (tdmpc2.py:203-204)
+        }
+        p.action[(size_t)e * p.A + a] = fminf(fmaxf(x, -1.f), 1.f);
+    }
+    for (int idx = tid; idx < p.H * p.A; idx += blockDim.x)
+        p.prev_mean[(size_t)e * p.H * p.A + idx] = smean[idx];  // _prev_mean.copy_(mean) (tdmpc2.py:205)
+}
+
+// ================================================================ weight packing kernels
+// dst[ct][kb][lane][r] = W[row = ct*32 + (lane&31)][k = kb*8 + 4*(lane>>5) + r]; the packed k axis is
+// [z columns (nz) | action columns (na, zero padded to a multiple of 8)], source columns are
+// [z (nz) | task_emb (nt) | action (na)] (tdmpc2/common/world_model.py:118-120).
+__global__ void k_pack_weight(const float *W, int out, int in, int nz, int nt, int na, int CT, int KB, float *dst) {
+    const size_t total = (size_t)CT * KB * 256;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int r = idx & 3, lane = (idx >> 2) & 63;
+        const size_t blk = idx >> 8;
+        const int kb = blk % KB, ct = blk / KB;
+        const int row = ct * 32 + (lane & 31);
+        const int k = kb * 8 + 4 * (lane >> 5) + r;
+        float v = 0.f;
+        if (row < out) {
+            int src = -1;
+            if (k < nz) src = k;
+            else if (k - nz < na) src = nz + nt + (k - nz);
+            if (src >= 0 && src < in) v = W[(size_t)row * in + src];
+        }
+        dst[idx] = v;
+    }
+}
+__global__ void k_copy_cols(const float *W, int out, int in, int col0, int ncols, float *dst) {
+    const size_t total = (size_t)out * ncols;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = idx % ncols;
+        const size_t r = idx / ncols;
+        dst[idx] = W[r * in + col0 + c];
+    }
+}
+__global__ void k_copy_pad(const float *src, int n, int npad, float *dst) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < npad; idx += gridDim.x * blockDim.x)
+        dst[idx] = idx < n ? src[idx] : 0.f;
+}
+
+// ================================================================ host side
+thread_local std::string g_err;
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) return fail(TDMPC2_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+struct HostLayer {
+    float *wp = nullptr, *bias = nullptr, *g = nullptr, *b = nullptr, *wemb = nullptr;
+    int KB = 0, CT = 0, out = 0;
+    bool bound = false;
+};
+struct HostNet {
+    HostLayer l[3];
+};
+
+}  // namespace
+
+struct tdmpc2_plan {
+    tdmpc2_plan_cfg cfg;
+    int Apad = 0, stride = 0, tiles = 0, nnets = 0;
+    size_t lds_bytes = 0;
+    HostNet dyn, rew, pi, term;
+    HostNet q[MAXQ];
+    std::vector<void *> allocs;
+    uint64_t bytes = 0;
+    // workspace
+    float *bins = nullptr, *actions = nullptr, *value = nullptr, *mean = nullptr, *std = nullptr, *cvec = nullptr,
+          *beff = nullptr, *zscratch = nullptr;
+    unsigned int call = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;
+    int ev_used = 0;
+};
+
+namespace {
+
+int dev_alloc(tdmpc2_plan *h, void **p, size_t bytes) {
+    HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+    h->allocs.push_back(*p);
+    h->bytes += bytes;
+    return 0;
+}
+
+LayerW to_dev(const HostLayer &l) { return LayerW{l.wp, l.bias, l.g, l.b, l.KB, l.CT}; }
+NetW to_dev(const HostNet &n) {
+    NetW w;
+    for (int i = 0; i < 3; ++i) w.l[i] = to_dev(n.l[i]);
+    return w;
+}
+
+HostNet *net_of(tdmpc2_plan *h, int net, int head) {
+    switch (net) {
+        case TDMPC2_NET_DYNAMICS: return &h->dyn;
+        case TDMPC2_NET_REWARD: return &h->rew;
+        case TDMPC2_NET_PI: return &h->pi;
+        case TDMPC2_NET_Q: return &h->q[head];
+        case TDMPC2_NET_TERMINATION: return &h->term;
+    }
+    return nullptr;
+}
+
+int check_ready(tdmpc2_plan *h) {
+    for (int i = 0; i < 3; ++i) {
+        if (!h->dyn.l[i].bound || !h->rew.l[i].bound || !h->pi.l[i].bound)
+            return fail(TDMPC2_ERR_STATE, "weights of layer %d of dynamics/reward/pi are not bound", i);
+        for (int qh = 0; qh < h->cfg.num_q; ++qh)
+            if (!h->q[qh].l[i].bound) return fail(TDMPC2_ERR_STATE, "weights of Q head %d layer %d are not bound", qh, i);
+    }
+    return 0;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bytes));
+    return 0;
+}
+
+int launch_setup(tdmpc2_plan *h, int E, const float *z0, const float *task_emb, const float *prev_mean,
+                 const unsigned char *t0, hipStream_t st) {
+    SetupParams p{};
+    p.E = E; p.H = h->cfg.horizon; p.A = h->cfg.action_dim; p.T = h->cfg.task_dim; p.multitask = h->cfg.multitask;
+    p.nq = h->cfg.num_q; p.nnets = h->nnets; p.stride = h->stride; p.max_std = h->cfg.max_std;
+    p.dyn = to_dev(h->dyn); p.rew = to_dev(h->rew); p.pi = to_dev(h->pi);
+    for (int i = 0; i < h->cfg.num_q; ++i) p.q[i] = to_dev(h->q[i]);
+    p.wemb[BE_DYN] = h->dyn.l[0].wemb; p.wemb[BE_REW] = h->rew.l[0].wemb; p.wemb[BE_PI] = h->pi.l[0].wemb;
+    for (int i = 0; i < h->cfg.num_q; ++i) p.wemb[BE_Q0 + i] = h->q[i].l[0].wemb;
+    p.z0 = z0; p.task_emb = task_emb; p.prev_mean = prev_mean; p.t0 = t0;
+    p.beff = h->beff; p.cvec = h->cvec; p.mean = h->mean; p.std = h->std;
+    hipLaunchKernelGGL(k_setup, dim3(E), dim3(NTHREADS), h->lds_bytes, st, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+void fill_rollout(tdmpc2_plan *h, RolloutParams &p, int E) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    p.E = E; p.N = c.num_samples; p.H = c.horizon; p.A = c.action_dim; p.Apad = h->Apad; p.P = c.num_pi_trajs;
+    p.stride = h->stride; p.tiles = h->tiles; p.nq = c.num_q; p.num_bins = c.num_bins; p.multitask = c.multitask;
+    p.nnets = h->nnets; p.log_std_min = c.log_std_min; p.log_std_dif = c.log_std_dif;
+    p.dyn = to_dev(h->dyn); p.rew = to_dev(h->rew); p.pi = to_dev(h->pi);
+    for (int i = 0; i < c.num_q; ++i) p.q[i] = to_dev(h->q[i]);
+    p.bins = h->bins; p.beff = h->beff; p.cvec = h->cvec; p.mean = h->mean; p.std = h->std;
+    p.actions = h->actions; p.value = h->value; p.zscratch = h->zscratch;
+    p.iters_total = c.iterations;
+}
+
+int validate_envs(tdmpc2_plan *h, int E) {
+    if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
+    if (E < 1 || E > h->cfg.max_envs) return fail(TDMPC2_ERR_INVALID, "n_envs=%d outside [1, max_envs=%d]", E, h->cfg.max_envs);
+    return check_ready(h);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tdmpc2_plan_abi_version(void) { return TDMPC2_PLAN_ABI_VERSION; }
+const char *tdmpc2_last_error(void) { return g_err.c_str(); }
+
+int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
+    if (!cfg || !out) return fail(TDMPC2_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const tdmpc2_plan_cfg &c = *cfg;
+    if (c.latent_dim != WIDTH || c.mlp_dim != WIDTH)
+        return fail(TDMPC2_ERR_UNSUPPORTED, "fused planner kernels are built for latent_dim == mlp_dim == %d (got %d / %d)",
+                    WIDTH, c.latent_dim, c.mlp_dim);
+    if (c.action_dim < 1 || c.action_dim > 64) return fail(TDMPC2_ERR_UNSUPPORTED, "action_dim %d outside [1, 64]", c.action_dim);
+    if (c.num_bins < 2 || c.num_bins > 128) return fail(TDMPC2_ERR_UNSUPPORTED, "num_bins %d outside [2, 128]", c.num_bins);
+    if (c.num_q < 2 || c.num_q > MAXQ) return fail(TDMPC2_ERR_UNSUPPORTED, "num_q %d outside [2, %d]", c.num_q, MAXQ);
+    if (c.horizon < 1 || c.horizon > MAXH) return fail(TDMPC2_ERR_UNSUPPORTED, "horizon %d outside [1, %d]", c.horizon, MAXH);
+    if (c.num_samples % ROWS != 0 || c.num_samples < ROWS || c.num_samples > 1024)
+        return fail(TDMPC2_ERR_UNSUPPORTED, "num_samples %d must be a multiple of %d in [%d, 1024]", c.num_samples, ROWS, ROWS);
+    if (c.num_pi_trajs < 0 || c.num_pi_trajs > ROWS || c.num_pi_trajs >= c.num_samples)
+        return fail(TDMPC2_ERR_UNSUPPORTED, "num_pi_trajs %d outside [0, %d]", c.num_pi_trajs, ROWS);
+    if (c.num_elites < 1 || c.num_elites > c.num_samples) return fail(TDMPC2_ERR_INVALID, "num_elites %d", c.num_elites);
+    if (c.simnorm_dim != 8) return fail(TDMPC2_ERR_UNSUPPORTED, "simnorm_dim %d (kernels are built for 8)", c.simnorm_dim);
+    if (c.episodic) return fail(TDMPC2_ERR_UNSUPPORTED, "episodic (termination head) planning is not built yet");
+    if (c.multitask && c.task_dim < 1) return fail(TDMPC2_ERR_INVALID, "multitask needs task_dim > 0");
+    if (c.iterations < 1 || c.max_envs < 1) return fail(TDMPC2_ERR_INVALID, "iterations / max_envs must be positive");
+    if (hipSetDevice(c.device) != hipSuccess) return fail(TDMPC2_ERR_HIP, "hipSetDevice(%d) failed", c.device);
+
+    tdmpc2_plan *h = new (std::nothrow) tdmpc2_plan();
+    if (!h) return fail(TDMPC2_ERR_INVALID, "out of host memory");
+    h->cfg = c;
+    h->Apad = (c.action_dim + 7) / 8 * 8;
+    // row stride: [z (512) | a (Apad) | 4 pad]; (WIDTH + Apad + 4) mod 64 is 4 * odd for Apad = 8 (mod 16)... the
+    // +4 makes consecutive rows start 4*odd banks apart in the worst case; see DESIGN.md (LDS layout).
+    h->stride = WIDTH + h->Apad + 4;
+    if ((h->stride / 4) % 2 == 0) h->stride += 4;  // keep stride/4 odd: conflict-free ds_read_b128 across 16 rows
+    h->tiles = c.num_samples / ROWS;
+    h->nnets = BE_Q0 + c.num_q;
+    h->lds_bytes = (size_t)ROWS * h->stride * 4 + (size_t)2 * c.horizon * c.action_dim * 4 + 64;
+    if (h->lds_bytes > 160 * 1024) {
+        const size_t need = h->lds_bytes;
+        delete h;
+        return fail(TDMPC2_ERR_UNSUPPORTED, "LDS tile of %zu bytes exceeds 160 KiB", need);
+    }
+    int rc = 0;
+    const size_t E = c.max_envs, H = c.horizon, N = c.num_samples, A = c.action_dim;
+    // torch.linspace(vmin, vmax, num_bins) in fp32 (math.py:80): float step, product rounded once
+    std::vector<float> bins(c.num_bins);
+    {
+        const float step = (c.vmax - c.vmin) / (float)(c.num_bins - 1);
+        for (int i = 0; i < c.num_bins; ++i)
+            bins[i] = (i < c.num_bins / 2) ? (float)((double)c.vmin + (double)step * i)
+                                           : (float)((double)c.vmax - (double)step * (c.num_bins - 1 - i));
+    }
+    if ((rc = dev_alloc(h, (void **)&h->bins, bins.size() * 4)) ||
+        (rc = dev_alloc(h, (void **)&h->actions, E * H * N * A * 4)) ||
+        (rc = dev_alloc(h, (void **)&h->value, E * N * 4)) ||
+        (rc = dev_alloc(h, (void **)&h->mean, E * H * A * 4)) ||
+        (rc = dev_alloc(h, (void **)&h->std, E * H * A * 4)) ||
+        (rc = dev_alloc(h, (void **)&h->cvec, E * 2 * WIDTH * 4)) ||
+        (rc = dev_alloc(h, (void **)&h->beff, E * h->nnets * WIDTH * 4)) ||
+        (rc = dev_alloc(h, (void **)&h->zscratch, E * h->tiles * ROWS * WIDTH * 4))) {
+        tdmpc2_plan_destroy(h);
+        return rc;
+    }
+    if (hipMemcpy(h->bins, bins.data(), bins.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        tdmpc2_plan_destroy(h);
+        return fail(TDMPC2_ERR_HIP, "hipMemcpy(bins) failed");
+    }
+    if ((rc = set_lds(k_setup, h->lds_bytes)) || (rc = set_lds(k_pitraj, h->lds_bytes)) ||
+        (rc = set_lds(k_rollout, h->lds_bytes))) {
+        tdmpc2_plan_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return TDMPC2_OK;
+}
+
+void tdmpc2_plan_destroy(tdmpc2_plan_t *h) {
+    if (!h) return;
+    for (void *p : h->allocs) (void)hipFree(p);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    delete h;
+}
+
+uint64_t tdmpc2_plan_device_bytes(const tdmpc2_plan_t *h) { return h ? h->bytes : 0; }
+
+int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *W, const float *b, const float *ln_g,
+                             const float *ln_b, int out_features, int in_features, void *stream) {
+    if (!h || !W || !b) return fail(TDMPC2_ERR_INVALID, "null argument");
+    if (layer < 0 || layer > 2) return fail(TDMPC2_ERR_INVALID, "layer %d outside [0, 2]", layer);
+    if (net < TDMPC2_NET_DYNAMICS || net > TDMPC2_NET_TERMINATION) return fail(TDMPC2_ERR_INVALID, "unknown net %d", net);
+    if (net == TDMPC2_NET_TERMINATION) return fail(TDMPC2_ERR_UNSUPPORTED, "termination head is not built yet");
+    const tdmpc2_plan_cfg &c = h->cfg;
+    hipStream_t st = (hipStream_t)stream;
+    const int heads = net == TDMPC2_NET_Q ? c.num_q : 1;
+    const bool takes_action = (net == TDMPC2_NET_DYNAMICS || net == TDMPC2_NET_REWARD || net == TDMPC2_NET_Q);
+    // expected shapes (tdmpc2/common/world_model.py:26-30)
+    int exp_in, exp_out;
+    if (layer == 0) {
+        exp_in = c.latent_dim + c.task_dim + (takes_action ? c.action_dim : 0);
+        exp_out = c.mlp_dim;
+    } else if (layer == 1) {
+        exp_in = c.mlp_dim;
+        exp_out = c.mlp_dim;
+    } else {
+        exp_in = c.mlp_dim;
+        exp_out = net == TDMPC2_NET_DYNAMICS ? c.latent_dim : net == TDMPC2_NET_PI ? 2 * c.action_dim : c.num_bins;
+    }
+    if (in_features != exp_in || out_features != exp_out)
+        return fail(TDMPC2_ERR_INVALID, "net %d layer %d: got [%d, %d], expected [%d, %d]", net, layer, out_features,
+                    in_features, exp_out, exp_in);
+    const bool has_ln = (layer < 2) || net == TDMPC2_NET_DYNAMICS;
+    if (has_ln && (!ln_g || !ln_b)) return fail(TDMPC2_ERR_INVALID, "net %d layer %d needs LayerNorm parameters", net, layer);
+    const int nz = (layer == 0) ? c.latent_dim : c.mlp_dim;
+    const int nt = (layer == 0) ? c.task_dim : 0;
+    const int na = (layer == 0 && takes_action) ? c.action_dim : 0;
+    const int napad = (na + 7) / 8 * 8;
+    const int KB = (nz + napad) / 8;
+    const int CT = (out_features + 31) / 32;
+    for (int hd = 0; hd < heads; ++hd) {
+        HostLayer &L = net_of(h, net, hd)->l[layer];
+        int rc;
+        if (!L.wp) {
+            if ((rc = dev_alloc(h, (void **)&L.wp, (size_t)CT * KB * 256 * 4))) return rc;
+            if ((rc = dev_alloc(h, (void **)&L.bias, (size_t)CT * 32 * 4))) return rc;
+            if (has_ln) {
+                if ((rc = dev_alloc(h, (void **)&L.g, (size_t)out_features * 4))) return rc;
+                if ((rc = dev_alloc(h, (void **)&L.b, (size_t)out_features * 4))) return rc;
+            }
+            if (nt > 0 && (rc = dev_alloc(h, (void **)&L.wemb, (size_t)out_features * nt * 4))) return rc;
+        }
+        L.KB = KB; L.CT = CT; L.out = out_features;
+        const float *Wh = W + (size_t)hd * out_features * in_features;
+        hipLaunchKernelGGL(k_pack_weight, dim3(512), dim3(256), 0, st, Wh, out_features, in_features, nz, nt, na, CT, KB, L.wp);
+        hipLaunchKernelGGL(k_copy_pad, dim3(1), dim3(256), 0, st, b + (size_t)hd * out_features, out_features, CT * 32, L.bias);
+        if (has_ln) {
+            hipLaunchKernelGGL(k_copy_pad, dim3(2), dim3(256), 0, st, ln_g + (size_t)hd * out_features, out_features, out_features, L.g);
+            hipLaunchKernelGGL(k_copy_pad, dim3(2), dim3(256), 0, st, ln_b + (size_t)hd * out_features, out_features, out_features, L.b);
+        }
+        if (nt > 0)
+            hipLaunchKernelGGL(k_copy_cols, dim3(64), dim3(256), 0, st, Wh, out_features, in_features, nz, nt, L.wemb);
+        HIP_TRY(hipGetLastError());
+        L.bound = true;
+    }
+    return TDMPC2_OK;
+}
+
+int tdmpc2_plan_set_profiling(tdmpc2_plan_t *h, int max_launches) {
+    if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
+    h->profiling = max_launches > 0;
+    if ((int)h->ev.size() < 2 * max_launches) {
+        const size_t old = h->ev.size();
+        h->ev.resize(2 * (size_t)max_launches);
+        for (size_t i = old; i < h->ev.size(); ++i) HIP_TRY(hipEventCreate(&h->ev[i]));
+    }
+    h->ev_used = 0;
+    return TDMPC2_OK;
+}
+
+int tdmpc2_plan_profile_read(tdmpc2_plan_t *h, float *rollout_ms_total, int *rollout_launches) {
+    if (!h || !rollout_ms_total || !rollout_launches) return fail(TDMPC2_ERR_INVALID, "null argument");
+    float total = 0.f;
+    for (int i = 0; i + 1 < h->ev_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(h->ev[i + 1]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+        total += ms;
+    }
+    *rollout_ms_total = total;
+    *rollout_launches = h->ev_used / 2;
+    h->ev_used = 0;
+    return TDMPC2_OK;
+}
+
+int tdmpc2_plan_run(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *task_emb, const float *act_mask,
+                    const float *disc_pow, float *prev_mean, const uint8_t *t0, int eval_mode, const tdmpc2_noise *tape,
+                    uint64_t seed, float *action, const tdmpc2_debug *dbg, void *stream) {
+    int rc = validate_envs(h, n_envs);
+    if (rc) return rc;
+    if (!z0 || !disc_pow || !prev_mean || !t0 || !action) return fail(TDMPC2_ERR_INVALID, "null argument");
+    const tdmpc2_plan_cfg &c = h->cfg;
+    if (c.multitask && (!task_emb || !act_mask)) return fail(TDMPC2_ERR_INVALID, "multitask plan needs task_emb and act_mask");
+    if (!c.multitask) { task_emb = nullptr; act_mask = nullptr; }
+    if (tape && (!tape->sample_eps || !tape->pi_eps || !tape->qidx || !tape->gumbel_exp ||
+                 (c.num_pi_trajs > 0 && !tape->pi_traj_eps) || (!eval_mode && !tape->final_eps)))
+        return fail(TDMPC2_ERR_INVALID, "noise tape has null fields");
+    hipStream_t st = (hipStream_t)stream;
+    const int E = n_envs, H = c.horizon, N = c.num_samples, A = c.action_dim, K = c.num_elites, P = c.num_pi_trajs,
+              I = c.iterations;
+    const unsigned call = h->call++;
+
+    if ((rc = launch_setup(h, E, z0, task_emb, prev_mean, t0, st))) return rc;
+    if (P > 0) {
+        PiTrajParams p{};
+        p.E = E; p.N = N; p.H = H; p.A = A; p.Apad = h->Apad; p.P = P; p.stride = h->stride; p.multitask = c.multitask;
+        p.nnets = h->nnets; p.log_std_min = c.log_std_min; p.log_std_dif = c.log_std_dif;
+        p.dyn = to_dev(h->dyn); p.pi = to_dev(h->pi);
+        p.z0 = z0; p.beff = h->beff; p.act_mask = act_mask; p.pi_traj_eps = tape ? tape->pi_traj_eps : nullptr;
+        p.seed = seed; p.call = call; p.actions = h->actions; p.zscratch = h->zscratch;
+        p.zscratch_estride = (long)h->tiles * ROWS * WIDTH;
+        hipLaunchKernelGGL(k_pitraj, dim3(E), dim3(NTHREADS), h->lds_bytes, st, p);
+        HIP_TRY(hipGetLastError());
+    }
+    RolloutParams rp{};
+    fill_rollout(h, rp, E);
+    rp.z0 = z0; rp.act_mask = act_mask; rp.disc_pow = disc_pow; rp.seed = seed; rp.call = call; rp.given_actions = 0;
+    const size_t refit_lds = ((size_t)N + 3 * K + 2 * H * A) * 4 + 64;
+    for (int it = 0; it < I; ++it) {
+        rp.iter = it;
+        if (tape) {
+            rp.sample_eps = tape->sample_eps + (size_t)it * H * (N - P) * A;
+            rp.sample_eps_estride = (long)I * H * (N - P) * A;
+            rp.pi_eps = tape->pi_eps + (size_t)it * N * A;
+            rp.pi_eps_estride = (long)I * N * A;
+            rp.qidx = tape->qidx + (size_t)it * 2;
+            rp.qidx_estride = (long)I * 2;
+        }
+        if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
+        hipLaunchKernelGGL(k_rollout, dim3(E * h->tiles), dim3(NTHREADS), h->lds_bytes, st, rp);
+        HIP_TRY(hipGetLastError());
+        if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) {
+            HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
+            h->ev_used += 2;
+        }
+        if (dbg && dbg->actions)
+            HIP_TRY(hipMemcpy2DAsync(dbg->actions + (size_t)it * H * N * A, (size_t)I * H * N * A * 4, h->actions,
+                                     (size_t)H * N * A * 4, (size_t)H * N * A * 4, E, hipMemcpyDeviceToDevice, st));
+        RefitParams fp{};
+        fp.E = E; fp.N = N; fp.H = H; fp.A = A; fp.K = K; fp.iter = it; fp.last = (it == I - 1); fp.eval_mode = eval_mode;
+        fp.temperature = c.temperature; fp.min_std = c.min_std; fp.max_std = c.max_std;
+        fp.value = h->value; fp.actions = h->actions; fp.act_mask = act_mask; fp.mean = h->mean; fp.std = h->std;
+        fp.gumbel_exp = tape ? tape->gumbel_exp : nullptr; fp.final_eps = tape ? tape->final_eps : nullptr;
+        fp.seed = seed; fp.call = call; fp.prev_mean = prev_mean; fp.action = action;
+        if (dbg) {
+            if (dbg->value) { fp.dbg_value = dbg->value + (size_t)it * N; fp.dbg_value_es = (long)I * N; }
+            if (dbg->elite_idx) { fp.dbg_idx = dbg->elite_idx + (size_t)it * K; fp.dbg_idx_es = (long)I * K; }
+            if (dbg->score) { fp.dbg_score = dbg->score + (size_t)it * K; fp.dbg_score_es = (long)I * K; }
+            if (dbg->mean) { fp.dbg_mean = dbg->mean + (size_t)it * H * A; fp.dbg_mean_es = (long)I * H * A; }
+            if (dbg->std) { fp.dbg_std = dbg->std + (size_t)it * H * A; fp.dbg_std_es = (long)I * H * A; }
+        }
+        hipLaunchKernelGGL(k_refit, dim3(E), dim3(N), refit_lds, st, fp);
+        HIP_TRY(hipGetLastError());
+    }
+    return TDMPC2_OK;
+}
+
+int tdmpc2_plan_estimate_value(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *task_emb,
+                               const float *act_mask, const float *disc_pow, const float *actions, const float *pi_eps,
+                               const int32_t *qidx, float *value, void *stream) {
+    return tdmpc2_plan_estimate_value_trace(h, n_envs, z0, task_emb, act_mask, disc_pow, actions, pi_eps, qidx, value,
+                                            nullptr, nullptr, stream);
+}
+
+int tdmpc2_plan_estimate_value_trace(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *task_emb,
+                                     const float *act_mask, const float *disc_pow, const float *actions,
+                                     const float *pi_eps, const int32_t *qidx, float *value, float *trace_tiles,
+                                     float *trace_scalars, void *stream) {
+    int rc = validate_envs(h, n_envs);
+    if (rc) return rc;
+    if (!z0 || !disc_pow || !actions || !pi_eps || !qidx || !value) return fail(TDMPC2_ERR_INVALID, "null argument");
+    const tdmpc2_plan_cfg &c = h->cfg;
+    if (c.multitask && (!task_emb || !act_mask)) return fail(TDMPC2_ERR_INVALID, "multitask needs task_emb and act_mask");
+    if (!c.multitask) { task_emb = nullptr; act_mask = nullptr; }
+    hipStream_t st = (hipStream_t)stream;
+    const int E = n_envs, N = c.num_samples, A = c.action_dim;
+    // setup needs prev_mean / t0 only for mean/std init, which this entry does not use: feed dummies
+    HIP_TRY(hipMemsetAsync(h->mean, 0, (size_t)E * c.horizon * A * 4, st));
+    HIP_TRY(hipMemsetAsync(h->value, 1, (size_t)E, st));  // E bytes of ones used as t0 = 1 flags (no warm start read)
+    if ((rc = launch_setup(h, E, z0, task_emb, h->mean, reinterpret_cast<const unsigned char *>(h->value), st))) return rc;
+    RolloutParams rp{};
+    fill_rollout(h, rp, E);
+    rp.z0 = z0; rp.act_mask = act_mask; rp.disc_pow = disc_pow; rp.given_actions = 1; rp.iter = 0;
+    rp.actions = const_cast<float *>(actions);
+    rp.value = value;
+    rp.pi_eps = pi_eps; rp.pi_eps_estride = (long)N * A;
+    rp.qidx = qidx; rp.qidx_estride = 2;
+    rp.trace_tiles = trace_tiles; rp.trace_scalars = trace_scalars;
+    hipLaunchKernelGGL(k_rollout, dim3(E * h->tiles), dim3(NTHREADS), h->lds_bytes, st, rp);
+    HIP_TRY(hipGetLastError());
+    return TDMPC2_OK;
+}
+
+int tdmpc2_plan_refit(tdmpc2_plan_t *h, int n_envs, float *value, const float *actions, const float *act_mask,
+                      float *mean, float *std, float *score, int32_t *elite_idx, void *stream) {
+    if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
+    if (n_envs < 1 || n_envs > h->cfg.max_envs) return fail(TDMPC2_ERR_INVALID, "n_envs=%d outside [1, %d]", n_envs, h->cfg.max_envs);
+    if (!value || !actions) return fail(TDMPC2_ERR_INVALID, "null argument");
+    const tdmpc2_plan_cfg &c = h->cfg;
+    hipStream_t st = (hipStream_t)stream;
+    RefitParams fp{};
+    fp.E = n_envs; fp.N = c.num_samples; fp.H = c.horizon; fp.A = c.action_dim; fp.K = c.num_elites; fp.last = 0;
+    fp.temperature = c.temperature; fp.min_std = c.min_std; fp.max_std = c.max_std;
+    fp.value = value; fp.actions = actions; fp.act_mask = c.multitask ? act_mask : nullptr;
+    fp.mean = mean ? mean : h->mean; fp.std = std ? std : h->std; fp.score = score; fp.elite_idx = elite_idx;
+    const size_t refit_lds = ((size_t)c.num_samples + 3 * c.num_elites + 2 * c.horizon * c.action_dim) * 4 + 64;
+    hipLaunchKernelGGL(k_refit, dim3(n_envs), dim3(c.num_samples), refit_lds, st, fp);
+    HIP_TRY(hipGetLastError());
+    return TDMPC2_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,287 @@
+"""ctypes binding of the planner's C ABI (include/tdmpc2_plan.h).
+
+The shared library `tdmpc2_amd/libtdmpc2_plan.so` is built in-tree by
+`tdmpc2_amd/csrc/build.sh` (hipcc, gfx950).  There is no CPU fallback: if the
+library is missing, or a planner is requested on a non-GPU device, this module
+raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtdmpc2_plan.so")
+_lib = None
+
+ABI_VERSION = 1
+
+# every symbol include/tdmpc2_plan.h declares (tests check the .so exports all of them)
+ABI_SYMBOLS = [
+    "tdmpc2_plan_abi_version", "tdmpc2_last_error", "tdmpc2_plan_create", "tdmpc2_plan_destroy",
+    "tdmpc2_plan_device_bytes", "tdmpc2_plan_bind_weights", "tdmpc2_plan_run", "tdmpc2_plan_estimate_value",
+    "tdmpc2_plan_estimate_value_trace", "tdmpc2_plan_refit", "tdmpc2_plan_set_profiling", "tdmpc2_plan_profile_read",
+]
+
+NET_DYNAMICS, NET_REWARD, NET_PI, NET_Q, NET_TERMINATION = range(5)
+
+
+class PlanCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("horizon", "num_samples", "num_elites", "num_pi_trajs", "iterations",
+                                          "action_dim", "latent_dim", "mlp_dim", "task_dim", "num_bins", "num_q",
+                                          "simnorm_dim")] + \
+               [(n, C.c_float) for n in ("vmin", "vmax", "min_std", "max_std", "temperature", "log_std_min",
+                                         "log_std_dif")] + \
+               [(n, C.c_int32) for n in ("multitask", "episodic", "max_envs", "device")]
+
+
+class Noise(C.Structure):
+    _fields_ = [("pi_traj_eps", C.c_void_p), ("sample_eps", C.c_void_p), ("pi_eps", C.c_void_p),
+                ("qidx", C.c_void_p), ("gumbel_exp", C.c_void_p), ("final_eps", C.c_void_p)]
+
+
+class Debug(C.Structure):
+    _fields_ = [("value", C.c_void_p), ("elite_idx", C.c_void_p), ("score", C.c_void_p), ("mean", C.c_void_p),
+                ("std", C.c_void_p), ("actions", C.c_void_p)]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen the planner library and declare its prototypes.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise NativeError(f"{_LIB_PATH} not found: build it with tdmpc2_amd/csrc/build.sh "
+                          "(or __graft_entry__.build()); there is no CPU fallback for the planner")
+    lib = C.CDLL(_LIB_PATH)
+    vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
+    lib.tdmpc2_plan_abi_version.restype = i32
+    lib.tdmpc2_last_error.restype = C.c_char_p
+    lib.tdmpc2_plan_create.argtypes = [C.POINTER(PlanCfg), C.POINTER(vp)]
+    lib.tdmpc2_plan_create.restype = i32
+    lib.tdmpc2_plan_destroy.argtypes = [vp]
+    lib.tdmpc2_plan_destroy.restype = None
+    lib.tdmpc2_plan_device_bytes.argtypes = [vp]
+    lib.tdmpc2_plan_device_bytes.restype = u64
+    lib.tdmpc2_plan_bind_weights.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, vp]
+    lib.tdmpc2_plan_bind_weights.restype = i32
+    lib.tdmpc2_plan_run.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, C.POINTER(Noise), u64, vp,
+                                    C.POINTER(Debug), vp]
+    lib.tdmpc2_plan_run.restype = i32
+    lib.tdmpc2_plan_estimate_value.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.tdmpc2_plan_estimate_value.restype = i32
+    lib.tdmpc2_plan_estimate_value_trace.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.tdmpc2_plan_estimate_value_trace.restype = i32
+    lib.tdmpc2_plan_refit.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.tdmpc2_plan_refit.restype = i32
+    lib.tdmpc2_plan_set_profiling.argtypes = [vp, i32]
+    lib.tdmpc2_plan_set_profiling.restype = i32
+    lib.tdmpc2_plan_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    lib.tdmpc2_plan_profile_read.restype = i32
+    if lib.tdmpc2_plan_abi_version() != ABI_VERSION:
+        raise NativeError(f"ABI version mismatch: library {lib.tdmpc2_plan_abi_version()}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk_tensor(name, t, dtype, shape, device):
+    if t.device != device:
+        raise ValueError(f"{name}: expected device {device}, got {t.device}")
+    if t.dtype != dtype:
+        raise ValueError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+class NativePlanner:
+    """Owns one `tdmpc2_plan_t` handle on one GPU.
+
+    Mirrors what the reference keeps as planner state in `TDMPC2.__init__`
+    (tdmpc2/tdmpc2.py:17-43): the world-model weights (re-packed on the device)
+    and the workspace for `max_envs` concurrent plans.
+    """
+
+    def __init__(self, cfg, iterations: int, device: torch.device, max_envs: int = 1,
+                 log_std_min: Optional[float] = None, log_std_dif: Optional[float] = None):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise NativeError(f"the planner runs on an MI355X only (device {device}); there is no CPU fallback")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.lib = load_library()
+        self.cfg = cfg
+        self.device = device
+        self.iterations = int(iterations)
+        self.max_envs = int(max_envs)
+        lsmin = float(cfg.log_std_min) if log_std_min is None else float(log_std_min)
+        lsdif = float(cfg.log_std_max) - float(cfg.log_std_min) if log_std_dif is None else float(log_std_dif)
+        c = PlanCfg(horizon=cfg.horizon, num_samples=cfg.num_samples, num_elites=cfg.num_elites,
+                    num_pi_trajs=cfg.num_pi_trajs, iterations=self.iterations, action_dim=cfg.action_dim,
+                    latent_dim=cfg.latent_dim, mlp_dim=cfg.mlp_dim, task_dim=cfg.task_dim, num_bins=cfg.num_bins,
+                    num_q=cfg.num_q, simnorm_dim=cfg.simnorm_dim, vmin=cfg.vmin, vmax=cfg.vmax, min_std=cfg.min_std,
+                    max_std=cfg.max_std, temperature=cfg.temperature, log_std_min=lsmin, log_std_dif=lsdif,
+                    multitask=int(bool(cfg.multitask)), episodic=int(bool(cfg.episodic)), max_envs=self.max_envs,
+                    device=device.index)
+        h = C.c_void_p()
+        self._check(self.lib.tdmpc2_plan_create(C.byref(c), C.byref(h)))
+        self._h = h
+        self._seed_calls = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc: int):
+        if rc != 0:
+            raise NativeError(f"tdmpc2_plan error {rc}: {self.lib.tdmpc2_last_error().decode()}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.tdmpc2_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self.lib.tdmpc2_plan_device_bytes(self._h))
+
+    # ------------------------------------------------------------------ weights
+    def bind_state_dict(self, sd: Dict[str, torch.Tensor]):
+        """Bind planner weights from a state dict in the reference's (new-format)
+        checkpoint key layout: `_dynamics.{i}.*`, `_reward.{i}.*`, `_pi.{i}.*`,
+        `_Qs.params.{i}.*` (stacked over num_q).  tdmpc2/common/layers.py:167-199."""
+        nets = [(NET_DYNAMICS, "_dynamics"), (NET_REWARD, "_reward"), (NET_PI, "_pi"), (NET_Q, "_Qs.params")]
+        keep = []
+        with torch.cuda.device(self.device):
+            for net, prefix in nets:
+                for layer in range(3):
+                    def get(name, required=True):
+                        k = f"{prefix}.{layer}.{name}"
+                        if k not in sd:
+                            if required:
+                                raise KeyError(f"state dict lacks {k}")
+                            return None
+                        t = sd[k].detach().to(self.device, torch.float32).contiguous()
+                        keep.append(t)
+                        return t
+                    W, b = get("weight"), get("bias")
+                    g, beta = get("ln.weight", False), get("ln.bias", False)
+                    out_f, in_f = int(W.shape[-2]), int(W.shape[-1])
+                    self._check(self.lib.tdmpc2_plan_bind_weights(self._h, net, layer, _ptr(W), _ptr(b), _ptr(g),
+                                                                  _ptr(beta), out_f, in_f, self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()  # sources may now be freed
+
+    # ------------------------------------------------------------------ planning
+    def _common_inputs(self, E, z0, task_emb, act_mask, disc_pow):
+        cfg, dev = self.cfg, self.device
+        _chk_tensor("z0", z0, torch.float32, (E, cfg.latent_dim), dev)
+        _chk_tensor("disc_pow", disc_pow, torch.float32, (E, cfg.horizon + 1), dev)
+        if cfg.multitask:
+            if task_emb is None or act_mask is None:
+                raise ValueError("multitask planning needs task_emb and act_mask")
+            _chk_tensor("task_emb", task_emb, torch.float32, (E, cfg.task_dim), dev)
+            _chk_tensor("act_mask", act_mask, torch.float32, (E, cfg.action_dim), dev)
+
+    def plan(self, z0, disc_pow, prev_mean, t0, eval_mode=False, task_emb=None, act_mask=None,
+             tape: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0, debug: bool = False,
+             out: Optional[torch.Tensor] = None):
+        """E plans in one call.  `prev_mean` [E,H,A] is updated in place.
+        Returns action [E,A] (device), or (action, stages) when `debug`."""
+        cfg, dev = self.cfg, self.device
+        E = int(z0.shape[0])
+        H, N, K, P, A, I = cfg.horizon, cfg.num_samples, cfg.num_elites, cfg.num_pi_trajs, cfg.action_dim, self.iterations
+        self._common_inputs(E, z0, task_emb, act_mask, disc_pow)
+        _chk_tensor("prev_mean", prev_mean, torch.float32, (E, H, A), dev)
+        _chk_tensor("t0", t0, torch.uint8, (E,), dev)
+        action = out if out is not None else torch.empty(E, A, device=dev, dtype=torch.float32)
+        _chk_tensor("action", action, torch.float32, (E, A), dev)
+        noise_p = None
+        if tape is not None:
+            shapes = {"pi_traj_eps": ((E, H, P, A), torch.float32), "sample_eps": ((E, I, H, N - P, A), torch.float32),
+                      "pi_eps": ((E, I, N, A), torch.float32), "qidx": ((E, I, 2), torch.int32),
+                      "gumbel_exp": ((E, K), torch.float32), "final_eps": ((E, A), torch.float32)}
+            for k, (shp, dt) in shapes.items():
+                _chk_tensor(f"tape[{k}]", tape[k], dt, shp, dev)
+            noise = Noise(**{k: tape[k].data_ptr() for k in shapes})
+            noise_p = C.byref(noise)
+        dbg_p, stages = None, None
+        if debug:
+            stages = {"value": torch.empty(E, I, N, device=dev), "elite_idx": torch.empty(E, I, K, device=dev, dtype=torch.int32),
+                      "score": torch.empty(E, I, K, device=dev), "mean": torch.empty(E, I, H, A, device=dev),
+                      "std": torch.empty(E, I, H, A, device=dev), "actions": torch.empty(E, I, H, N, A, device=dev)}
+            dbg = Debug(**{k: v.data_ptr() for k, v in stages.items()})
+            dbg_p = C.byref(dbg)
+        with torch.cuda.device(dev):
+            self._check(self.lib.tdmpc2_plan_run(self._h, E, _ptr(z0), _ptr(task_emb), _ptr(act_mask), _ptr(disc_pow),
+                                                 _ptr(prev_mean), _ptr(t0), int(bool(eval_mode)), noise_p,
+                                                 C.c_uint64(int(seed) & (2**64 - 1)), _ptr(action), dbg_p, self._stream()))
+        return (action, stages) if debug else action
+
+    def estimate_value(self, z0, disc_pow, actions, pi_eps, qidx, task_emb=None, act_mask=None, trace=False):
+        """TDMPC2._estimate_value (tdmpc2/tdmpc2.py:122-136) on given action sequences -> value [E,N].
+        With `trace`, also returns (tiles [E*N/64, 5H+7, 64, L], scalars [E, N, H+2+A])."""
+        cfg, dev = self.cfg, self.device
+        E = int(z0.shape[0])
+        self._common_inputs(E, z0, task_emb, act_mask, disc_pow)
+        _chk_tensor("actions", actions, torch.float32, (E, cfg.horizon, cfg.num_samples, cfg.action_dim), dev)
+        _chk_tensor("pi_eps", pi_eps, torch.float32, (E, cfg.num_samples, cfg.action_dim), dev)
+        _chk_tensor("qidx", qidx, torch.int32, (E, 2), dev)
+        value = torch.empty(E, cfg.num_samples, device=dev, dtype=torch.float32)
+        tiles = scalars = None
+        if trace:
+            tiles = torch.zeros(E * cfg.num_samples // 64, 5 * cfg.horizon + 7, 64, cfg.latent_dim, device=dev)
+            scalars = torch.zeros(E, cfg.num_samples, cfg.horizon + 2 + cfg.action_dim, device=dev)
+        with torch.cuda.device(dev):
+            self._check(self.lib.tdmpc2_plan_estimate_value_trace(
+                self._h, E, _ptr(z0), _ptr(task_emb), _ptr(act_mask), _ptr(disc_pow), _ptr(actions), _ptr(pi_eps),
+                _ptr(qidx), _ptr(value), _ptr(tiles), _ptr(scalars), self._stream()))
+        return (value, tiles, scalars) if trace else value
+
+    def refit(self, value, actions, act_mask=None):
+        """Elite select + refit (tdmpc2/tdmpc2.py:184-197).  `value` [E,N] gets nan_to_num in place.
+        Returns (mean, std, score, elite_idx)."""
+        cfg, dev = self.cfg, self.device
+        E = int(value.shape[0])
+        H, N, K, A = cfg.horizon, cfg.num_samples, cfg.num_elites, cfg.action_dim
+        _chk_tensor("value", value, torch.float32, (E, N), dev)
+        _chk_tensor("actions", actions, torch.float32, (E, H, N, A), dev)
+        mean = torch.empty(E, H, A, device=dev)
+        std = torch.empty(E, H, A, device=dev)
+        score = torch.empty(E, K, device=dev)
+        idx = torch.empty(E, K, device=dev, dtype=torch.int32)
+        with torch.cuda.device(dev):
+            self._check(self.lib.tdmpc2_plan_refit(self._h, E, _ptr(value), _ptr(actions), _ptr(act_mask), _ptr(mean),
+                                                   _ptr(std), _ptr(score), _ptr(idx), self._stream()))
+        return mean, std, score, idx
+
+    # ------------------------------------------------------------------ profiling
+    def set_profiling(self, max_launches: int):
+        """Bracket up to `max_launches` rollout-kernel launches with HIP events (0 = off)."""
+        self._check(self.lib.tdmpc2_plan_set_profiling(self._h, int(max_launches)))
+
+    def profile_read(self):
+        ms, n = C.c_float(), C.c_int()
+        self._check(self.lib.tdmpc2_plan_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return float(ms.value), int(n.value)

@@ -1,0 +1,164 @@
+"""TDMPC2: the drop-in boundary (reference tdmpc2/tdmpc2.py:11-120,138-206).
+
+Same constructor argument (`cfg`), same `act(obs, t0, eval_mode, task)` /
+`plan(obs, t0, eval_mode, task)` / `load(fp)` / `save(fp)` signatures, same
+`model` attribute names and checkpoint layout, same `_prev_mean` buffer — so
+the reference's `evaluate.py:57-59,80` works unchanged with this class.  The
+planning itself (everything of `_plan` after `encode`) runs in the HIP library;
+there is no PyTorch or CPU fallback for it.
+
+Extension over the reference (whose planner is hard-wired to one environment,
+tdmpc2.py:111,163): `act_batch` / `plan_batch` plan E independent environments
+in one call — the vectorised-env case the north star shards across GPUs.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+
+from . import checkpoint
+from .config import get_discount
+from .native import NativePlanner
+from .world_model import WorldModel
+
+
+class TDMPC2(torch.nn.Module):
+    def __init__(self, cfg, device: Optional[torch.device] = None, max_envs: int = 1):
+        super().__init__()
+        self.cfg = cfg
+        if device is None:
+            device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))  # reference: cuda:0
+        self.device = torch.device(device)
+        self.model = WorldModel(cfg).to(self.device)
+        self.model.eval()
+        self.cfg.iterations += 2 * int(cfg.action_dim >= 20)  # reference tdmpc2.py:34
+        if cfg.multitask:  # reference tdmpc2.py:35-37
+            self.discount = torch.tensor([get_discount(cfg, ep_len) for ep_len in cfg.episode_lengths],
+                                         device=self.device)
+        else:
+            self.discount = get_discount(cfg, cfg.episode_length)
+        self._prev_mean = torch.nn.Buffer(torch.zeros(cfg.horizon, cfg.action_dim, device=self.device))
+        self.max_envs = int(max_envs)
+        self._planner: Optional[NativePlanner] = None
+        self._prev_mean_batch = None
+        self._seed = int(getattr(cfg, "seed", 0))
+        self.noise_tape = None  # optional dict of device tensors (tdmpc2_noise) for reproducible plans
+        self._one = torch.ones(1, dtype=torch.uint8, device=self.device) if self.device.type == "cuda" else None
+        self._zero = torch.zeros(1, dtype=torch.uint8, device=self.device) if self.device.type == "cuda" else None
+
+    # ------------------------------------------------------------------ checkpoint I/O
+    def save(self, fp):
+        """reference tdmpc2.py:72-79."""
+        torch.save({"model": self.model.state_dict()}, fp)
+
+    def load(self, fp):
+        """reference tdmpc2.py:81-95: path or dict; old- and new-format Q keys."""
+        if isinstance(fp, dict):
+            state_dict = fp
+        else:
+            state_dict = torch.load(fp, map_location=self.device, weights_only=False)
+        state_dict = state_dict["model"] if "model" in state_dict else state_dict
+        state_dict = checkpoint.convert_state_dict(dict(state_dict))
+        self.model.load_state_dict(state_dict)
+        self.sync_planner_weights()
+
+    # ------------------------------------------------------------------ native planner
+    def planner(self) -> NativePlanner:
+        if self._planner is None:
+            self._planner = NativePlanner(self.cfg, self.cfg.iterations, self.device, max_envs=self.max_envs,
+                                          log_std_min=float(self.model.log_std_min),
+                                          log_std_dif=float(self.model.log_std_dif))
+            self._planner.bind_state_dict(self.model.planner_state_dict())
+        return self._planner
+
+    def sync_planner_weights(self):
+        """Re-pack the model's current weights into the planner (after load / a training step)."""
+        if self._planner is not None:
+            self._planner.bind_state_dict(self.model.planner_state_dict())
+
+    def _disc_pow(self, tasks):
+        """discount^0..discount^H exactly as tdmpc2.py:126,130-132 accumulates it: python-float
+        products (single task) or fp32 tensor products (multitask)."""
+        H = self.cfg.horizon
+        if self.cfg.multitask:
+            g = self.discount[tasks.long()].to(torch.float32)  # [E]
+            cols = [torch.ones_like(g)]
+            for _ in range(H):
+                cols.append(cols[-1] * g)
+            return torch.stack(cols, dim=1).contiguous()
+        d, vals = 1, []
+        for _ in range(H + 1):
+            vals.append(float(d))
+            d = d * self.discount
+        return torch.tensor(vals, dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------ reference API
+    @property
+    def plan(self):
+        """reference tdmpc2.py:45-55 (there: optionally torch.compile'd; here: the HIP planner)."""
+        return self._plan
+
+    @torch.no_grad()
+    def act(self, obs, t0=False, eval_mode=False, task=None):
+        """reference tdmpc2.py:97-120."""
+        obs = obs.to(self.device, non_blocking=True).unsqueeze(0)
+        if task is not None:
+            task = torch.tensor([task], device=self.device)
+        if self.cfg.mpc:
+            return self.plan(obs, t0=t0, eval_mode=eval_mode, task=task).cpu()
+        z = self.model.encode(obs, task)
+        action, info = self.model.pi(z, task)
+        if eval_mode:
+            action = info["mean"]
+        return action[0].cpu()
+
+    @torch.no_grad()
+    def _plan(self, obs, t0=False, eval_mode=False, task=None):
+        """reference tdmpc2.py:138-206.  obs [1, obs_dim] on device; task int64[1] or None."""
+        z = self.model.encode(obs, task)  # host-side PyTorch-ROCm, as in the reference
+        a = self._plan_latent(z.contiguous(), self._one if t0 else self._zero, eval_mode, task,
+                              self._prev_mean.view(1, *self._prev_mean.shape))
+        return a[0]
+
+    # ------------------------------------------------------------------ vectorised extension
+    @torch.no_grad()
+    def plan_batch(self, obs, t0, eval_mode=False, tasks=None):
+        """E environments at once.  obs [E, obs_dim]; t0 bool[E] (or bool); tasks int64[E] or None."""
+        obs = obs.to(self.device)
+        E = obs.shape[0]
+        if self.cfg.multitask:
+            tasks = torch.as_tensor(tasks, device=self.device).long()
+            emb = self.model._task_emb(tasks)  # max_norm renorm happens inside the lookup
+            z = self.model._encoder[self.cfg.obs](torch.cat([obs, emb], dim=-1))
+        else:
+            tasks = None
+            z = self.model._encoder[self.cfg.obs](obs)
+        if self._prev_mean_batch is None or self._prev_mean_batch.shape[0] != E:
+            self._prev_mean_batch = torch.zeros(E, self.cfg.horizon, self.cfg.action_dim, device=self.device)
+        if isinstance(t0, bool):
+            t0 = torch.full((E,), int(t0), dtype=torch.uint8, device=self.device)
+        else:
+            t0 = torch.as_tensor(t0, device=self.device).to(torch.uint8)
+        return self._plan_latent(z.contiguous(), t0, eval_mode, tasks, self._prev_mean_batch)
+
+    @torch.no_grad()
+    def act_batch(self, obs, t0, eval_mode=False, tasks=None):
+        return self.plan_batch(obs, t0, eval_mode, tasks).cpu()
+
+    def _plan_latent(self, z, t0, eval_mode, tasks, prev_mean):
+        E = z.shape[0]
+        planner = self.planner()
+        if E > planner.max_envs:
+            raise ValueError(f"{E} environments exceed max_envs={planner.max_envs} given at construction")
+        emb = mask = None
+        if self.cfg.multitask:
+            emb = self.model._task_emb(tasks.long()).to(torch.float32).contiguous()
+            mask = self.model._action_masks[tasks.long()].contiguous()
+            disc = self._disc_pow(tasks)
+        else:
+            disc = self._disc_pow(None).unsqueeze(0).repeat(E, 1).contiguous()
+        self._seed += 1
+        return planner.plan(z.to(torch.float32), disc, prev_mean, t0, eval_mode=eval_mode, task_emb=emb,
+                            act_mask=mask, tape=self.noise_tape, seed=self._seed)

@@ -1,0 +1,75 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/tdmpc2_plan.h declares;
+the host logic fails loudly without a GPU (no compute calls here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "tdmpc2_plan.h")
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tdmpc2_[a-z_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from tdmpc2_amd import native
+
+    if not os.path.exists(native.lib_path()):
+        subprocess.run([os.path.join(ROOT, "tdmpc2_amd", "csrc", "build.sh")], check=True)
+    return ctypes.CDLL(native.lib_path())
+
+
+def test_header_and_binding_agree():
+    from tdmpc2_amd import native
+
+    assert _declared_symbols() == sorted(native.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for sym in _declared_symbols():
+        assert hasattr(lib, sym), sym
+    lib.tdmpc2_plan_abi_version.restype = ctypes.c_int
+    assert lib.tdmpc2_plan_abi_version() == 1
+
+
+def test_cfg_struct_matches_header_layout():
+    from tdmpc2_amd import native
+
+    # 12 int32 + 7 float + 4 int32, no padding
+    assert ctypes.sizeof(native.PlanCfg) == 23 * 4
+    assert ctypes.sizeof(native.Noise) == 6 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(native.Debug) == 6 * ctypes.sizeof(ctypes.c_void_p)
+
+
+def test_invalid_arguments_report_errors(lib):
+    lib.tdmpc2_plan_create.restype = ctypes.c_int
+    lib.tdmpc2_last_error.restype = ctypes.c_char_p
+    assert lib.tdmpc2_plan_create(None, None) != 0
+    assert b"null" in lib.tdmpc2_last_error()
+
+
+def test_no_cpu_fallback():
+    import torch
+    from tdmpc2_amd.config import named_config
+    from tdmpc2_amd.native import NativeError, NativePlanner
+
+    with pytest.raises(NativeError):
+        NativePlanner(named_config("c1"), 6, torch.device("cpu"))
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under tdmpc2_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "tdmpc2_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "/root/reference" not in txt, f

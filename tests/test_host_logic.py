@@ -1,0 +1,119 @@
+"""CPU: host-side mirror of the reference interface — config derivations, checkpoint key layout,
+discount powers, the encoder."""
+import numpy as np
+import pytest
+import torch
+
+from tdmpc2_amd import checkpoint, synth
+from tdmpc2_amd.config import Config, get_discount, named_config, parse_cfg, planner_iterations
+from tdmpc2_amd.world_model import WorldModel
+from tests.helpers import load_golden
+
+
+def test_model_size_table_and_task_dim_rules():
+    # reference common/__init__.py:1-24, parser.py:59-78
+    c = named_config("c1")
+    assert (c.latent_dim, c.mlp_dim, c.num_q, c.task_dim, c.multitask) == (512, 512, 5, 0, False)
+    assert abs(c.bin_size - 0.2) < 1e-12
+    c3 = named_config("c3")
+    assert (c3.latent_dim, c3.mlp_dim, c3.task_dim, len(c3.tasks)) == (768, 1792, 64, 30)
+    c4 = named_config("c4")
+    assert (c4.latent_dim, c4.mlp_dim, c4.num_q, c4.task_dim, len(c4.tasks)) == (1376, 4096, 8, 96, 80)
+    assert parse_cfg(Config(task="mt30", model_size=19)).latent_dim == 512  # parser.py:67-68
+    assert parse_cfg(Config(task="mt30", model_size=1)).task_dim == 96
+    with pytest.raises(ValueError):
+        parse_cfg(Config(model_size=7))
+
+
+def test_iterations_and_discount_heuristics():
+    # tdmpc2.py:34, 57-70
+    assert planner_iterations(named_config("c1")) == 6
+    assert planner_iterations(named_config("c2")) == 8
+    cfg = named_config("c1")
+    assert abs(get_discount(cfg, 500) - 0.99) < 1e-12
+    assert get_discount(cfg, 25) == 0.95 and get_discount(cfg, 100000) == 0.995
+
+
+def test_parameter_count_matches_model_name():
+    wm = WorldModel(named_config("c1"))
+    n = sum(p.numel() for p in wm.parameters())
+    assert 4.9e6 < n < 5.0e6  # "5M"; SURVEY.md appendix B: 4.96 M
+
+
+def test_state_dict_has_reference_keys():
+    wm = WorldModel(named_config("mt5"))
+    keys = set(wm.state_dict())
+    for k in ["_encoder.state.0.weight", "_encoder.state.0.ln.bias", "_dynamics.2.ln.weight", "_reward.2.bias",
+              "_pi.1.ln.weight", "_task_emb.weight", "_action_masks", "log_std_min", "log_std_dif",
+              "_Qs.params.0.weight", "_Qs.params.1.ln.bias", "_Qs.params.2.bias", "_Qs.params.__batch_size",
+              "_detach_Qs_params.0.weight", "_target_Qs_params.2.weight", "_target_Qs_params.__device"]:
+        assert k in keys, k
+    assert "_reward.2.ln.weight" not in keys and "_Qs.params.2.ln.weight" not in keys
+    assert wm.state_dict()["_Qs.params.0.weight"].shape == (5, 512, 512 + 64 + 6)
+
+
+def test_old_and_new_checkpoint_formats_load():
+    cfg = named_config("tiny")
+    wm = WorldModel(cfg)
+    syn = {k: torch.as_tensor(v) for k, v in synth.make_state_dict(cfg, 0).items()}
+    wm.load_state_dict(checkpoint.convert_state_dict(syn))
+    new = wm.state_dict()
+    old = checkpoint.to_old_format(new)
+    assert "_Qs.params.9" in old and "_target_Qs.params.0" in old and "_detach_Qs_params.0.weight" not in old
+    wm2 = WorldModel(cfg)
+    wm2.load_state_dict(old)  # pre-hook converts
+    for k, v in new.items():
+        if torch.is_tensor(v):
+            assert torch.equal(v, wm2.state_dict()[k]), k
+    # mapping rule n = 4*layer + {weight, bias, ln.weight, ln.bias} (reference layers.py:175-193)
+    assert torch.equal(old["_Qs.params.6"], new["_Qs.params.1.ln.weight"])
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_mt", "c1"])
+def test_encoder_matches_reference_golden(name):
+    from oracle import cases
+
+    c = cases.build_case(name)
+    wm = WorldModel(c["cfg"]).eval()
+    wm.load_state_dict(checkpoint.convert_state_dict({k: torch.as_tensor(v) for k, v in c["sd"].items()}))
+    g = load_golden(name)
+    obs = synth.make_obs(c["cfg"], c["n_envs"], seed=3)
+    with torch.no_grad():
+        for e in range(c["n_envs"]):
+            task = None if c["tasks"] is None else torch.tensor([c["tasks"][e]])
+            z = wm.encode(torch.as_tensor(obs[e:e + 1]), task)[0].numpy()
+            np.testing.assert_allclose(z, g["encode_z"][e], atol=1e-6, rtol=1e-5)
+
+
+def test_host_world_model_matches_oracle_pieces():
+    from oracle import cases
+    from oracle import planner_oracle as po
+
+    c = cases.build_case("tiny_mt")
+    cfg = c["cfg"]
+    sd = {k: torch.as_tensor(v) for k, v in c["sd"].items()}
+    wm = WorldModel(cfg).eval()
+    wm.load_state_dict(checkpoint.convert_state_dict(dict(sd)))
+    om = po.OracleModel(cfg, sd)
+    z = torch.as_tensor(c["z0"][:1]).repeat(5, 1)
+    a = torch.rand(5, cfg.action_dim) * 2 - 1
+    t = 4
+    with torch.no_grad():
+        tt = torch.tensor([t])
+        assert torch.allclose(wm.next(z, a, tt), om.next(z, a, t), atol=1e-6)
+        assert torch.allclose(wm.reward(z, a, tt), om.reward(z, a, t), atol=1e-5)
+        qa = wm.Q(z, a, tt, return_type="all")
+        qo = po.ensemble_forward(om.sd, "_Qs.params", torch.cat([om.task_emb(z, t), a], -1))
+        assert torch.allclose(qa, qo, atol=1e-5)
+
+
+def test_synthetic_inputs_are_deterministic():
+    cfg = named_config("c1")
+    a = synth.make_state_dict(cfg, 0)
+    b = synth.make_state_dict(cfg, 0)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    z = synth.make_latents(cfg, 3, 1)
+    assert np.allclose(z.reshape(3, -1, 8).sum(-1), 1.0, atol=1e-6) and (z >= 0).all()
+    t = synth.make_noise_tape(cfg, 2, 6, 2)
+    assert t["sample_eps"].shape == (2, 6, 3, 488, 6) and t["qidx"].shape == (2, 6, 2)
+    assert (t["qidx"][..., 0] != t["qidx"][..., 1]).all()
