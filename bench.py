@@ -62,7 +62,11 @@ def cpu_baseline(cfg, iterations, sd_np, budget_s=12.0):
     on a bounded sample of the same workload.  Test infrastructure used as a reported baseline only."""
     from oracle import planner_oracle as po
 
-    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    threads = max(1, min(threads, 64))  # torch's intra-op pool does not scale past the physical cores
     torch.set_num_threads(threads)
     model = po.OracleModel(cfg, {k: torch.as_tensor(v) for k, v in sd_np.items()})
     z0 = synth.make_latents(cfg, 1, seed=1)
@@ -76,7 +80,10 @@ def cpu_baseline(cfg, iterations, sd_np, budget_s=12.0):
                              task=None, discount=disc, iterations=iterations)
 
     with torch.no_grad():
+        tw = time.perf_counter()
         one(True)  # warm-up
+        print(f"[bench] cpu baseline: {threads} threads, warm-up plan {time.perf_counter() - tw:.2f} s", file=sys.stderr,
+              flush=True)
         n, t_start = 0, time.perf_counter()
         while True:
             one(False)
@@ -102,6 +109,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
+    t_boot = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -146,7 +154,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_boot:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    log(f"planner ready: {planner.device_bytes / 2**20:.0f} MiB on device, E={E} I={I}")
     step(0, cold)
+    torch.cuda.synchronize(device)
+    log("first (cold) step done")
     for i in range(W):
         step(1 + i, warm)
     planner.set_profiling(K * I)
@@ -156,6 +171,7 @@ def main():
         step(100 + i, warm)
     fence()
     elapsed = time.perf_counter() - t_start
+    log(f"timed region: {K} steps in {elapsed:.3f} s")
     roll_ms, roll_n = planner.profile_read()
     planner.set_profiling(0)
     if world > 1:
@@ -224,7 +240,10 @@ def main():
         "extra": extra,
     }
     if world == 1 and not args.skip_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(cfg, I, sd_np, args.cpu_budget)
+        try:
+            line["cpu_baseline"] = cpu_baseline(cfg, I, sd_np, args.cpu_budget)
+        except Exception as ex:  # the baseline is a reported number, never a reason to lose the measurement
+            line["cpu_baseline"] = {"value": None, "error": repr(ex)}
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -105,12 +105,17 @@ def _compare_stages(name, c, got, ref_stages, ref_action, ref_prev):
             dm = np.abs(got["mean"][e, it] - ref_stages["mean"][e, it]).max()
             ds = np.abs(got["std"][e, it] - ref_stages["std"][e, it]).max()
             worst["mean"], worst["std"] = max(worst["mean"], dm), max(worst["std"], ds)
-            assert dm < ACT_ATOL and ds < ACT_ATOL, (name, e, it, dm, ds)
+            # first-order conditioning of the refit: score_k = exp(temperature * (v_k - v_max)), so an absolute
+            # value error eps_v moves mean/std (actions are in [-1, 1]) by up to ~4 * temperature * eps_v.
+            # For value ranges of a few units this is far below 1e-4; synthetic heads with |v| ~ 200 need it.
+            eps_v = np.abs(got["value"][e, it].astype(np.float64) - ref_stages["value"][e, it]).max()
+            tol = ACT_ATOL + 4.0 * cfg.temperature * eps_v
+            assert dm < tol and ds < tol, (name, e, it, dm, ds, tol)
         if not diverged:
             da = np.abs(got["action"][e] - ref_action[e]).max()
             worst["action"] = max(worst["action"], da)
-            assert da < ACT_ATOL, (name, e, da)
-            assert np.abs(got["prev_mean"][e] - ref_prev[e]).max() < ACT_ATOL
+            assert da < tol, (name, e, da)
+            assert np.abs(got["prev_mean"][e] - ref_prev[e]).max() < tol
     print(f"[{name}] worst errors {worst}, elite-boundary swaps {swaps}")
 
 
@@ -149,6 +154,36 @@ def test_plan_matches_oracle(name):
                               c["discounts"], c["iterations"])
     got = _run_native(c, model, planner)
     _compare_stages(name, c, got, {k: v.numpy() for k, v in st.items()}, a.numpy(), pm.numpy())
+
+
+def test_error_attribution_against_fp64():
+    """Who is closer to exact arithmetic?  The fp64 oracle is the truth; the HIP planner (exact-fp32 MFMA)
+    must be no further from it than the torch-CPU fp32 arithmetic the reference itself runs (x3 slack)."""
+    from oracle import planner_oracle as po
+    from tests.gpu_common import case_on_gpu, dev, plan_inputs
+
+    for name in ("c1", "c2"):
+        c, model, planner = case_on_gpu(name)
+        cfg = c["cfg"]
+        model64 = po.OracleModel(cfg, model.sd, dtype=torch.float64)
+        inp = plan_inputs(c, model)
+        E, H, N, A = c["n_envs"], cfg.horizon, cfg.num_samples, cfg.action_dim
+        g = torch.Generator().manual_seed(7)
+        actions = torch.rand(E, H, N, A, generator=g) * 2 - 1
+        eps = torch.randn(E, N, A, generator=g)
+        qidx = torch.tensor([[0, 2], [4, 1]][:E], dtype=torch.int32)
+        got = planner.estimate_value(inp["z0"], inp["disc_pow"], actions.to(dev()).contiguous(),
+                                     eps.to(dev()).contiguous(), qidx.to(dev()).contiguous()).cpu().double()
+        for e in range(E):
+            z = torch.as_tensor(c["z0"][e:e + 1]).repeat(N, 1)
+            v32 = po.estimate_value(model, z, actions[e], None, c["discounts"][e], eps[e], qidx[e]).squeeze(1).double()
+            v64 = po.estimate_value(model64, z.double(), actions[e].double(), None, c["discounts"][e], eps[e].double(),
+                                    qidx[e]).squeeze(1)
+            scale = v64.abs().clamp_min(1.0)
+            err_hip = ((got[e] - v64).abs() / scale).max().item()
+            err_ref = ((v32 - v64).abs() / scale).max().item()
+            print(f"[{name}] env {e}: |HIP - fp64| {err_hip:.3e}   |torch fp32 - fp64| {err_ref:.3e}")
+            assert err_hip < 3 * err_ref + 1e-6, (name, e, err_hip, err_ref)
 
 
 def test_plan_is_deterministic_and_tape_pure():
