@@ -57,6 +57,20 @@ def disc_pow_rows(cfg, n_envs, device):
     return torch.tensor(vals, dtype=torch.float32, device=device).repeat(n_envs, 1).contiguous()
 
 
+def pmc_traffic(workgroups):
+    """HBM-side bytes per k_rollout launch from the committed rocprofv3 --pmc passes (FETCH_SIZE with the gfx950
+    x2 correction + WRITE_SIZE; tools/gpu_pmc.sh -> tools/pmc_summary.py --json).  bench.py cannot read PMC
+    counters from inside its own process, so the figure comes from the profile of the same launch geometry;
+    None if no profile of that geometry is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_k_rollout.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return float(d["by_workgroups"][str(workgroups)]["traffic_bytes"]), d.get("source")
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(cfg, iterations, sd_np, budget_s=12.0):
     """The oracle (= the reference's planner math as plain torch CPU ops) timed on this box's host cores
     on a bounded sample of the same workload.  Test infrastructure used as a reported baseline only."""
@@ -207,6 +221,7 @@ def main():
     value = plans / elapsed
     launch_s = (roll_ms / 1e3) / max(roll_n, 1)
     achieved = flops_rollout_launch(cfg, E) / launch_s / 1e12
+    traffic, traffic_src = pmc_traffic(E * cfg.num_samples // 64)
     line = {
         "metric": "plan() calls/sec (H=3, 512 samples, 6 iters)",
         "value": round(value, 2),
@@ -230,7 +245,9 @@ def main():
         },
         "roofline": {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "bytes per launch (HBM/fabric side of L2: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
+            "traffic_source": traffic_src,
             "kernel": "k_rollout", "launches_timed": roll_n, "avg_launch_ms": round(1e3 * launch_s, 4),
             "note": "achieved = as-written FLOPs of one CEM iteration (all num_q Q heads, SURVEY 8(d)) x envs / "
                     "mean k_rollout duration (HIP events on the launch stream); the kernel executes fewer "
