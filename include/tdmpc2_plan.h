@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define TDMPC2_PLAN_ABI_VERSION 1
+#define TDMPC2_PLAN_ABI_VERSION 2
 
 typedef struct tdmpc2_plan tdmpc2_plan_t;
 
@@ -52,7 +52,16 @@ typedef struct tdmpc2_plan_cfg {
     int32_t multitask, episodic;
     int32_t max_envs;                 /* workspace is sized for this many concurrent plans */
     int32_t device;                   /* HIP device ordinal */
+    int32_t path;                     /* enum tdmpc2_path: which kernel family runs the rollout */
 } tdmpc2_plan_cfg;
+
+/* Two kernel families implement the same math (results agree to fp32 round-off):
+ *   FUSED   one persistent workgroup per 64 sample rows keeps activations in LDS for a whole CEM
+ *           iteration; built for latent_dim == mlp_dim == 512 (every 5M model), non-episodic.
+ *   LAYERED one MFMA GEMM launch per nn.Linear over all E*N rows, activations in HBM; any
+ *           latent_dim / mlp_dim that are multiples of 32 (1M ... 317M models), episodic or not.
+ * AUTO picks FUSED when the configuration fits it, else LAYERED. */
+enum tdmpc2_path { TDMPC2_PATH_AUTO = 0, TDMPC2_PATH_FUSED = 1, TDMPC2_PATH_LAYERED = 2 };
 
 enum tdmpc2_net {
     TDMPC2_NET_DYNAMICS = 0,    /* WorldModel._dynamics     world_model.py:26 */
@@ -103,6 +112,9 @@ void tdmpc2_plan_destroy(tdmpc2_plan_t *h);
 /* Bytes of device memory held by the handle (packed weights + workspace). */
 uint64_t tdmpc2_plan_device_bytes(const tdmpc2_plan_t *h);
 
+/* The kernel family the handle resolved to (TDMPC2_PATH_FUSED or TDMPC2_PATH_LAYERED). */
+int tdmpc2_plan_path(const tdmpc2_plan_t *h);
+
 /* Hand one layer of one network to the planner.  Pointers are device fp32 in
  * the checkpoint's own layout (nn.Linear: W[out,in] row-major, b[out];
  * LayerNorm ln_g/ln_b[out], NULL for the plain output layers).  For
@@ -141,7 +153,7 @@ int tdmpc2_plan_estimate_value(tdmpc2_plan_t *h, int n_envs, const float *z0, co
  *   trace_tiles   [E*N/64, 5H+7, 64, L]  per 64-row tile, in execution order: for t < H {reward h1, reward h2,
  *                 dynamics h1, dynamics h2, z_{t+1}}, then {pi h1, pi h2, z_H, Q_a h1, Q_a h2, Q_b h1, Q_b h2}
  *   trace_scalars [E, N, H+2+A]          r_0..r_{H-1}, Q_a, Q_b, a_H[A]
- * Either may be NULL. */
+ * Either may be NULL.  LAYERED handles dump scalars only (trace_tiles must be NULL there). */
 int tdmpc2_plan_estimate_value_trace(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *task_emb,
                                      const float *act_mask, const float *disc_pow, const float *actions,
                                      const float *pi_eps, const int32_t *qidx, float *value,
@@ -154,9 +166,10 @@ int tdmpc2_plan_refit(tdmpc2_plan_t *h, int n_envs, float *value, const float *a
                       const float *act_mask, float *mean, float *std, float *score,
                       int32_t *elite_idx, void *stream);
 
-/* Live timing of the dominant (rollout) kernel: after set_profiling(h, n > 0) every rollout launch
- * is bracketed by HIP events recorded on the caller's stream (up to n launches are kept; n = 0 turns
- * it off).  profile_read synchronises those events, returns their summed duration and the number of
+/* Live timing of the dominant (rollout) stage: after set_profiling(h, n > 0) every rollout launch
+ * (FUSED: one k_rollout kernel; LAYERED: the GEMM / row-kernel sequence of one CEM iteration's
+ * _estimate_value) is bracketed by HIP events recorded on the caller's stream (up to n are kept;
+ * n = 0 turns it off).  profile_read synchronises those events, returns their summed duration and the number of
  * launches measured, and rewinds the buffer. */
 int tdmpc2_plan_set_profiling(tdmpc2_plan_t *h, int max_launches);
 int tdmpc2_plan_profile_read(tdmpc2_plan_t *h, float *rollout_ms_total, int *rollout_launches);

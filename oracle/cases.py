@@ -22,13 +22,20 @@ CASES = {
     "c1_wide": ("c1", {}, 1, False, 0.1),
     "c2": ("c2", {}, 2, False, 0.06),
     "mt5": ("mt5", {}, 2, False, 0.06),
+    # layered kernel family (any latent_dim / mlp_dim, episodic termination head)
+    "small": ("small", {}, 3, False, 0.06),
+    "small_ep": ("small", dict(episodic=True), 2, False, 0.06),
+    "small_mt": ("small", dict(task="mt30"), 3, False, 0.06),
+    "c1_ep": ("c1", dict(episodic=True), 1, False, 0.06),
+    "c3": ("c3", {}, 2, False, 0.03),                   # mt30 48M: L768 M1792 T64
+    "c4": ("c4", dict(iterations=2), 1, False, 0.02),   # mt80 317M: L1376 M4096 nq8 T96, H5 N1024 (2 CEM iterations)
 }
 
 
 def build_case(name: str):
     cfg_name, overrides, E, eval_mode, head_std = CASES[name]
     cfg = named_config(cfg_name, **overrides)
-    if cfg.multitask and name == "tiny_mt":
+    if cfg.multitask and name in ("tiny_mt", "small_mt", "c3", "c4"):
         # heterogeneous action dims / episode lengths to exercise masks and per-task discounts
         n = len(cfg.tasks)
         cfg.action_dims = [cfg.action_dim - (i % 3) for i in range(n)]

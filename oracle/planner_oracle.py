@@ -331,4 +331,5 @@ def trace_estimate_value(model: OracleModel, z, actions, task, discount, pi_eps,
     tiles += [ph[0], ph[1], z] + qh
     value = G + disc * ((qv[0] + qv[1]) / 2)
     scalars = torch.cat(rs + qv + [a], dim=-1)
-    return value.squeeze(1), torch.stack(tiles), scalars
+    same = all(t.shape == tiles[0].shape for t in tiles)  # latent_dim == mlp_dim (the fused size class)
+    return value.squeeze(1), (torch.stack(tiles) if same else tiles), scalars

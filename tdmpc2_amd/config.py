@@ -132,6 +132,18 @@ def named_config(name: str, **overrides) -> Config:
                      horizon=5, num_samples=1024)
     elif name == "mt5":  # multitask at the 5M dims (fused-kernel size class)
         cfg = Config(task="mt30", model_size=5, action_dim=6, obs_shape={"state": (24,)}, episode_length=500)
+    elif name == "c4_l1024":  # BASELINE.json's text for configs[3] says latent_dim=1024 (not the reference's 1376)
+        cfg = Config(task="mt80", model_size=317, action_dim=6, obs_shape={"state": (39,)}, episode_length=500,
+                     horizon=5, num_samples=1024)
+        cfg = parse_cfg(cfg)
+        cfg.latent_dim = 1024
+        for k, v in overrides.items():
+            setattr(cfg, k, v)
+        return cfg
+    elif name == "small":  # small dims on the layered kernel family's tiling (num_samples % 128 == 0, dims % 32 == 0)
+        cfg = Config(task="walker-run", model_size=None, latent_dim=64, mlp_dim=96, enc_dim=32, num_q=3,
+                     action_dim=5, obs_shape={"state": (11,)}, num_samples=128, num_elites=16, num_pi_trajs=8,
+                     horizon=3, iterations=3)
     elif name == "tiny":  # small dims for fast CPU tests of the oracle / host logic
         cfg = Config(task="cheetah-run", model_size=None, latent_dim=64, mlp_dim=64, enc_dim=32, num_q=3,
                      action_dim=4, obs_shape={"state": (9,)}, num_samples=64, num_elites=8, num_pi_trajs=8,

@@ -1,0 +1,238 @@
+// Host orchestration of the layer-at-a-time planner path (kernels: layered_kernels.cuh).
+// Included by tdmpc2_plan.hip inside its anonymous namespace, after `struct tdmpc2_plan`.
+#pragma once
+
+#define LAUNCH_CHECK()                                                                       \
+    do {                                                                                     \
+        hipError_t _e = hipGetLastError();                                                   \
+        if (_e != hipSuccess) return fail(TDMPC2_ERR_HIP, "launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+// One nn.Linear over `rows_p` (padded) rows.  `slot` = index of the net in beff (multitask first layers), -1 otherwise.
+int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t rows_p, int rows_per_env,
+             const HostLayer &ly, long w_sel_stride, long bias_sel_stride, int slot, const int *sel, float *out, int ldo) {
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.K = ly.KB * 8; p.wp = ly.wp; p.w_sel_stride = sel ? w_sel_stride : 0;
+    p.CT = ly.CT; p.ncolblk = (ly.CT + 3) / 4;
+    if (slot >= 0 && h->cfg.multitask) {
+        p.bias = h->beff + (size_t)slot * h->lay.Mp;
+        p.bias_env_stride = (long)h->nnets * h->lay.Mp;
+        p.bias_sel_stride = sel ? h->lay.Mp : 0;
+    } else {
+        p.bias = ly.bias;
+        p.bias_env_stride = 0;
+        p.bias_sel_stride = sel ? bias_sel_stride : 0;
+    }
+    p.sel = sel; p.sel_stride = 2; p.rows_per_env = rows_per_env; p.out = out; p.ldo = ldo;
+    const int nblocks = (int)(rows_p / GBM) * p.ncolblk;
+    hipLaunchKernelGGL(g_gemm, dim3(nblocks), dim3(GTHREADS), 0, st, p);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int lay_ln(tdmpc2_plan *h, hipStream_t st, int act, float *x, int ld, int width, size_t rows, int rows_per_env,
+           const HostLayer &ly, long gb_sel_stride, const int *sel) {
+    LnActParams p{};
+    p.x = x; p.ld = ld; p.width = width; p.rows = (int)rows; p.rows_per_env = rows_per_env;
+    p.g = ly.g; p.b = ly.b; p.gb_sel_stride = sel ? gb_sel_stride : 0; p.sel = sel; p.sel_stride = 2;
+    const int grid = (int)((rows + RW_THREADS / 64 - 1) / (RW_THREADS / 64));
+    if (act == 0) hipLaunchKernelGGL(l_ln_act<0>, dim3(grid), dim3(RW_THREADS), 0, st, p);
+    else hipLaunchKernelGGL(l_ln_act<1>, dim3(grid), dim3(RW_THREADS), 0, st, p);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// strides between consecutive Q heads of layer `l` (slab allocation in bind_weights)
+inline long q_wstride(const tdmpc2_plan *h, int l) { return h->cfg.num_q > 1 ? (long)(h->q[1].l[l].wp - h->q[0].l[l].wp) : 0; }
+inline long q_bstride(const tdmpc2_plan *h, int l) { return h->cfg.num_q > 1 ? (long)(h->q[1].l[l].bias - h->q[0].l[l].bias) : 0; }
+inline long q_gstride(const tdmpc2_plan *h, int l) { return h->cfg.num_q > 1 ? (long)(h->q[1].l[l].g - h->q[0].l[l].g) : 0; }
+
+// X -> hidden 1 (HA) -> hidden 2 (HB): the two NormedLinear(Mish) layers of a reference `mlp` (layers.py:121-133).
+int lay_hidden(tdmpc2_plan *h, hipStream_t st, const HostNet &net, int slot, size_t rows, size_t rows_p, int rpe,
+               const int *sel, bool is_q) {
+    const Layered &L = h->lay;
+    int rc;
+    if ((rc = lay_gemm(h, st, L.X, L.Kin, rows_p, rpe, net.l[0], is_q ? q_wstride(h, 0) : 0, is_q ? q_bstride(h, 0) : 0, slot,
+                       sel, L.HA, L.Mp))) return rc;
+    if ((rc = lay_ln(h, st, 0, L.HA, L.Mp, h->cfg.mlp_dim, rows, rpe, net.l[0], is_q ? q_gstride(h, 0) : 0, sel))) return rc;
+    if ((rc = lay_gemm(h, st, L.HA, L.Mp, rows_p, rpe, net.l[1], is_q ? q_wstride(h, 1) : 0, is_q ? q_bstride(h, 1) : 0, -1,
+                       sel, L.HB, L.Mp))) return rc;
+    return lay_ln(h, st, 0, L.HB, L.Mp, h->cfg.mlp_dim, rows, rpe, net.l[1], is_q ? q_gstride(h, 1) : 0, sel);
+}
+
+// z <- next(z, a): dynamics MLP with SimNorm output written back into X[:, 0:L)  (world_model.py:114-121)
+int lay_dynamics(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rpe) {
+    const Layered &L = h->lay;
+    int rc;
+    if ((rc = lay_hidden(h, st, h->dyn, BE_DYN, rows, rows_p, rpe, nullptr, false))) return rc;
+    if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, rpe, h->dyn.l[2], 0, 0, -1, nullptr, L.X, L.Kin))) return rc;
+    return lay_ln(h, st, 1, L.X, L.Kin, h->cfg.latent_dim, rows, rpe, h->dyn.l[2], 0, nullptr);
+}
+
+// a <- pi(z) into X[:, L:L+A) (+ actions[e, t, n < P] for the policy-prior trajectories)  (world_model.py:144-184)
+int lay_policy(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rpe, int nvalid, const float *mask,
+               const float *eps, long eps_estride, unsigned long long seed, unsigned call, int site, int iter,
+               float *actions, int t, float *trace = nullptr) {
+    const Layered &L = h->lay;
+    const tdmpc2_plan_cfg &c = h->cfg;
+    int rc;
+    if ((rc = lay_hidden(h, st, h->pi, BE_PI, rows, rows_p, rpe, nullptr, false))) return rc;
+    if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, rpe, h->pi.l[2], 0, 0, -1, nullptr, L.LG, L.ldl))) return rc;
+    PiHeadParams p{};
+    p.lg = L.LG; p.ld = L.ldl; p.rows = (int)rows; p.rows_per_env = rpe; p.nvalid = nvalid; p.A = c.action_dim;
+    p.L = c.latent_dim; p.ldx = L.Kin; p.lsmin = c.log_std_min; p.lsdif = c.log_std_dif; p.mask = mask;
+    p.eps = eps; p.eps_estride = eps_estride; p.seed = seed; p.call = call; p.site = site; p.iter = iter;
+    p.X = L.X; p.actions = actions; p.t = t; p.H = c.horizon; p.N = c.num_samples; p.trace = trace;
+    const int total = (int)rows * c.action_dim;
+    hipLaunchKernelGGL(l_pi_head, dim3((total + 255) / 256), dim3(256), 0, st, p);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int lay_twohot(tdmpc2_plan *h, hipStream_t st, size_t rows, int rpe, int mode, int t, const float *disc_pow, float *value,
+               float *trace) {
+    const Layered &L = h->lay;
+    TwoHotParams p{};
+    p.lg = L.LG; p.ld = L.ldl; p.rows = (int)rows; p.rows_per_env = rpe; p.num_bins = h->cfg.num_bins; p.mode = mode;
+    p.t = t; p.H = h->cfg.horizon; p.bins = h->bins; p.disc_pow = disc_pow; p.G = L.G; p.qtmp = L.QT; p.value = value;
+    p.term = h->cfg.episodic ? L.TERM : nullptr; p.trace = trace; p.trace_ld = h->cfg.horizon + 2 + h->cfg.action_dim;
+    const int grid = (int)((rows + RW_THREADS / 64 - 1) / (RW_THREADS / 64));
+    hipLaunchKernelGGL(l_twohot, dim3(grid), dim3(RW_THREADS), 0, st, p);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+int lay_setup(tdmpc2_plan *h, hipStream_t st, int E, const float *task_emb, const float *prev_mean, const unsigned char *t0,
+              bool init_dist) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    if (!c.multitask && !init_dist) return 0;
+    LSetupParams p{};
+    p.E = E; p.H = c.horizon; p.A = c.action_dim; p.T = c.task_dim; p.M = c.mlp_dim; p.Mp = h->lay.Mp; p.nnets = h->nnets;
+    p.multitask = c.multitask; p.max_std = c.max_std;
+    p.bias[BE_DYN] = h->dyn.l[0].bias; p.wemb[BE_DYN] = h->dyn.l[0].wemb;
+    p.bias[BE_REW] = h->rew.l[0].bias; p.wemb[BE_REW] = h->rew.l[0].wemb;
+    p.bias[BE_PI] = h->pi.l[0].bias; p.wemb[BE_PI] = h->pi.l[0].wemb;
+    for (int i = 0; i < c.num_q; ++i) { p.bias[BE_Q0 + i] = h->q[i].l[0].bias; p.wemb[BE_Q0 + i] = h->q[i].l[0].wemb; }
+    p.task_emb = task_emb; p.prev_mean = prev_mean; p.t0 = t0; p.beff = h->beff;
+    p.mean = init_dist ? h->mean : nullptr; p.std = h->std;
+    hipLaunchKernelGGL(l_setup, dim3(E), dim3(256), 0, st, p);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// TDMPC2._estimate_value (tdmpc2/tdmpc2.py:122-136) for E plans with the step actions in `actions` [E,H,N,A].
+int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float *act_mask, const float *disc_pow,
+                       const float *actions, const float *pi_eps, long pi_eps_estride, const int *qidx /* dense [E,2] */,
+                       unsigned long long seed, unsigned call, int iter, float *value, float *trace) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    const Layered &L = h->lay;
+    const int N = c.num_samples, H = c.horizon, A = c.action_dim;
+    const size_t rows = (size_t)E * N, rows_p = round_up(rows, GBM);
+    int rc;
+    hipLaunchKernelGGL(l_init_x, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM);
+    LAUNCH_CHECK();
+    for (int t = 0; t < H; ++t) {
+        const int total = (int)rows * A;
+        hipLaunchKernelGGL(l_set_action, dim3((total + 255) / 256), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, A, N, H, t,
+                           (int)rows, actions);
+        LAUNCH_CHECK();
+        // reward(z, a_t) -> two_hot_inv -> G += disc * (1 - term) * r
+        if ((rc = lay_hidden(h, st, h->rew, BE_REW, rows, rows_p, N, nullptr, false))) return rc;
+        if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, N, h->rew.l[2], 0, 0, -1, nullptr, L.LG, L.ldl))) return rc;
+        if ((rc = lay_twohot(h, st, rows, N, 0, t, disc_pow, value, trace))) return rc;
+        // z = next(z, a_t)
+        if ((rc = lay_dynamics(h, st, rows, rows_p, N))) return rc;
+        if (c.episodic) {  // termination head on the new latent (tdmpc2.py:133-134)
+            if ((rc = lay_hidden(h, st, h->term, -1, rows, rows_p, N, nullptr, false))) return rc;
+            if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, N, h->term.l[2], 0, 0, -1, nullptr, L.LG, L.ldl))) return rc;
+            hipLaunchKernelGGL(l_term, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, L.LG, L.ldl, (int)rows, L.TERM);
+            LAUNCH_CHECK();
+        }
+    }
+    // a_H = pi(z_H); value = G + disc^H (1 - term) avg of the two selected Q heads
+    if ((rc = lay_policy(h, st, rows, rows_p, N, N, act_mask, pi_eps, pi_eps_estride, seed, call, SITE_PI, iter, nullptr, 0,
+                         trace))) return rc;
+    for (int j = 0; j < 2; ++j) {
+        if ((rc = lay_hidden(h, st, h->q[0], BE_Q0, rows, rows_p, N, qidx + j, true))) return rc;
+        if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, N, h->q[0].l[2], q_wstride(h, 2), q_bstride(h, 2), -1, qidx + j, L.LG,
+                           L.ldl))) return rc;
+        if ((rc = lay_twohot(h, st, rows, N, 1 + j, 0, disc_pow, value, trace))) return rc;
+    }
+    return 0;
+}
+
+// The P policy-prior trajectories (tdmpc2/tdmpc2.py:154-160): rows n < P of actions[E, H, N, A].
+int lay_pitraj(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float *act_mask, const float *tape_eps,
+               unsigned long long seed, unsigned call) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    const Layered &L = h->lay;
+    const int P = c.num_pi_trajs, H = c.horizon, A = c.action_dim, rpe = L.Ppad;
+    const size_t rows = (size_t)E * rpe, rows_p = round_up(rows, GBM);
+    int rc;
+    hipLaunchKernelGGL(l_init_x, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, rpe, z0, (float *)nullptr,
+                       (float *)nullptr);
+    LAUNCH_CHECK();
+    for (int t = 0; t < H; ++t) {
+        // tape layout [E, H, P, A]: env stride H*P*A, this step's slice at t*P*A
+        const float *eps = tape_eps ? tape_eps + (size_t)t * P * A : nullptr;
+        if ((rc = lay_policy(h, st, rows, rows_p, rpe, P, act_mask, eps, (long)H * P * A, seed, call, SITE_PITRAJ, t,
+                             h->actions, t))) return rc;
+        if (t == H - 1) break;
+        if ((rc = lay_dynamics(h, st, rows, rows_p, rpe))) return rc;
+    }
+    return 0;
+}
+
+// Everything of TDMPC2._plan after encode() (tdmpc2/tdmpc2.py:154-206) on the layered path.
+int lay_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float *task_emb, const float *act_mask,
+            const float *disc_pow, float *prev_mean, const uint8_t *t0, int eval_mode, const tdmpc2_noise *tape,
+            uint64_t seed, float *action, const tdmpc2_debug *dbg) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    const int H = c.horizon, N = c.num_samples, A = c.action_dim, K = c.num_elites, P = c.num_pi_trajs, I = c.iterations;
+    const unsigned call = h->call++;
+    int rc;
+    if ((rc = lay_setup(h, st, E, task_emb, prev_mean, t0, true))) return rc;
+    if (P > 0 && (rc = lay_pitraj(h, st, E, z0, act_mask, tape ? tape->pi_traj_eps : nullptr, seed, call))) return rc;
+    const size_t refit_lds = ((size_t)N + 3 * K + 2 * H * A) * 4 + 64;
+    for (int it = 0; it < I; ++it) {
+        SampleParams sp{};
+        sp.E = E; sp.H = H; sp.N = N; sp.A = A; sp.P = P; sp.iter = it; sp.mean = h->mean; sp.std = h->std; sp.mask = act_mask;
+        sp.eps = tape ? tape->sample_eps + (size_t)it * H * (N - P) * A : nullptr;
+        sp.eps_estride = (long)I * H * (N - P) * A;
+        sp.seed = seed; sp.call = call; sp.actions = h->actions;
+        hipLaunchKernelGGL(l_sample, dim3(1024), dim3(256), 0, st, sp);
+        LAUNCH_CHECK();
+        if (tape) hipLaunchKernelGGL(l_copy_qidx, dim3((E + 255) / 256), dim3(256), 0, st, E, tape->qidx + (size_t)it * 2, (long)I * 2, h->lay.qidx);
+        else hipLaunchKernelGGL(l_qidx, dim3((E + 255) / 256), dim3(256), 0, st, E, c.num_q, it, (unsigned long long)seed, call, h->lay.qidx);
+        LAUNCH_CHECK();
+        if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
+        if ((rc = lay_estimate_value(h, st, E, z0, act_mask, disc_pow, h->actions,
+                                     tape ? tape->pi_eps + (size_t)it * N * A : nullptr, (long)I * N * A, h->lay.qidx, seed, call,
+                                     it, h->value, nullptr))) return rc;
+        if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) {
+            HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
+            h->ev_used += 2;
+        }
+        if (dbg && dbg->actions)
+            HIP_TRY(hipMemcpy2DAsync(dbg->actions + (size_t)it * H * N * A, (size_t)I * H * N * A * 4, h->actions,
+                                     (size_t)H * N * A * 4, (size_t)H * N * A * 4, E, hipMemcpyDeviceToDevice, st));
+        RefitParams fp{};
+        fp.E = E; fp.N = N; fp.H = H; fp.A = A; fp.K = K; fp.iter = it; fp.last = (it == I - 1); fp.eval_mode = eval_mode;
+        fp.temperature = c.temperature; fp.min_std = c.min_std; fp.max_std = c.max_std;
+        fp.value = h->value; fp.actions = h->actions; fp.act_mask = act_mask; fp.mean = h->mean; fp.std = h->std;
+        fp.gumbel_exp = tape ? tape->gumbel_exp : nullptr; fp.final_eps = tape ? tape->final_eps : nullptr;
+        fp.seed = seed; fp.call = call; fp.prev_mean = prev_mean; fp.action = action;
+        if (dbg) {
+            if (dbg->value) { fp.dbg_value = dbg->value + (size_t)it * N; fp.dbg_value_es = (long)I * N; }
+            if (dbg->elite_idx) { fp.dbg_idx = dbg->elite_idx + (size_t)it * K; fp.dbg_idx_es = (long)I * K; }
+            if (dbg->score) { fp.dbg_score = dbg->score + (size_t)it * K; fp.dbg_score_es = (long)I * K; }
+            if (dbg->mean) { fp.dbg_mean = dbg->mean + (size_t)it * H * A; fp.dbg_mean_es = (long)I * H * A; }
+            if (dbg->std) { fp.dbg_std = dbg->std + (size_t)it * H * A; fp.dbg_std_es = (long)I * H * A; }
+        }
+        hipLaunchKernelGGL(k_refit, dim3(E), dim3(N), refit_lds, st, fp);
+        LAUNCH_CHECK();
+    }
+    return TDMPC2_OK;
+}

@@ -1,0 +1,411 @@
+// Layer-at-a-time planner kernels for ANY (latent_dim, mlp_dim): the 19M / 48M / 317M world models
+// (c3, c4, c5) and episodic (termination-head) planning at every size.
+//
+// The fused kernel (k_rollout) keeps a 64-row activation tile in LDS across a whole CEM iteration, which only
+// fits for 512-wide layers.  Here activations live in HBM (288 GB: [E*N, mlp_dim] fp32 per buffer) and every
+// nn.Linear of the reference becomes one LDS-tiled fp32-MFMA GEMM launch over all E*N sample rows of all
+// plans, followed by one row-wise kernel for the LayerNorm / Mish / SimNorm / two-hot / policy-head math
+// (reference: tdmpc2/common/layers.py:94-133, tdmpc2/common/math.py:12-83, tdmpc2/common/world_model.py:114-216).
+// Included by tdmpc2_plan.hip inside its anonymous namespace (device helpers mish_f, symexp_f, group_*, rng_* are
+// defined there).
+#pragma once
+
+constexpr int GBM = 128;          // rows per GEMM workgroup
+constexpr int GBN = 128;          // output columns per GEMM workgroup (4 column tiles of 32)
+constexpr int GBK = 32;           // k-chunk staged through LDS
+constexpr int GLD = GBK + 4;      // LDS row stride in floats (stride/4 = 9, odd -> conflict-free ds_read_b128)
+constexpr int GTHREADS = 256;     // 4 wavefronts: 2 (rows) x 2 (cols), each 64 x 64 = 2x2 MFMA tiles
+
+// out[r, c] = sum_k A[r, k] * W[c, k] + bias(r)[c]          (pre-activation of one nn.Linear)
+struct GemmParams {
+    const float *A;     // [Rp, lda] fp32 row-major, Rp a multiple of GBM
+    int lda;
+    int K;              // contraction length, multiple of GBK (weights zero-padded)
+    const float *wp;    // packed [CT][K/8][64][4] (k_pack_weight), + sel * w_sel_stride for ensembles
+    long w_sel_stride;
+    int CT;             // output column tiles of 32
+    int ncolblk;        // ceil(CT / 4)
+    const float *bias;  // bias(r) = bias + env(r) * bias_env_stride + sel * bias_sel_stride, CT*32 valid floats
+    long bias_env_stride, bias_sel_stride;
+    const int *sel;     // per-plan ensemble member (Q heads) or null; requires rows_per_env % GBM == 0
+    long sel_stride;
+    int rows_per_env;   // env(r) = r / rows_per_env
+    float *out;         // [Rp, ldo]
+    int ldo;
+};
+
+__global__ __launch_bounds__(GTHREADS, 2) void g_gemm(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) float As[2][GBM * GLD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    // XCD-aware tile order: hardware places block b on XCD b % 8; give every XCD a contiguous run of tiles
+    // (column blocks fastest) so the A row panel and the k-slices of W a run shares stay in that XCD's L2.
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int tile = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+    const int rb = tile / p.ncolblk, cb = tile % p.ncolblk;
+    const int row0 = rb * GBM;
+    const int sel = p.sel ? p.sel[(size_t)(row0 / p.rows_per_env) * p.sel_stride] : 0;
+    const int KB = p.K / 8;
+    const int ct0 = cb * 4 + wc * 2;
+    const bool v0 = ct0 < p.CT, v1 = ct0 + 1 < p.CT;
+    const f32x4 *wbase = reinterpret_cast<const f32x4 *>(p.wp + (size_t)sel * p.w_sel_stride);
+    const f32x4 *w0 = wbase + (size_t)(v0 ? ct0 : p.CT - 1) * KB * 64 + lane;
+    const f32x4 *w1 = wbase + (size_t)(v1 ? ct0 + 1 : p.CT - 1) * KB * 64 + lane;
+
+    // A staging: thread -> rows (tid >> 3) + 32 i, float4 column tid & 7 of the 32-wide chunk (128 B per row, coalesced)
+    const int srow = tid >> 3, sc4 = tid & 7;
+    const float *ag = p.A + (size_t)(row0 + srow) * p.lda + 4 * sc4;
+    f32x4 stage[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage[i] = *reinterpret_cast<const f32x4 *>(ag + (size_t)(32 * i) * p.lda);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(&As[0][(srow + 32 * i) * GLD + 4 * sc4]) = stage[i];
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
+
+    const int i32 = lane & 31, h = lane >> 5;
+    const int nchunks = p.K / GBK;
+    f32x4 bn0 = w0[0], bn1 = w1[0];
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + 1 < nchunks;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                stage[i] = *reinterpret_cast<const f32x4 *>(ag + (size_t)(32 * i) * p.lda + (size_t)(c + 1) * GBK);
+        }
+        const float *as = &As[c & 1][0];
+        const float *a0p = as + (wr * 64 + i32) * GLD + 4 * h;
+        const float *a1p = a0p + 32 * GLD;
+#pragma unroll
+        for (int kb = 0; kb < GBK / 8; ++kb) {
+            const f32x4 b0 = bn0, b1 = bn1;
+            const int kn = c * (GBK / 8) + kb + 1;
+            const int knc = kn < KB ? kn : KB - 1;
+            bn0 = w0[(size_t)knc * 64];
+            bn1 = w1[(size_t)knc * 64];
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p + kb * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(a1p + kb * 8);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b0[r], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b1[r], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b0[r], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b1[r], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (more) {
+            float *dst = &As[(c + 1) & 1][0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(dst + (srow + 32 * i) * GLD + 4 * sc4) = stage[i];
+        }
+        __syncthreads();
+    }
+
+    // epilogue: + bias, store.  C/D fragment: lane holds column (lane & 31), rows (reg&3) + 8 (reg>>2) + 4 (lane>>5).
+    const float *bsel = p.bias + (size_t)sel * p.bias_sel_stride;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (!(c == 0 ? v0 : v1)) continue;
+        const int col = (ct0 + c) * 32 + i32;
+        const float bshared = p.bias_env_stride == 0 ? bsel[col] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = row0 + wr * 64 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                float bv = bshared;
+                if (p.bias_env_stride != 0) bv = bsel[(size_t)(row / p.rows_per_env) * p.bias_env_stride + col];
+                p.out[(size_t)row * p.ldo + col] = acc[rt][c][reg] + bv;
+            }
+    }
+}
+
+// ---------------------------------------------------------------- row-wise kernels: one wavefront per row
+constexpr int RW_THREADS = 256;  // 4 rows per workgroup
+
+// In place: x <- ACT(LayerNorm(x)) over `width` columns of each row (width % 4 == 0).  ACT 0 Mish, 1 SimNorm(8).
+// Per-plan ensemble member selection for the LayerNorm affine parameters like g_gemm.
+struct LnActParams {
+    float *x;
+    int ld, width, rows, rows_per_env;
+    const float *g, *b;
+    long gb_sel_stride;
+    const int *sel;
+    long sel_stride;
+};
+
+template <int ACT>
+__global__ __launch_bounds__(RW_THREADS) void l_ln_act(LnActParams p) {
+    const int row = blockIdx.x * (RW_THREADS / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= p.rows) return;
+    const int sel = p.sel ? p.sel[(size_t)(row / p.rows_per_env) * p.sel_stride] : 0;
+    const float *g = p.g + (size_t)sel * p.gb_sel_stride, *bb = p.b + (size_t)sel * p.gb_sel_stride;
+    float *xr = p.x + (size_t)row * p.ld;
+    const int n4 = p.width / 4;
+    float s = 0.f;
+    for (int q = lane; q < n4; q += 64) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + 4 * q);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float mean = group_sum<64>(s) / (float)p.width;
+    float ss = 0.f;
+    for (int q = lane; q < n4; q += 64) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[e] - mean;
+            ss += d * d;
+        }
+    }
+    const float var = group_sum<64>(ss) / (float)p.width;
+    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+    // SimNorm groups of 8 columns = the float4 of this lane and of lane ^ 1; every lane of a pair must take part in
+    // the shuffles, so the loop bound is rounded up to a whole wave and out-of-range lanes carry -inf / 0.
+    const int n4r = (n4 + 63) / 64 * 64;
+    for (int q = lane; q < n4r; q += 64) {
+        const bool ok = q < n4;
+        f32x4 y;
+        if (ok) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + 4 * q);
+            const f32x4 gg = *reinterpret_cast<const f32x4 *>(g + 4 * q);
+            const f32x4 be = *reinterpret_cast<const f32x4 *>(bb + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[e] - mean) * rstd * gg[e] + be[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = -INFINITY;
+        }
+        if (ACT == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = mish_f(y[e]);
+        } else {
+            float m = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
+            m = fmaxf(m, __shfl_xor(m, 1));
+            float es = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = ok ? expf(y[e] - m) : 0.f;
+                es += y[e];
+            }
+            es += __shfl_xor(es, 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = y[e] / es;
+        }
+        if (ok) *reinterpret_cast<f32x4 *>(xr + 4 * q) = y;
+    }
+}
+
+// two_hot_inv of one row of logits (tdmpc2/common/math.py:74-83); result in every lane.
+__device__ __forceinline__ float twohot_wave(const float *lg, const float *bins, int num_bins, int lane) {
+    float v0 = lane < num_bins ? lg[lane] : -INFINITY;
+    float v1 = lane + 64 < num_bins ? lg[lane + 64] : -INFINITY;
+    const float m = group_max<64>(fmaxf(v0, v1));
+    v0 = lane < num_bins ? expf(v0 - m) : 0.f;
+    v1 = lane + 64 < num_bins ? expf(v1 - m) : 0.f;
+    const float es = group_sum<64>(v0 + v1);
+    float x = 0.f;
+    if (lane < num_bins) x += (v0 / es) * bins[lane];
+    if (lane + 64 < num_bins) x += (v1 / es) * bins[lane + 64];
+    return symexp_f(group_sum<64>(x));
+}
+
+// Two-hot heads.  mode 0: reward of step t  -> G += disc[t] * (1 - term) * r          (tdmpc2/tdmpc2.py:128-130)
+//                 mode 1: first Q head       -> qtmp = q
+//                 mode 2: second Q head      -> value = G + disc[H] * (1 - term) * (qtmp + q) / 2   (tdmpc2.py:136)
+struct TwoHotParams {
+    const float *lg;
+    int ld, rows, rows_per_env, num_bins, mode, t, H;
+    const float *bins, *disc_pow;  // disc_pow [E, H+1]
+    float *G, *qtmp, *value;       // [rows]
+    const float *term;             // [rows] or null (non-episodic)
+    float *trace;                  // optional [rows, trace_ld]: r_0..r_{H-1}, Q_a, Q_b, (a_H[A] written by l_pi_head)
+    int trace_ld;
+};
+
+__global__ __launch_bounds__(RW_THREADS) void l_twohot(TwoHotParams p) {
+    const int row = blockIdx.x * (RW_THREADS / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= p.rows) return;
+    const float r = twohot_wave(p.lg + (size_t)row * p.ld, p.bins, p.num_bins, lane);
+    if (lane != 0) return;
+    const float *disc = p.disc_pow + (size_t)(row / p.rows_per_env) * (p.H + 1);
+    const float live = p.term ? 1.f - p.term[row] : 1.f;
+    if (p.mode == 0) {
+        const float g0 = p.t == 0 ? 0.f : p.G[row];
+        p.G[row] = g0 + disc[p.t] * live * r;
+        if (p.trace) p.trace[(size_t)row * p.trace_ld + p.t] = r;
+    } else if (p.mode == 1) {
+        p.qtmp[row] = r;
+        if (p.trace) p.trace[(size_t)row * p.trace_ld + p.H] = r;
+    } else {
+        p.value[row] = p.G[row] + disc[p.H] * live * ((p.qtmp[row] + r) / 2.f);
+        if (p.trace) p.trace[(size_t)row * p.trace_ld + p.H + 1] = r;
+    }
+}
+
+// Termination head (tdmpc2/common/world_model.py:132-141, tdmpc2/tdmpc2.py:133-134):
+// term <- clip(term + (sigmoid(logit) > 0.5), max = 1).  One thread per row.
+__global__ void l_term(const float *lg, int ld, int rows, float *term) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const float pr = 1.f / (1.f + expf(-lg[(size_t)row * ld]));
+    const float tnew = term[row] + (pr > 0.5f ? 1.f : 0.f);
+    term[row] = fminf(tnew, 1.f);
+}
+
+// Policy head (world_model.py:152-174): action = tanh(mu + eps * exp(log_std)) -> X[row, L + a]; optionally also
+// into actions[e, t, n, a] (policy-prior trajectories).  One thread per (row, a).
+struct PiHeadParams {
+    const float *lg;  // [rows, ld]: mu[0..A) | log_std[A..2A)
+    int ld, rows, rows_per_env, nvalid /* rows per env that are real */, A, L, ldx;
+    float lsmin, lsdif;
+    const float *mask;      // [E, A] or null
+    const float *eps;       // tape: eps[env * eps_estride + n * A + a], or null -> Philox
+    long eps_estride;
+    unsigned long long seed;
+    unsigned int call;
+    int site, iter;
+    float *X;               // [rows, ldx]
+    float *actions;         // [E, H, N, A] or null
+    int t, H, N;
+    float *trace;           // optional [rows, H+2+A]: a_H into columns H+2..
+};
+
+__global__ void l_pi_head(PiHeadParams p) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.rows * p.A) return;
+    const int row = idx / p.A, a = idx % p.A;
+    const int e = row / p.rows_per_env, n = row % p.rows_per_env;
+    const float *lr = p.lg + (size_t)row * p.ld;
+    float mu = lr[a];
+    float ls = p.lsmin + 0.5f * p.lsdif * (tanhf(lr[p.A + a]) + 1.f);
+    float eps = 0.f;
+    if (n < p.nvalid) {
+        const unsigned ridx = (unsigned)((size_t)n * p.A + a);
+        eps = p.eps ? p.eps[(size_t)e * p.eps_estride + ridx] : rng_normal(p.seed, p.call, p.site, p.iter, e, ridx);
+    }
+    if (p.mask) {
+        const float mk = p.mask[(size_t)e * p.A + a];
+        mu *= mk;
+        ls *= mk;
+        eps *= mk;
+    }
+    const float act = tanhf(mu + eps * expf(ls));
+    p.X[(size_t)row * p.ldx + p.L + a] = act;
+    if (p.actions && n < p.nvalid) p.actions[(((size_t)e * p.H + p.t) * p.N + n) * p.A + a] = act;
+    if (p.trace) p.trace[(size_t)row * (p.H + 2 + p.A) + p.H + 2 + a] = act;
+}
+
+// X[row, 0:L) <- z0[env]; X[row, L:ldx) <- 0; G, term <- 0.  One workgroup per row.
+__global__ void l_init_x(float *X, int ldx, int L, int rows_per_env, const float *z0, float *G, float *term) {
+    const int row = blockIdx.x;
+    const float *z = z0 + (size_t)(row / rows_per_env) * L;
+    float *xr = X + (size_t)row * ldx;
+    for (int c = threadIdx.x; c < ldx; c += blockDim.x) xr[c] = c < L ? z[c] : 0.f;
+    if (threadIdx.x == 0) {
+        if (G) G[row] = 0.f;
+        if (term) term[row] = 0.f;
+    }
+}
+
+// Sampling of one CEM iteration (tdmpc2/tdmpc2.py:176-181) for all steps: rows n >= P of actions[E, H, N, A].
+struct SampleParams {
+    int E, H, N, A, P, iter;
+    const float *mean, *std;  // [E, H, A]
+    const float *mask;        // [E, A] or null
+    const float *eps;         // tape slice of this iteration [.., H, N-P, A], env stride below; null -> Philox
+    long eps_estride;
+    unsigned long long seed;
+    unsigned int call;
+    float *actions;
+};
+
+__global__ void l_sample(SampleParams p) {
+    const size_t total = (size_t)p.E * p.H * (p.N - p.P) * p.A;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int a = idx % p.A;
+        size_t r = idx / p.A;
+        const int n = r % (p.N - p.P);
+        r /= (p.N - p.P);
+        const int t = r % p.H, e = r / p.H;
+        const unsigned ridx = (unsigned)(((size_t)t * (p.N - p.P) + n) * p.A + a);
+        const float z = p.eps ? p.eps[(size_t)e * p.eps_estride + ridx] : rng_normal(p.seed, p.call, SITE_SAMPLE, p.iter, e, ridx);
+        float v = p.mean[((size_t)e * p.H + t) * p.A + a] + p.std[((size_t)e * p.H + t) * p.A + a] * z;
+        v = fminf(fmaxf(v, -1.f), 1.f);
+        if (p.mask) v *= p.mask[(size_t)e * p.A + a];
+        p.actions[(((size_t)e * p.H + t) * p.N + p.P + n) * p.A + a] = v;
+    }
+}
+
+// X[row, L + a] <- actions[e, t, n, a]
+__global__ void l_set_action(float *X, int ldx, int L, int A, int N, int H, int t, int rows, const float *actions) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * A) return;
+    const int row = idx / A, a = idx % A;
+    const int e = row / N, n = row % N;
+    X[(size_t)row * ldx + L + a] = actions[(((size_t)e * H + t) * N + n) * A + a];
+}
+
+// Per-plan set-up of the layered path (grid E): effective first-layer biases b + W[:, L:L+T] . task_emb for every net
+// (multitask), mean / std initialisation and warm start (tdmpc2/tdmpc2.py:164-167).
+struct LSetupParams {
+    int E, H, A, T, M, Mp, nnets, multitask;
+    float max_std;
+    const float *bias[4 + MAXQ];  // first-layer biases [Mp]
+    const float *wemb[4 + MAXQ];  // [M, T] task-embedding columns of each first layer (null when the net is absent)
+    const float *task_emb, *prev_mean;
+    const unsigned char *t0;
+    float *beff, *mean, *std;
+};
+
+__global__ void l_setup(LSetupParams p) {
+    const int e = blockIdx.x, tid = threadIdx.x;
+    if (p.multitask) {
+        const float *emb = p.task_emb + (size_t)e * p.T;
+        for (int net = 0; net < p.nnets; ++net) {
+            if (!p.wemb[net]) continue;
+            for (int c = tid; c < p.Mp; c += blockDim.x) {
+                float s = 0.f;
+                if (c < p.M) {
+                    const float *w = p.wemb[net] + (size_t)c * p.T;
+                    for (int k = 0; k < p.T; ++k) s = fmaf(w[k], emb[k], s);
+                }
+                p.beff[((size_t)e * p.nnets + net) * p.Mp + c] = p.bias[net][c] + s;
+            }
+        }
+    }
+    if (p.mean) {
+        for (int idx = tid; idx < p.H * p.A; idx += blockDim.x) {
+            const int t = idx / p.A;
+            float m = 0.f;
+            if (!p.t0[e] && t < p.H - 1) m = p.prev_mean[(size_t)e * p.H * p.A + idx + p.A];
+            p.mean[(size_t)e * p.H * p.A + idx] = m;
+            p.std[(size_t)e * p.H * p.A + idx] = p.max_std;
+        }
+    }
+}
+
+// qidx of this iteration from Philox when no tape is given: two distinct heads, uniform over ordered pairs.
+__global__ void l_qidx(int E, int nq, int iter, unsigned long long seed, unsigned int call, int *qidx) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const uint4 r = rng_raw(seed, call, SITE_QIDX, iter, e, 0);
+    int q0 = (int)(r.x % (unsigned)nq), q1 = (int)(r.y % (unsigned)(nq - 1));
+    if (q1 >= q0) ++q1;
+    qidx[2 * e] = q0;
+    qidx[2 * e + 1] = q1;
+}
+
+// value[e, n] <- vrow[e * N + n]  is the identity layout; copy of the tape's qidx slice into the dense [E, 2] buffer.
+__global__ void l_copy_qidx(int E, const int *src, long estride, int *dst) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    dst[2 * e] = src[(size_t)e * estride];
+    dst[2 * e + 1] = src[(size_t)e * estride + 1];
+}

@@ -895,6 +895,8 @@ __global__ void k_copy_pad(const float *src, int n, int npad, float *dst) {
         dst[idx] = idx < n ? src[idx] : 0.f;
 }
 
+#include "layered_kernels.cuh"
+
 // ================================================================ host side
 thread_local std::string g_err;
 int fail(int code, const char *fmt, ...) {
@@ -923,8 +925,20 @@ struct HostNet {
 
 }  // namespace
 
+// Workspace of the layer-at-a-time path (layered_kernels.cuh): activations of all E*N sample rows in HBM.
+struct Layered {
+    bool on = false;
+    int Kin = 0;    // row stride of X = first-layer K: round_up(L + A, 32)
+    int Mp = 0;     // mlp_dim (multiple of 32)
+    int ldl = 0;    // row stride of the head-logit buffer
+    int Ppad = 0;   // rows per plan in the policy-prior pass: round_up(P, 32)
+    float *X = nullptr, *HA = nullptr, *HB = nullptr, *LG = nullptr, *G = nullptr, *QT = nullptr, *TERM = nullptr;
+    int *qidx = nullptr;  // [E, 2] heads of the current iteration
+};
+
 struct tdmpc2_plan {
     tdmpc2_plan_cfg cfg;
+    Layered lay;
     int Apad = 0, stride = 0, tiles = 0, nnets = 0;
     size_t lds_bytes = 0;
     HostNet dyn, rew, pi, term;
@@ -974,6 +988,8 @@ int check_ready(tdmpc2_plan *h) {
             return fail(TDMPC2_ERR_STATE, "weights of layer %d of dynamics/reward/pi are not bound", i);
         for (int qh = 0; qh < h->cfg.num_q; ++qh)
             if (!h->q[qh].l[i].bound) return fail(TDMPC2_ERR_STATE, "weights of Q head %d layer %d are not bound", qh, i);
+        if (h->cfg.episodic && !h->term.l[i].bound)
+            return fail(TDMPC2_ERR_STATE, "weights of layer %d of the termination head are not bound", i);
     }
     return 0;
 }
@@ -1019,6 +1035,8 @@ int validate_envs(tdmpc2_plan *h, int E) {
     return check_ready(h);
 }
 
+#include "layered_host.cuh"
+
 }  // namespace
 
 extern "C" {
@@ -1030,9 +1048,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
     if (!cfg || !out) return fail(TDMPC2_ERR_INVALID, "null argument");
     *out = nullptr;
     const tdmpc2_plan_cfg &c = *cfg;
-    if (c.latent_dim != WIDTH || c.mlp_dim != WIDTH)
-        return fail(TDMPC2_ERR_UNSUPPORTED, "fused planner kernels are built for latent_dim == mlp_dim == %d (got %d / %d)",
-                    WIDTH, c.latent_dim, c.mlp_dim);
+    // ---- limits common to both kernel families
     if (c.action_dim < 1 || c.action_dim > 64) return fail(TDMPC2_ERR_UNSUPPORTED, "action_dim %d outside [1, 64]", c.action_dim);
     if (c.num_bins < 2 || c.num_bins > 128) return fail(TDMPC2_ERR_UNSUPPORTED, "num_bins %d outside [2, 128]", c.num_bins);
     if (c.num_q < 2 || c.num_q > MAXQ) return fail(TDMPC2_ERR_UNSUPPORTED, "num_q %d outside [2, %d]", c.num_q, MAXQ);
@@ -1043,29 +1059,47 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
         return fail(TDMPC2_ERR_UNSUPPORTED, "num_pi_trajs %d outside [0, %d]", c.num_pi_trajs, ROWS);
     if (c.num_elites < 1 || c.num_elites > c.num_samples) return fail(TDMPC2_ERR_INVALID, "num_elites %d", c.num_elites);
     if (c.simnorm_dim != 8) return fail(TDMPC2_ERR_UNSUPPORTED, "simnorm_dim %d (kernels are built for 8)", c.simnorm_dim);
-    if (c.episodic) return fail(TDMPC2_ERR_UNSUPPORTED, "episodic (termination head) planning is not built yet");
     if (c.multitask && c.task_dim < 1) return fail(TDMPC2_ERR_INVALID, "multitask needs task_dim > 0");
+    if (c.multitask && c.episodic)  // the reference asserts the same: tdmpc2/common/world_model.py:136
+        return fail(TDMPC2_ERR_UNSUPPORTED, "termination head with task ids is not supported (reference world_model.py:136)");
     if (c.iterations < 1 || c.max_envs < 1) return fail(TDMPC2_ERR_INVALID, "iterations / max_envs must be positive");
+    if (c.latent_dim < 8 || c.mlp_dim < 8 || c.latent_dim % 8 != 0)
+        return fail(TDMPC2_ERR_UNSUPPORTED, "latent_dim %d / mlp_dim %d", c.latent_dim, c.mlp_dim);
+    // ---- kernel family
+    const bool fits_fused = c.latent_dim == WIDTH && c.mlp_dim == WIDTH && !c.episodic;
+    const bool fits_layered = c.latent_dim % 32 == 0 && c.mlp_dim % 32 == 0 && c.num_samples % GBM == 0;
+    int path = c.path;
+    if (path == TDMPC2_PATH_AUTO) path = fits_fused ? TDMPC2_PATH_FUSED : TDMPC2_PATH_LAYERED;
+    if (path == TDMPC2_PATH_FUSED && !fits_fused)
+        return fail(TDMPC2_ERR_UNSUPPORTED, "fused planner kernels are built for latent_dim == mlp_dim == %d, non-episodic "
+                    "(got %d / %d, episodic %d)", WIDTH, c.latent_dim, c.mlp_dim, c.episodic);
+    if (path == TDMPC2_PATH_LAYERED && !fits_layered)
+        return fail(TDMPC2_ERR_UNSUPPORTED, "layered planner kernels need latent_dim %% 32 == 0, mlp_dim %% 32 == 0 and "
+                    "num_samples %% %d == 0 (got %d / %d / %d)", GBM, c.latent_dim, c.mlp_dim, c.num_samples);
+    if (path != TDMPC2_PATH_FUSED && path != TDMPC2_PATH_LAYERED) return fail(TDMPC2_ERR_INVALID, "unknown path %d", c.path);
     if (hipSetDevice(c.device) != hipSuccess) return fail(TDMPC2_ERR_HIP, "hipSetDevice(%d) failed", c.device);
 
     tdmpc2_plan *h = new (std::nothrow) tdmpc2_plan();
     if (!h) return fail(TDMPC2_ERR_INVALID, "out of host memory");
     h->cfg = c;
+    h->cfg.path = path;
+    h->lay.on = (path == TDMPC2_PATH_LAYERED);
     h->Apad = (c.action_dim + 7) / 8 * 8;
-    // row stride: [z (512) | a (Apad) | 4 pad]; (WIDTH + Apad + 4) mod 64 is 4 * odd for Apad = 8 (mod 16)... the
-    // +4 makes consecutive rows start 4*odd banks apart in the worst case; see DESIGN.md (LDS layout).
-    h->stride = WIDTH + h->Apad + 4;
-    if ((h->stride / 4) % 2 == 0) h->stride += 4;  // keep stride/4 odd: conflict-free ds_read_b128 across 16 rows
     h->tiles = c.num_samples / ROWS;
     h->nnets = BE_Q0 + c.num_q;
-    h->lds_bytes = (size_t)ROWS * h->stride * 4 + (size_t)2 * c.horizon * c.action_dim * 4 + 64;
-    if (h->lds_bytes > 160 * 1024) {
-        const size_t need = h->lds_bytes;
-        delete h;
-        return fail(TDMPC2_ERR_UNSUPPORTED, "LDS tile of %zu bytes exceeds 160 KiB", need);
-    }
     int rc = 0;
     const size_t E = c.max_envs, H = c.horizon, N = c.num_samples, A = c.action_dim;
+    if (!h->lay.on) {
+        // row stride: [z (512) | a (Apad) | pad] with stride/4 odd: conflict-free ds_read_b128 across 16 rows
+        h->stride = WIDTH + h->Apad + 4;
+        if ((h->stride / 4) % 2 == 0) h->stride += 4;
+        h->lds_bytes = (size_t)ROWS * h->stride * 4 + (size_t)2 * c.horizon * c.action_dim * 4 + 64;
+        if (h->lds_bytes > 160 * 1024) {
+            const size_t need = h->lds_bytes;
+            delete h;
+            return fail(TDMPC2_ERR_UNSUPPORTED, "LDS tile of %zu bytes exceeds 160 KiB", need);
+        }
+    }
     // torch.linspace(vmin, vmax, num_bins) in fp32 (math.py:80): float step, product rounded once
     std::vector<float> bins(c.num_bins);
     {
@@ -1078,19 +1112,46 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
         (rc = dev_alloc(h, (void **)&h->actions, E * H * N * A * 4)) ||
         (rc = dev_alloc(h, (void **)&h->value, E * N * 4)) ||
         (rc = dev_alloc(h, (void **)&h->mean, E * H * A * 4)) ||
-        (rc = dev_alloc(h, (void **)&h->std, E * H * A * 4)) ||
-        (rc = dev_alloc(h, (void **)&h->cvec, E * 2 * WIDTH * 4)) ||
-        (rc = dev_alloc(h, (void **)&h->beff, E * h->nnets * WIDTH * 4)) ||
-        (rc = dev_alloc(h, (void **)&h->zscratch, E * h->tiles * ROWS * WIDTH * 4))) {
+        (rc = dev_alloc(h, (void **)&h->std, E * H * A * 4))) {
         tdmpc2_plan_destroy(h);
         return rc;
+    }
+    if (!h->lay.on) {
+        if ((rc = dev_alloc(h, (void **)&h->cvec, E * 2 * WIDTH * 4)) ||
+            (rc = dev_alloc(h, (void **)&h->beff, E * h->nnets * WIDTH * 4)) ||
+            (rc = dev_alloc(h, (void **)&h->zscratch, E * h->tiles * ROWS * WIDTH * 4))) {
+            tdmpc2_plan_destroy(h);
+            return rc;
+        }
+    } else {
+        Layered &L = h->lay;
+        L.Kin = (int)round_up((size_t)c.latent_dim + A, GBK);
+        L.Mp = c.mlp_dim;
+        L.ldl = (int)round_up((size_t)(c.num_bins > 2 * c.action_dim ? c.num_bins : 2 * c.action_dim), 32);
+        L.Ppad = (int)round_up((size_t)(c.num_pi_trajs > 0 ? c.num_pi_trajs : 1), 32);
+        const size_t Rp = round_up(E * N, GBM);  // the policy-prior pass (E * Ppad rows) reuses the same buffers
+        // beff is read per ROW of a GEMM tile; tiles of the policy-prior pass may run past the last plan: + 4 plans
+        if ((rc = dev_alloc(h, (void **)&L.X, Rp * L.Kin * 4)) || (rc = dev_alloc(h, (void **)&L.HA, Rp * L.Mp * 4)) ||
+            (rc = dev_alloc(h, (void **)&L.HB, Rp * L.Mp * 4)) || (rc = dev_alloc(h, (void **)&L.LG, Rp * L.ldl * 4)) ||
+            (rc = dev_alloc(h, (void **)&L.G, Rp * 4)) || (rc = dev_alloc(h, (void **)&L.QT, Rp * 4)) ||
+            (rc = dev_alloc(h, (void **)&L.TERM, Rp * 4)) || (rc = dev_alloc(h, (void **)&L.qidx, E * 2 * 4)) ||
+            (rc = dev_alloc(h, (void **)&h->beff, (E + 4) * h->nnets * L.Mp * 4))) {
+            tdmpc2_plan_destroy(h);
+            return rc;
+        }
+        // stale rows of padded tiles are computed but never read back; start them finite
+        if (hipMemset(L.X, 0, Rp * L.Kin * 4) != hipSuccess || hipMemset(L.HA, 0, Rp * L.Mp * 4) != hipSuccess ||
+            hipMemset(L.HB, 0, Rp * L.Mp * 4) != hipSuccess || hipMemset(h->beff, 0, (E + 4) * h->nnets * L.Mp * 4) != hipSuccess) {
+            tdmpc2_plan_destroy(h);
+            return fail(TDMPC2_ERR_HIP, "hipMemset(workspace) failed");
+        }
     }
     if (hipMemcpy(h->bins, bins.data(), bins.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
         tdmpc2_plan_destroy(h);
         return fail(TDMPC2_ERR_HIP, "hipMemcpy(bins) failed");
     }
-    if ((rc = set_lds(k_setup, h->lds_bytes)) || (rc = set_lds(k_pitraj, h->lds_bytes)) ||
-        (rc = set_lds(k_rollout, h->lds_bytes))) {
+    if (!h->lay.on && ((rc = set_lds(k_setup, h->lds_bytes)) || (rc = set_lds(k_pitraj, h->lds_bytes)) ||
+                       (rc = set_lds(k_rollout, h->lds_bytes)))) {
         tdmpc2_plan_destroy(h);
         return rc;
     }
@@ -1106,14 +1167,16 @@ void tdmpc2_plan_destroy(tdmpc2_plan_t *h) {
 }
 
 uint64_t tdmpc2_plan_device_bytes(const tdmpc2_plan_t *h) { return h ? h->bytes : 0; }
+int tdmpc2_plan_path(const tdmpc2_plan_t *h) { return h ? h->cfg.path : -1; }
 
 int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *W, const float *b, const float *ln_g,
                              const float *ln_b, int out_features, int in_features, void *stream) {
     if (!h || !W || !b) return fail(TDMPC2_ERR_INVALID, "null argument");
     if (layer < 0 || layer > 2) return fail(TDMPC2_ERR_INVALID, "layer %d outside [0, 2]", layer);
     if (net < TDMPC2_NET_DYNAMICS || net > TDMPC2_NET_TERMINATION) return fail(TDMPC2_ERR_INVALID, "unknown net %d", net);
-    if (net == TDMPC2_NET_TERMINATION) return fail(TDMPC2_ERR_UNSUPPORTED, "termination head is not built yet");
     const tdmpc2_plan_cfg &c = h->cfg;
+    if (net == TDMPC2_NET_TERMINATION && !c.episodic)
+        return fail(TDMPC2_ERR_INVALID, "termination head bound on a non-episodic planner");
     hipStream_t st = (hipStream_t)stream;
     const int heads = net == TDMPC2_NET_Q ? c.num_q : 1;
     const bool takes_action = (net == TDMPC2_NET_DYNAMICS || net == TDMPC2_NET_REWARD || net == TDMPC2_NET_Q);
@@ -1127,7 +1190,9 @@ int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *
         exp_out = c.mlp_dim;
     } else {
         exp_in = c.mlp_dim;
-        exp_out = net == TDMPC2_NET_DYNAMICS ? c.latent_dim : net == TDMPC2_NET_PI ? 2 * c.action_dim : c.num_bins;
+        exp_out = net == TDMPC2_NET_DYNAMICS ? c.latent_dim
+                  : net == TDMPC2_NET_PI ? 2 * c.action_dim
+                  : net == TDMPC2_NET_TERMINATION ? 1 : c.num_bins;
     }
     if (in_features != exp_in || out_features != exp_out)
         return fail(TDMPC2_ERR_INVALID, "net %d layer %d: got [%d, %d], expected [%d, %d]", net, layer, out_features,
@@ -1137,28 +1202,45 @@ int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *
     const int nz = (layer == 0) ? c.latent_dim : c.mlp_dim;
     const int nt = (layer == 0) ? c.task_dim : 0;
     const int na = (layer == 0 && takes_action) ? c.action_dim : 0;
-    const int napad = (na + 7) / 8 * 8;
-    const int KB = (nz + napad) / 8;
+    // packed contraction length: FUSED pads the action columns to a multiple of 8 (one k-block), LAYERED pads the
+    // whole row to a multiple of the GEMM k-chunk
+    const int Kp = h->lay.on ? (int)round_up((size_t)nz + na, GBK) : nz + (na + 7) / 8 * 8;
+    const int KB = Kp / 8;
     const int CT = (out_features + 31) / 32;
+    // one slab per tensor kind holding all ensemble members at a constant stride (the layered GEMM selects a member
+    // per plan by stride); allocated on first bind
+    const size_t wsz = (size_t)CT * KB * 256, bsz = (size_t)CT * 32, gsz = round_up((size_t)out_features, 4),
+                 esz = (size_t)out_features * (nt > 0 ? nt : 0);
+    HostLayer &L0 = net_of(h, net, 0)->l[layer];
+    if (!L0.wp) {
+        float *wslab = nullptr, *bslab = nullptr, *gslab = nullptr, *betaslab = nullptr, *eslab = nullptr;
+        int rc;
+        if ((rc = dev_alloc(h, (void **)&wslab, heads * wsz * 4))) return rc;
+        if ((rc = dev_alloc(h, (void **)&bslab, heads * bsz * 4))) return rc;
+        if (has_ln) {
+            if ((rc = dev_alloc(h, (void **)&gslab, heads * gsz * 4))) return rc;
+            if ((rc = dev_alloc(h, (void **)&betaslab, heads * gsz * 4))) return rc;
+        }
+        if (nt > 0 && (rc = dev_alloc(h, (void **)&eslab, heads * esz * 4))) return rc;
+        for (int hd = 0; hd < heads; ++hd) {
+            HostLayer &L = net_of(h, net, hd)->l[layer];
+            L.wp = wslab + hd * wsz;
+            L.bias = bslab + hd * bsz;
+            L.g = has_ln ? gslab + hd * gsz : nullptr;
+            L.b = has_ln ? betaslab + hd * gsz : nullptr;
+            L.wemb = nt > 0 ? eslab + hd * esz : nullptr;
+        }
+    }
     for (int hd = 0; hd < heads; ++hd) {
         HostLayer &L = net_of(h, net, hd)->l[layer];
-        int rc;
-        if (!L.wp) {
-            if ((rc = dev_alloc(h, (void **)&L.wp, (size_t)CT * KB * 256 * 4))) return rc;
-            if ((rc = dev_alloc(h, (void **)&L.bias, (size_t)CT * 32 * 4))) return rc;
-            if (has_ln) {
-                if ((rc = dev_alloc(h, (void **)&L.g, (size_t)out_features * 4))) return rc;
-                if ((rc = dev_alloc(h, (void **)&L.b, (size_t)out_features * 4))) return rc;
-            }
-            if (nt > 0 && (rc = dev_alloc(h, (void **)&L.wemb, (size_t)out_features * nt * 4))) return rc;
-        }
         L.KB = KB; L.CT = CT; L.out = out_features;
         const float *Wh = W + (size_t)hd * out_features * in_features;
         hipLaunchKernelGGL(k_pack_weight, dim3(512), dim3(256), 0, st, Wh, out_features, in_features, nz, nt, na, CT, KB, L.wp);
         hipLaunchKernelGGL(k_copy_pad, dim3(1), dim3(256), 0, st, b + (size_t)hd * out_features, out_features, CT * 32, L.bias);
         if (has_ln) {
-            hipLaunchKernelGGL(k_copy_pad, dim3(2), dim3(256), 0, st, ln_g + (size_t)hd * out_features, out_features, out_features, L.g);
-            hipLaunchKernelGGL(k_copy_pad, dim3(2), dim3(256), 0, st, ln_b + (size_t)hd * out_features, out_features, out_features, L.b);
+            const int gb = (out_features + 255) / 256;
+            hipLaunchKernelGGL(k_copy_pad, dim3(gb), dim3(256), 0, st, ln_g + (size_t)hd * out_features, out_features, out_features, L.g);
+            hipLaunchKernelGGL(k_copy_pad, dim3(gb), dim3(256), 0, st, ln_b + (size_t)hd * out_features, out_features, out_features, L.b);
         }
         if (nt > 0)
             hipLaunchKernelGGL(k_copy_cols, dim3(64), dim3(256), 0, st, Wh, out_features, in_features, nz, nt, L.wemb);
@@ -1208,6 +1290,8 @@ int tdmpc2_plan_run(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *
                  (c.num_pi_trajs > 0 && !tape->pi_traj_eps) || (!eval_mode && !tape->final_eps)))
         return fail(TDMPC2_ERR_INVALID, "noise tape has null fields");
     hipStream_t st = (hipStream_t)stream;
+    if (h->lay.on)
+        return lay_run(h, st, n_envs, z0, task_emb, act_mask, disc_pow, prev_mean, t0, eval_mode, tape, seed, action, dbg);
     const int E = n_envs, H = c.horizon, N = c.num_samples, A = c.action_dim, K = c.num_elites, P = c.num_pi_trajs,
               I = c.iterations;
     const unsigned call = h->call++;
@@ -1286,6 +1370,14 @@ int tdmpc2_plan_estimate_value_trace(tdmpc2_plan_t *h, int n_envs, const float *
     if (!c.multitask) { task_emb = nullptr; act_mask = nullptr; }
     hipStream_t st = (hipStream_t)stream;
     const int E = n_envs, N = c.num_samples, A = c.action_dim;
+    if (h->lay.on) {
+        if (trace_tiles) return fail(TDMPC2_ERR_UNSUPPORTED, "the layered path dumps trace_scalars only");
+        if ((rc = lay_setup(h, st, E, task_emb, nullptr, nullptr, false))) return rc;
+        hipLaunchKernelGGL(l_copy_qidx, dim3((E + 255) / 256), dim3(256), 0, st, E, qidx, 2L, h->lay.qidx);
+        HIP_TRY(hipGetLastError());
+        return lay_estimate_value(h, st, E, z0, act_mask, disc_pow, actions, pi_eps, (long)N * A, h->lay.qidx, 0, 0, 0, value,
+                                  trace_scalars);
+    }
     // setup needs prev_mean / t0 only for mean/std init, which this entry does not use: feed dummies
     HIP_TRY(hipMemsetAsync(h->mean, 0, (size_t)E * c.horizon * A * 4, st));
     HIP_TRY(hipMemsetAsync(h->value, 1, (size_t)E, st));  // E bytes of ones used as t0 = 1 flags (no warm start read)

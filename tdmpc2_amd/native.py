@@ -16,16 +16,17 @@ import torch
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtdmpc2_plan.so")
 _lib = None
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/tdmpc2_plan.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
     "tdmpc2_plan_abi_version", "tdmpc2_last_error", "tdmpc2_plan_create", "tdmpc2_plan_destroy",
-    "tdmpc2_plan_device_bytes", "tdmpc2_plan_bind_weights", "tdmpc2_plan_run", "tdmpc2_plan_estimate_value",
+    "tdmpc2_plan_device_bytes", "tdmpc2_plan_path", "tdmpc2_plan_bind_weights", "tdmpc2_plan_run", "tdmpc2_plan_estimate_value",
     "tdmpc2_plan_estimate_value_trace", "tdmpc2_plan_refit", "tdmpc2_plan_set_profiling", "tdmpc2_plan_profile_read",
 ]
 
 NET_DYNAMICS, NET_REWARD, NET_PI, NET_Q, NET_TERMINATION = range(5)
+PATH_AUTO, PATH_FUSED, PATH_LAYERED = range(3)  # enum tdmpc2_path
 
 
 class PlanCfg(C.Structure):
@@ -34,7 +35,7 @@ class PlanCfg(C.Structure):
                                           "simnorm_dim")] + \
                [(n, C.c_float) for n in ("vmin", "vmax", "min_std", "max_std", "temperature", "log_std_min",
                                          "log_std_dif")] + \
-               [(n, C.c_int32) for n in ("multitask", "episodic", "max_envs", "device")]
+               [(n, C.c_int32) for n in ("multitask", "episodic", "max_envs", "device", "path")]
 
 
 class Noise(C.Structure):
@@ -73,6 +74,8 @@ def load_library():
     lib.tdmpc2_plan_destroy.restype = None
     lib.tdmpc2_plan_device_bytes.argtypes = [vp]
     lib.tdmpc2_plan_device_bytes.restype = u64
+    lib.tdmpc2_plan_path.argtypes = [vp]
+    lib.tdmpc2_plan_path.restype = i32
     lib.tdmpc2_plan_bind_weights.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, vp]
     lib.tdmpc2_plan_bind_weights.restype = i32
     lib.tdmpc2_plan_run.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, C.POINTER(Noise), u64, vp,
@@ -119,7 +122,7 @@ class NativePlanner:
     """
 
     def __init__(self, cfg, iterations: int, device: torch.device, max_envs: int = 1,
-                 log_std_min: Optional[float] = None, log_std_dif: Optional[float] = None):
+                 log_std_min: Optional[float] = None, log_std_dif: Optional[float] = None, path: int = PATH_AUTO):
         device = torch.device(device)
         if device.type != "cuda":
             raise NativeError(f"the planner runs on an MI355X only (device {device}); there is no CPU fallback")
@@ -138,10 +141,11 @@ class NativePlanner:
                     num_q=cfg.num_q, simnorm_dim=cfg.simnorm_dim, vmin=cfg.vmin, vmax=cfg.vmax, min_std=cfg.min_std,
                     max_std=cfg.max_std, temperature=cfg.temperature, log_std_min=lsmin, log_std_dif=lsdif,
                     multitask=int(bool(cfg.multitask)), episodic=int(bool(cfg.episodic)), max_envs=self.max_envs,
-                    device=device.index)
+                    device=device.index, path=int(path))
         h = C.c_void_p()
         self._check(self.lib.tdmpc2_plan_create(C.byref(c), C.byref(h)))
         self._h = h
+        self.path = int(self.lib.tdmpc2_plan_path(h))  # PATH_FUSED or PATH_LAYERED
         self._seed_calls = 0
 
     # ------------------------------------------------------------------ plumbing
@@ -173,6 +177,8 @@ class NativePlanner:
         checkpoint key layout: `_dynamics.{i}.*`, `_reward.{i}.*`, `_pi.{i}.*`,
         `_Qs.params.{i}.*` (stacked over num_q).  tdmpc2/common/layers.py:167-199."""
         nets = [(NET_DYNAMICS, "_dynamics"), (NET_REWARD, "_reward"), (NET_PI, "_pi"), (NET_Q, "_Qs.params")]
+        if self.cfg.episodic:
+            nets.append((NET_TERMINATION, "_termination"))
         keep = []
         with torch.cuda.device(self.device):
             for net, prefix in nets:
@@ -251,7 +257,8 @@ class NativePlanner:
         value = torch.empty(E, cfg.num_samples, device=dev, dtype=torch.float32)
         tiles = scalars = None
         if trace:
-            tiles = torch.zeros(E * cfg.num_samples // 64, 5 * cfg.horizon + 7, 64, cfg.latent_dim, device=dev)
+            if self.path == PATH_FUSED:  # the layered path dumps the per-row scalars only
+                tiles = torch.zeros(E * cfg.num_samples // 64, 5 * cfg.horizon + 7, 64, cfg.latent_dim, device=dev)
             scalars = torch.zeros(E, cfg.num_samples, cfg.horizon + 2 + cfg.action_dim, device=dev)
         with torch.cuda.device(dev):
             self._check(self.lib.tdmpc2_plan_estimate_value_trace(

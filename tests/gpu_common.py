@@ -12,19 +12,25 @@ def dev():
     return torch.device("cuda", 0)
 
 
-def case_on_gpu(name):
-    """(case dict, oracle model, NativePlanner with the case's weights bound)."""
-    if name in _cache:
-        return _cache[name]
+def case_on_gpu(name, path=0):
+    """(case dict, oracle model, NativePlanner with the case's weights bound).  path: 0 auto, 1 fused, 2 layered."""
+    if (name, path) in _cache:
+        return _cache[(name, path)]
     from tdmpc2_amd.native import NativePlanner
 
-    c = cases.build_case(name)
-    sd = {k: torch.as_tensor(v) for k, v in c["sd"].items()}
-    model = po.OracleModel(c["cfg"], sd)
-    planner = NativePlanner(c["cfg"], c["iterations"], dev(), max_envs=max(4, c["n_envs"]))
-    planner.bind_state_dict({k: v for k, v in sd.items()})
-    _cache[name] = (c, model, planner)
-    return _cache[name]
+    for (n, _), (c, model, _) in list(_cache.items()):
+        if n == name:
+            break
+    else:
+        c = cases.build_case(name)
+        model = po.OracleModel(c["cfg"], {k: torch.as_tensor(v) for k, v in c["sd"].items()})
+    if c["cfg"].latent_dim > 1024:  # 317M-class weights: keep one such case resident at a time
+        for k in [k for k in _cache if _cache[k][0]["cfg"].latent_dim > 1024 and k[0] != name]:
+            del _cache[k]
+    planner = NativePlanner(c["cfg"], c["iterations"], dev(), max_envs=max(2, c["n_envs"]), path=path)
+    planner.bind_state_dict(model.sd)
+    _cache[(name, path)] = (c, model, planner)
+    return _cache[(name, path)]
 
 
 def plan_inputs(c, model):

@@ -36,14 +36,14 @@ def test_library_exports_every_declared_symbol(lib):
     for sym in _declared_symbols():
         assert hasattr(lib, sym), sym
     lib.tdmpc2_plan_abi_version.restype = ctypes.c_int
-    assert lib.tdmpc2_plan_abi_version() == 1
+    assert lib.tdmpc2_plan_abi_version() == 2
 
 
 def test_cfg_struct_matches_header_layout():
     from tdmpc2_amd import native
 
-    # 12 int32 + 7 float + 4 int32, no padding
-    assert ctypes.sizeof(native.PlanCfg) == 23 * 4
+    # 12 int32 + 7 float + 5 int32, no padding
+    assert ctypes.sizeof(native.PlanCfg) == 24 * 4
     assert ctypes.sizeof(native.Noise) == 6 * ctypes.sizeof(ctypes.c_void_p)
     assert ctypes.sizeof(native.Debug) == 6 * ctypes.sizeof(ctypes.c_void_p)
 

@@ -1,0 +1,153 @@
+"""-m gpu parity tests of the LAYERED kernel family (one MFMA GEMM per nn.Linear, activations in HBM): every
+model size the fused 512-wide kernels do not cover (BASELINE configs c3 mt30-48M, c4 mt80-317M) and episodic
+planning with the termination head — against the reference golden fixtures and the oracle.
+
+Tolerances as in tests/test_gpu_planner.py (north_star: within 1e-4 fp32).
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import VALUE_RTOL, load_golden, value_err
+from tests.test_gpu_planner import _compare_stages, _oracle_stage_inputs, _run_native
+
+pytestmark = pytest.mark.gpu
+
+PATH_FUSED, PATH_LAYERED = 1, 2
+LAYERED_CASES = ["small", "small_ep", "small_mt", "c1_ep", "c3", "c4"]
+
+
+@pytest.mark.parametrize("name", LAYERED_CASES)
+def test_layered_plan_matches_reference_golden(name):
+    """Whole plan() with the recorded noise tape against the outputs of the reference's own code."""
+    from tests.gpu_common import case_on_gpu
+
+    c, model, planner = case_on_gpu(name)
+    assert planner.path == PATH_LAYERED
+    g = load_golden(name)
+    got = _run_native(c, model, planner)
+    assert np.isfinite(got["action"]).all() and np.abs(got["action"]).max() <= 1.0
+    _compare_stages(name, c, got, g, g["action"], g["prev_mean_out"])
+
+
+@pytest.mark.parametrize("name", ["c1", "mt5", "c2"])
+def test_layered_family_on_fused_size_class(name):
+    """The 512-wide cases run on BOTH kernel families: the layered one must also match the reference golden, and
+    the two families' first-iteration values agree to fp32 round-off."""
+    from tests.gpu_common import case_on_gpu
+
+    c, model, lay = case_on_gpu(name, PATH_LAYERED)
+    _, _, fus = case_on_gpu(name, PATH_FUSED)
+    assert lay.path == PATH_LAYERED and fus.path == PATH_FUSED
+    g = load_golden(name)
+    got = _run_native(c, model, lay)
+    _compare_stages(name, c, got, g, g["action"], g["prev_mean_out"])
+    ref = _run_native(c, model, fus)
+    err = value_err(got["value"][:, 0], ref["value"][:, 0])
+    print(f"[{name}] layered vs fused first-iteration value rel err {err:.3e}")
+    assert err < 2e-5
+
+
+@pytest.mark.parametrize("name", ["small", "small_ep", "small_mt", "c1_ep", "c3"])
+def test_layered_estimate_value_matches_oracle(name):
+    """_estimate_value (tdmpc2.py:122-136, incl. the termination head when episodic) on identical actions."""
+    from tests.gpu_common import case_on_gpu, dev, plan_inputs
+
+    c, model, planner = case_on_gpu(name)
+    inp = plan_inputs(c, model)
+    E = c["n_envs"]
+    for it in (0, c["iterations"] - 1):
+        acts, eps, qidx, want = [], [], [], []
+        for e in range(E):
+            _, _, st = _oracle_stage_inputs(c, model, e)
+            acts.append(st["actions"][it])
+            eps.append(torch.as_tensor(c["tape"]["pi_eps"][e, it]))
+            qidx.append(torch.as_tensor(c["tape"]["qidx"][e, it]))
+            want.append(st["value"][it])
+        got = planner.estimate_value(inp["z0"], inp["disc_pow"], torch.stack(acts).to(dev()).contiguous(),
+                                     torch.stack(eps).to(dev()).contiguous(),
+                                     torch.stack(qidx).to(dev()).to(torch.int32).contiguous(),
+                                     task_emb=inp["task_emb"], act_mask=inp["act_mask"]).cpu().numpy()
+        err = value_err(got, torch.stack(want).numpy())
+        print(f"[{name}] iteration {it}: value rel err {err:.3e}")
+        assert np.isfinite(got).all()
+        assert err < VALUE_RTOL, (name, it, err)
+
+
+def test_layered_trace_scalars_match_oracle():
+    """Per-row rewards, the two Q values and a_H against the oracle's layer-level trace (episodic off)."""
+    from oracle import planner_oracle as po
+    from tests.gpu_common import case_on_gpu, dev, plan_inputs
+
+    c, model, planner = case_on_gpu("small")
+    cfg = c["cfg"]
+    inp = plan_inputs(c, model)
+    E, H, N, A = c["n_envs"], cfg.horizon, cfg.num_samples, cfg.action_dim
+    g = torch.Generator().manual_seed(3)
+    actions = torch.rand(E, H, N, A, generator=g) * 2 - 1
+    eps = torch.randn(E, N, A, generator=g)
+    qidx = torch.tensor([[0, 2], [1, 0], [2, 1]][:E], dtype=torch.int32)
+    v, tiles, scal = planner.estimate_value(inp["z0"], inp["disc_pow"], actions.to(dev()).contiguous(),
+                                            eps.to(dev()).contiguous(), qidx.to(dev()).contiguous(), trace=True)
+    assert tiles is None
+    for e in range(E):
+        z = torch.as_tensor(c["z0"][e:e + 1]).repeat(N, 1)
+        wv, _, ws = po.trace_estimate_value(model, z, actions[e], None, c["discounts"][e], eps[e], qidx[e])
+        np.testing.assert_allclose(scal[e].cpu().numpy(), ws.numpy(), atol=2e-5, rtol=2e-5)
+        np.testing.assert_allclose(v[e].cpu().numpy(), wv.numpy(), atol=2e-5, rtol=2e-5)
+
+
+def test_layered_large_model_property_c4_l1024():
+    """BASELINE.json's text for configs[3] (latent_dim 1024, H5 N1024, 317M-class widths) at full size, checked
+    through size-independent properties: finite values, permutation equivariance over sample rows (bit-exact: the
+    arithmetic per row does not depend on the row's position) and agreement of two plans run in one batch with
+    the same plans run alone."""
+    from tdmpc2_amd import synth
+    from tdmpc2_amd.config import named_config
+    from tdmpc2_amd.native import NativePlanner
+    from tests.gpu_common import dev, disc_pow
+
+    cfg = named_config("c4_l1024")
+    sd = {k: torch.as_tensor(v) for k, v in synth.make_state_dict(cfg, seed=0).items()}
+    planner = NativePlanner(cfg, 1, dev(), max_envs=2)
+    planner.bind_state_dict(sd)
+    assert planner.path == PATH_LAYERED
+    E, H, N, A = 2, cfg.horizon, cfg.num_samples, cfg.action_dim
+    z0 = torch.as_tensor(synth.make_latents(cfg, E, seed=1)).to(dev())
+    tasks = [3, 41]
+    emb = []
+    for t in tasks:
+        e = sd["_task_emb.weight"][t]
+        n = e.norm(2)
+        emb.append(e * (1.0 / (n + 1e-7)) if n > 1.0 else e)
+    emb = torch.stack(emb).to(dev()).contiguous()
+    mask = sd["_action_masks"][torch.tensor(tasks)].to(dev()).contiguous()
+    disc = disc_pow(cfg, [0.99, 0.99]).to(dev())
+    g = torch.Generator().manual_seed(0)
+    actions = (torch.rand(E, H, N, A, generator=g) * 2 - 1).to(dev())
+    eps = torch.randn(E, N, A, generator=g).to(dev())
+    qidx = torch.tensor([[0, 7], [5, 2]], dtype=torch.int32, device=dev())
+    v = planner.estimate_value(z0, disc, actions, eps, qidx, task_emb=emb, act_mask=mask)
+    assert torch.isfinite(v).all() and v.std() > 0
+    perm = torch.randperm(N, generator=g).to(dev())
+    v2 = planner.estimate_value(z0, disc, actions[:, :, perm].contiguous(), eps[:, perm].contiguous(), qidx,
+                                task_emb=emb, act_mask=mask)
+    assert torch.equal(v[:, perm], v2)
+    for e in range(E):
+        ve = planner.estimate_value(z0[e:e + 1].contiguous(), disc[e:e + 1].contiguous(), actions[e:e + 1].contiguous(),
+                                    eps[e:e + 1].contiguous(), qidx[e:e + 1].contiguous(),
+                                    task_emb=emb[e:e + 1].contiguous(), act_mask=mask[e:e + 1].contiguous())
+        assert torch.equal(ve[0], v[e])
+    planner.close()
+
+
+def test_layered_errors_are_loud():
+    from tdmpc2_amd.config import named_config
+    from tdmpc2_amd.native import NativeError, NativePlanner
+
+    with pytest.raises(NativeError):  # tiny: num_samples 64 is not a multiple of the GEMM row tile
+        NativePlanner(named_config("tiny"), 3, torch.device("cuda", 0), path=PATH_LAYERED)
+    with pytest.raises(NativeError):  # the fused family is built for 512-wide layers only
+        NativePlanner(named_config("c3"), 6, torch.device("cuda", 0), path=PATH_FUSED)
+    with pytest.raises(NativeError):  # termination head with task ids: the reference asserts the same
+        NativePlanner(named_config("c3", episodic=True), 6, torch.device("cuda", 0))
