@@ -91,7 +91,8 @@ def cpu_baseline(cfg, iterations, sd_np, budget_s=12.0):
     def one(t0):
         nonlocal prev
         a, prev, _ = po.plan(model, z0=torch.as_tensor(z0), tape=tape, prev_mean=prev, t0=t0, eval_mode=False,
-                             task=None, discount=disc, iterations=iterations)
+                             task=0 if cfg.multitask else None,
+                             discount=torch.tensor(disc) if cfg.multitask else disc, iterations=iterations)
 
     with torch.no_grad():
         tw = time.perf_counter()
@@ -103,7 +104,7 @@ def cpu_baseline(cfg, iterations, sd_np, budget_s=12.0):
             one(False)
             n += 1
             el = time.perf_counter() - t_start
-            if (el >= budget_s and n >= 3) or n >= 64:
+            if (el >= budget_s and n >= (3 if el < 4 * budget_s else 1)) or n >= 64:
                 break
     return {"value": round(n / el, 3), "unit": "plans/s", "cores": int(torch.get_num_threads()), "kind": "port",
             "sample": f"{n} sequential plan() calls of the same workload (1 env, recorded noise tape) after 1 warm-up, "
@@ -119,6 +120,11 @@ def main():
     ap.add_argument("--envs", type=int, default=256, help="independent environments planned per GPU per step")
     ap.add_argument("--config", default="c2", help="c1 cheetah-run 5M | c2 dog-run 5M (BASELINE configs[1])")
     ap.add_argument("--iterations", type=int, default=6, help="CEM iterations (the metric is quoted at 6)")
+    ap.add_argument("--path", default="auto", choices=["auto", "fused", "layered"],
+                    help="kernel family (auto: fused for 512-wide models, layered otherwise)")
+    ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "split"],
+                    help="contraction arithmetic: exact-fp32 MFMA or f16x2-split on the f16 matrix pipe (fp32-class "
+                         "accuracy); auto = split on the fused family, fp32 on the layered one")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -149,18 +155,30 @@ def main():
     sd = {k: (torch.as_tensor(v).to(device) if rank == 0 else torch.zeros(v.shape, dtype=torch.float32, device=device))
           for k, v in sd_np.items()}
     broadcast_state_dict(sd, src=0)
-    planner = NativePlanner(cfg, I, device, max_envs=E)
+    path = {"auto": 0, "fused": 1, "layered": 2}[args.path]
+    prec = {"auto": 0, "fp32": 1, "split": 2}[args.precision]
+    planner = NativePlanner(cfg, I, device, max_envs=E, path=path, precision=prec)
+    family = {1: "fused", 2: "layered"}[planner.path]
+    arith = {1: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 2: "f16x2 split (3x v_mfma_f32_32x32x16_f16, fp32 accumulate)"}[planner.precision]
     planner.bind_state_dict(sd)
 
     z0 = torch.as_tensor(synth.make_latents(cfg, E, seed=1000 + rank)).to(device)
     disc = disc_pow_rows(cfg, E, device)
+    emb = mask = None
+    if cfg.multitask:  # one plan per task id, round-robin (the reference plans the tasks one at a time)
+        tasks = torch.arange(E) % len(cfg.tasks)
+        w = torch.as_tensor(sd_np["_task_emb.weight"])[tasks]
+        n = w.norm(dim=1, keepdim=True)
+        emb = torch.where(n > 1.0, w / (n + 1e-7), w).to(device).contiguous()  # nn.Embedding(max_norm=1)
+        mask = torch.as_tensor(sd_np["_action_masks"])[tasks].to(device).contiguous()
     prev = torch.zeros(E, cfg.horizon, cfg.action_dim, device=device)
     cold = torch.ones(E, dtype=torch.uint8, device=device)
     warm = torch.zeros(E, dtype=torch.uint8, device=device)
     out = torch.empty(E, cfg.action_dim, device=device)
 
     def step(i, flags):
-        planner.plan(z0, disc, prev, flags, eval_mode=False, tape=None, seed=(rank << 32) + i, out=out)
+        planner.plan(z0, disc, prev, flags, eval_mode=False, task_emb=emb, act_mask=mask, tape=None,
+                     seed=(rank << 32) + i, out=out)
 
     def fence():
         torch.cuda.synchronize(device)
@@ -197,17 +215,19 @@ def main():
     extra = {}
     if rank == 0:
         # single-environment latency (the reference's E = 1 semantics), reported beside the throughput
-        one = NativePlanner(cfg, I, device, max_envs=1)
+        one = NativePlanner(cfg, I, device, max_envs=1, path=path, precision=prec)
         one.bind_state_dict(sd)
         z1, d1 = z0[:1].contiguous(), disc[:1].contiguous()
+        e1 = emb[:1].contiguous() if emb is not None else None
+        m1 = mask[:1].contiguous() if mask is not None else None
         p1 = torch.zeros(1, cfg.horizon, cfg.action_dim, device=device)
         o1 = torch.empty(1, cfg.action_dim, device=device)
         for i in range(2):
-            one.plan(z1, d1, p1, warm[:1], seed=i, out=o1)
+            one.plan(z1, d1, p1, warm[:1], seed=i, out=o1, task_emb=e1, act_mask=m1)
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
         for i in range(5):
-            one.plan(z1, d1, p1, warm[:1], seed=10 + i, out=o1)
+            one.plan(z1, d1, p1, warm[:1], seed=10 + i, out=o1, task_emb=e1, act_mask=m1)
         torch.cuda.synchronize(device)
         extra["latency_ms_single_env"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
 
@@ -221,7 +241,7 @@ def main():
     value = plans / elapsed
     launch_s = (roll_ms / 1e3) / max(roll_n, 1)
     achieved = flops_rollout_launch(cfg, E) / launch_s / 1e12
-    traffic, traffic_src = pmc_traffic(E * cfg.num_samples // 64)
+    traffic, traffic_src = pmc_traffic(E * cfg.num_samples // 64) if family == "fused" else (None, None)
     line = {
         "metric": "plan() calls/sec (H=3, 512 samples, 6 iters)",
         "value": round(value, 2),
@@ -236,11 +256,11 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"{args.config}: {cfg.task} 5M-class world model (L{cfg.latent_dim} M{cfg.mlp_dim} A{cfg.action_dim} "
-                        f"nq{cfg.num_q}), plan() H={cfg.horizon} N={cfg.num_samples} K={cfg.num_elites} "
+            "workload": f"{args.config}: {cfg.task} world model (L{cfg.latent_dim} M{cfg.mlp_dim} A{cfg.action_dim} "
+                        f"nq{cfg.num_q} T{cfg.task_dim}), plan() H={cfg.horizon} N={cfg.num_samples} K={cfg.num_elites} "
                         f"P={cfg.num_pi_trajs} I={I}, {E} independent envs per GPU per step, random-init weights, "
                         f"SimNorm latents, in-kernel Philox noise",
-            "envs_per_gpu": E, "iterations": I, "parallelism": f"env-sharded x{world}",
+            "envs_per_gpu": E, "iterations": I, "parallelism": f"env-sharded x{world}", "kernel_family": family, "arithmetic": arith,
             "gflop_per_plan_as_written": round(flops_plan(cfg, I) / 1e9, 3),
         },
         "roofline": {
@@ -248,10 +268,11 @@ def main():
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
             "traffic_unit": "bytes per launch (HBM/fabric side of L2: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
             "traffic_source": traffic_src,
-            "kernel": "k_rollout", "launches_timed": roll_n, "avg_launch_ms": round(1e3 * launch_s, 4),
+            "kernel": "k_rollout" if family == "fused" else "g_gemm + row kernels of one _estimate_value",
+            "launches_timed": roll_n, "avg_launch_ms": round(1e3 * launch_s, 4),
             "note": "achieved = as-written FLOPs of one CEM iteration (all num_q Q heads, SURVEY 8(d)) x envs / "
-                    "mean k_rollout duration (HIP events on the launch stream); the kernel executes fewer "
-                    "(2 of num_q heads, shared z0 product at t=0); peak = fp32-input MFMA (exact fp32)",
+                    "mean duration of that iteration's rollout stage (HIP events on the launch stream); the kernels "
+                    "execute fewer (2 of num_q heads; fused: shared z0 product at t=0); peak = fp32-input MFMA (exact fp32)",
         },
         "plan_tflops_as_written": round(value * flops_plan(cfg, I) / 1e12, 2),
         "extra": extra,

@@ -53,6 +53,7 @@ typedef struct tdmpc2_plan_cfg {
     int32_t max_envs;                 /* workspace is sized for this many concurrent plans */
     int32_t device;                   /* HIP device ordinal */
     int32_t path;                     /* enum tdmpc2_path: which kernel family runs the rollout */
+    int32_t precision;                /* enum tdmpc2_precision: how the fp32 contractions are carried out */
 } tdmpc2_plan_cfg;
 
 /* Two kernel families implement the same math (results agree to fp32 round-off):
@@ -62,6 +63,14 @@ typedef struct tdmpc2_plan_cfg {
  *           latent_dim / mlp_dim that are multiples of 32 (1M ... 317M models), episodic or not.
  * AUTO picks FUSED when the configuration fits it, else LAYERED. */
 enum tdmpc2_path { TDMPC2_PATH_AUTO = 0, TDMPC2_PATH_FUSED = 1, TDMPC2_PATH_LAYERED = 2 };
+
+/* Arithmetic of the nn.Linear contractions (everything else is fp32 in both modes):
+ *   FP32       v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation (bitwise an fmaf chain).
+ *   SPLIT_F16  every fp32 operand is carried as hi + lo f16 pieces (22 significand bits) and a product is
+ *              a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation: fp32-class
+ *              error (checked against fp64 in the tests) at up to 16/3 of the fp32 matrix rate.  FUSED only.
+ * AUTO = SPLIT_F16 where available (FUSED), FP32 otherwise. */
+enum tdmpc2_precision { TDMPC2_PREC_AUTO = 0, TDMPC2_PREC_FP32 = 1, TDMPC2_PREC_SPLIT_F16 = 2 };
 
 enum tdmpc2_net {
     TDMPC2_NET_DYNAMICS = 0,    /* WorldModel._dynamics     world_model.py:26 */
@@ -112,8 +121,9 @@ void tdmpc2_plan_destroy(tdmpc2_plan_t *h);
 /* Bytes of device memory held by the handle (packed weights + workspace). */
 uint64_t tdmpc2_plan_device_bytes(const tdmpc2_plan_t *h);
 
-/* The kernel family the handle resolved to (TDMPC2_PATH_FUSED or TDMPC2_PATH_LAYERED). */
+/* The kernel family / arithmetic the handle resolved to (never the AUTO values). */
 int tdmpc2_plan_path(const tdmpc2_plan_t *h);
+int tdmpc2_plan_precision(const tdmpc2_plan_t *h);
 
 /* Hand one layer of one network to the planner.  Pointers are device fp32 in
  * the checkpoint's own layout (nn.Linear: W[out,in] row-major, b[out];

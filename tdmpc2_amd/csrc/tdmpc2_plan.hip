@@ -63,12 +63,13 @@ struct NetW {
     LayerW l[3];
 };
 
-struct RolloutParams {
+template <class NET>
+struct RolloutParamsT {
     int E, N, H, A, Apad, P, stride, tiles, nq, num_bins, multitask, given_actions, iter, iters_total;
     int nnets;  // vectors per plan in `beff`
     float log_std_min, log_std_dif;
-    NetW dyn, rew, pi;
-    NetW q[MAXQ];
+    NET dyn, rew, pi;
+    NET q[MAXQ];
     const float *bins;
     const float *z0;        // [E,L]
     const float *beff;      // [E,nnets,WIDTH] effective first-layer biases (multitask) or null
@@ -91,6 +92,7 @@ struct RolloutParams {
     float *trace_tiles;    // optional [E*tiles, 5H+7, 64, WIDTH] activations after each phase
     float *trace_scalars;  // optional [E, N, H+2+A]: r_0..r_{H-1}, Q_a, Q_b, a_H[A]
 };
+using RolloutParams = RolloutParamsT<NetW>;
 
 // net slots inside `beff`
 enum { BE_DYN = 0, BE_REW = 1, BE_PI = 2, BE_Q0 = 3 };
@@ -453,16 +455,18 @@ __device__ __forceinline__ void dump_tile(const Ctx &c, float *trace, int nslot,
 // grid = E.  (1) effective first-layer biases b + W[:, L:L+T] . task_emb (multitask);
 // (2) cvec = z0-part (+ bias) of the reward / dynamics first layers (all rows share z0 at t = 0,
 //     tdmpc2/tdmpc2.py:163); (3) mean / std initialisation and warm start (tdmpc2.py:164-167).
-struct SetupParams {
+template <class NET>
+struct SetupParamsT {
     int E, H, A, T, multitask, nq, nnets, stride;
     float max_std;
-    NetW dyn, rew, pi;
-    NetW q[MAXQ];
+    NET dyn, rew, pi;
+    NET q[MAXQ];
     const float *wemb[3 + MAXQ];  // [out=WIDTH][T] task-embedding columns of each first layer
     const float *z0, *task_emb, *prev_mean;
     const unsigned char *t0;
     float *beff, *cvec, *mean, *std;
 };
+using SetupParams = SetupParamsT<NetW>;
 
 __global__ __launch_bounds__(NTHREADS, 2) void k_setup(SetupParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -510,10 +514,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void k_setup(SetupParams p) {
 
 // ================================================================ kernel: policy-prior trajectories
 // grid = E (rows < P of one tile are meaningful).  tdmpc2/tdmpc2.py:154-160.
-struct PiTrajParams {
+template <class NET>
+struct PiTrajParamsT {
     int E, N, H, A, Apad, P, stride, multitask, nnets;
     float log_std_min, log_std_dif;
-    NetW dyn, pi;
+    NET dyn, pi;
     const float *z0, *beff, *act_mask;
     const float *pi_traj_eps;  // [E,H,P,A] or null
     unsigned long long seed;
@@ -522,6 +527,7 @@ struct PiTrajParams {
     float *zscratch;  // [E,64,WIDTH] (tile 0 of each plan)
     long zscratch_estride;
 };
+using PiTrajParams = PiTrajParamsT<NetW>;
 
 __global__ __launch_bounds__(NTHREADS, 2) void k_pitraj(PiTrajParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -895,6 +901,7 @@ __global__ void k_copy_pad(const float *src, int n, int npad, float *dst) {
         dst[idx] = idx < n ? src[idx] : 0.f;
 }
 
+#include "fused_split.cuh"
 #include "layered_kernels.cuh"
 
 // ================================================================ host side
@@ -916,8 +923,12 @@ int fail(int code, const char *fmt, ...) {
 
 struct HostLayer {
     float *wp = nullptr, *bias = nullptr, *g = nullptr, *b = nullptr, *wemb = nullptr;
-    int KB = 0, CT = 0, out = 0;
-    bool bound = false;
+    // f16x2-split form (fused_split.cuh): hi/lo packed weights, per-matrix power-of-two scales (device scalars)
+    _Float16 *wps = nullptr;
+    float *wscale = nullptr, *oscale = nullptr;
+    unsigned int *maxbits = nullptr;
+    int KB = 0, CT = 0, out = 0;  // KB: k-blocks of 8 (fp32 MFMA) or of 16 (split)
+    bool bound = false, alloc = false;
 };
 struct HostNet {
     HostLayer l[3];
@@ -939,6 +950,7 @@ struct Layered {
 struct tdmpc2_plan {
     tdmpc2_plan_cfg cfg;
     Layered lay;
+    bool split = false;  // fused kernels on the f16 matrix pipe with hi/lo operand split (fused_split.cuh)
     int Apad = 0, stride = 0, tiles = 0, nnets = 0;
     size_t lds_bytes = 0;
     HostNet dyn, rew, pi, term;
@@ -964,10 +976,15 @@ int dev_alloc(tdmpc2_plan *h, void **p, size_t bytes) {
     return 0;
 }
 
-LayerW to_dev(const HostLayer &l) { return LayerW{l.wp, l.bias, l.g, l.b, l.KB, l.CT}; }
-NetW to_dev(const HostNet &n) {
+template <class NET> NET to_dev(const HostNet &n);
+template <> NetW to_dev<NetW>(const HostNet &n) {
     NetW w;
-    for (int i = 0; i < 3; ++i) w.l[i] = to_dev(n.l[i]);
+    for (int i = 0; i < 3; ++i) w.l[i] = LayerW{n.l[i].wp, n.l[i].bias, n.l[i].g, n.l[i].b, n.l[i].KB, n.l[i].CT};
+    return w;
+}
+template <> NetS to_dev<NetS>(const HostNet &n) {
+    NetS w;
+    for (int i = 0; i < 3; ++i) w.l[i] = LayerS{n.l[i].wps, n.l[i].bias, n.l[i].g, n.l[i].b, n.l[i].oscale, n.l[i].KB, n.l[i].CT};
     return w;
 }
 
@@ -1001,29 +1018,44 @@ int set_lds(K kernel, size_t bytes) {
     return 0;
 }
 
+// Kernel family of the fused path by operand form: NetW = exact fp32 MFMA, NetS = f16x2 split.
+template <class NET> struct Kern;
+template <> struct Kern<NetW> {
+    static void setup(const SetupParamsT<NetW> &p, int E, size_t lds, hipStream_t st) { hipLaunchKernelGGL(k_setup, dim3(E), dim3(NTHREADS), lds, st, p); }
+    static void pitraj(const PiTrajParamsT<NetW> &p, int E, size_t lds, hipStream_t st) { hipLaunchKernelGGL(k_pitraj, dim3(E), dim3(NTHREADS), lds, st, p); }
+    static void rollout(const RolloutParamsT<NetW> &p, int grid, size_t lds, hipStream_t st) { hipLaunchKernelGGL(k_rollout, dim3(grid), dim3(NTHREADS), lds, st, p); }
+};
+template <> struct Kern<NetS> {
+    static void setup(const SetupParamsT<NetS> &p, int E, size_t lds, hipStream_t st) { hipLaunchKernelGGL(ks_setup, dim3(E), dim3(NTHREADS), lds, st, p); }
+    static void pitraj(const PiTrajParamsT<NetS> &p, int E, size_t lds, hipStream_t st) { hipLaunchKernelGGL(ks_pitraj, dim3(E), dim3(NTHREADS), lds, st, p); }
+    static void rollout(const RolloutParamsT<NetS> &p, int grid, size_t lds, hipStream_t st) { hipLaunchKernelGGL(ks_rollout, dim3(grid), dim3(NTHREADS), lds, st, p); }
+};
+
+template <class NET>
 int launch_setup(tdmpc2_plan *h, int E, const float *z0, const float *task_emb, const float *prev_mean,
                  const unsigned char *t0, hipStream_t st) {
-    SetupParams p{};
+    SetupParamsT<NET> p{};
     p.E = E; p.H = h->cfg.horizon; p.A = h->cfg.action_dim; p.T = h->cfg.task_dim; p.multitask = h->cfg.multitask;
     p.nq = h->cfg.num_q; p.nnets = h->nnets; p.stride = h->stride; p.max_std = h->cfg.max_std;
-    p.dyn = to_dev(h->dyn); p.rew = to_dev(h->rew); p.pi = to_dev(h->pi);
-    for (int i = 0; i < h->cfg.num_q; ++i) p.q[i] = to_dev(h->q[i]);
+    p.dyn = to_dev<NET>(h->dyn); p.rew = to_dev<NET>(h->rew); p.pi = to_dev<NET>(h->pi);
+    for (int i = 0; i < h->cfg.num_q; ++i) p.q[i] = to_dev<NET>(h->q[i]);
     p.wemb[BE_DYN] = h->dyn.l[0].wemb; p.wemb[BE_REW] = h->rew.l[0].wemb; p.wemb[BE_PI] = h->pi.l[0].wemb;
     for (int i = 0; i < h->cfg.num_q; ++i) p.wemb[BE_Q0 + i] = h->q[i].l[0].wemb;
     p.z0 = z0; p.task_emb = task_emb; p.prev_mean = prev_mean; p.t0 = t0;
     p.beff = h->beff; p.cvec = h->cvec; p.mean = h->mean; p.std = h->std;
-    hipLaunchKernelGGL(k_setup, dim3(E), dim3(NTHREADS), h->lds_bytes, st, p);
+    Kern<NET>::setup(p, E, h->lds_bytes, st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-void fill_rollout(tdmpc2_plan *h, RolloutParams &p, int E) {
+template <class NET>
+void fill_rollout(tdmpc2_plan *h, RolloutParamsT<NET> &p, int E) {
     const tdmpc2_plan_cfg &c = h->cfg;
     p.E = E; p.N = c.num_samples; p.H = c.horizon; p.A = c.action_dim; p.Apad = h->Apad; p.P = c.num_pi_trajs;
     p.stride = h->stride; p.tiles = h->tiles; p.nq = c.num_q; p.num_bins = c.num_bins; p.multitask = c.multitask;
     p.nnets = h->nnets; p.log_std_min = c.log_std_min; p.log_std_dif = c.log_std_dif;
-    p.dyn = to_dev(h->dyn); p.rew = to_dev(h->rew); p.pi = to_dev(h->pi);
-    for (int i = 0; i < c.num_q; ++i) p.q[i] = to_dev(h->q[i]);
+    p.dyn = to_dev<NET>(h->dyn); p.rew = to_dev<NET>(h->rew); p.pi = to_dev<NET>(h->pi);
+    for (int i = 0; i < c.num_q; ++i) p.q[i] = to_dev<NET>(h->q[i]);
     p.bins = h->bins; p.beff = h->beff; p.cvec = h->cvec; p.mean = h->mean; p.std = h->std;
     p.actions = h->actions; p.value = h->value; p.zscratch = h->zscratch;
     p.iters_total = c.iterations;
@@ -1036,6 +1068,95 @@ int validate_envs(tdmpc2_plan *h, int E) {
 }
 
 #include "layered_host.cuh"
+
+// Everything of TDMPC2._plan after encode() (tdmpc2/tdmpc2.py:154-206) on the fused 512-wide path.
+template <class NET>
+int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float *task_emb, const float *act_mask,
+              const float *disc_pow, float *prev_mean, const uint8_t *t0, int eval_mode, const tdmpc2_noise *tape,
+              uint64_t seed, float *action, const tdmpc2_debug *dbg) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    const int H = c.horizon, N = c.num_samples, A = c.action_dim, K = c.num_elites, P = c.num_pi_trajs, I = c.iterations;
+    const unsigned call = h->call++;
+    int rc;
+    if ((rc = launch_setup<NET>(h, E, z0, task_emb, prev_mean, t0, st))) return rc;
+    if (P > 0) {
+        PiTrajParamsT<NET> p{};
+        p.E = E; p.N = N; p.H = H; p.A = A; p.Apad = h->Apad; p.P = P; p.stride = h->stride; p.multitask = c.multitask;
+        p.nnets = h->nnets; p.log_std_min = c.log_std_min; p.log_std_dif = c.log_std_dif;
+        p.dyn = to_dev<NET>(h->dyn); p.pi = to_dev<NET>(h->pi);
+        p.z0 = z0; p.beff = h->beff; p.act_mask = act_mask; p.pi_traj_eps = tape ? tape->pi_traj_eps : nullptr;
+        p.seed = seed; p.call = call; p.actions = h->actions; p.zscratch = h->zscratch;
+        p.zscratch_estride = (long)h->tiles * ROWS * WIDTH;
+        Kern<NET>::pitraj(p, E, h->lds_bytes, st);
+        HIP_TRY(hipGetLastError());
+    }
+    RolloutParamsT<NET> rp{};
+    fill_rollout<NET>(h, rp, E);
+    rp.z0 = z0; rp.act_mask = act_mask; rp.disc_pow = disc_pow; rp.seed = seed; rp.call = call; rp.given_actions = 0;
+    const size_t refit_lds = ((size_t)N + 3 * K + 2 * H * A) * 4 + 64;
+    for (int it = 0; it < I; ++it) {
+        rp.iter = it;
+        if (tape) {
+            rp.sample_eps = tape->sample_eps + (size_t)it * H * (N - P) * A;
+            rp.sample_eps_estride = (long)I * H * (N - P) * A;
+            rp.pi_eps = tape->pi_eps + (size_t)it * N * A;
+            rp.pi_eps_estride = (long)I * N * A;
+            rp.qidx = tape->qidx + (size_t)it * 2;
+            rp.qidx_estride = (long)I * 2;
+        }
+        if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
+        Kern<NET>::rollout(rp, E * h->tiles, h->lds_bytes, st);
+        HIP_TRY(hipGetLastError());
+        if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) {
+            HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
+            h->ev_used += 2;
+        }
+        if (dbg && dbg->actions)
+            HIP_TRY(hipMemcpy2DAsync(dbg->actions + (size_t)it * H * N * A, (size_t)I * H * N * A * 4, h->actions,
+                                     (size_t)H * N * A * 4, (size_t)H * N * A * 4, E, hipMemcpyDeviceToDevice, st));
+        RefitParams fp{};
+        fp.E = E; fp.N = N; fp.H = H; fp.A = A; fp.K = K; fp.iter = it; fp.last = (it == I - 1); fp.eval_mode = eval_mode;
+        fp.temperature = c.temperature; fp.min_std = c.min_std; fp.max_std = c.max_std;
+        fp.value = h->value; fp.actions = h->actions; fp.act_mask = act_mask; fp.mean = h->mean; fp.std = h->std;
+        fp.gumbel_exp = tape ? tape->gumbel_exp : nullptr; fp.final_eps = tape ? tape->final_eps : nullptr;
+        fp.seed = seed; fp.call = call; fp.prev_mean = prev_mean; fp.action = action;
+        if (dbg) {
+            if (dbg->value) { fp.dbg_value = dbg->value + (size_t)it * N; fp.dbg_value_es = (long)I * N; }
+            if (dbg->elite_idx) { fp.dbg_idx = dbg->elite_idx + (size_t)it * K; fp.dbg_idx_es = (long)I * K; }
+            if (dbg->score) { fp.dbg_score = dbg->score + (size_t)it * K; fp.dbg_score_es = (long)I * K; }
+            if (dbg->mean) { fp.dbg_mean = dbg->mean + (size_t)it * H * A; fp.dbg_mean_es = (long)I * H * A; }
+            if (dbg->std) { fp.dbg_std = dbg->std + (size_t)it * H * A; fp.dbg_std_es = (long)I * H * A; }
+        }
+        hipLaunchKernelGGL(k_refit, dim3(E), dim3(N), refit_lds, st, fp);
+        HIP_TRY(hipGetLastError());
+    }
+    return TDMPC2_OK;
+}
+
+// TDMPC2._estimate_value (tdmpc2/tdmpc2.py:122-136) on given action sequences, fused path.
+template <class NET>
+int fused_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float *task_emb,
+                         const float *act_mask, const float *disc_pow, const float *actions, const float *pi_eps,
+                         const int32_t *qidx, float *value, float *trace_tiles, float *trace_scalars) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    const int N = c.num_samples, A = c.action_dim;
+    int rc;
+    // setup needs prev_mean / t0 only for mean/std init, which this entry does not use: feed dummies
+    HIP_TRY(hipMemsetAsync(h->mean, 0, (size_t)E * c.horizon * A * 4, st));
+    HIP_TRY(hipMemsetAsync(h->value, 1, (size_t)E, st));  // E bytes of ones used as t0 = 1 flags (no warm start read)
+    if ((rc = launch_setup<NET>(h, E, z0, task_emb, h->mean, reinterpret_cast<const unsigned char *>(h->value), st))) return rc;
+    RolloutParamsT<NET> rp{};
+    fill_rollout<NET>(h, rp, E);
+    rp.z0 = z0; rp.act_mask = act_mask; rp.disc_pow = disc_pow; rp.given_actions = 1; rp.iter = 0;
+    rp.actions = const_cast<float *>(actions);
+    rp.value = value;
+    rp.pi_eps = pi_eps; rp.pi_eps_estride = (long)N * A;
+    rp.qidx = qidx; rp.qidx_estride = 2;
+    rp.trace_tiles = trace_tiles; rp.trace_scalars = trace_scalars;
+    Kern<NET>::rollout(rp, E * h->tiles, h->lds_bytes, st);
+    HIP_TRY(hipGetLastError());
+    return TDMPC2_OK;
+}
 
 }  // namespace
 
@@ -1077,23 +1198,37 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
         return fail(TDMPC2_ERR_UNSUPPORTED, "layered planner kernels need latent_dim %% 32 == 0, mlp_dim %% 32 == 0 and "
                     "num_samples %% %d == 0 (got %d / %d / %d)", GBM, c.latent_dim, c.mlp_dim, c.num_samples);
     if (path != TDMPC2_PATH_FUSED && path != TDMPC2_PATH_LAYERED) return fail(TDMPC2_ERR_INVALID, "unknown path %d", c.path);
+    int prec = c.precision;
+    if (prec == TDMPC2_PREC_AUTO) prec = path == TDMPC2_PATH_FUSED ? TDMPC2_PREC_SPLIT_F16 : TDMPC2_PREC_FP32;
+    if (prec != TDMPC2_PREC_FP32 && prec != TDMPC2_PREC_SPLIT_F16) return fail(TDMPC2_ERR_INVALID, "unknown precision %d", c.precision);
+    if (prec == TDMPC2_PREC_SPLIT_F16 && path != TDMPC2_PATH_FUSED)
+        return fail(TDMPC2_ERR_UNSUPPORTED, "the f16x2-split arithmetic is built for the fused kernel family only");
     if (hipSetDevice(c.device) != hipSuccess) return fail(TDMPC2_ERR_HIP, "hipSetDevice(%d) failed", c.device);
 
     tdmpc2_plan *h = new (std::nothrow) tdmpc2_plan();
     if (!h) return fail(TDMPC2_ERR_INVALID, "out of host memory");
     h->cfg = c;
     h->cfg.path = path;
+    h->cfg.precision = prec;
     h->lay.on = (path == TDMPC2_PATH_LAYERED);
-    h->Apad = (c.action_dim + 7) / 8 * 8;
+    h->split = (prec == TDMPC2_PREC_SPLIT_F16);
+    h->Apad = h->split ? (c.action_dim + 15) / 16 * 16 : (c.action_dim + 7) / 8 * 8;
     h->tiles = c.num_samples / ROWS;
     h->nnets = BE_Q0 + c.num_q;
     int rc = 0;
     const size_t E = c.max_envs, H = c.horizon, N = c.num_samples, A = c.action_dim;
     if (!h->lay.on) {
-        // row stride: [z (512) | a (Apad) | pad] with stride/4 odd: conflict-free ds_read_b128 across 16 rows
-        h->stride = WIDTH + h->Apad + 4;
-        if ((h->stride / 4) % 2 == 0) h->stride += 4;
-        h->lds_bytes = (size_t)ROWS * h->stride * 4 + (size_t)2 * c.horizon * c.action_dim * 4 + 64;
+        if (h->split) {
+            // operand form: row = [hi: SH halfs | lo: SH halfs | 8 pad]; row stride in dwords SH + 4 = 4 x odd
+            const int SH = WIDTH + h->Apad;
+            h->stride = 2 * SH + 8;  // in halfs
+            h->lds_bytes = (size_t)ROWS * h->stride * 2 + (size_t)2 * c.horizon * c.action_dim * 4 + 64;
+        } else {
+            // row stride: [z (512) | a (Apad) | pad] with stride/4 odd: conflict-free ds_read_b128 across 16 rows
+            h->stride = WIDTH + h->Apad + 4;
+            if ((h->stride / 4) % 2 == 0) h->stride += 4;
+            h->lds_bytes = (size_t)ROWS * h->stride * 4 + (size_t)2 * c.horizon * c.action_dim * 4 + 64;
+        }
         if (h->lds_bytes > 160 * 1024) {
             const size_t need = h->lds_bytes;
             delete h;
@@ -1150,8 +1285,13 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
         tdmpc2_plan_destroy(h);
         return fail(TDMPC2_ERR_HIP, "hipMemcpy(bins) failed");
     }
-    if (!h->lay.on && ((rc = set_lds(k_setup, h->lds_bytes)) || (rc = set_lds(k_pitraj, h->lds_bytes)) ||
-                       (rc = set_lds(k_rollout, h->lds_bytes)))) {
+    if (!h->lay.on && !h->split && ((rc = set_lds(k_setup, h->lds_bytes)) || (rc = set_lds(k_pitraj, h->lds_bytes)) ||
+                                    (rc = set_lds(k_rollout, h->lds_bytes)))) {
+        tdmpc2_plan_destroy(h);
+        return rc;
+    }
+    if (h->split && ((rc = set_lds(ks_setup, h->lds_bytes)) || (rc = set_lds(ks_pitraj, h->lds_bytes)) ||
+                     (rc = set_lds(ks_rollout, h->lds_bytes)))) {
         tdmpc2_plan_destroy(h);
         return rc;
     }
@@ -1168,6 +1308,7 @@ void tdmpc2_plan_destroy(tdmpc2_plan_t *h) {
 
 uint64_t tdmpc2_plan_device_bytes(const tdmpc2_plan_t *h) { return h ? h->bytes : 0; }
 int tdmpc2_plan_path(const tdmpc2_plan_t *h) { return h ? h->cfg.path : -1; }
+int tdmpc2_plan_precision(const tdmpc2_plan_t *h) { return h ? h->cfg.precision : -1; }
 
 int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *W, const float *b, const float *ln_g,
                              const float *ln_b, int out_features, int in_features, void *stream) {
@@ -1204,17 +1345,19 @@ int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *
     const int na = (layer == 0 && takes_action) ? c.action_dim : 0;
     // packed contraction length: FUSED pads the action columns to a multiple of 8 (one k-block), LAYERED pads the
     // whole row to a multiple of the GEMM k-chunk
-    const int Kp = h->lay.on ? (int)round_up((size_t)nz + na, GBK) : nz + (na + 7) / 8 * 8;
-    const int KB = Kp / 8;
+    const int Kp = h->lay.on ? (int)round_up((size_t)nz + na, GBK) : h->split ? nz + (na + 15) / 16 * 16 : nz + (na + 7) / 8 * 8;
+    const int KB = h->split ? Kp / 16 : Kp / 8;
     const int CT = (out_features + 31) / 32;
     // one slab per tensor kind holding all ensemble members at a constant stride (the layered GEMM selects a member
     // per plan by stride); allocated on first bind
-    const size_t wsz = (size_t)CT * KB * 256, bsz = (size_t)CT * 32, gsz = round_up((size_t)out_features, 4),
+    const size_t wsz = h->split ? (size_t)CT * KB * 512 /* floats' worth of 1024 halfs */ : (size_t)CT * KB * 256,
+                 bsz = (size_t)CT * 32, gsz = round_up((size_t)out_features, 4),
                  esz = (size_t)out_features * (nt > 0 ? nt : 0);
     HostLayer &L0 = net_of(h, net, 0)->l[layer];
-    if (!L0.wp) {
-        float *wslab = nullptr, *bslab = nullptr, *gslab = nullptr, *betaslab = nullptr, *eslab = nullptr;
+    if (!L0.alloc) {
+        float *wslab = nullptr, *bslab = nullptr, *gslab = nullptr, *betaslab = nullptr, *eslab = nullptr, *sslab = nullptr;
         int rc;
+        if (h->split && (rc = dev_alloc(h, (void **)&sslab, heads * 4 * 4))) return rc;
         if ((rc = dev_alloc(h, (void **)&wslab, heads * wsz * 4))) return rc;
         if ((rc = dev_alloc(h, (void **)&bslab, heads * bsz * 4))) return rc;
         if (has_ln) {
@@ -1224,7 +1367,15 @@ int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *
         if (nt > 0 && (rc = dev_alloc(h, (void **)&eslab, heads * esz * 4))) return rc;
         for (int hd = 0; hd < heads; ++hd) {
             HostLayer &L = net_of(h, net, hd)->l[layer];
-            L.wp = wslab + hd * wsz;
+            L.alloc = true;
+            if (h->split) {
+                L.wps = reinterpret_cast<_Float16 *>(wslab + hd * wsz);
+                L.wscale = sslab + hd * 4;
+                L.oscale = sslab + hd * 4 + 1;
+                L.maxbits = reinterpret_cast<unsigned int *>(sslab + hd * 4 + 2);
+            } else {
+                L.wp = wslab + hd * wsz;
+            }
             L.bias = bslab + hd * bsz;
             L.g = has_ln ? gslab + hd * gsz : nullptr;
             L.b = has_ln ? betaslab + hd * gsz : nullptr;
@@ -1235,7 +1386,15 @@ int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *
         HostLayer &L = net_of(h, net, hd)->l[layer];
         L.KB = KB; L.CT = CT; L.out = out_features;
         const float *Wh = W + (size_t)hd * out_features * in_features;
-        hipLaunchKernelGGL(k_pack_weight, dim3(512), dim3(256), 0, st, Wh, out_features, in_features, nz, nt, na, CT, KB, L.wp);
+        if (h->split) {
+            HIP_TRY(hipMemsetAsync(L.maxbits, 0, 4, st));
+            hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, st, Wh, (size_t)out_features * in_features, L.maxbits);
+            hipLaunchKernelGGL(k_wscale, dim3(1), dim3(1), 0, st, L.maxbits, L.wscale, L.oscale);
+            hipLaunchKernelGGL(k_pack_split, dim3(512), dim3(256), 0, st, Wh, out_features, in_features, nz, nt, na, CT, KB,
+                               L.wscale, L.wps);
+        } else {
+            hipLaunchKernelGGL(k_pack_weight, dim3(512), dim3(256), 0, st, Wh, out_features, in_features, nz, nt, na, CT, KB, L.wp);
+        }
         hipLaunchKernelGGL(k_copy_pad, dim3(1), dim3(256), 0, st, b + (size_t)hd * out_features, out_features, CT * 32, L.bias);
         if (has_ln) {
             const int gb = (out_features + 255) / 256;
@@ -1292,63 +1451,9 @@ int tdmpc2_plan_run(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *
     hipStream_t st = (hipStream_t)stream;
     if (h->lay.on)
         return lay_run(h, st, n_envs, z0, task_emb, act_mask, disc_pow, prev_mean, t0, eval_mode, tape, seed, action, dbg);
-    const int E = n_envs, H = c.horizon, N = c.num_samples, A = c.action_dim, K = c.num_elites, P = c.num_pi_trajs,
-              I = c.iterations;
-    const unsigned call = h->call++;
-
-    if ((rc = launch_setup(h, E, z0, task_emb, prev_mean, t0, st))) return rc;
-    if (P > 0) {
-        PiTrajParams p{};
-        p.E = E; p.N = N; p.H = H; p.A = A; p.Apad = h->Apad; p.P = P; p.stride = h->stride; p.multitask = c.multitask;
-        p.nnets = h->nnets; p.log_std_min = c.log_std_min; p.log_std_dif = c.log_std_dif;
-        p.dyn = to_dev(h->dyn); p.pi = to_dev(h->pi);
-        p.z0 = z0; p.beff = h->beff; p.act_mask = act_mask; p.pi_traj_eps = tape ? tape->pi_traj_eps : nullptr;
-        p.seed = seed; p.call = call; p.actions = h->actions; p.zscratch = h->zscratch;
-        p.zscratch_estride = (long)h->tiles * ROWS * WIDTH;
-        hipLaunchKernelGGL(k_pitraj, dim3(E), dim3(NTHREADS), h->lds_bytes, st, p);
-        HIP_TRY(hipGetLastError());
-    }
-    RolloutParams rp{};
-    fill_rollout(h, rp, E);
-    rp.z0 = z0; rp.act_mask = act_mask; rp.disc_pow = disc_pow; rp.seed = seed; rp.call = call; rp.given_actions = 0;
-    const size_t refit_lds = ((size_t)N + 3 * K + 2 * H * A) * 4 + 64;
-    for (int it = 0; it < I; ++it) {
-        rp.iter = it;
-        if (tape) {
-            rp.sample_eps = tape->sample_eps + (size_t)it * H * (N - P) * A;
-            rp.sample_eps_estride = (long)I * H * (N - P) * A;
-            rp.pi_eps = tape->pi_eps + (size_t)it * N * A;
-            rp.pi_eps_estride = (long)I * N * A;
-            rp.qidx = tape->qidx + (size_t)it * 2;
-            rp.qidx_estride = (long)I * 2;
-        }
-        if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
-        hipLaunchKernelGGL(k_rollout, dim3(E * h->tiles), dim3(NTHREADS), h->lds_bytes, st, rp);
-        HIP_TRY(hipGetLastError());
-        if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) {
-            HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
-            h->ev_used += 2;
-        }
-        if (dbg && dbg->actions)
-            HIP_TRY(hipMemcpy2DAsync(dbg->actions + (size_t)it * H * N * A, (size_t)I * H * N * A * 4, h->actions,
-                                     (size_t)H * N * A * 4, (size_t)H * N * A * 4, E, hipMemcpyDeviceToDevice, st));
-        RefitParams fp{};
-        fp.E = E; fp.N = N; fp.H = H; fp.A = A; fp.K = K; fp.iter = it; fp.last = (it == I - 1); fp.eval_mode = eval_mode;
-        fp.temperature = c.temperature; fp.min_std = c.min_std; fp.max_std = c.max_std;
-        fp.value = h->value; fp.actions = h->actions; fp.act_mask = act_mask; fp.mean = h->mean; fp.std = h->std;
-        fp.gumbel_exp = tape ? tape->gumbel_exp : nullptr; fp.final_eps = tape ? tape->final_eps : nullptr;
-        fp.seed = seed; fp.call = call; fp.prev_mean = prev_mean; fp.action = action;
-        if (dbg) {
-            if (dbg->value) { fp.dbg_value = dbg->value + (size_t)it * N; fp.dbg_value_es = (long)I * N; }
-            if (dbg->elite_idx) { fp.dbg_idx = dbg->elite_idx + (size_t)it * K; fp.dbg_idx_es = (long)I * K; }
-            if (dbg->score) { fp.dbg_score = dbg->score + (size_t)it * K; fp.dbg_score_es = (long)I * K; }
-            if (dbg->mean) { fp.dbg_mean = dbg->mean + (size_t)it * H * A; fp.dbg_mean_es = (long)I * H * A; }
-            if (dbg->std) { fp.dbg_std = dbg->std + (size_t)it * H * A; fp.dbg_std_es = (long)I * H * A; }
-        }
-        hipLaunchKernelGGL(k_refit, dim3(E), dim3(N), refit_lds, st, fp);
-        HIP_TRY(hipGetLastError());
-    }
-    return TDMPC2_OK;
+    if (h->split)
+        return fused_run<NetS>(h, st, n_envs, z0, task_emb, act_mask, disc_pow, prev_mean, t0, eval_mode, tape, seed, action, dbg);
+    return fused_run<NetW>(h, st, n_envs, z0, task_emb, act_mask, disc_pow, prev_mean, t0, eval_mode, tape, seed, action, dbg);
 }
 
 int tdmpc2_plan_estimate_value(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *task_emb,
@@ -1378,21 +1483,11 @@ int tdmpc2_plan_estimate_value_trace(tdmpc2_plan_t *h, int n_envs, const float *
         return lay_estimate_value(h, st, E, z0, act_mask, disc_pow, actions, pi_eps, (long)N * A, h->lay.qidx, 0, 0, 0, value,
                                   trace_scalars);
     }
-    // setup needs prev_mean / t0 only for mean/std init, which this entry does not use: feed dummies
-    HIP_TRY(hipMemsetAsync(h->mean, 0, (size_t)E * c.horizon * A * 4, st));
-    HIP_TRY(hipMemsetAsync(h->value, 1, (size_t)E, st));  // E bytes of ones used as t0 = 1 flags (no warm start read)
-    if ((rc = launch_setup(h, E, z0, task_emb, h->mean, reinterpret_cast<const unsigned char *>(h->value), st))) return rc;
-    RolloutParams rp{};
-    fill_rollout(h, rp, E);
-    rp.z0 = z0; rp.act_mask = act_mask; rp.disc_pow = disc_pow; rp.given_actions = 1; rp.iter = 0;
-    rp.actions = const_cast<float *>(actions);
-    rp.value = value;
-    rp.pi_eps = pi_eps; rp.pi_eps_estride = (long)N * A;
-    rp.qidx = qidx; rp.qidx_estride = 2;
-    rp.trace_tiles = trace_tiles; rp.trace_scalars = trace_scalars;
-    hipLaunchKernelGGL(k_rollout, dim3(E * h->tiles), dim3(NTHREADS), h->lds_bytes, st, rp);
-    HIP_TRY(hipGetLastError());
-    return TDMPC2_OK;
+    if (h->split)
+        return fused_estimate_value<NetS>(h, st, E, z0, task_emb, act_mask, disc_pow, actions, pi_eps, qidx, value, trace_tiles,
+                                          trace_scalars);
+    return fused_estimate_value<NetW>(h, st, E, z0, task_emb, act_mask, disc_pow, actions, pi_eps, qidx, value, trace_tiles,
+                                      trace_scalars);
 }
 
 int tdmpc2_plan_refit(tdmpc2_plan_t *h, int n_envs, float *value, const float *actions, const float *act_mask,

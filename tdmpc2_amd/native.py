@@ -21,12 +21,13 @@ ABI_VERSION = 2
 # every symbol include/tdmpc2_plan.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
     "tdmpc2_plan_abi_version", "tdmpc2_last_error", "tdmpc2_plan_create", "tdmpc2_plan_destroy",
-    "tdmpc2_plan_device_bytes", "tdmpc2_plan_path", "tdmpc2_plan_bind_weights", "tdmpc2_plan_run", "tdmpc2_plan_estimate_value",
+    "tdmpc2_plan_device_bytes", "tdmpc2_plan_path", "tdmpc2_plan_precision", "tdmpc2_plan_bind_weights", "tdmpc2_plan_run", "tdmpc2_plan_estimate_value",
     "tdmpc2_plan_estimate_value_trace", "tdmpc2_plan_refit", "tdmpc2_plan_set_profiling", "tdmpc2_plan_profile_read",
 ]
 
 NET_DYNAMICS, NET_REWARD, NET_PI, NET_Q, NET_TERMINATION = range(5)
 PATH_AUTO, PATH_FUSED, PATH_LAYERED = range(3)  # enum tdmpc2_path
+PREC_AUTO, PREC_FP32, PREC_SPLIT_F16 = range(3)  # enum tdmpc2_precision
 
 
 class PlanCfg(C.Structure):
@@ -35,7 +36,7 @@ class PlanCfg(C.Structure):
                                           "simnorm_dim")] + \
                [(n, C.c_float) for n in ("vmin", "vmax", "min_std", "max_std", "temperature", "log_std_min",
                                          "log_std_dif")] + \
-               [(n, C.c_int32) for n in ("multitask", "episodic", "max_envs", "device", "path")]
+               [(n, C.c_int32) for n in ("multitask", "episodic", "max_envs", "device", "path", "precision")]
 
 
 class Noise(C.Structure):
@@ -76,6 +77,8 @@ def load_library():
     lib.tdmpc2_plan_device_bytes.restype = u64
     lib.tdmpc2_plan_path.argtypes = [vp]
     lib.tdmpc2_plan_path.restype = i32
+    lib.tdmpc2_plan_precision.argtypes = [vp]
+    lib.tdmpc2_plan_precision.restype = i32
     lib.tdmpc2_plan_bind_weights.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, vp]
     lib.tdmpc2_plan_bind_weights.restype = i32
     lib.tdmpc2_plan_run.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, C.POINTER(Noise), u64, vp,
@@ -122,7 +125,8 @@ class NativePlanner:
     """
 
     def __init__(self, cfg, iterations: int, device: torch.device, max_envs: int = 1,
-                 log_std_min: Optional[float] = None, log_std_dif: Optional[float] = None, path: int = PATH_AUTO):
+                 log_std_min: Optional[float] = None, log_std_dif: Optional[float] = None, path: int = PATH_AUTO,
+                 precision: int = PREC_AUTO):
         device = torch.device(device)
         if device.type != "cuda":
             raise NativeError(f"the planner runs on an MI355X only (device {device}); there is no CPU fallback")
@@ -141,11 +145,12 @@ class NativePlanner:
                     num_q=cfg.num_q, simnorm_dim=cfg.simnorm_dim, vmin=cfg.vmin, vmax=cfg.vmax, min_std=cfg.min_std,
                     max_std=cfg.max_std, temperature=cfg.temperature, log_std_min=lsmin, log_std_dif=lsdif,
                     multitask=int(bool(cfg.multitask)), episodic=int(bool(cfg.episodic)), max_envs=self.max_envs,
-                    device=device.index, path=int(path))
+                    device=device.index, path=int(path), precision=int(precision))
         h = C.c_void_p()
         self._check(self.lib.tdmpc2_plan_create(C.byref(c), C.byref(h)))
         self._h = h
         self.path = int(self.lib.tdmpc2_plan_path(h))  # PATH_FUSED or PATH_LAYERED
+        self.precision = int(self.lib.tdmpc2_plan_precision(h))  # PREC_FP32 or PREC_SPLIT_F16
         self._seed_calls = 0
 
     # ------------------------------------------------------------------ plumbing

@@ -12,14 +12,16 @@ def dev():
     return torch.device("cuda", 0)
 
 
-def case_on_gpu(name, path=0):
-    """(case dict, oracle model, NativePlanner with the case's weights bound).  path: 0 auto, 1 fused, 2 layered."""
-    if (name, path) in _cache:
-        return _cache[(name, path)]
+def case_on_gpu(name, path=0, precision=0):
+    """(case dict, oracle model, NativePlanner with the case's weights bound).
+    path: 0 auto, 1 fused, 2 layered; precision: 0 auto, 1 exact-fp32 MFMA, 2 f16x2 split."""
+    key = (name, path, precision)
+    if key in _cache:
+        return _cache[key]
     from tdmpc2_amd.native import NativePlanner
 
-    for (n, _), (c, model, _) in list(_cache.items()):
-        if n == name:
+    for k, (c, model, _) in list(_cache.items()):
+        if k[0] == name:
             break
     else:
         c = cases.build_case(name)
@@ -27,10 +29,10 @@ def case_on_gpu(name, path=0):
     if c["cfg"].latent_dim > 1024:  # 317M-class weights: keep one such case resident at a time
         for k in [k for k in _cache if _cache[k][0]["cfg"].latent_dim > 1024 and k[0] != name]:
             del _cache[k]
-    planner = NativePlanner(c["cfg"], c["iterations"], dev(), max_envs=max(2, c["n_envs"]), path=path)
+    planner = NativePlanner(c["cfg"], c["iterations"], dev(), max_envs=max(2, c["n_envs"]), path=path, precision=precision)
     planner.bind_state_dict(model.sd)
-    _cache[(name, path)] = (c, model, planner)
-    return _cache[(name, path)]
+    _cache[key] = (c, model, planner)
+    return _cache[key]
 
 
 def plan_inputs(c, model):

@@ -37,7 +37,7 @@ def test_layered_family_on_fused_size_class(name):
     from tests.gpu_common import case_on_gpu
 
     c, model, lay = case_on_gpu(name, PATH_LAYERED)
-    _, _, fus = case_on_gpu(name, PATH_FUSED)
+    _, _, fus = case_on_gpu(name, PATH_FUSED, 1)
     assert lay.path == PATH_LAYERED and fus.path == PATH_FUSED
     g = load_golden(name)
     got = _run_native(c, model, lay)

@@ -11,12 +11,13 @@ SLOT_NAMES_T = ["reward.h1", "reward.h2", "dynamics.h1", "dynamics.h2", "z_next"
 SLOT_NAMES_END = ["pi.h1", "pi.h2", "z_H", "Qa.h1", "Qa.h2", "Qb.h1", "Qb.h2"]
 
 
+@pytest.mark.parametrize("prec", [1, 2], ids=["fp32", "split"])
 @pytest.mark.parametrize("name", ["c1", "c2", "mt5"])
-def test_every_fused_phase_matches_unfused_torch(name):
+def test_every_fused_phase_matches_unfused_torch(name, prec):
     from oracle import planner_oracle as po
     from tests.gpu_common import case_on_gpu, dev, plan_inputs
 
-    c, model, planner = case_on_gpu(name)
+    c, model, planner = case_on_gpu(name, 1, prec)
     cfg = c["cfg"]
     inp = plan_inputs(c, model)
     E, H, N, A = c["n_envs"], cfg.horizon, cfg.num_samples, cfg.action_dim

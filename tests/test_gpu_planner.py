@@ -13,6 +13,8 @@ from tests.helpers import ACT_ATOL, VALUE_RTOL, boundary_gap, elite_sets_equal, 
 pytestmark = pytest.mark.gpu
 
 FUSED_CASES = ["c1", "c1_wide", "c2", "mt5"]
+# the fused family in both arithmetic modes: exact-fp32 MFMA (1) and the f16x2 split on the f16 matrix pipe (2)
+PRECS = pytest.mark.parametrize("prec", [1, 2], ids=["fp32", "split"])
 
 
 def _oracle_stage_inputs(c, model, e):
@@ -26,12 +28,14 @@ def _oracle_stage_inputs(c, model, e):
     return a, pm, st
 
 
+@PRECS
 @pytest.mark.parametrize("name", FUSED_CASES)
-def test_estimate_value_matches_oracle(name):
+def test_estimate_value_matches_oracle(name, prec):
     """_estimate_value (tdmpc2.py:122-136) on identical action sequences, every env and two iterations."""
     from tests.gpu_common import case_on_gpu, dev, plan_inputs
 
-    c, model, planner = case_on_gpu(name)
+    c, model, planner = case_on_gpu(name, 1, prec)
+    assert planner.precision == prec
     inp = plan_inputs(c, model)
     E = c["n_envs"]
     for it in (0, c["iterations"] - 1):
@@ -132,38 +136,42 @@ def _run_native(c, model, planner):
     return got
 
 
+@PRECS
 @pytest.mark.parametrize("name", FUSED_CASES)
-def test_plan_matches_reference_golden(name):
+def test_plan_matches_reference_golden(name, prec):
     """Whole plan() with the recorded noise tape against the outputs of the reference's own code."""
     from tests.gpu_common import case_on_gpu
 
-    c, model, planner = case_on_gpu(name)
+    c, model, planner = case_on_gpu(name, 1, prec)
     g = load_golden(name)
     got = _run_native(c, model, planner)
     assert np.isfinite(got["action"]).all() and np.abs(got["action"]).max() <= 1.0
     _compare_stages(name, c, got, g, g["action"], g["prev_mean_out"])
 
 
+@PRECS
 @pytest.mark.parametrize("name", ["c1", "mt5"])
-def test_plan_matches_oracle(name):
+def test_plan_matches_oracle(name, prec):
     from oracle import planner_oracle as po
     from tests.gpu_common import case_on_gpu
 
-    c, model, planner = case_on_gpu(name)
+    c, model, planner = case_on_gpu(name, 1, prec)
     a, pm, st = po.plan_batch(model, c["z0"], c["tape"], c["prev_mean"], c["t0"], c["eval_mode"], c["tasks"],
                               c["discounts"], c["iterations"])
     got = _run_native(c, model, planner)
     _compare_stages(name, c, got, {k: v.numpy() for k, v in st.items()}, a.numpy(), pm.numpy())
 
 
-def test_error_attribution_against_fp64():
-    """Who is closer to exact arithmetic?  The fp64 oracle is the truth; the HIP planner (exact-fp32 MFMA)
-    must be no further from it than the torch-CPU fp32 arithmetic the reference itself runs (x3 slack)."""
+@PRECS
+def test_error_attribution_against_fp64(prec):
+    """Who is closer to exact arithmetic?  The fp64 oracle is the truth; the HIP planner — exact-fp32 MFMA, and the
+    f16x2-split arithmetic on the f16 matrix pipe — must be no further from it than the torch-CPU fp32 arithmetic
+    the reference itself runs (x3 slack): the split mode is NOT a reduced-precision mode."""
     from oracle import planner_oracle as po
     from tests.gpu_common import case_on_gpu, dev, plan_inputs
 
-    for name in ("c1", "c2"):
-        c, model, planner = case_on_gpu(name)
+    for name in ("c1", "c2", "c1_wide"):
+        c, model, planner = case_on_gpu(name, 1, prec)
         cfg = c["cfg"]
         model64 = po.OracleModel(cfg, model.sd, dtype=torch.float64)
         inp = plan_inputs(c, model)
@@ -174,6 +182,7 @@ def test_error_attribution_against_fp64():
         qidx = torch.tensor([[0, 2], [4, 1]][:E], dtype=torch.int32)
         got = planner.estimate_value(inp["z0"], inp["disc_pow"], actions.to(dev()).contiguous(),
                                      eps.to(dev()).contiguous(), qidx.to(dev()).contiguous()).cpu().double()
+        mode = {1: "fp32 MFMA", 2: "f16x2 split"}[prec]
         for e in range(E):
             z = torch.as_tensor(c["z0"][e:e + 1]).repeat(N, 1)
             v32 = po.estimate_value(model, z, actions[e], None, c["discounts"][e], eps[e], qidx[e]).squeeze(1).double()
@@ -182,26 +191,28 @@ def test_error_attribution_against_fp64():
             scale = v64.abs().clamp_min(1.0)
             err_hip = ((got[e] - v64).abs() / scale).max().item()
             err_ref = ((v32 - v64).abs() / scale).max().item()
-            print(f"[{name}] env {e}: |HIP - fp64| {err_hip:.3e}   |torch fp32 - fp64| {err_ref:.3e}")
+            print(f"[{name}] env {e}: |HIP {mode} - fp64| {err_hip:.3e}   |torch fp32 - fp64| {err_ref:.3e}")
             assert err_hip < 3 * err_ref + 1e-6, (name, e, err_hip, err_ref)
 
 
-def test_plan_is_deterministic_and_tape_pure():
+@PRECS
+def test_plan_is_deterministic_and_tape_pure(prec):
     from tests.gpu_common import case_on_gpu
 
-    c, model, planner = case_on_gpu("c1")
+    c, model, planner = case_on_gpu("c1", 1, prec)
     a = _run_native(c, model, planner)
     b = _run_native(c, model, planner)
     for k in a:
         assert np.array_equal(a[k], b[k]), k
 
 
-def test_value_permutation_equivariance():
+@PRECS
+def test_value_permutation_equivariance(prec):
     """Size-independent property: sample rows are independent in _estimate_value, so permuting the
     action sequences permutes the values (bit-exactly: same arithmetic per row)."""
     from tests.gpu_common import case_on_gpu, dev, plan_inputs
 
-    c, model, planner = case_on_gpu("c1")
+    c, model, planner = case_on_gpu("c1", 1, prec)
     cfg = c["cfg"]
     inp = plan_inputs(c, model)
     E, H, N, A = c["n_envs"], cfg.horizon, cfg.num_samples, cfg.action_dim
