@@ -36,12 +36,17 @@ struct NetS {
     LayerS l[3];
 };
 
-struct CtxS {
+// The action padding (16, 32, 48 or 64 columns) is a template parameter: with compile-time row strides every LDS
+// address of the unrolled epilogues is base + immediate; with a run-time stride the compiler pre-computes hundreds of
+// addresses, hoists them out of the step loop and spills them.
+template <int APAD>
+struct CtxT {
+    static constexpr int SH = WIDTH + APAD;  // plane length in halfs
+    static constexpr int RSH = 2 * SH + 8;   // row stride in halfs (row stride in dwords = SH + 4 = 4 x odd)
     _Float16 *act;  // LDS tile, operand form: row r at act + r * RSH: [hi: SH halfs | lo: SH halfs | 8 pad]
-    int RSH, SH;    // row stride / plane length in halfs; RSH = 2 SH + 8 (row stride in dwords = SH + 4 = 4 x odd)
     int tid, wave, lane;
     __device__ __forceinline__ float *f32() const { return reinterpret_cast<float *>(act); }  // staging view [64][RSF]
-    __device__ __forceinline__ int RSF() const { return RSH / 2; }
+    static constexpr __device__ __forceinline__ int RSF() { return RSH / 2; }
 };
 
 __device__ __forceinline__ float mish_fast(float x) {
@@ -65,55 +70,72 @@ __device__ __forceinline__ void split4(const f32x4 y, f16x4 &hi, f16x4 &lo) {
 // ---------------------------------------------------------------- contraction loops
 // v_mfma_f32_32x32x16_f16: lane l supplies A[i = l & 31][k = 8 (l >> 5) .. +7] and B[k = 8 (l >> 5) .. +7][j = l & 31].
 // Wave w of 8 owns output columns [64 w, 64 w + 64) for both 32-row tiles: acc[set][row tile][col tile].
-template <int NS>
-__device__ __forceinline__ void kloop_s(const CtxS &c, const _Float16 *const (&wp)[NS], const int (&KB)[NS], int kb0,
-                                        int kb1, f32x16 (&acc)[NS][2][2]) {
+// B fragments are prefetched PF k-blocks ahead (PF x 16 VGPRs): at the f16 matrix rate one k-block is only
+// 12 MFMAs = 384 pipe cycles per wave, far shorter than an L2 round trip under load.
+#ifndef SPLIT_PF
+#define SPLIT_PF 4
+#endif
+constexpr int PF = SPLIT_PF;
+struct BFrag {
+    f16x8 h[2], l[2];
+};
+// B-fragment addressing: wave-uniform byte pointers (SGPR pairs, advanced by scalar arithmetic) + ONE 32-bit lane
+// offset, made opaque so that the compiler cannot fully unroll the k-loop into per-k-block 64-bit VGPR addresses and
+// hoist them out of the step loop (that cost ~1000 spilled registers).
+__device__ __forceinline__ f16x8 ldw(const char *ubase, unsigned voff, int imm) {
+    return *reinterpret_cast<const f16x8 *>(ubase + voff + imm);
+}
+__device__ __forceinline__ void load_b(BFrag &b, const char *u0, const char *u1, unsigned voff) {
+    b.h[0] = ldw(u0, voff, 0);
+    b.l[0] = ldw(u0, voff, 1024);
+    b.h[1] = ldw(u1, voff, 0);
+    b.l[1] = ldw(u1, voff, 1024);
+}
+template <class CT>
+__device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, int kb1, f32x16 (&acc)[2][2]) {
     const int i = c.lane & 31, hh = c.lane >> 5;
-    const _Float16 *a0p = c.act + i * c.RSH + 8 * hh;
+    const _Float16 *a0p = c.act + i * c.RSH + 8 * hh + kb0 * 16;
     const _Float16 *a1p = a0p + 32 * c.RSH;
-    const f16x8 *w[NS][2];
-    f16x8 bnh[NS][2], bnl[NS][2];
+    // one k-block of one column tile = 2 planes x 64 lanes x 16 B = 2048 B
+    const char *u0 = reinterpret_cast<const char *>(ly.wp) + ((size_t)(2 * c.wave) * ly.KB + kb0) * 2048;
+    const char *u1 = u0 + (size_t)ly.KB * 2048;
+    unsigned voff = (unsigned)c.lane * 16u;
+    asm volatile("" : "+v"(voff));
+    const int nk = kb1 - kb0;
+    BFrag ring[PF];
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
+    for (int d = 0; d < PF; ++d) {
+        const int kd = d < nk ? d : nk - 1;
+        load_b(ring[d], u0 + (size_t)kd * 2048, u1 + (size_t)kd * 2048, voff);
+    }
+#pragma unroll 1
+    for (int k = 0; k < nk; k += PF) {
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-            w[s][cc] = reinterpret_cast<const f16x8 *>(wp[s]) + (size_t)(2 * c.wave + cc) * KB[s] * 128 + c.lane;
-            bnh[s][cc] = w[s][cc][(size_t)kb0 * 128];
-            bnl[s][cc] = w[s][cc][(size_t)kb0 * 128 + 64];
-        }
-#pragma unroll 2
-    for (int kb = kb0; kb < kb1; ++kb) {
-        f16x8 bh[NS][2], bl[NS][2];
-        const int kn = (kb + 1 < kb1) ? kb + 1 : kb;
+        for (int d = 0; d < PF; ++d) {
+            const int kk = k + d;
+            if (kk < nk) {  // wave-uniform
+                const BFrag b = ring[d];
+                const int kn = kk + PF < nk ? kk + PF : nk - 1;
+                load_b(ring[d], u0 + (size_t)kn * 2048, u1 + (size_t)kn * 2048, voff);
+                const f16x8 ah0 = *reinterpret_cast<const f16x8 *>(a0p + kk * 16);
+                const f16x8 al0 = *reinterpret_cast<const f16x8 *>(a0p + c.SH + kk * 16);
+                const f16x8 ah1 = *reinterpret_cast<const f16x8 *>(a1p + kk * 16);
+                const f16x8 al1 = *reinterpret_cast<const f16x8 *>(a1p + c.SH + kk * 16);
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+                for (int cc = 0; cc < 2; ++cc) {
+                    acc[0][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, b.h[cc], acc[0][cc], 0, 0, 0);
+                    acc[1][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, b.h[cc], acc[1][cc], 0, 0, 0);
+                }
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                bh[s][cc] = bnh[s][cc];
-                bl[s][cc] = bnl[s][cc];
-                bnh[s][cc] = w[s][cc][(size_t)kn * 128];
-                bnl[s][cc] = w[s][cc][(size_t)kn * 128 + 64];
-            }
-        const f16x8 ah0 = *reinterpret_cast<const f16x8 *>(a0p + kb * 16);
-        const f16x8 al0 = *reinterpret_cast<const f16x8 *>(a0p + c.SH + kb * 16);
-        const f16x8 ah1 = *reinterpret_cast<const f16x8 *>(a1p + kb * 16);
-        const f16x8 al1 = *reinterpret_cast<const f16x8 *>(a1p + c.SH + kb * 16);
+                for (int cc = 0; cc < 2; ++cc) {
+                    acc[0][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, b.l[cc], acc[0][cc], 0, 0, 0);
+                    acc[1][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, b.l[cc], acc[1][cc], 0, 0, 0);
+                }
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                acc[s][0][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[s][cc], acc[s][0][cc], 0, 0, 0);
-                acc[s][1][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh[s][cc], acc[s][1][cc], 0, 0, 0);
-            }
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                acc[s][0][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[s][cc], acc[s][0][cc], 0, 0, 0);
-                acc[s][1][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl[s][cc], acc[s][1][cc], 0, 0, 0);
-            }
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc) {
-                acc[s][0][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[s][cc], acc[s][0][cc], 0, 0, 0);
-                acc[s][1][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[s][cc], acc[s][1][cc], 0, 0, 0);
+                for (int cc = 0; cc < 2; ++cc) {
+                    acc[0][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, b.h[cc], acc[0][cc], 0, 0, 0);
+                    acc[1][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, b.h[cc], acc[1][cc], 0, 0, 0);
+                }
             }
         }
     }
@@ -121,32 +143,53 @@ __device__ __forceinline__ void kloop_s(const CtxS &c, const _Float16 *const (&w
 
 // One 32x32 output tile (row tile rt, column tile ct): the narrow output layers.  Three independent accumulators
 // (one per product kind) keep the matrix pipe issuing back to back; they are summed at the end.
-__device__ __forceinline__ void kloop_tile_s(const CtxS &c, const LayerS &ly, int ct, int rt, int kb0, int kb1, f32x16 &acc) {
+template <class CT>
+__device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int ct, int rt, int kb0, int kb1, f32x16 &acc) {
+#ifndef SPLIT_PFT
+#define SPLIT_PFT 8
+#endif
+    constexpr int PFT = SPLIT_PFT;  // only 3 MFMAs (96 pipe cycles) per k-block here: prefetch deeper
     const int i = c.lane & 31, hh = c.lane >> 5;
-    const _Float16 *ap = c.act + (rt * 32 + i) * c.RSH + 8 * hh;
-    const f16x8 *w = reinterpret_cast<const f16x8 *>(ly.wp) + (size_t)ct * ly.KB * 128 + c.lane;
+    const _Float16 *ap = c.act + (rt * 32 + i) * c.RSH + 8 * hh + kb0 * 16;
+    const char *u = reinterpret_cast<const char *>(ly.wp) + ((size_t)ct * ly.KB + kb0) * 2048;  // uniform
+    unsigned voff = (unsigned)c.lane * 16u;
+    asm volatile("" : "+v"(voff));
+    const int nk = kb1 - kb0;
     f32x16 a1, a2;
 #pragma unroll
     for (int e = 0; e < 16; ++e) a1[e] = a2[e] = 0.f;
-    f16x8 bnh = w[(size_t)kb0 * 128], bnl = w[(size_t)kb0 * 128 + 64];
-#pragma unroll 2
-    for (int kb = kb0; kb < kb1; ++kb) {
-        const f16x8 bh = bnh, bl = bnl;
-        const int kn = (kb + 1 < kb1) ? kb + 1 : kb;
-        bnh = w[(size_t)kn * 128];
-        bnl = w[(size_t)kn * 128 + 64];
-        const f16x8 ah = *reinterpret_cast<const f16x8 *>(ap + kb * 16);
-        const f16x8 al = *reinterpret_cast<const f16x8 *>(ap + c.SH + kb * 16);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a1, 0, 0, 0);
-        a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a2, 0, 0, 0);
+    f16x8 rh[PFT], rl[PFT];
+#pragma unroll
+    for (int d = 0; d < PFT; ++d) {
+        const int kd = d < nk ? d : nk - 1;
+        rh[d] = ldw(u + (size_t)kd * 2048, voff, 0);
+        rl[d] = ldw(u + (size_t)kd * 2048, voff, 1024);
+    }
+#pragma unroll 1
+    for (int k = 0; k < nk; k += PFT) {
+#pragma unroll
+        for (int d = 0; d < PFT; ++d) {
+            const int kk = k + d;
+            if (kk < nk) {
+                const f16x8 bh = rh[d], bl = rl[d];
+                const int kn = kk + PFT < nk ? kk + PFT : nk - 1;
+                rh[d] = ldw(u + (size_t)kn * 2048, voff, 0);
+                rl[d] = ldw(u + (size_t)kn * 2048, voff, 1024);
+                const f16x8 ah = *reinterpret_cast<const f16x8 *>(ap + kk * 16);
+                const f16x8 al = *reinterpret_cast<const f16x8 *>(ap + c.SH + kk * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a1, 0, 0, 0);
+                a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a2, 0, 0, 0);
+            }
+        }
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] += a1[e] + a2[e];
 }
 
 // acc * oscale + bias -> fp32 staging view.  C/D fragment: lane holds column (l & 31), rows (reg&3) + 8 (reg>>2) + 4 (l>>5).
-__device__ __forceinline__ void store_full_s(const CtxS &c, const f32x16 (&acc)[2][2], float osc, const float *bias) {
+template <class CT>
+__device__ __forceinline__ void store_full_s(const CT &c, const f32x16 (&acc)[2][2], float osc, const float *bias) {
     float *f = c.f32();
     const int RSF = c.RSF();
     const int j = c.lane & 31, hh = c.lane >> 5;
@@ -163,7 +206,28 @@ __device__ __forceinline__ void store_full_s(const CtxS &c, const f32x16 (&acc)[
             }
     }
 }
-__device__ __forceinline__ void store_tile_s(const CtxS &c, const f32x16 &acc, float osc, const float *bias, int ct, int rt) {
+// the same into a dense global tile [64][WIDTH] (pre-activation parked in L2 instead of 64 held accumulators)
+template <class CT>
+__device__ __forceinline__ void store_full_global(const CT &c, const f32x16 (&acc)[2][2], float osc, const float *bias, float *dst) {
+    const int j = c.lane & 31, hh = c.lane >> 5;
+    // one 32-bit lane offset against the wave-uniform tile base; made opaque so that the 64 store addresses are formed
+    // here (base + constant) instead of being hoisted out of the step loop as 64 live 64-bit pointers (spills)
+    unsigned lane_off = (unsigned)(4 * hh * WIDTH + 2 * c.wave * 32 + j);
+    asm volatile("" : "+v"(lane_off));
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        const float bv = bias[(2 * c.wave + cc) * 32 + j];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const unsigned koff = (unsigned)((rt * 32 + (reg & 3) + 8 * (reg >> 2)) * WIDTH + cc * 32);
+                dst[lane_off + koff] = fmaf(acc[rt][cc][reg], osc, bv);
+            }
+    }
+}
+template <class CT>
+__device__ __forceinline__ void store_tile_s(const CT &c, const f32x16 &acc, float osc, const float *bias, int ct, int rt) {
     float *f = c.f32();
     const int RSF = c.RSF();
     const int j = c.lane & 31, hh = c.lane >> 5;
@@ -180,10 +244,11 @@ __device__ __forceinline__ void store_tile_s(const CtxS &c, const f32x16 &acc, f
 // Thread t owns row (t >> 3) and the sixteen 4-column chunks {part + 8 q}, part = t & 7; the 8 owners of a row are 8
 // adjacent lanes of ONE wave, and the row's staging bytes alias only that row's operand bytes, so "read the whole
 // slice, then write" needs no barrier.  LayerNorm: biased variance, eps 1e-5 (layers.py:101).  ACT 0 Mish, 1 SimNorm(8).
-template <int ACT>
-__device__ __forceinline__ void ln_rows_s(const CtxS &c, const float *g, const float *b, float *gcopy /* optional [64][WIDTH] fp32 */) {
+template <int ACT, class CT>
+__device__ __forceinline__ void ln_rows_s(const CT &c, const float *g, const float *b, float *gcopy /* optional [64][WIDTH] fp32 */,
+                                          const float *gsrc = nullptr /* pre-activation tile in global instead of the staging view */) {
     const int row = c.tid >> 3, part = c.tid & 7;
-    const float *rp = c.f32() + row * c.RSF() + 4 * part;
+    const float *rp = gsrc ? gsrc + row * WIDTH + 4 * part : c.f32() + row * c.RSF() + 4 * part;
     f32x4 v[16];
     float s = 0.f;
 #pragma unroll
@@ -237,27 +302,27 @@ __device__ __forceinline__ void ln_rows_s(const CtxS &c, const float *g, const f
 }
 
 // two_hot_inv (math.py:74-83) on fp32 logits in the staging view.
-__device__ __forceinline__ float twohot_rows_s(const CtxS &c, const float *bins, int num_bins) {
+template <class CT>
+__device__ __forceinline__ float twohot_rows_s(const CT &c, const float *bins, int num_bins) {
     return twohot_rows(c.f32(), c.RSF(), bins, num_bins, c.tid);
 }
 
-template <int ACT>
-__device__ __forceinline__ void layer_full_s(const CtxS &c, const LayerS &ly, const float *bias, int kb0, int kb1,
+template <int ACT, class CT>
+__device__ __forceinline__ void layer_full_s(const CT &c, const LayerS &ly, const float *bias, int kb0, int kb1,
                                              float *gcopy = nullptr) {
-    f32x16 acc[1][2][2];
-    zero4(acc[0]);
-    const _Float16 *const wp[1] = {ly.wp};
-    const int KB[1] = {ly.KB};
-    kloop_s<1>(c, wp, KB, kb0, kb1, acc);
+    f32x16 acc[2][2];
+    zero4(acc);
+    kloop_s(c, ly, kb0, kb1, acc);
     const float osc = *ly.oscale;
     __syncthreads();
-    store_full_s(c, acc[0], osc, bias);
+    store_full_s(c, acc, osc, bias);
     __syncthreads();
     ln_rows_s<ACT>(c, ly.g, ly.b, gcopy);
     __syncthreads();
 }
 
-__device__ __forceinline__ float head_twohot_s(const CtxS &c, const LayerS &ly, const float *bins, int num_bins) {
+template <class CT>
+__device__ __forceinline__ float head_twohot_s(const CT &c, const LayerS &ly, const float *bins, int num_bins) {
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -273,7 +338,8 @@ __device__ __forceinline__ float head_twohot_s(const CtxS &c, const LayerS &ly, 
 }
 
 // write one action value into the operand-form action columns of a row
-__device__ __forceinline__ void put_action(const CtxS &c, int row, int a, float v) {
+template <class CT>
+__device__ __forceinline__ void put_action(const CT &c, int row, int a, float v) {
     const float vs = v * ACT_SCALE;
     const _Float16 h = (_Float16)vs;
     _Float16 *rp = c.act + row * c.RSH + WIDTH + a;
@@ -283,8 +349,8 @@ __device__ __forceinline__ void put_action(const CtxS &c, int row, int a, float 
 
 // Policy prior output layer + squashed Gaussian sample (world_model.py:152-173); action -> operand-form action columns
 // (zero for padded columns) and optionally gdst[row * A + a] for rows < nvalid.
-template <typename EpsFn>
-__device__ __forceinline__ void head_pi_s(const CtxS &c, const LayerS &ly, int A, int Apad, float lsmin, float lsdif,
+template <class CT, typename EpsFn>
+__device__ __forceinline__ void head_pi_s(const CT &c, const LayerS &ly, int A, int Apad, float lsmin, float lsdif,
                                           const float *mask, EpsFn eps, float *gdst, int nvalid, float *tsc) {
     f32x16 acc;
 #pragma unroll
@@ -320,7 +386,8 @@ __device__ __forceinline__ void head_pi_s(const CtxS &c, const LayerS &ly, int A
 }
 
 // global fp32 [64][WIDTH] -> operand-form z columns
-__device__ __forceinline__ void tile_from_global_s(const CtxS &c, const float *src) {
+template <class CT>
+__device__ __forceinline__ void tile_from_global_s(const CT &c, const float *src) {
     for (int idx = c.tid; idx < ROWS * (WIDTH / 4); idx += NTHREADS) {
         const int row = idx / (WIDTH / 4), c4 = idx % (WIDTH / 4);
         const f32x4 y = *reinterpret_cast<const f32x4 *>(src + row * WIDTH + 4 * c4);
@@ -331,7 +398,8 @@ __device__ __forceinline__ void tile_from_global_s(const CtxS &c, const float *s
         *reinterpret_cast<f16x4 *>(hp + c.SH) = lo;
     }
 }
-__device__ __forceinline__ void tile_broadcast_row_s(const CtxS &c, const float *src_row) {
+template <class CT>
+__device__ __forceinline__ void tile_broadcast_row_s(const CT &c, const float *src_row) {
     for (int idx = c.tid; idx < ROWS * (WIDTH / 4); idx += NTHREADS) {
         const int row = idx / (WIDTH / 4), c4 = idx % (WIDTH / 4);
         const f32x4 y = *reinterpret_cast<const f32x4 *>(src_row + 4 * c4);
@@ -343,7 +411,8 @@ __device__ __forceinline__ void tile_broadcast_row_s(const CtxS &c, const float 
     }
 }
 // operand form -> fp32 trace dump (hi + lo, unscaled)
-__device__ __forceinline__ void dump_tile_s(const CtxS &c, float *trace, int nslot, int slot) {
+template <class CT>
+__device__ __forceinline__ void dump_tile_s(const CT &c, float *trace, int nslot, int slot) {
     if (!trace) return;
     float *dst = trace + ((size_t)blockIdx.x * nslot + slot) * ROWS * WIDTH;
     for (int idx = c.tid; idx < ROWS * WIDTH; idx += NTHREADS) {
@@ -354,11 +423,11 @@ __device__ __forceinline__ void dump_tile_s(const CtxS &c, float *trace, int nsl
 }
 
 // ================================================================ kernel: per-plan setup (cf. k_setup)
+template <int APAD>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x, tid = threadIdx.x;
-    const int SH = (p.stride - 8) / 2;
-    CtxS c{reinterpret_cast<_Float16 *>(smem), p.stride, SH, tid, tid >> 6, tid & 63};
+    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     if (p.multitask) {
         const float *emb = p.task_emb + (size_t)e * p.T;
         for (int net = 0; net < p.nnets; ++net) {
@@ -382,9 +451,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
     f32x16 acc[2][2][2];
     zero4(acc[0]);
     zero4(acc[1]);
-    const _Float16 *const wp[2] = {p.rew.l[0].wp, p.dyn.l[0].wp};
-    const int KB[2] = {p.rew.l[0].KB, p.dyn.l[0].KB};
-    kloop_s<2>(c, wp, KB, 0, ZKB16, acc);
+    kloop_s(c, p.rew.l[0], 0, ZKB16, acc[0]);
+    kloop_s(c, p.dyn.l[0], 0, ZKB16, acc[1]);
     const float *b_rew = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_REW) * WIDTH : p.rew.l[0].bias;
     const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
     const float o_rew = *p.rew.l[0].oscale, o_dyn = *p.dyn.l[0].oscale;
@@ -399,11 +467,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
 }
 
 // ================================================================ kernel: policy-prior trajectories (cf. k_pitraj)
+template <int APAD>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x, tid = threadIdx.x;
-    const int SH = (p.stride - 8) / 2;
-    CtxS c{reinterpret_cast<_Float16 *>(smem), p.stride, SH, tid, tid >> 6, tid & 63};
+    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
     const float *b_pi = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_PI) * WIDTH : p.pi.l[0].bias;
     const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
@@ -435,13 +503,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) 
 }
 
 // ================================================================ kernel: one CEM iteration's rollouts (cf. k_rollout)
+template <int APAD>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x / p.tiles, tile = blockIdx.x % p.tiles;
     const int tid = threadIdx.x;
-    const int SH = (p.stride - 8) / 2;
-    CtxS c{reinterpret_cast<_Float16 *>(smem), p.stride, SH, tid, tid >> 6, tid & 63};
-    float *sm_mean = smem + ROWS * p.stride / 2;  // [H*A] after the tile
+    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    float *sm_mean = smem + ROWS * c.RSH / 2;  // [H*A] after the tile
     float *sm_std = sm_mean + p.H * p.A;
     const int row0 = tile * ROWS;
     const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
@@ -501,18 +569,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
             }
         }
         __syncthreads();
-        // ---- first layers of reward and dynamics in one pass over [z_t | a_t]
-        f32x16 acc[2][2][2];
-        zero4(acc[0]);
-        zero4(acc[1]);
+        // ---- first layers of dynamics and reward over the same [z_t | a_t] tile; the dynamics pre-activation is parked
+        // in the workgroup's L2-resident scratch tile until the reward chain is done (64 VGPRs not held)
         {
-            const _Float16 *const wp[2] = {p.rew.l[0].wp, p.dyn.l[0].wp};
-            const int KB[2] = {p.rew.l[0].KB, p.dyn.l[0].KB};
-            kloop_s<2>(c, wp, KB, t == 0 ? ZKB16 : 0, KBA, acc);
+            f32x16 acc[2][2];
+            zero4(acc);
+            kloop_s(c, p.dyn.l[0], t == 0 ? ZKB16 : 0, KBA, acc);
+            store_full_global(c, acc, *p.dyn.l[0].oscale, t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn, zs);
+            zero4(acc);
+            kloop_s(c, p.rew.l[0], t == 0 ? ZKB16 : 0, KBA, acc);
+            const float o_rew = *p.rew.l[0].oscale;
+            __syncthreads();
+            store_full_s(c, acc, o_rew, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew);
         }
-        const float o_rew = *p.rew.l[0].oscale, o_dyn = *p.dyn.l[0].oscale;
-        __syncthreads();
-        store_full_s(c, acc[0], o_rew, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew);
         __syncthreads();
         ln_rows_s<0>(c, p.rew.l[0].g, p.rew.l[0].b, nullptr);
         __syncthreads();
@@ -523,10 +592,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
         const float r = head_twohot_s(c, p.rew.l[2], p.bins, p.num_bins);
         if (tsc && (tid & 7) == 0) tsc[t] = r;
         G += disc[t] * r;
-        // ---- dynamics: release the held first layer, layers 2 and 3 (SimNorm)
-        store_full_s(c, acc[1], o_dyn, t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn);
-        __syncthreads();
-        ln_rows_s<0>(c, p.dyn.l[0].g, p.dyn.l[0].b, nullptr);
+        // ---- dynamics: pick the parked first layer up from L2, layers 2 and 3 (SimNorm)
+        ln_rows_s<0>(c, p.dyn.l[0].g, p.dyn.l[0].b, nullptr, zs);
         __syncthreads();
         dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 2);
         layer_full_s<0>(c, p.dyn.l[1], p.dyn.l[1].bias, 0, ZKB16);
@@ -552,17 +619,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
     __syncthreads();
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 2);
     // ---- Q(z_H, a_H): the two selected heads, first layers in one pass (world_model.py:186-216)
-    f32x16 acc[2][2][2];
-    zero4(acc[0]);
-    zero4(acc[1]);
     {
-        const _Float16 *const wp[2] = {p.q[q0].l[0].wp, p.q[q1].l[0].wp};
-        const int KB[2] = {p.q[q0].l[0].KB, p.q[q1].l[0].KB};
-        kloop_s<2>(c, wp, KB, 0, KBA, acc);
+        // z_H has been read back from zs above (tile_from_global_s + barrier): the scratch tile is free to park the
+        // second head's first-layer pre-activation
+        f32x16 acc[2][2];
+        zero4(acc);
+        kloop_s(c, p.q[q1].l[0], 0, KBA, acc);
+        store_full_global(c, acc, *p.q[q1].l[0].oscale, b_q1, zs);
+        zero4(acc);
+        kloop_s(c, p.q[q0].l[0], 0, KBA, acc);
+        const float o_q0 = *p.q[q0].l[0].oscale;
+        __syncthreads();
+        store_full_s(c, acc, o_q0, b_q0);
     }
-    const float o_q0 = *p.q[q0].l[0].oscale, o_q1 = *p.q[q1].l[0].oscale;
-    __syncthreads();
-    store_full_s(c, acc[0], o_q0, b_q0);
     __syncthreads();
     ln_rows_s<0>(c, p.q[q0].l[0].g, p.q[q0].l[0].b, nullptr);
     __syncthreads();
@@ -570,9 +639,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
     layer_full_s<0>(c, p.q[q0].l[1], p.q[q0].l[1].bias, 0, ZKB16);
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 4);
     const float qa = head_twohot_s(c, p.q[q0].l[2], p.bins, p.num_bins);
-    store_full_s(c, acc[1], o_q1, b_q1);
-    __syncthreads();
-    ln_rows_s<0>(c, p.q[q1].l[0].g, p.q[q1].l[0].b, nullptr);
+    ln_rows_s<0>(c, p.q[q1].l[0].g, p.q[q1].l[0].b, nullptr, zs);
     __syncthreads();
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 5);
     layer_full_s<0>(c, p.q[q1].l[1], p.q[q1].l[1].bias, 0, ZKB16);

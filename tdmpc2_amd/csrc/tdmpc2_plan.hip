@@ -1025,10 +1025,17 @@ template <> struct Kern<NetW> {
     static void pitraj(const PiTrajParamsT<NetW> &p, int E, size_t lds, hipStream_t st) { hipLaunchKernelGGL(k_pitraj, dim3(E), dim3(NTHREADS), lds, st, p); }
     static void rollout(const RolloutParamsT<NetW> &p, int grid, size_t lds, hipStream_t st) { hipLaunchKernelGGL(k_rollout, dim3(grid), dim3(NTHREADS), lds, st, p); }
 };
-template <> struct Kern<NetS> {
-    static void setup(const SetupParamsT<NetS> &p, int E, size_t lds, hipStream_t st) { hipLaunchKernelGGL(ks_setup, dim3(E), dim3(NTHREADS), lds, st, p); }
-    static void pitraj(const PiTrajParamsT<NetS> &p, int E, size_t lds, hipStream_t st) { hipLaunchKernelGGL(ks_pitraj, dim3(E), dim3(NTHREADS), lds, st, p); }
-    static void rollout(const RolloutParamsT<NetS> &p, int grid, size_t lds, hipStream_t st) { hipLaunchKernelGGL(ks_rollout, dim3(grid), dim3(NTHREADS), lds, st, p); }
+#define SPLIT_DISPATCH(KERNEL, APAD, GRID)                                                                       \
+    switch (APAD) {                                                                                                \
+        case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(GRID), dim3(NTHREADS), lds, st, p); break;                   \
+        case 32: hipLaunchKernelGGL(KERNEL<32>, dim3(GRID), dim3(NTHREADS), lds, st, p); break;                   \
+        case 48: hipLaunchKernelGGL(KERNEL<48>, dim3(GRID), dim3(NTHREADS), lds, st, p); break;                   \
+        default: hipLaunchKernelGGL(KERNEL<64>, dim3(GRID), dim3(NTHREADS), lds, st, p); break;                   \
+    }
+template <> struct Kern<NetS> {  // the split kernels are instantiated per action padding (compile-time LDS strides)
+    static void setup(const SetupParamsT<NetS> &p, int E, size_t lds, hipStream_t st) { SPLIT_DISPATCH(ks_setup, (p.stride - 8) / 2 - WIDTH, E) }
+    static void pitraj(const PiTrajParamsT<NetS> &p, int E, size_t lds, hipStream_t st) { SPLIT_DISPATCH(ks_pitraj, p.Apad, E) }
+    static void rollout(const RolloutParamsT<NetS> &p, int grid, size_t lds, hipStream_t st) { SPLIT_DISPATCH(ks_rollout, p.Apad, grid) }
 };
 
 template <class NET>
@@ -1290,10 +1297,17 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
         tdmpc2_plan_destroy(h);
         return rc;
     }
-    if (h->split && ((rc = set_lds(ks_setup, h->lds_bytes)) || (rc = set_lds(ks_pitraj, h->lds_bytes)) ||
-                     (rc = set_lds(ks_rollout, h->lds_bytes)))) {
-        tdmpc2_plan_destroy(h);
-        return rc;
+    if (h->split) {
+        switch (h->Apad) {
+            case 16: rc = set_lds(ks_setup<16>, h->lds_bytes) || set_lds(ks_pitraj<16>, h->lds_bytes) || set_lds(ks_rollout<16>, h->lds_bytes); break;
+            case 32: rc = set_lds(ks_setup<32>, h->lds_bytes) || set_lds(ks_pitraj<32>, h->lds_bytes) || set_lds(ks_rollout<32>, h->lds_bytes); break;
+            case 48: rc = set_lds(ks_setup<48>, h->lds_bytes) || set_lds(ks_pitraj<48>, h->lds_bytes) || set_lds(ks_rollout<48>, h->lds_bytes); break;
+            default: rc = set_lds(ks_setup<64>, h->lds_bytes) || set_lds(ks_pitraj<64>, h->lds_bytes) || set_lds(ks_rollout<64>, h->lds_bytes); break;
+        }
+        if (rc) {
+            tdmpc2_plan_destroy(h);
+            return TDMPC2_ERR_HIP;
+        }
     }
     *out = h;
     return TDMPC2_OK;
