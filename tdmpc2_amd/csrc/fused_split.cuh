@@ -44,6 +44,7 @@ struct CtxT {
     static constexpr int SH = WIDTH + APAD;  // plane length in halfs
     static constexpr int RSH = 2 * SH + 8;   // row stride in halfs (row stride in dwords = SH + 4 = 4 x odd)
     _Float16 *act;  // LDS tile, operand form: row r at act + r * RSH: [hi: SH halfs | lo: SH halfs | 8 pad]
+    float *stats;   // LDS [8 waves][64 rows][2]: per-wave LayerNorm partials
     int tid, wave, lane;
     __device__ __forceinline__ float *f32() const { return reinterpret_cast<float *>(act); }  // staging view [64][RSF]
     static constexpr __device__ __forceinline__ int RSF() { return RSH / 2; }
@@ -54,7 +55,7 @@ __device__ __forceinline__ float mish_fast(float x) {
     // exponent is clamped instead of branching (tdmpc2/common/layers.py:103)
     const float e = __expf(fminf(x, 20.f));
     const float n = e * (e + 2.f);
-    return x * __fdividef(n, n + 2.f);
+    return x * (n * __builtin_amdgcn_rcpf(n + 2.f));  // v_rcp_f32: 1 ulp; __fdividef expands to the full division
 }
 
 __device__ __forceinline__ void split4(const f32x4 y, f16x4 &hi, f16x4 &lo) {
@@ -82,9 +83,27 @@ struct BFrag {
 // B-fragment addressing: wave-uniform byte pointers (SGPR pairs, advanced by scalar arithmetic) + ONE 32-bit lane
 // offset, made opaque so that the compiler cannot fully unroll the k-loop into per-k-block 64-bit VGPR addresses and
 // hoist them out of the step loop (that cost ~1000 spilled registers).
+// SPLIT_ABL_* macros exist for ablation timing builds only (tools/ablate.sh); the shipped library defines none.
 __device__ __forceinline__ f16x8 ldw(const char *ubase, unsigned voff, int imm) {
+#ifdef SPLIT_ABL_NO_BLOAD
+    f16x8 r;
+    const _Float16 v = (_Float16)(float)(voff + imm);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = v;
+    return r;
+#else
     return *reinterpret_cast<const f16x8 *>(ubase + voff + imm);
+#endif
 }
+#ifdef SPLIT_ABL_NO_MFMA
+__device__ __forceinline__ f32x16 fake_mfma(f16x8 a, f16x8 b, f32x16 c) {
+    c[0] += (float)a[0] * (float)b[0];  // keeps the dependence on the operand loads, costs one VALU op
+    return c;
+}
+#define SPLIT_MFMA(a, b, c) fake_mfma(a, b, c)
+#else
+#define SPLIT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#endif
 __device__ __forceinline__ void load_b(BFrag &b, const char *u0, const char *u1, unsigned voff) {
     b.h[0] = ldw(u0, voff, 0);
     b.l[0] = ldw(u0, voff, 1024);
@@ -123,18 +142,18 @@ __device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, 
                 const f16x8 al1 = *reinterpret_cast<const f16x8 *>(a1p + c.SH + kk * 16);
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) {
-                    acc[0][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, b.h[cc], acc[0][cc], 0, 0, 0);
-                    acc[1][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, b.h[cc], acc[1][cc], 0, 0, 0);
+                    acc[0][cc] = SPLIT_MFMA(ah0, b.h[cc], acc[0][cc]);
+                    acc[1][cc] = SPLIT_MFMA(ah1, b.h[cc], acc[1][cc]);
                 }
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) {
-                    acc[0][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, b.l[cc], acc[0][cc], 0, 0, 0);
-                    acc[1][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, b.l[cc], acc[1][cc], 0, 0, 0);
+                    acc[0][cc] = SPLIT_MFMA(ah0, b.l[cc], acc[0][cc]);
+                    acc[1][cc] = SPLIT_MFMA(ah1, b.l[cc], acc[1][cc]);
                 }
 #pragma unroll
                 for (int cc = 0; cc < 2; ++cc) {
-                    acc[0][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, b.h[cc], acc[0][cc], 0, 0, 0);
-                    acc[1][cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, b.h[cc], acc[1][cc], 0, 0, 0);
+                    acc[0][cc] = SPLIT_MFMA(al0, b.h[cc], acc[0][cc]);
+                    acc[1][cc] = SPLIT_MFMA(al1, b.h[cc], acc[1][cc]);
                 }
             }
         }
@@ -177,9 +196,9 @@ __device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int 
                 rl[d] = ldw(u + (size_t)kn * 2048, voff, 1024);
                 const f16x8 ah = *reinterpret_cast<const f16x8 *>(ap + kk * 16);
                 const f16x8 al = *reinterpret_cast<const f16x8 *>(ap + c.SH + kk * 16);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, a1, 0, 0, 0);
-                a2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, a2, 0, 0, 0);
+                acc = SPLIT_MFMA(ah, bh, acc);
+                a1 = SPLIT_MFMA(ah, bl, a1);
+                a2 = SPLIT_MFMA(al, bh, a2);
             }
         }
     }
@@ -241,63 +260,100 @@ __device__ __forceinline__ void store_tile_s(const CT &c, const f32x16 &acc, flo
 }
 
 // ---------------------------------------------------------------- row epilogue: staging (fp32) -> operand form (hi/lo f16)
-// Thread t owns row (t >> 3) and the sixteen 4-column chunks {part + 8 q}, part = t & 7; the 8 owners of a row are 8
-// adjacent lanes of ONE wave, and the row's staging bytes alias only that row's operand bytes, so "read the whole
-// slice, then write" needs no barrier.  LayerNorm: biased variance, eps 1e-5 (layers.py:101).  ACT 0 Mish, 1 SimNorm(8).
+// Lane = row, wave w = columns [64 w, 64 w + 64): the LayerNorm affine parameters and every column offset are
+// wave-uniform (scalar loads, immediates), SimNorm groups of 8 are thread-local, and no cross-lane shuffles are needed.
+// Row statistics are combined across the 8 waves through a small LDS exchange with Chan's parallel-variance formula
+// (per-wave mean and sum of squared deviations: as robust as the two-pass form).  The barrier of that exchange also
+// separates every wave's reads of the staging view from the operand-form writes that alias it.
+// LayerNorm: biased variance, eps 1e-5 (layers.py:101).  ACT 0 Mish, 1 SimNorm(8) (layers.py:84-88).
 template <int ACT, class CT>
 __device__ __forceinline__ void ln_rows_s(const CT &c, const float *g, const float *b, float *gcopy /* optional [64][WIDTH] fp32 */,
                                           const float *gsrc = nullptr /* pre-activation tile in global instead of the staging view */) {
-    const int row = c.tid >> 3, part = c.tid & 7;
-    const float *rp = gsrc ? gsrc + row * WIDTH + 4 * part : c.f32() + row * c.RSF() + 4 * part;
+    const int row = c.lane, col0 = 64 * c.wave;
+    const float *rp = gsrc ? gsrc + row * WIDTH + col0 : c.f32() + row * c.RSF() + col0;
     f32x4 v[16];
     float s = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        v[q] = *reinterpret_cast<const f32x4 *>(rp + 32 * q);
+        v[q] = *reinterpret_cast<const f32x4 *>(rp + 4 * q);
         s += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
     }
-    const float mean = group_sum<8>(s) * (1.0f / WIDTH);
-    float ss = 0.f;
+    const float mw = s * (1.0f / 64.f);
+    float m2 = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float d = v[q][e] - mean;
-            ss = fmaf(d, d, ss);
+            const float d = v[q][e] - mw;
+            m2 = fmaf(d, d, m2);
         }
-    const float var = group_sum<8>(ss) * (1.0f / WIDTH);
-    const float rstd = 1.0f / sqrtf(var + LN_EPS);
-    _Float16 *hp = c.act + row * c.RSH + 4 * part;
+    float *stats = c.stats;  // [8 waves][64 rows][2]
+    stats[(c.wave * 64 + row) * 2 + 0] = mw;
+    stats[(c.wave * 64 + row) * 2 + 1] = m2;
+    __syncthreads();
+    float mean = 0.f, msum = 0.f;
+    float pm[8];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int col = 4 * part + 32 * q;
-        const f32x4 gg = *reinterpret_cast<const f32x4 *>(g + col);
-        const f32x4 bb = *reinterpret_cast<const f32x4 *>(b + col);
-        f32x4 y;
+    for (int w = 0; w < 8; ++w) {
+        pm[w] = stats[(w * 64 + row) * 2 + 0];
+        msum += stats[(w * 64 + row) * 2 + 1];
+        mean += pm[w];
+    }
+    mean *= 0.125f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = fmaf((v[q][e] - mean) * rstd, gg[e], bb[e]);
+    for (int w = 0; w < 8; ++w) {
+        const float d = pm[w] - mean;
+        msum = fmaf(64.f * d, d, msum);
+    }
+    const float rstd = 1.0f / sqrtf(msum * (1.0f / WIDTH) + LN_EPS);
+    const float shift = -mean * rstd;
+    _Float16 *hp = c.act + row * c.RSH + col0;
+    const float *gw = g + col0, *bw = b + col0;  // wave-uniform
+#ifdef SPLIT_ABL_NO_EPI
+    if (mean == 12345.f)  // never true: the activation math below is skipped
+#endif
+#pragma unroll
+    for (int q2 = 0; q2 < 8; ++q2) {  // two float4 chunks = one SimNorm group of 8 columns
+        f32x4 y[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = 2 * q2 + u;
+            const f32x4 gg = *reinterpret_cast<const f32x4 *>(gw + 4 * q);
+            const f32x4 bb = *reinterpret_cast<const f32x4 *>(bw + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[u][e] = fmaf(fmaf(v[q][e], rstd, shift), gg[e], bb[e]);
+        }
         if (ACT == 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = mish_fast(y[e]);
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[u][e] = mish_fast(y[u][e]);
         } else {
-            float m = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
-            m = fmaxf(m, __shfl_xor(m, 1));
+            float m = fmaxf(fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[0][2], y[0][3])),
+                            fmaxf(fmaxf(y[1][0], y[1][1]), fmaxf(y[1][2], y[1][3])));
             float es = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                y[e] = __expf(y[e] - m);
-                es += y[e];
-            }
-            es += __shfl_xor(es, 1);
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[u][e] = __expf(y[u][e] - m);
+                    es += y[u][e];
+                }
             const float inv = 1.0f / es;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = y[e] * inv;
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[u][e] *= inv;
         }
-        f16x4 hi, lo;
-        split4(y, hi, lo);
-        *reinterpret_cast<f16x4 *>(hp + 32 * q) = hi;
-        *reinterpret_cast<f16x4 *>(hp + c.SH + 32 * q) = lo;
-        if (gcopy) *reinterpret_cast<f32x4 *>(gcopy + row * WIDTH + col) = y;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int q = 2 * q2 + u;
+            f16x4 hi, lo;
+            split4(y[u], hi, lo);
+            *reinterpret_cast<f16x4 *>(hp + 4 * q) = hi;
+            *reinterpret_cast<f16x4 *>(hp + c.SH + 4 * q) = lo;
+            if (gcopy) *reinterpret_cast<f32x4 *>(gcopy + row * WIDTH + col0 + 4 * q) = y[u];
+        }
     }
 }
 
@@ -427,7 +483,8 @@ template <int APAD>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x, tid = threadIdx.x;
-    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2, tid,
+                 __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     if (p.multitask) {
         const float *emb = p.task_emb + (size_t)e * p.T;
         for (int net = 0; net < p.nnets; ++net) {
@@ -471,7 +528,8 @@ template <int APAD>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x, tid = threadIdx.x;
-    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2, tid,
+                 __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
     const float *b_pi = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_PI) * WIDTH : p.pi.l[0].bias;
     const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
@@ -508,8 +566,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x / p.tiles, tile = blockIdx.x % p.tiles;
     const int tid = threadIdx.x;
-    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
-    float *sm_mean = smem + ROWS * c.RSH / 2;  // [H*A] after the tile
+    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2, tid,
+                 __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    float *sm_mean = smem + ROWS * c.RSH / 2 + 1024;  // [H*A] after the tile and the LayerNorm partials
     float *sm_std = sm_mean + p.H * p.A;
     const int row0 = tile * ROWS;
     const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;

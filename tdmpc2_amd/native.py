@@ -13,7 +13,8 @@ from typing import Dict, Optional
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtdmpc2_plan.so")
+# TDMPC2_PLAN_LIB points profiling runs at an ablation build of the same library (tools/ablate.sh)
+_LIB_PATH = os.environ.get("TDMPC2_PLAN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtdmpc2_plan.so")
 _lib = None
 
 ABI_VERSION = 2
