@@ -17,6 +17,21 @@
 // Included by tdmpc2_plan.hip inside its anonymous namespace.
 #pragma once
 
+// In-kernel phase timers (profiling builds only: -DSPLIT_TIMING, see tools/ablate.sh): wave 0 of every workgroup sums
+// the shader-clock cycles it spends in each phase class into p.timing[class].
+#ifdef SPLIT_TIMING
+#define TIMER_FIELDS mutable unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}; mutable unsigned long long t_last = 0, t_begin = 0;
+#define TIMER_START(c) { (c).t_last = (c).t_begin = __builtin_amdgcn_s_memtime(); }
+#define TIMER_MARK(c, cls) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); (c).t_acc[cls] += t_now - (c).t_last; (c).t_last = t_now; }
+#define TIMER_FLUSH(c, ptr) if ((ptr) && threadIdx.x == 0) { for (int i_ = 0; i_ < 6; ++i_) atomicAdd((ptr) + i_, (c).t_acc[i_]); atomicAdd((ptr) + 14, (c).t_last - (c).t_begin); atomicAdd((ptr) + 15, 1ull); }
+#else
+#define TIMER_FIELDS
+#define TIMER_START(c)
+#define TIMER_MARK(c, cls)
+#define TIMER_FLUSH(c, ptr)
+#endif
+enum { T_KLOOP = 0, T_EPI = 1, T_HEAD = 2, T_ACT = 3, T_PARK = 4, T_TILE = 5 };
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -45,7 +60,9 @@ struct CtxT {
     static constexpr int RSH = 2 * SH + 8;   // row stride in halfs (row stride in dwords = SH + 4 = 4 x odd)
     _Float16 *act;  // LDS tile, operand form: row r at act + r * RSH: [hi: SH halfs | lo: SH halfs | 8 pad]
     float *stats;   // LDS [8 waves][64 rows][2]: per-wave LayerNorm partials
+    float *prm;     // LDS [3][WIDTH]: the current layer's bias | ln weight | ln bias
     int tid, wave, lane;
+    TIMER_FIELDS
     __device__ __forceinline__ float *f32() const { return reinterpret_cast<float *>(act); }  // staging view [64][RSF]
     static constexpr __device__ __forceinline__ int RSF() { return RSH / 2; }
 };
@@ -66,6 +83,17 @@ __device__ __forceinline__ void split4(const f32x4 y, f16x4 &hi, f16x4 &lo) {
         hi[e] = h;
         lo[e] = (_Float16)(ys - (float)h);
     }
+}
+
+// Two standard normals from ONE Philox4x32-10 call (Box-Muller, both branches) with the hardware log / sin / cos:
+// the sampled distribution only has to be N(0,1) to sampling accuracy (fast mode; parity runs replay a noise tape).
+__device__ __forceinline__ void rng_normal2(unsigned long long seed, unsigned call, int site, int iter, int env, unsigned pair,
+                                            float &n0, float &n1) {
+    const uint4 r = rng_raw(seed, call, site, iter, env, pair);
+    const float u1 = u01(r.x), u2 = u01(r.y);
+    const float rad = __builtin_amdgcn_sqrtf(-2.f * __logf(u1));
+    n0 = rad * __builtin_amdgcn_cosf(u2);  // v_cos_f32 / v_sin_f32 take the angle in revolutions
+    n1 = rad * __builtin_amdgcn_sinf(u2);
 }
 
 // ---------------------------------------------------------------- contraction loops
@@ -110,6 +138,20 @@ __device__ __forceinline__ void load_b(BFrag &b, const char *u0, const char *u1,
     b.h[1] = ldw(u1, voff, 0);
     b.l[1] = ldw(u1, voff, 1024);
 }
+struct AFrag {
+    f16x8 h0, l0, h1, l1;  // hi / lo pieces of the two 32-row sample tiles
+};
+template <class CT>
+__device__ __forceinline__ void load_a(AFrag &a, const _Float16 *a0p, const _Float16 *a1p, int kk) {
+    a.h0 = *reinterpret_cast<const f16x8 *>(a0p + kk * 16);
+    a.l0 = *reinterpret_cast<const f16x8 *>(a0p + CT::SH + kk * 16);
+    a.h1 = *reinterpret_cast<const f16x8 *>(a1p + kk * 16);
+    a.l1 = *reinterpret_cast<const f16x8 *>(a1p + CT::SH + kk * 16);
+}
+// Software pipeline, per k-block: [read the NEXT block's activation fragments from LDS] [12 MFMAs on the current
+// block] [issue the weight loads for block + PF into the ring slot just consumed] [sched_barrier].  The barrier pins
+// the order: without it the machine scheduler sinks the prefetch loads to their first use (the next outer iteration)
+// and the loop runs load -> wait -> compute with no overlap.
 template <class CT>
 __device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, int kb1, f32x16 (&acc)[2][2]) {
     const int i = c.lane & 31, hh = c.lane >> 5;
@@ -127,56 +169,63 @@ __device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, 
         const int kd = d < nk ? d : nk - 1;
         load_b(ring[d], u0 + (size_t)kd * 2048, u1 + (size_t)kd * 2048, voff);
     }
+    AFrag an;
+    load_a<CT>(an, a0p, a1p, 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int k = 0; k < nk; k += PF) {
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
             const int kk = k + d;
             if (kk < nk) {  // wave-uniform
-                const BFrag b = ring[d];
+                const AFrag a = an;
+                load_a<CT>(an, a0p, a1p, kk + 1 < nk ? kk + 1 : kk);
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    acc[0][cc] = SPLIT_MFMA(ring[d].h[cc], a.h0, acc[0][cc]);
+                    acc[1][cc] = SPLIT_MFMA(ring[d].h[cc], a.h1, acc[1][cc]);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    acc[0][cc] = SPLIT_MFMA(ring[d].l[cc], a.h0, acc[0][cc]);
+                    acc[1][cc] = SPLIT_MFMA(ring[d].l[cc], a.h1, acc[1][cc]);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    acc[0][cc] = SPLIT_MFMA(ring[d].h[cc], a.l0, acc[0][cc]);
+                    acc[1][cc] = SPLIT_MFMA(ring[d].h[cc], a.l1, acc[1][cc]);
+                }
                 const int kn = kk + PF < nk ? kk + PF : nk - 1;
                 load_b(ring[d], u0 + (size_t)kn * 2048, u1 + (size_t)kn * 2048, voff);
-                const f16x8 ah0 = *reinterpret_cast<const f16x8 *>(a0p + kk * 16);
-                const f16x8 al0 = *reinterpret_cast<const f16x8 *>(a0p + c.SH + kk * 16);
-                const f16x8 ah1 = *reinterpret_cast<const f16x8 *>(a1p + kk * 16);
-                const f16x8 al1 = *reinterpret_cast<const f16x8 *>(a1p + c.SH + kk * 16);
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    acc[0][cc] = SPLIT_MFMA(ah0, b.h[cc], acc[0][cc]);
-                    acc[1][cc] = SPLIT_MFMA(ah1, b.h[cc], acc[1][cc]);
-                }
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    acc[0][cc] = SPLIT_MFMA(ah0, b.l[cc], acc[0][cc]);
-                    acc[1][cc] = SPLIT_MFMA(ah1, b.l[cc], acc[1][cc]);
-                }
-#pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    acc[0][cc] = SPLIT_MFMA(al0, b.h[cc], acc[0][cc]);
-                    acc[1][cc] = SPLIT_MFMA(al1, b.h[cc], acc[1][cc]);
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
 }
 
-// One 32x32 output tile (row tile rt, column tile ct): the narrow output layers.  Three independent accumulators
-// (one per product kind) keep the matrix pipe issuing back to back; they are summed at the end.
+// Narrow output layers (two-hot / policy heads): wave `ct` < CT computes column tile ct for BOTH 32-row tiles, so every
+// weight fragment is fetched once per workgroup and feeds 6 MFMAs; six independent accumulators (row tile x product
+// kind) keep the matrix pipe issuing back to back.  Activations are the A operand here: C[sample][logit].
 template <class CT>
-__device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int ct, int rt, int kb0, int kb1, f32x16 &acc) {
+__device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int ct, int kb0, int kb1, f32x16 (&out)[2]) {
 #ifndef SPLIT_PFT
-#define SPLIT_PFT 8
+#define SPLIT_PFT 6
 #endif
-    constexpr int PFT = SPLIT_PFT;  // only 3 MFMAs (96 pipe cycles) per k-block here: prefetch deeper
+    constexpr int PFT = SPLIT_PFT;
     const int i = c.lane & 31, hh = c.lane >> 5;
-    const _Float16 *ap = c.act + (rt * 32 + i) * c.RSH + 8 * hh + kb0 * 16;
+    const _Float16 *a0p = c.act + i * c.RSH + 8 * hh + kb0 * 16;
+    const _Float16 *a1p = a0p + 32 * c.RSH;
     const char *u = reinterpret_cast<const char *>(ly.wp) + ((size_t)ct * ly.KB + kb0) * 2048;  // uniform
     unsigned voff = (unsigned)c.lane * 16u;
     asm volatile("" : "+v"(voff));
     const int nk = kb1 - kb0;
-    f32x16 a1, a2;
+    f32x16 acc[2][3];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) a1[e] = a2[e] = 0.f;
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][t][e] = 0.f;
     f16x8 rh[PFT], rl[PFT];
 #pragma unroll
     for (int d = 0; d < PFT; ++d) {
@@ -184,71 +233,216 @@ __device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int 
         rh[d] = ldw(u + (size_t)kd * 2048, voff, 0);
         rl[d] = ldw(u + (size_t)kd * 2048, voff, 1024);
     }
+    AFrag an;
+    load_a<CT>(an, a0p, a1p, 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int k = 0; k < nk; k += PFT) {
 #pragma unroll
         for (int d = 0; d < PFT; ++d) {
             const int kk = k + d;
             if (kk < nk) {
-                const f16x8 bh = rh[d], bl = rl[d];
+                const AFrag a = an;
+                load_a<CT>(an, a0p, a1p, kk + 1 < nk ? kk + 1 : kk);
+                acc[0][0] = SPLIT_MFMA(a.h0, rh[d], acc[0][0]);
+                acc[1][0] = SPLIT_MFMA(a.h1, rh[d], acc[1][0]);
+                acc[0][1] = SPLIT_MFMA(a.h0, rl[d], acc[0][1]);
+                acc[1][1] = SPLIT_MFMA(a.h1, rl[d], acc[1][1]);
+                acc[0][2] = SPLIT_MFMA(a.l0, rh[d], acc[0][2]);
+                acc[1][2] = SPLIT_MFMA(a.l1, rh[d], acc[1][2]);
                 const int kn = kk + PFT < nk ? kk + PFT : nk - 1;
                 rh[d] = ldw(u + (size_t)kn * 2048, voff, 0);
                 rl[d] = ldw(u + (size_t)kn * 2048, voff, 1024);
-                const f16x8 ah = *reinterpret_cast<const f16x8 *>(ap + kk * 16);
-                const f16x8 al = *reinterpret_cast<const f16x8 *>(ap + c.SH + kk * 16);
-                acc = SPLIT_MFMA(ah, bh, acc);
-                a1 = SPLIT_MFMA(ah, bl, a1);
-                a2 = SPLIT_MFMA(al, bh, a2);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] += a1[e] + a2[e];
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[r][e] = acc[r][0][e] + (acc[r][1][e] + acc[r][2][e]);
 }
 
-// acc * oscale + bias -> fp32 staging view.  C/D fragment: lane holds column (l & 31), rows (reg&3) + 8 (reg>>2) + 4 (l>>5).
+// ---------------------------------------------------------------- register-resident epilogue of the 512-wide layers
+// kloop_s issues the MFMAs with the WEIGHT fragment as the A operand, so the 32x32 C tile is C[feature][sample]:
+// lane (j = l & 31, hh = l >> 5) holds, for sample rows 32 st + j (st = 0, 1), the features
+//     F(ft, m, r) = 64 wave + 32 ft + 8 m + 4 hh + r        (ft = 0, 1; m = reg >> 2; r = reg & 3)
+// i.e. half of the wave's 64 output features of that row; lane l ^ 32 holds the other half.  LayerNorm statistics are
+// therefore thread-local sums plus ONE cross-lane exchange, combined over the 8 waves through a 4 KB LDS table with
+// Chan's parallel-variance formula; normalisation, activation and the hi/lo split run on the accumulators in place
+// and the operand form is written straight back to the LDS tile: no fp32 staging pass, 3 barriers per layer.
+// LayerNorm: biased variance, eps 1e-5 (layers.py:101).  ACT 0 Mish, 1 SimNorm over 8 consecutive features
+// (layers.py:84-88) = this lane's 4 + the partner lane's 4.
+constexpr int PRM_FLOATS = 3 * WIDTH;  // LDS copy of the layer's bias | ln weight | ln bias
+
+// raw accumulators <-> a dense global tile in register order (coalesced 1 KiB per wave instruction)
 template <class CT>
-__device__ __forceinline__ void store_full_s(const CT &c, const f32x16 (&acc)[2][2], float osc, const float *bias) {
-    float *f = c.f32();
-    const int RSF = c.RSF();
+__device__ __forceinline__ void park(const CT &c, const f32x16 (&acc)[2][2], float *dst) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[st][ft][4 * m + r];
+                const int idx4 = ((c.wave * 2 + st) * 2 + ft) * 4 + m;
+                *reinterpret_cast<f32x4 *>(dst + ((size_t)idx4 * 64 + c.lane) * 4) = v;
+            }
+}
+template <class CT>
+__device__ __forceinline__ void unpark(const CT &c, f32x16 (&acc)[2][2], const float *src) {
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int idx4 = ((c.wave * 2 + st) * 2 + ft) * 4 + m;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(src + ((size_t)idx4 * 64 + c.lane) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = v[r];
+            }
+}
+
+// values in register order -> operand form in the LDS tile (hi / lo planes), scaled by ACT_SCALE
+template <class CT>
+__device__ __forceinline__ void regs_to_tile(const CT &c, const f32x16 (&y)[2][2]) {
     const int j = c.lane & 31, hh = c.lane >> 5;
 #pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-        const int col = (2 * c.wave + cc) * 32 + j;
-        const float bv = bias[col];
+    for (int st = 0; st < 2; ++st) {
+        _Float16 *hp = c.act + (32 * st + j) * c.RSH + 64 * c.wave + 4 * hh;
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                f[row * RSF + col] = fmaf(acc[rt][cc][reg], osc, bv);
+            for (int m = 0; m < 4; ++m) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = y[st][ft][4 * m + r];
+                f16x4 hi, lo;
+                split4(v, hi, lo);
+                *reinterpret_cast<f16x4 *>(hp + 32 * ft + 8 * m) = hi;
+                *reinterpret_cast<f16x4 *>(hp + c.SH + 32 * ft + 8 * m) = lo;
             }
     }
 }
-// the same into a dense global tile [64][WIDTH] (pre-activation parked in L2 instead of 64 held accumulators)
+
+// Stage the layer's bias / LayerNorm affine vectors in LDS (read back per feature group with two addresses per wave).
 template <class CT>
-__device__ __forceinline__ void store_full_global(const CT &c, const f32x16 (&acc)[2][2], float osc, const float *bias, float *dst) {
-    const int j = c.lane & 31, hh = c.lane >> 5;
-    // one 32-bit lane offset against the wave-uniform tile base; made opaque so that the 64 store addresses are formed
-    // here (base + constant) instead of being hoisted out of the step loop as 64 live 64-bit pointers (spills)
-    unsigned lane_off = (unsigned)(4 * hh * WIDTH + 2 * c.wave * 32 + j);
-    asm volatile("" : "+v"(lane_off));
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc) {
-        const float bv = bias[(2 * c.wave + cc) * 32 + j];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const unsigned koff = (unsigned)((rt * 32 + (reg & 3) + 8 * (reg >> 2)) * WIDTH + cc * 32);
-                dst[lane_off + koff] = fmaf(acc[rt][cc][reg], osc, bv);
-            }
-    }
+__device__ __forceinline__ void stage_params(const CT &c, const float *bias, const float *g, const float *b) {
+    c.prm[c.tid] = bias[c.tid];
+    c.prm[WIDTH + c.tid] = g[c.tid];
+    c.prm[2 * WIDTH + c.tid] = b[c.tid];
 }
+
+// acc (raw MFMA sums) -> ACT(LayerNorm(acc * osc + bias)) -> operand form in the LDS tile (+ optional register-order
+// fp32 copy `zcopy` in global).  Contains two barriers; the caller adds the one before the next contraction.
+// Precondition: stage_params() was called by all threads after the previous epilogue's last barrier.
+template <int ACT, class CT>
+__device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[2][2], float osc, float *zcopy) {
+    const int j = c.lane & 31, hh = c.lane >> 5;
+    __syncthreads();  // (1) every wave is done reading the operand tile; the staged parameters are visible
+    const float *pb = c.prm + 64 * c.wave + 4 * hh;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(pb + 32 * ft + 8 * m);
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = fmaf(acc[st][ft][4 * m + r], osc, b4[r]);
+        }
+    // per-wave partial statistics of the two sample rows this lane works on
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        float s = 0.f;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += acc[st][ft][e];
+        s += __shfl_xor(s, 32);
+        const float mw = s * (1.0f / 64.f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float d = acc[st][ft][e] - mw;
+                m2 = fmaf(d, d, m2);
+            }
+        m2 += __shfl_xor(m2, 32);
+        if (hh == 0) {
+            c.stats[(c.wave * 64 + 32 * st + j) * 2 + 0] = mw;
+            c.stats[(c.wave * 64 + 32 * st + j) * 2 + 1] = m2;
+        }
+    }
+    __syncthreads();  // (2)
+    float rstd[2], shift[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+        float pm[8], mean = 0.f, msum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            pm[w] = c.stats[(w * 64 + 32 * st + j) * 2 + 0];
+            msum += c.stats[(w * 64 + 32 * st + j) * 2 + 1];
+            mean += pm[w];
+        }
+        mean *= 0.125f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const float d = pm[w] - mean;
+            msum = fmaf(64.f * d, d, msum);
+        }
+        rstd[st] = 1.0f / sqrtf(msum * (1.0f / WIDTH) + LN_EPS);
+        shift[st] = -mean * rstd[st];
+    }
+#ifdef SPLIT_ABL_NO_EPI
+    if (rstd[0] == 12345.f)  // never true: the activation math below is skipped
+#endif
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4 *>(pb + WIDTH + 32 * ft + 8 * m);
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(pb + 2 * WIDTH + 32 * ft + 8 * m);
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[r] = fmaf(fmaf(acc[st][ft][4 * m + r], rstd[st], shift[st]), g4[r], b4[r]);
+                if (ACT == 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = mish_fast(y[r]);
+                } else {
+                    float mx = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    float es = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        y[r] = __expf(y[r] - mx);
+                        es += y[r];
+                    }
+                    es += __shfl_xor(es, 32);
+                    const float inv = 1.0f / es;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] *= inv;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = y[r];
+            }
+        }
+    regs_to_tile(c, acc);
+    if (zcopy) park(c, acc, zcopy);
+}
+
+// Narrow output layers (two-hot / policy heads): acc * oscale + bias -> fp32 logits in the staging view of the tile.
+// C/D fragment of kloop_tile_s (activations as the A operand): lane holds column (l & 31), rows (reg&3) + 8 (reg>>2) + 4 (l>>5).
 template <class CT>
 __device__ __forceinline__ void store_tile_s(const CT &c, const f32x16 &acc, float osc, const float *bias, int ct, int rt) {
     float *f = c.f32();
-    const int RSF = c.RSF();
+    constexpr int RSF = CT::RSF();
     const int j = c.lane & 31, hh = c.lane >> 5;
     const int col = ct * 32 + j;
     const float bv = bias[col];
@@ -259,134 +453,58 @@ __device__ __forceinline__ void store_tile_s(const CT &c, const f32x16 &acc, flo
     }
 }
 
-// ---------------------------------------------------------------- row epilogue: staging (fp32) -> operand form (hi/lo f16)
-// Lane = row, wave w = columns [64 w, 64 w + 64): the LayerNorm affine parameters and every column offset are
-// wave-uniform (scalar loads, immediates), SimNorm groups of 8 are thread-local, and no cross-lane shuffles are needed.
-// Row statistics are combined across the 8 waves through a small LDS exchange with Chan's parallel-variance formula
-// (per-wave mean and sum of squared deviations: as robust as the two-pass form).  The barrier of that exchange also
-// separates every wave's reads of the staging view from the operand-form writes that alias it.
-// LayerNorm: biased variance, eps 1e-5 (layers.py:101).  ACT 0 Mish, 1 SimNorm(8) (layers.py:84-88).
-template <int ACT, class CT>
-__device__ __forceinline__ void ln_rows_s(const CT &c, const float *g, const float *b, float *gcopy /* optional [64][WIDTH] fp32 */,
-                                          const float *gsrc = nullptr /* pre-activation tile in global instead of the staging view */) {
-    const int row = c.lane, col0 = 64 * c.wave;
-    const float *rp = gsrc ? gsrc + row * WIDTH + col0 : c.f32() + row * c.RSF() + col0;
-    f32x4 v[16];
-    float s = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        v[q] = *reinterpret_cast<const f32x4 *>(rp + 4 * q);
-        s += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
-    }
-    const float mw = s * (1.0f / 64.f);
-    float m2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = v[q][e] - mw;
-            m2 = fmaf(d, d, m2);
-        }
-    float *stats = c.stats;  // [8 waves][64 rows][2]
-    stats[(c.wave * 64 + row) * 2 + 0] = mw;
-    stats[(c.wave * 64 + row) * 2 + 1] = m2;
-    __syncthreads();
-    float mean = 0.f, msum = 0.f;
-    float pm[8];
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        pm[w] = stats[(w * 64 + row) * 2 + 0];
-        msum += stats[(w * 64 + row) * 2 + 1];
-        mean += pm[w];
-    }
-    mean *= 0.125f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) {
-        const float d = pm[w] - mean;
-        msum = fmaf(64.f * d, d, msum);
-    }
-    const float rstd = 1.0f / sqrtf(msum * (1.0f / WIDTH) + LN_EPS);
-    const float shift = -mean * rstd;
-    _Float16 *hp = c.act + row * c.RSH + col0;
-    const float *gw = g + col0, *bw = b + col0;  // wave-uniform
-#ifdef SPLIT_ABL_NO_EPI
-    if (mean == 12345.f)  // never true: the activation math below is skipped
-#endif
-#pragma unroll
-    for (int q2 = 0; q2 < 8; ++q2) {  // two float4 chunks = one SimNorm group of 8 columns
-        f32x4 y[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int q = 2 * q2 + u;
-            const f32x4 gg = *reinterpret_cast<const f32x4 *>(gw + 4 * q);
-            const f32x4 bb = *reinterpret_cast<const f32x4 *>(bw + 4 * q);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[u][e] = fmaf(fmaf(v[q][e], rstd, shift), gg[e], bb[e]);
-        }
-        if (ACT == 0) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[u][e] = mish_fast(y[u][e]);
-        } else {
-            float m = fmaxf(fmaxf(fmaxf(y[0][0], y[0][1]), fmaxf(y[0][2], y[0][3])),
-                            fmaxf(fmaxf(y[1][0], y[1][1]), fmaxf(y[1][2], y[1][3])));
-            float es = 0.f;
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    y[u][e] = __expf(y[u][e] - m);
-                    es += y[u][e];
-                }
-            const float inv = 1.0f / es;
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[u][e] *= inv;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int q = 2 * q2 + u;
-            f16x4 hi, lo;
-            split4(y[u], hi, lo);
-            *reinterpret_cast<f16x4 *>(hp + 4 * q) = hi;
-            *reinterpret_cast<f16x4 *>(hp + c.SH + 4 * q) = lo;
-            if (gcopy) *reinterpret_cast<f32x4 *>(gcopy + row * WIDTH + col0 + 4 * q) = y[u];
-        }
-    }
-}
-
 // two_hot_inv (math.py:74-83) on fp32 logits in the staging view.
+// softmax(logits) . bins -> symexp; the softmax normalisation is applied once to the weighted sum.
 template <class CT>
 __device__ __forceinline__ float twohot_rows_s(const CT &c, const float *bins, int num_bins) {
-    return twohot_rows(c.f32(), c.RSF(), bins, num_bins, c.tid);
+    const int row = c.tid >> 3, part = c.tid & 7;
+    const float *rp = c.f32() + row * c.RSF();
+    float v[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int jj = part + 8 * q;
+        v[q] = (jj < num_bins) ? rp[jj] : -INFINITY;
+        m = fmaxf(m, v[q]);
+    }
+    m = group_max<8>(m);
+    float es = 0.f, x = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int jj = part + 8 * q;
+        const float ev = (jj < num_bins) ? __expf(v[q] - m) : 0.f;
+        es += ev;
+        x = fmaf(ev, (jj < num_bins) ? bins[jj] : 0.f, x);
+    }
+    es = group_sum<8>(es);
+    x = group_sum<8>(x);
+    return symexp_f(x / es);
 }
 
 template <int ACT, class CT>
 __device__ __forceinline__ void layer_full_s(const CT &c, const LayerS &ly, const float *bias, int kb0, int kb1,
-                                             float *gcopy = nullptr) {
+                                             float *zcopy = nullptr) {
     f32x16 acc[2][2];
     zero4(acc);
+    stage_params(c, bias, ly.g, ly.b);
     kloop_s(c, ly, kb0, kb1, acc);
-    const float osc = *ly.oscale;
+    TIMER_MARK(c, T_KLOOP)
+    epi_t<ACT>(c, acc, *ly.oscale, zcopy);
     __syncthreads();
-    store_full_s(c, acc, osc, bias);
-    __syncthreads();
-    ln_rows_s<ACT>(c, ly.g, ly.b, gcopy);
-    __syncthreads();
+    TIMER_MARK(c, T_EPI)
 }
 
 template <class CT>
 __device__ __forceinline__ float head_twohot_s(const CT &c, const LayerS &ly, const float *bins, int num_bins) {
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const int rt = c.wave & 1, ct = c.wave >> 1;
-    if (ct < ly.CT) kloop_tile_s(c, ly, ct, rt, 0, ZKB16, acc);
+    f32x16 acc[2];
+    const int ct = c.wave;
+    if (ct < ly.CT) kloop_tile_s(c, ly, ct, 0, ZKB16, acc);
     const float osc = *ly.oscale;
     __syncthreads();
-    if (ct < ly.CT) store_tile_s(c, acc, osc, ly.bias, ct, rt);
+    if (ct < ly.CT) {
+        store_tile_s(c, acc[0], osc, ly.bias, ct, 0);
+        store_tile_s(c, acc[1], osc, ly.bias, ct, 1);
+    }
     __syncthreads();
     const float r = twohot_rows_s(c, bins, num_bins);
     __syncthreads();
@@ -408,14 +526,15 @@ __device__ __forceinline__ void put_action(const CT &c, int row, int a, float v)
 template <class CT, typename EpsFn>
 __device__ __forceinline__ void head_pi_s(const CT &c, const LayerS &ly, int A, int Apad, float lsmin, float lsdif,
                                           const float *mask, EpsFn eps, float *gdst, int nvalid, float *tsc) {
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const int rt = c.wave & 1, ct = c.wave >> 1;
-    if (ct < ly.CT) kloop_tile_s(c, ly, ct, rt, 0, ZKB16, acc);
+    f32x16 acc[2];
+    const int ct = c.wave;
+    if (ct < ly.CT) kloop_tile_s(c, ly, ct, 0, ZKB16, acc);
     const float osc = *ly.oscale;
     __syncthreads();
-    if (ct < ly.CT) store_tile_s(c, acc, osc, ly.bias, ct, rt);
+    if (ct < ly.CT) {
+        store_tile_s(c, acc[0], osc, ly.bias, ct, 0);
+        store_tile_s(c, acc[1], osc, ly.bias, ct, 1);
+    }
     __syncthreads();
     const int row = c.tid >> 3, part = c.tid & 7;
     const float *rp = c.f32() + row * c.RSF();
@@ -441,18 +560,12 @@ __device__ __forceinline__ void head_pi_s(const CT &c, const LayerS &ly, int A, 
     __syncthreads();
 }
 
-// global fp32 [64][WIDTH] -> operand-form z columns
+// register-order fp32 tile in global (written by park / epi_t's zcopy) -> operand-form z columns
 template <class CT>
 __device__ __forceinline__ void tile_from_global_s(const CT &c, const float *src) {
-    for (int idx = c.tid; idx < ROWS * (WIDTH / 4); idx += NTHREADS) {
-        const int row = idx / (WIDTH / 4), c4 = idx % (WIDTH / 4);
-        const f32x4 y = *reinterpret_cast<const f32x4 *>(src + row * WIDTH + 4 * c4);
-        f16x4 hi, lo;
-        split4(y, hi, lo);
-        _Float16 *hp = c.act + row * c.RSH + 4 * c4;
-        *reinterpret_cast<f16x4 *>(hp) = hi;
-        *reinterpret_cast<f16x4 *>(hp + c.SH) = lo;
-    }
+    f32x16 y[2][2];
+    unpark(c, y, src);
+    regs_to_tile(c, y);
 }
 template <class CT>
 __device__ __forceinline__ void tile_broadcast_row_s(const CT &c, const float *src_row) {
@@ -483,8 +596,8 @@ template <int APAD>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x, tid = threadIdx.x;
-    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2, tid,
-                 __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2,
+                 smem + ROWS * CtxT<APAD>::RSH / 2 + 1024, tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     if (p.multitask) {
         const float *emb = p.task_emb + (size_t)e * p.T;
         for (int net = 0; net < p.nnets; ++net) {
@@ -513,13 +626,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
     const float *b_rew = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_REW) * WIDTH : p.rew.l[0].bias;
     const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
     const float o_rew = *p.rew.l[0].oscale, o_dyn = *p.dyn.l[0].oscale;
-    if ((c.lane >> 5) == 0) {  // row 0 of the tile: register 0 of row tile 0 in lanes 0..31
+    if ((c.lane & 31) == 0) {  // sample row 0 of the tile: lanes 0 (hh = 0) and 32 (hh = 1), sample tile 0
+        const int hh = c.lane >> 5;
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const int col = (2 * c.wave + ct) * 32 + (c.lane & 31);
-            p.cvec[((size_t)e * 2 + 0) * WIDTH + col] = fmaf(acc[0][0][ct][0], o_rew, b_rew[col]);
-            p.cvec[((size_t)e * 2 + 1) * WIDTH + col] = fmaf(acc[1][0][ct][0], o_dyn, b_dyn[col]);
-        }
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int col = 64 * c.wave + 32 * ft + 8 * (reg >> 2) + 4 * hh + (reg & 3);
+                p.cvec[((size_t)e * 2 + 0) * WIDTH + col] = fmaf(acc[0][0][ft][reg], o_rew, b_rew[col]);
+                p.cvec[((size_t)e * 2 + 1) * WIDTH + col] = fmaf(acc[1][0][ft][reg], o_dyn, b_dyn[col]);
+            }
     }
 }
 
@@ -528,17 +644,27 @@ template <int APAD>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x, tid = threadIdx.x;
-    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2, tid,
-                 __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2,
+                 smem + ROWS * CtxT<APAD>::RSH / 2 + 1024, tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
     const float *b_pi = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_PI) * WIDTH : p.pi.l[0].bias;
     const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
     float *zs = p.zscratch + (size_t)e * p.zscratch_estride;
     const int KBA = ZKB16 + p.Apad / 16;
     tile_broadcast_row_s(c, p.z0 + (size_t)e * WIDTH);
-    for (int idx = tid; idx < ROWS * WIDTH / 4; idx += NTHREADS)
-        *reinterpret_cast<f32x4 *>(zs + 4 * idx) =
-            *reinterpret_cast<const f32x4 *>(p.z0 + (size_t)e * WIDTH + 4 * (idx % (WIDTH / 4)));
+    {  // zs <- z0 for every sample row, in register order (what tile_from_global_s reads back)
+        f32x16 y[2][2];
+        const int hh = c.lane >> 5;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 z = *reinterpret_cast<const f32x4 *>(p.z0 + (size_t)e * WIDTH + 64 * c.wave + 32 * ft + 8 * m + 4 * hh);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[0][ft][4 * m + r] = y[1][ft][4 * m + r] = z[r];
+            }
+        park(c, y, zs);
+    }
     __syncthreads();
     for (int t = 0; t < p.H; ++t) {
         layer_full_s<0>(c, p.pi.l[0], b_pi, 0, ZKB16);
@@ -566,9 +692,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x / p.tiles, tile = blockIdx.x % p.tiles;
     const int tid = threadIdx.x;
-    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2, tid,
-                 __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
-    float *sm_mean = smem + ROWS * c.RSH / 2 + 1024;  // [H*A] after the tile and the LayerNorm partials
+    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2,
+                 smem + ROWS * CtxT<APAD>::RSH / 2 + 1024, tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    float *sm_mean = smem + ROWS * c.RSH / 2 + 1024 + PRM_FLOATS;  // [H*A] after the tile, LayerNorm partials, layer parameters
     float *sm_std = sm_mean + p.H * p.A;
     const int row0 = tile * ROWS;
     const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
@@ -600,60 +726,81 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
     __syncthreads();
 
     float G = 0.f;
+    TIMER_START(c)
     for (int t = 0; t < p.H; ++t) {
-        // ---- actions of step t (tdmpc2.py:176-181) -> operand-form action columns
+        // ---- actions of step t (tdmpc2.py:176-181) -> operand-form action columns; a thread handles PAIRS of action
+        // columns so that one Philox call feeds two samples
         {
             float *ag = p.actions + ((size_t)e * p.H + t) * p.N * p.A;
-            for (int idx = tid; idx < ROWS * p.Apad; idx += NTHREADS) {
-                const int row = idx / p.Apad, a = idx % p.Apad;
+            const int hp = p.Apad / 2;
+            for (int idx = tid; idx < ROWS * hp; idx += NTHREADS) {
+                const int row = idx / hp, a0 = 2 * (idx % hp);
                 const int n = row0 + row;
-                float v = 0.f;
-                if (a < p.A) {
-                    if (p.given_actions || n < p.P) {
-                        v = ag[(size_t)n * p.A + a];
-                    } else {
-                        float r;
-                        const unsigned ridx = (unsigned)(((size_t)t * (p.N - p.P) + (n - p.P)) * p.A + a);
-                        if (p.sample_eps)
-                            r = p.sample_eps[(size_t)e * p.sample_eps_estride + ridx];
-                        else
-                            r = rng_normal(p.seed, p.call, SITE_SAMPLE, p.iter, e, ridx);
-                        v = sm_mean[t * p.A + a] + sm_std[t * p.A + a] * r;
-                        v = fminf(fmaxf(v, -1.f), 1.f);
-                    }
-                    if (mask && !p.given_actions) v *= mask[a];
-                    if (!p.given_actions) ag[(size_t)n * p.A + a] = v;
+                float v[2] = {0.f, 0.f};
+                const bool sampled = !(p.given_actions || n < p.P);
+                float z[2] = {0.f, 0.f};
+                if (sampled && a0 < p.A && !p.sample_eps) {
+                    const unsigned pair = (unsigned)(((size_t)t * (p.N - p.P) + (n - p.P)) * hp + a0 / 2);
+                    rng_normal2(p.seed, p.call, SITE_SAMPLE, p.iter, e, pair, z[0], z[1]);
                 }
-                put_action(c, row, a, v);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int a = a0 + u;
+                    if (a < p.A) {
+                        if (!sampled) {
+                            v[u] = ag[(size_t)n * p.A + a];
+                        } else {
+                            float r = z[u];
+                            if (p.sample_eps)
+                                r = p.sample_eps[(size_t)e * p.sample_eps_estride +
+                                                 (unsigned)(((size_t)t * (p.N - p.P) + (n - p.P)) * p.A + a)];
+                            v[u] = sm_mean[t * p.A + a] + sm_std[t * p.A + a] * r;
+                            v[u] = fminf(fmaxf(v[u], -1.f), 1.f);
+                        }
+                        if (mask && !p.given_actions) v[u] *= mask[a];
+                        if (!p.given_actions) ag[(size_t)n * p.A + a] = v[u];
+                    }
+                    put_action(c, row, a, v[u]);
+                }
             }
         }
         __syncthreads();
-        // ---- first layers of dynamics and reward over the same [z_t | a_t] tile; the dynamics pre-activation is parked
-        // in the workgroup's L2-resident scratch tile until the reward chain is done (64 VGPRs not held)
+        TIMER_MARK(c, T_ACT)
+        // ---- first layers of dynamics and reward over the same [z_t | a_t] tile; the raw dynamics accumulators are
+        // parked in the workgroup's L2-resident scratch tile until the reward chain is done (64 VGPRs not held)
         {
             f32x16 acc[2][2];
             zero4(acc);
             kloop_s(c, p.dyn.l[0], t == 0 ? ZKB16 : 0, KBA, acc);
-            store_full_global(c, acc, *p.dyn.l[0].oscale, t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn, zs);
+            TIMER_MARK(c, T_KLOOP)
+            park(c, acc, zs);
+            TIMER_MARK(c, T_PARK)
             zero4(acc);
+            stage_params(c, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew, p.rew.l[0].g, p.rew.l[0].b);
             kloop_s(c, p.rew.l[0], t == 0 ? ZKB16 : 0, KBA, acc);
-            const float o_rew = *p.rew.l[0].oscale;
-            __syncthreads();
-            store_full_s(c, acc, o_rew, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew);
+            TIMER_MARK(c, T_KLOOP)
+            epi_t<0>(c, acc, *p.rew.l[0].oscale, nullptr);
         }
         __syncthreads();
-        ln_rows_s<0>(c, p.rew.l[0].g, p.rew.l[0].b, nullptr);
-        __syncthreads();
+        TIMER_MARK(c, T_EPI)
         dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 0);
         // ---- reward: layer 2, two-hot head
         layer_full_s<0>(c, p.rew.l[1], p.rew.l[1].bias, 0, ZKB16);
         dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 1);
         const float r = head_twohot_s(c, p.rew.l[2], p.bins, p.num_bins);
+        TIMER_MARK(c, T_HEAD)
         if (tsc && (tid & 7) == 0) tsc[t] = r;
         G += disc[t] * r;
         // ---- dynamics: pick the parked first layer up from L2, layers 2 and 3 (SimNorm)
-        ln_rows_s<0>(c, p.dyn.l[0].g, p.dyn.l[0].b, nullptr, zs);
+        {
+            f32x16 acc[2][2];
+            stage_params(c, t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn, p.dyn.l[0].g, p.dyn.l[0].b);
+            unpark(c, acc, zs);
+            TIMER_MARK(c, T_PARK)
+            epi_t<0>(c, acc, *p.dyn.l[0].oscale, nullptr);
+        }
         __syncthreads();
+        TIMER_MARK(c, T_EPI)
         dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 2);
         layer_full_s<0>(c, p.dyn.l[1], p.dyn.l[1].bias, 0, ZKB16);
         dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 3);
@@ -674,36 +821,48 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
         head_pi_s(c, p.pi.l[2], p.A, p.Apad, p.log_std_min, p.log_std_dif, mask, eps, nullptr, 0,
                   tsc ? tsc + p.H + 2 : nullptr);
     }
+    TIMER_MARK(c, T_HEAD)
     tile_from_global_s(c, zs);
     __syncthreads();
+    TIMER_MARK(c, T_TILE)
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 2);
     // ---- Q(z_H, a_H): the two selected heads, first layers in one pass (world_model.py:186-216)
     {
-        // z_H has been read back from zs above (tile_from_global_s + barrier): the scratch tile is free to park the
-        // second head's first-layer pre-activation
+        // z_H has been read back from zs above: the scratch tile is free to park the second head's raw first layer
         f32x16 acc[2][2];
         zero4(acc);
         kloop_s(c, p.q[q1].l[0], 0, KBA, acc);
-        store_full_global(c, acc, *p.q[q1].l[0].oscale, b_q1, zs);
+        TIMER_MARK(c, T_KLOOP)
+        park(c, acc, zs);
+        TIMER_MARK(c, T_PARK)
         zero4(acc);
+        stage_params(c, b_q0, p.q[q0].l[0].g, p.q[q0].l[0].b);
         kloop_s(c, p.q[q0].l[0], 0, KBA, acc);
-        const float o_q0 = *p.q[q0].l[0].oscale;
-        __syncthreads();
-        store_full_s(c, acc, o_q0, b_q0);
+        TIMER_MARK(c, T_KLOOP)
+        epi_t<0>(c, acc, *p.q[q0].l[0].oscale, nullptr);
     }
     __syncthreads();
-    ln_rows_s<0>(c, p.q[q0].l[0].g, p.q[q0].l[0].b, nullptr);
-    __syncthreads();
+    TIMER_MARK(c, T_EPI)
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 3);
     layer_full_s<0>(c, p.q[q0].l[1], p.q[q0].l[1].bias, 0, ZKB16);
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 4);
     const float qa = head_twohot_s(c, p.q[q0].l[2], p.bins, p.num_bins);
-    ln_rows_s<0>(c, p.q[q1].l[0].g, p.q[q1].l[0].b, nullptr, zs);
+    TIMER_MARK(c, T_HEAD)
+    {
+        f32x16 acc[2][2];
+        stage_params(c, b_q1, p.q[q1].l[0].g, p.q[q1].l[0].b);
+        unpark(c, acc, zs);
+        TIMER_MARK(c, T_PARK)
+        epi_t<0>(c, acc, *p.q[q1].l[0].oscale, nullptr);
+    }
     __syncthreads();
+    TIMER_MARK(c, T_EPI)
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 5);
     layer_full_s<0>(c, p.q[q1].l[1], p.q[q1].l[1].bias, 0, ZKB16);
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 6);
     const float qb = head_twohot_s(c, p.q[q1].l[2], p.bins, p.num_bins);
+    TIMER_MARK(c, T_HEAD)
+    TIMER_FLUSH(c, p.timing)
     if (tsc && (tid & 7) == 0) {
         tsc[p.H] = qa;
         tsc[p.H + 1] = qb;

@@ -30,6 +30,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -91,6 +92,7 @@ struct RolloutParamsT {
     float *zscratch;  // [E*tiles,64,WIDTH]
     float *trace_tiles;    // optional [E*tiles, 5H+7, 64, WIDTH] activations after each phase
     float *trace_scalars;  // optional [E, N, H+2+A]: r_0..r_{H-1}, Q_a, Q_b, a_H[A]
+    unsigned long long *timing;  // profiling builds (-DSPLIT_TIMING): 16 cycle counters summed over workgroups, else null
 };
 using RolloutParams = RolloutParamsT<NetW>;
 
@@ -961,6 +963,7 @@ struct tdmpc2_plan {
     float *bins = nullptr, *actions = nullptr, *value = nullptr, *mean = nullptr, *std = nullptr, *cvec = nullptr,
           *beff = nullptr, *zscratch = nullptr;
     unsigned int call = 0;
+    unsigned long long *timing = nullptr;  // TDMPC2_TIMING=1 with a -DSPLIT_TIMING build: in-kernel phase cycle counters
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> ev;
@@ -1066,6 +1069,7 @@ void fill_rollout(tdmpc2_plan *h, RolloutParamsT<NET> &p, int E) {
     p.bins = h->bins; p.beff = h->beff; p.cvec = h->cvec; p.mean = h->mean; p.std = h->std;
     p.actions = h->actions; p.value = h->value; p.zscratch = h->zscratch;
     p.iters_total = c.iterations;
+    p.timing = h->timing;
 }
 
 int validate_envs(tdmpc2_plan *h, int E) {
@@ -1229,7 +1233,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             // operand form: row = [hi: SH halfs | lo: SH halfs | 8 pad]; row stride in dwords SH + 4 = 4 x odd
             const int SH = WIDTH + h->Apad;
             h->stride = 2 * SH + 8;  // in halfs
-            h->lds_bytes = (size_t)ROWS * h->stride * 2 + 4096 /* LayerNorm partials */ + (size_t)2 * c.horizon * c.action_dim * 4 + 64;
+            h->lds_bytes = (size_t)ROWS * h->stride * 2 + 4096 /* LayerNorm partials */ + 3 * WIDTH * 4 /* layer parameters */ + (size_t)2 * c.horizon * c.action_dim * 4 + 64;
         } else {
             // row stride: [z (512) | a (Apad) | pad] with stride/4 odd: conflict-free ds_read_b128 across 16 rows
             h->stride = WIDTH + h->Apad + 4;
@@ -1309,12 +1313,26 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             return TDMPC2_ERR_HIP;
         }
     }
+    if (getenv("TDMPC2_TIMING")) {
+        if (dev_alloc(h, (void **)&h->timing, 16 * 8) == 0) (void)hipMemset(h->timing, 0, 16 * 8);
+    }
     *out = h;
     return TDMPC2_OK;
 }
 
 void tdmpc2_plan_destroy(tdmpc2_plan_t *h) {
     if (!h) return;
+    if (h->timing) {  // in-kernel phase timers of a -DSPLIT_TIMING build (tools/ablate.sh)
+        unsigned long long t[16];
+        if (hipMemcpy(t, h->timing, sizeof t, hipMemcpyDeviceToHost) == hipSuccess && t[15] > 0) {
+            static const char *names[16] = {"kloop", "epilogue", "head", "actions", "park/unpark", "tile_from_global", "", "",
+                                            "", "", "", "", "", "", "total", "workgroups"};
+            fprintf(stderr, "[tdmpc2_plan timing max_envs=%d] mean cycles per workgroup (wave 0):", h->cfg.max_envs);
+            for (int i = 0; i < 15; ++i)
+                if (names[i][0]) fprintf(stderr, " %s=%.0f", names[i], (double)t[i] / (double)t[15]);
+            fprintf(stderr, "\n");
+        }
+    }
     for (void *p : h->allocs) (void)hipFree(p);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;

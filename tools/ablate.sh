@@ -4,7 +4,7 @@
 # then `gpurun -- bash tools/ablate.sh run`.
 set -u
 R="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
-VARIANTS=("full:" "nomfma:-DSPLIT_ABL_NO_MFMA" "nobload:-DSPLIT_ABL_NO_BLOAD" "noepi:-DSPLIT_ABL_NO_EPI" "nomfma_nobload:-DSPLIT_ABL_NO_MFMA -DSPLIT_ABL_NO_BLOAD" "${ABLATE_EXTRA:-full2:}")
+VARIANTS=("full:" "nomfma:-DSPLIT_ABL_NO_MFMA" "nobload:-DSPLIT_ABL_NO_BLOAD" "noepi:-DSPLIT_ABL_NO_EPI" "nomfma_nobload:-DSPLIT_ABL_NO_MFMA -DSPLIT_ABL_NO_BLOAD" "timing:-DSPLIT_TIMING" "${ABLATE_EXTRA:-full2:}")
 mkdir -p "$R/build/ablate"
 if [ "${1:-build}" = "build" ]; then
   for v in "${VARIANTS[@]}"; do
@@ -16,7 +16,7 @@ if [ "${1:-build}" = "build" ]; then
 else
   for v in "${VARIANTS[@]}"; do
     name="${v%%:*}"
-    TDMPC2_PLAN_LIB="$R/build/ablate/lib_${name}.so" timeout 120 python "$R/bench.py" --steps 5 --warmup 2 --skip-cpu-baseline ${ABLATE_BENCH_ARGS:-} 2>/dev/null \
+    TDMPC2_TIMING=1 TDMPC2_PLAN_LIB="$R/build/ablate/lib_${name}.so" timeout 120 python "$R/bench.py" --steps 5 --warmup 2 --skip-cpu-baseline ${ABLATE_BENCH_ARGS:-} 2> >(grep "tdmpc2_plan timing" >&2) \
       | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$name', 'plans/s', d['value'], 'rollout_ms', d['roofline']['avg_launch_ms'], 'lat1_ms', d['extra'].get('latency_ms_single_env'))"
   done
 fi
