@@ -25,6 +25,7 @@ from tdmpc2_amd import synth  # noqa: E402
 from tdmpc2_amd.config import get_discount, named_config  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+F16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: BF16/F16 MFMA, dense (the 2:1-sparsity figure is NOT used)
 
 
 def per_row_macs(cfg):
@@ -57,12 +58,12 @@ def disc_pow_rows(cfg, n_envs, device):
     return torch.tensor(vals, dtype=torch.float32, device=device).repeat(n_envs, 1).contiguous()
 
 
-def pmc_traffic(workgroups):
+def pmc_traffic(workgroups, kernel="k_rollout"):
     """HBM-side bytes per k_rollout launch from the committed rocprofv3 --pmc passes (FETCH_SIZE with the gfx950
     x2 correction + WRITE_SIZE; tools/gpu_pmc.sh -> tools/pmc_summary.py --json).  bench.py cannot read PMC
     counters from inside its own process, so the figure comes from the profile of the same launch geometry;
     None if no profile of that geometry is committed."""
-    path = os.path.join(ROOT, "profiles", "pmc_k_rollout.json")
+    path = os.path.join(ROOT, "profiles", f"pmc_{kernel}.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -231,6 +232,30 @@ def main():
         torch.cuda.synchronize(device)
         extra["latency_ms_single_env"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
 
+        if planner.precision == 2 and K >= 2:
+            # companion measurement of the same workload with the exact-fp32 MFMA kernels (a few steps), so that one
+            # bench line carries both arithmetic modes
+            ex = NativePlanner(cfg, I, device, max_envs=E, path=path, precision=1)
+            ex.bind_state_dict(sd)
+            pe = torch.zeros_like(prev)
+            for i in range(2):
+                ex.plan(z0, disc, pe, warm, task_emb=emb, act_mask=mask, seed=900 + i, out=out)
+            ex.set_profiling(3 * I)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for i in range(3):
+                ex.plan(z0, disc, pe, warm, task_emb=emb, act_mask=mask, seed=910 + i, out=out)
+            torch.cuda.synchronize(device)
+            el = time.perf_counter() - t1
+            ms, n = ex.profile_read()
+            ach = flops_rollout_launch(cfg, E) / (ms / 1e3 / max(n, 1)) / 1e12
+            extra["exact_fp32_mode"] = {
+                "value": round(3 * E / el, 2), "unit": "plans/s (this rank)", "steps": 3,
+                "arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32): bitwise an fmaf chain",
+                "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms / max(n, 1), 4)}}
+            ex.close()
+
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -241,7 +266,10 @@ def main():
     value = plans / elapsed
     launch_s = (roll_ms / 1e3) / max(roll_n, 1)
     achieved = flops_rollout_launch(cfg, E) / launch_s / 1e12
-    traffic, traffic_src = pmc_traffic(E * cfg.num_samples // 64) if family == "fused" else (None, None)
+    split = planner.precision == 2
+    kernel = ("ks_rollout" if split else "k_rollout") if family == "fused" else "g_gemm + row kernels of one _estimate_value"
+    traffic, traffic_src = pmc_traffic(E * cfg.num_samples // 64, kernel) if family == "fused" else (None, None)
+    peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
     line = {
         "metric": "plan() calls/sec (H=3, 512 samples, 6 iters)",
         "value": round(value, 2),
@@ -253,7 +281,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32",  # inputs, outputs, accumulation and all non-GEMM math; the products' arithmetic is in config.arithmetic
         "data": "synthetic",
         "config": {
             "workload": f"{args.config}: {cfg.task} world model (L{cfg.latent_dim} M{cfg.mlp_dim} A{cfg.action_dim} "
@@ -264,17 +292,23 @@ def main():
             "gflop_per_plan_as_written": round(flops_plan(cfg, I) / 1e9, 3),
         },
         "roofline": {
-            "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic,
             "traffic_unit": "bytes per launch (HBM/fabric side of L2: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
             "traffic_source": traffic_src,
-            "kernel": "k_rollout" if family == "fused" else "g_gemm + row kernels of one _estimate_value",
+            "kernel": kernel,
             "launches_timed": roll_n, "avg_launch_ms": round(1e3 * launch_s, 4),
-            "note": "achieved = as-written FLOPs of one CEM iteration (all num_q Q heads, SURVEY 8(d)) x envs / "
+            "note": "achieved = ALGORITHMIC (as-written) FLOPs of one CEM iteration (all num_q Q heads, SURVEY 8(d)) x envs / "
                     "mean duration of that iteration's rollout stage (HIP events on the launch stream); the kernels "
-                    "execute fewer (2 of num_q heads; fused: shared z0 product at t=0); peak = fp32-input MFMA (exact fp32)",
+                    "execute fewer algorithmic FLOPs (2 of num_q heads; fused: shared z0 product at t=0)"
+                    + ("; peak = dense f16 MFMA; the f16x2-split arithmetic spends 3 MFMA FLOPs per algorithmic FLOP "
+                       "(a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulate, fp32-class error), so the ceiling of this "
+                       "arithmetic in algorithmic FLOPs is peak/3" if split else "; peak = fp32-input MFMA (exact fp32)"),
         },
         "plan_tflops_as_written": round(value * flops_plan(cfg, I) / 1e12, 2),
+        **({"roofline_split_arithmetic": {"peak_algorithmic": round(F16_MFMA_PEAK_TFLOPS / 3, 1), "unit": "TFLOP/s",
+                                          "frac": round(achieved / (F16_MFMA_PEAK_TFLOPS / 3), 4),
+                                          "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 3)}} if split else {}),
         "extra": extra,
     }
     if world == 1 and not args.skip_cpu_baseline:

@@ -5,7 +5,7 @@
 //         a_hi.b_hi + a_hi.b_lo + a_lo.b_hi                       (the dropped a_lo.b_lo term is ~2^-22 relative)
 // accumulated in fp32.  The matrix pipe issues f16 MFMAs at 16x the rate of v_mfma_f32_32x32x2_f32, so the contraction
 // runs at up to 16/3 of the exact-fp32 kernels' roof while the error against an fp64 evaluation of the same network
-// stays in the fp32 round-off class (measured: tests/test_gpu_split.py; CPU emulation in DESIGN.md).
+// stays in the fp32 round-off class (measured: tests/test_gpu_planner.py::test_error_attribution_against_fp64; CPU emulation: oracle/split_probe.py).
 // Operands are pre-scaled by powers of two so that the lo pieces stay in the f16 normal range: activations by 2^5,
 // each weight matrix by 2^kw with max|W| 2^kw in [2^13, 2^14) (k_wscale); the fp32 accumulator is multiplied back by
 // the exact 2^-(kw+5) in the epilogue.
@@ -60,7 +60,6 @@ struct CtxT {
     static constexpr int RSH = 2 * SH + 8;   // row stride in halfs (row stride in dwords = SH + 4 = 4 x odd)
     _Float16 *act;  // LDS tile, operand form: row r at act + r * RSH: [hi: SH halfs | lo: SH halfs | 8 pad]
     float *stats;   // LDS [8 waves][64 rows][2]: per-wave LayerNorm partials
-    float *prm;     // LDS [3][WIDTH]: the current layer's bias | ln weight | ln bias
     int tid, wave, lane;
     TIMER_FIELDS
     __device__ __forceinline__ float *f32() const { return reinterpret_cast<float *>(act); }  // staging view [64][RSF]
@@ -270,10 +269,9 @@ __device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int 
 // i.e. half of the wave's 64 output features of that row; lane l ^ 32 holds the other half.  LayerNorm statistics are
 // therefore thread-local sums plus ONE cross-lane exchange, combined over the 8 waves through a 4 KB LDS table with
 // Chan's parallel-variance formula; normalisation, activation and the hi/lo split run on the accumulators in place
-// and the operand form is written straight back to the LDS tile: no fp32 staging pass, 3 barriers per layer.
+// and the operand form is written straight back to the LDS tile: no fp32 staging pass, 2 barriers per layer.
 // LayerNorm: biased variance, eps 1e-5 (layers.py:101).  ACT 0 Mish, 1 SimNorm over 8 consecutive features
 // (layers.py:84-88) = this lane's 4 + the partner lane's 4.
-constexpr int PRM_FLOATS = 3 * WIDTH;  // LDS copy of the layer's bias | ln weight | ln bias
 
 // raw accumulators <-> a dense global tile in register order (coalesced 1 KiB per wave instruction)
 template <class CT>
@@ -328,32 +326,40 @@ __device__ __forceinline__ void regs_to_tile(const CT &c, const f32x16 (&y)[2][2
     }
 }
 
-// Stage the layer's bias / LayerNorm affine vectors in LDS (read back per feature group with two addresses per wave).
+// This lane's 32 parameter values (bias, or a LayerNorm affine vector) in accumulator order: eight float4 at
+// 64 wave + 32 ft + 8 m + 4 hh -- two distinct addresses per wave instruction, served from L1.
+struct PFrag {
+    f32x4 v[2][4];  // [ft][m]
+};
 template <class CT>
-__device__ __forceinline__ void stage_params(const CT &c, const float *bias, const float *g, const float *b) {
-    c.prm[c.tid] = bias[c.tid];
-    c.prm[WIDTH + c.tid] = g[c.tid];
-    c.prm[2 * WIDTH + c.tid] = b[c.tid];
-}
-
-// acc (raw MFMA sums) -> ACT(LayerNorm(acc * osc + bias)) -> operand form in the LDS tile (+ optional register-order
-// fp32 copy `zcopy` in global).  Contains two barriers; the caller adds the one before the next contraction.
-// Precondition: stage_params() was called by all threads after the previous epilogue's last barrier.
-template <int ACT, class CT>
-__device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[2][2], float osc, float *zcopy) {
-    const int j = c.lane & 31, hh = c.lane >> 5;
-    __syncthreads();  // (1) every wave is done reading the operand tile; the staged parameters are visible
-    const float *pb = c.prm + 64 * c.wave + 4 * hh;
+__device__ __forceinline__ void load_pfrag(const CT &c, PFrag &f, const float *vec) {
+    const float *p = vec + 64 * c.wave + 4 * (c.lane >> 5);
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(pb + 32 * ft + 8 * m);
+        for (int m = 0; m < 4; ++m) f.v[ft][m] = *reinterpret_cast<const f32x4 *>(p + 32 * ft + 8 * m);
+}
+
+// acc (raw MFMA sums) -> ACT(LayerNorm(acc * osc + bias)) -> operand form in the LDS tile (+ optional register-order
+// fp32 copy `zcopy` in global).  `bias` was loaded BEFORE the contraction (its latency hides behind the k-loop), the
+// affine vectors are loaded here and land while the statistics are exchanged.  One barrier inside (the statistics
+// exchange, which also orders every wave's last read of the operand tile before the first write of the new one);
+// the caller adds the one before the next contraction.
+template <int ACT, class CT>
+__device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[2][2], float osc, const PFrag &bias, const float *g, const float *b,
+                                      float *zcopy) {
+    const int j = c.lane & 31, hh = c.lane >> 5;
+    PFrag gf, bf;
+    load_pfrag(c, gf, g);
+    load_pfrag(c, bf, b);
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int st = 0; st < 2; ++st)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = fmaf(acc[st][ft][4 * m + r], osc, b4[r]);
-        }
+                for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = fmaf(acc[st][ft][4 * m + r], osc, bias.v[ft][m][r]);
     // per-wave partial statistics of the two sample rows this lane works on
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
@@ -378,7 +384,7 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[2][2], float os
             c.stats[(c.wave * 64 + 32 * st + j) * 2 + 1] = m2;
         }
     }
-    __syncthreads();  // (2)
+    __syncthreads();
     float rstd[2], shift[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
@@ -405,8 +411,7 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[2][2], float os
     for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const f32x4 g4 = *reinterpret_cast<const f32x4 *>(pb + WIDTH + 32 * ft + 8 * m);
-            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(pb + 2 * WIDTH + 32 * ft + 8 * m);
+            const f32x4 g4 = gf.v[ft][m], b4 = bf.v[ft][m];
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 float y[4];
@@ -486,10 +491,11 @@ __device__ __forceinline__ void layer_full_s(const CT &c, const LayerS &ly, cons
                                              float *zcopy = nullptr) {
     f32x16 acc[2][2];
     zero4(acc);
-    stage_params(c, bias, ly.g, ly.b);
+    PFrag bf;
+    load_pfrag(c, bf, bias);
     kloop_s(c, ly, kb0, kb1, acc);
     TIMER_MARK(c, T_KLOOP)
-    epi_t<ACT>(c, acc, *ly.oscale, zcopy);
+    epi_t<ACT>(c, acc, *ly.oscale, bf, ly.g, ly.b, zcopy);
     __syncthreads();
     TIMER_MARK(c, T_EPI)
 }
@@ -596,8 +602,8 @@ template <int APAD>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x, tid = threadIdx.x;
-    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2,
-                 smem + ROWS * CtxT<APAD>::RSH / 2 + 1024, tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2, tid,
+                 __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     if (p.multitask) {
         const float *emb = p.task_emb + (size_t)e * p.T;
         for (int net = 0; net < p.nnets; ++net) {
@@ -644,8 +650,8 @@ template <int APAD>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x, tid = threadIdx.x;
-    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2,
-                 smem + ROWS * CtxT<APAD>::RSH / 2 + 1024, tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2, tid,
+                 __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
     const float *b_pi = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_PI) * WIDTH : p.pi.l[0].bias;
     const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
@@ -692,9 +698,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x / p.tiles, tile = blockIdx.x % p.tiles;
     const int tid = threadIdx.x;
-    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2,
-                 smem + ROWS * CtxT<APAD>::RSH / 2 + 1024, tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
-    float *sm_mean = smem + ROWS * c.RSH / 2 + 1024 + PRM_FLOATS;  // [H*A] after the tile, LayerNorm partials, layer parameters
+    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2, tid,
+                 __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    float *sm_mean = smem + ROWS * c.RSH / 2 + 1024;  // [H*A] after the tile and the LayerNorm partials
     float *sm_std = sm_mean + p.H * p.A;
     const int row0 = tile * ROWS;
     const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
@@ -776,10 +782,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
             park(c, acc, zs);
             TIMER_MARK(c, T_PARK)
             zero4(acc);
-            stage_params(c, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew, p.rew.l[0].g, p.rew.l[0].b);
+            PFrag bf;
+            load_pfrag(c, bf, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew);
             kloop_s(c, p.rew.l[0], t == 0 ? ZKB16 : 0, KBA, acc);
             TIMER_MARK(c, T_KLOOP)
-            epi_t<0>(c, acc, *p.rew.l[0].oscale, nullptr);
+            epi_t<0>(c, acc, *p.rew.l[0].oscale, bf, p.rew.l[0].g, p.rew.l[0].b, nullptr);
         }
         __syncthreads();
         TIMER_MARK(c, T_EPI)
@@ -794,10 +801,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
         // ---- dynamics: pick the parked first layer up from L2, layers 2 and 3 (SimNorm)
         {
             f32x16 acc[2][2];
-            stage_params(c, t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn, p.dyn.l[0].g, p.dyn.l[0].b);
+            PFrag bf;
+            load_pfrag(c, bf, t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn);
             unpark(c, acc, zs);
             TIMER_MARK(c, T_PARK)
-            epi_t<0>(c, acc, *p.dyn.l[0].oscale, nullptr);
+            epi_t<0>(c, acc, *p.dyn.l[0].oscale, bf, p.dyn.l[0].g, p.dyn.l[0].b, nullptr);
         }
         __syncthreads();
         TIMER_MARK(c, T_EPI)
@@ -836,10 +844,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
         park(c, acc, zs);
         TIMER_MARK(c, T_PARK)
         zero4(acc);
-        stage_params(c, b_q0, p.q[q0].l[0].g, p.q[q0].l[0].b);
+        PFrag bf;
+        load_pfrag(c, bf, b_q0);
         kloop_s(c, p.q[q0].l[0], 0, KBA, acc);
         TIMER_MARK(c, T_KLOOP)
-        epi_t<0>(c, acc, *p.q[q0].l[0].oscale, nullptr);
+        epi_t<0>(c, acc, *p.q[q0].l[0].oscale, bf, p.q[q0].l[0].g, p.q[q0].l[0].b, nullptr);
     }
     __syncthreads();
     TIMER_MARK(c, T_EPI)
@@ -850,10 +859,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
     TIMER_MARK(c, T_HEAD)
     {
         f32x16 acc[2][2];
-        stage_params(c, b_q1, p.q[q1].l[0].g, p.q[q1].l[0].b);
+        PFrag bf;
+        load_pfrag(c, bf, b_q1);
         unpark(c, acc, zs);
         TIMER_MARK(c, T_PARK)
-        epi_t<0>(c, acc, *p.q[q1].l[0].oscale, nullptr);
+        epi_t<0>(c, acc, *p.q[q1].l[0].oscale, bf, p.q[q1].l[0].g, p.q[q1].l[0].b, nullptr);
     }
     __syncthreads();
     TIMER_MARK(c, T_EPI)

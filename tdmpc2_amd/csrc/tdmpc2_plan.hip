@@ -1233,7 +1233,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             // operand form: row = [hi: SH halfs | lo: SH halfs | 8 pad]; row stride in dwords SH + 4 = 4 x odd
             const int SH = WIDTH + h->Apad;
             h->stride = 2 * SH + 8;  // in halfs
-            h->lds_bytes = (size_t)ROWS * h->stride * 2 + 4096 /* LayerNorm partials */ + 3 * WIDTH * 4 /* layer parameters */ + (size_t)2 * c.horizon * c.action_dim * 4 + 64;
+            h->lds_bytes = (size_t)ROWS * h->stride * 2 + 4096 /* LayerNorm partials */ + (size_t)2 * c.horizon * c.action_dim * 4 + 64;
         } else {
             // row stride: [z (512) | a (Apad) | pad] with stride/4 odd: conflict-free ds_read_b128 across 16 rows
             h->stride = WIDTH + h->Apad + 4;

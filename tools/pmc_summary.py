@@ -69,7 +69,8 @@ def emit_json(root, out_path, kernel="k_rollout"):
         with open(path) as f:
             for r in csv.DictReader(f):
                 name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
-                if name != kernel or r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
+                base = name.replace("void ", "").split("<")[0]
+                if base != kernel or r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
                     continue
                 wgs = str(int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1))
                 res.setdefault(wgs, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
@@ -86,6 +87,6 @@ def emit_json(root, out_path, kernel="k_rollout"):
 
 if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[2] == "--json":
-        emit_json(sys.argv[1], sys.argv[3])
+        emit_json(sys.argv[1], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "k_rollout")
     else:
         main()

@@ -34,9 +34,10 @@ def main():
     agg = defaultdict(list)
     meta = {}
     for name, gx, wx, lds, vg, ag, sg, dur in rows:
-        short = name.split("(")[0].replace("(anonymous namespace)::", "")
-        if name.startswith("(anonymous namespace)::"):
-            short = name[len("(anonymous namespace)::"):].split("(")[0]
+        short = name.replace("(anonymous namespace)::", "")
+        if short.startswith("void "):
+            short = short[5:]
+        short = short.split("(")[0]
         key = (short[:48], gx // max(wx, 1))
         agg[key].append(dur)
         meta[key] = (wx, lds, vg, ag, sg)
