@@ -34,7 +34,11 @@ CASES = {
 
 def build_case(name: str):
     cfg_name, overrides, E, eval_mode, head_std = CASES[name]
-    cfg = named_config(cfg_name, **overrides)
+    return build_custom(named_config(cfg_name, **overrides), E, eval_mode, head_std, name=name)
+
+
+def build_custom(cfg, E: int, eval_mode: bool = False, head_std: float = 0.06, name: str = "", t0=None):
+    """A case from an arbitrary config (edge-case tests build these on the fly; no golden fixture)."""
     if cfg.multitask and name in ("tiny_mt", "small_mt", "c3", "c4"):
         # heterogeneous action dims / episode lengths to exercise masks and per-task discounts
         n = len(cfg.tasks)
@@ -49,7 +53,7 @@ def build_case(name: str):
     z0 = synth.make_latents(cfg, E, seed=1)
     tape = synth.make_noise_tape(cfg, E, I, seed=2)
     prev = np.random.default_rng(5).uniform(-0.5, 0.5, (E, cfg.horizon, cfg.action_dim)).astype(np.float32)
-    t0 = np.array([(e % 2 == 0) for e in range(E)])
+    t0 = np.array([(e % 2 == 0) for e in range(E)]) if t0 is None else np.asarray(t0, dtype=bool)
     if cfg.multitask:
         tasks = [(7 * e + 3) % len(cfg.tasks) for e in range(E)]
         disc_t = torch.tensor([get_discount(cfg, L) for L in cfg.episode_lengths])  # tdmpc2.py:35-37
