@@ -13,6 +13,26 @@ inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 // One nn.Linear over `rows_p` (padded) rows.  `slot` = index of the net in beff (multitask first layers), -1 otherwise.
 int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t rows_p, int rows_per_env,
              const HostLayer &ly, long w_sel_stride, long bias_sel_stride, int slot, const int *sel, float *out, int ldo) {
+    if (h->split) {
+        GemmSParams q{};
+        q.A = reinterpret_cast<const _Float16 *>(A); q.lda = lda; q.K = ly.KB * 16; q.wp = ly.wps;
+        q.w_sel_stride = sel ? w_sel_stride : 0; q.oscale = ly.oscale; q.osc_sel_stride = sel ? 4 : 0;  // slab of 4 floats per head
+        q.CT = ly.CT; q.ncolblk = (ly.CT + 3) / 4;
+        if (slot >= 0 && h->cfg.multitask) {
+            q.bias = h->beff + (size_t)slot * h->lay.Mp;
+            q.bias_env_stride = (long)h->nnets * h->lay.Mp;
+            q.bias_sel_stride = sel ? h->lay.Mp : 0;
+        } else {
+            q.bias = ly.bias;
+            q.bias_env_stride = 0;
+            q.bias_sel_stride = sel ? bias_sel_stride : 0;
+        }
+        q.sel = sel; q.sel_stride = 2; q.rows_per_env = rows_per_env; q.out = out; q.ldo = ldo;
+        const int nblk = (int)(rows_p / GBM) * q.ncolblk;
+        hipLaunchKernelGGL(g_gemm_s, dim3(nblk), dim3(GTHREADS), 0, st, q);
+        LAUNCH_CHECK();
+        return 0;
+    }
     GemmParams p{};
     p.A = A; p.lda = lda; p.K = ly.KB * 8; p.wp = ly.wp; p.w_sel_stride = sel ? w_sel_stride : 0;
     p.CT = ly.CT; p.ncolblk = (ly.CT + 3) / 4;
@@ -37,15 +57,24 @@ int lay_ln(tdmpc2_plan *h, hipStream_t st, int act, float *x, int ld, int width,
     LnActParams p{};
     p.x = x; p.ld = ld; p.width = width; p.rows = (int)rows; p.rows_per_env = rows_per_env;
     p.g = ly.g; p.b = ly.b; p.gb_sel_stride = sel ? gb_sel_stride : 0; p.sel = sel; p.sel_stride = 2;
+    p.pad_to = ld;  // whole row: only X has columns beyond `width`
     const int grid = (int)((rows + RW_THREADS / 64 - 1) / (RW_THREADS / 64));
-    if (act == 0) hipLaunchKernelGGL(l_ln_act<0>, dim3(grid), dim3(RW_THREADS), 0, st, p);
-    else hipLaunchKernelGGL(l_ln_act<1>, dim3(grid), dim3(RW_THREADS), 0, st, p);
+    if (h->split) {
+        if (act == 0) hipLaunchKernelGGL(l_ln_act_s<0>, dim3(grid), dim3(RW_THREADS), 0, st, p);
+        else hipLaunchKernelGGL(l_ln_act_s<1>, dim3(grid), dim3(RW_THREADS), 0, st, p);
+    } else {
+        if (act == 0) hipLaunchKernelGGL(l_ln_act<0>, dim3(grid), dim3(RW_THREADS), 0, st, p);
+        else hipLaunchKernelGGL(l_ln_act<1>, dim3(grid), dim3(RW_THREADS), 0, st, p);
+    }
     LAUNCH_CHECK();
     return 0;
 }
 
 // strides between consecutive Q heads of layer `l` (slab allocation in bind_weights)
-inline long q_wstride(const tdmpc2_plan *h, int l) { return h->cfg.num_q > 1 ? (long)(h->q[1].l[l].wp - h->q[0].l[l].wp) : 0; }
+inline long q_wstride(const tdmpc2_plan *h, int l) {
+    if (h->cfg.num_q < 2) return 0;
+    return h->split ? (long)(h->q[1].l[l].wps - h->q[0].l[l].wps) : (long)(h->q[1].l[l].wp - h->q[0].l[l].wp);
+}
 inline long q_bstride(const tdmpc2_plan *h, int l) { return h->cfg.num_q > 1 ? (long)(h->q[1].l[l].bias - h->q[0].l[l].bias) : 0; }
 inline long q_gstride(const tdmpc2_plan *h, int l) { return h->cfg.num_q > 1 ? (long)(h->q[1].l[l].g - h->q[0].l[l].g) : 0; }
 
@@ -86,7 +115,8 @@ int lay_policy(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int r
     p.eps = eps; p.eps_estride = eps_estride; p.seed = seed; p.call = call; p.site = site; p.iter = iter;
     p.X = L.X; p.actions = actions; p.t = t; p.H = c.horizon; p.N = c.num_samples; p.trace = trace;
     const int total = (int)rows * c.action_dim;
-    hipLaunchKernelGGL(l_pi_head, dim3((total + 255) / 256), dim3(256), 0, st, p);
+    if (h->split) hipLaunchKernelGGL(l_pi_head_s, dim3((total + 255) / 256), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(l_pi_head, dim3((total + 255) / 256), dim3(256), 0, st, p);
     LAUNCH_CHECK();
     return 0;
 }
@@ -131,12 +161,17 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
     const int N = c.num_samples, H = c.horizon, A = c.action_dim;
     const size_t rows = (size_t)E * N, rows_p = round_up(rows, GBM);
     int rc;
-    hipLaunchKernelGGL(l_init_x, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM);
+    if (h->split) hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM);
+    else hipLaunchKernelGGL(l_init_x, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM);
     LAUNCH_CHECK();
     for (int t = 0; t < H; ++t) {
         const int total = (int)rows * A;
-        hipLaunchKernelGGL(l_set_action, dim3((total + 255) / 256), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, A, N, H, t,
-                           (int)rows, actions);
+        if (h->split)
+            hipLaunchKernelGGL(l_set_action_s, dim3((total + 255) / 256), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, A, N, H, t,
+                               (int)rows, actions);
+        else
+            hipLaunchKernelGGL(l_set_action, dim3((total + 255) / 256), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, A, N, H, t,
+                               (int)rows, actions);
         LAUNCH_CHECK();
         // reward(z, a_t) -> two_hot_inv -> G += disc * (1 - term) * r
         if ((rc = lay_hidden(h, st, h->rew, BE_REW, rows, rows_p, N, nullptr, false))) return rc;
@@ -171,8 +206,12 @@ int lay_pitraj(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const flo
     const int P = c.num_pi_trajs, H = c.horizon, A = c.action_dim, rpe = L.Ppad;
     const size_t rows = (size_t)E * rpe, rows_p = round_up(rows, GBM);
     int rc;
-    hipLaunchKernelGGL(l_init_x, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, rpe, z0, (float *)nullptr,
-                       (float *)nullptr);
+    if (h->split)
+        hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, rpe, z0, (float *)nullptr,
+                           (float *)nullptr);
+    else
+        hipLaunchKernelGGL(l_init_x, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, rpe, z0, (float *)nullptr,
+                           (float *)nullptr);
     LAUNCH_CHECK();
     for (int t = 0; t < H; ++t) {
         // tape layout [E, H, P, A]: env stride H*P*A, this step's slice at t*P*A

@@ -139,6 +139,7 @@ struct LnActParams {
     long gb_sel_stride;
     const int *sel;
     long sel_stride;
+    int pad_to;  // operand-form rows (split arithmetic): columns [width, pad_to) are zeroed in both planes
 };
 
 template <int ACT>

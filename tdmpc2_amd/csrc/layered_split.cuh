@@ -1,0 +1,283 @@
+// f16x2-split arithmetic (see fused_split.cuh) for the layer-at-a-time family: the 19M / 48M / 317M world models.
+//
+// Activations that feed a GEMM are stored in HBM in OPERAND FORM: a row of `ld` columns occupies the same ld * 4
+// bytes as an fp32 row, laid out [hi: ld halfs | lo: ld halfs] with hi = f16(32 x), lo = f16(32 x - hi).  The row
+// kernels that produce an activation (l_ln_act_s, l_init_x_s, l_set_action_s, l_pi_head_s) write that form once, so the
+// GEMM stages plain copies; GEMM outputs (pre-activations, head logits) stay fp32 and are converted in place, one
+// wavefront per row, by the LayerNorm kernel.
+// g_gemm_s: 128 x 128 output tile per 256-thread workgroup; wave w owns the 32 output columns [32 w, 32 w + 32) for all
+// 128 rows (4 row tiles x 1 column tile): every weight fragment (2 KB per k16-block, from L2) feeds 12 MFMAs and the
+// row fragments come from LDS (8 ds_read_b128 per block) -- weight bytes per MFMA are half of the fused kernel's.
+// Included by tdmpc2_plan.hip inside its anonymous namespace, after fused_split.cuh and layered_kernels.cuh.
+#pragma once
+
+constexpr int GS_LDH = GBK + 8;  // LDS row stride of one plane in halfs: 80 B = 20 dwords = 4 x odd -> conflict-free b128
+
+struct GemmSParams {
+    const _Float16 *A;  // operand form [Rp, lda]: row r at (char*)A + r * lda * 4: [hi lda halfs | lo lda halfs]
+    int lda;
+    int K;              // contraction length, multiple of GBK
+    const _Float16 *wp; // split-packed [CT][K/16][2][64][8] (k_pack_split), + sel * w_sel_stride (in halfs)
+    long w_sel_stride;
+    const float *oscale; // device scalar(s): 2^-(kw + 5), + sel * osc_sel_stride
+    long osc_sel_stride;
+    int CT, ncolblk;
+    const float *bias;
+    long bias_env_stride, bias_sel_stride;
+    const int *sel;
+    long sel_stride;
+    int rows_per_env;
+    float *out;         // fp32 [Rp, ldo]
+    int ldo;
+};
+
+__global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
+    __shared__ __attribute__((aligned(16))) _Float16 As[2][2][GBM * GS_LDH];  // [buffer][plane][row][k]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int tile = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+    const int rb = tile / p.ncolblk, cb = tile % p.ncolblk;
+    const int row0 = rb * GBM;
+    const int sel = p.sel ? p.sel[(size_t)(row0 / p.rows_per_env) * p.sel_stride] : 0;
+    const int KB = p.K / 16;
+    const int ct = cb * 4 + wave;
+    const bool valid = ct < p.CT;
+    // weight fragments: wave-uniform byte pointer + opaque 32-bit lane offset (see fused_split.cuh)
+    const char *u = reinterpret_cast<const char *>(p.wp + (size_t)sel * p.w_sel_stride) + (size_t)(valid ? ct : p.CT - 1) * KB * 2048;
+    unsigned voff = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(voff));
+
+    // A staging: 128 rows x 2 planes x 4 sixteen-byte pieces per 32-wide chunk = 1024 pieces, 4 per thread
+    const char *ab = reinterpret_cast<const char *>(p.A) + (size_t)row0 * p.lda * 4;
+    int g_off[4], l_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        const int plane = idx >> 9, r = (idx >> 2) & 127, c16 = idx & 3;
+        g_off[i] = r * p.lda * 4 + plane * p.lda * 2 + c16 * 16;
+        l_off[i] = (plane * GBM * GS_LDH + r * GS_LDH) * 2 + c16 * 16;
+    }
+    f32x4 stage[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) stage[i] = *reinterpret_cast<const f32x4 *>(ab + g_off[i]);
+    char *lds = reinterpret_cast<char *>(&As[0][0][0]);
+    constexpr int BUF_BYTES = 2 * GBM * GS_LDH * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(lds + l_off[i]) = stage[i];
+    __syncthreads();
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+    const int i32 = lane & 31, hh = lane >> 5;
+    const int nchunks = p.K / GBK;
+    constexpr int PFB = 4;
+    f16x8 rh[PFB], rl[PFB];
+#pragma unroll
+    for (int d = 0; d < PFB; ++d) {
+        const int kd = d < KB ? d : KB - 1;
+        rh[d] = ldw(u + (size_t)kd * 2048, voff, 0);
+        rl[d] = ldw(u + (size_t)kd * 2048, voff, 1024);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c < nchunks; c += 2) {  // two chunks (4 k16-blocks = one turn of the weight ring) per iteration
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int ch = c + cc;
+            if (ch < nchunks) {  // uniform
+                const bool more = ch + 1 < nchunks;
+                if (more) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        stage[i] = *reinterpret_cast<const f32x4 *>(ab + g_off[i] + (size_t)(ch + 1) * GBK * 2);
+                }
+                const _Float16 *ah = &As[ch & 1][0][0] + i32 * GS_LDH + 8 * hh;
+                const _Float16 *al = &As[ch & 1][1][0] + i32 * GS_LDH + 8 * hh;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const int d = cc * 2 + kb;
+                    f16x8 fh[4], fl[4];
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) {
+                        fh[rt] = *reinterpret_cast<const f16x8 *>(ah + rt * 32 * GS_LDH + kb * 16);
+                        fl[rt] = *reinterpret_cast<const f16x8 *>(al + rt * 32 * GS_LDH + kb * 16);
+                    }
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) acc[rt] = SPLIT_MFMA(fh[rt], rh[d], acc[rt]);
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) acc[rt] = SPLIT_MFMA(fh[rt], rl[d], acc[rt]);
+#pragma unroll
+                    for (int rt = 0; rt < 4; ++rt) acc[rt] = SPLIT_MFMA(fl[rt], rh[d], acc[rt]);
+                    const int kn = ch * 2 + kb + PFB;
+                    const int knc = kn < KB ? kn : KB - 1;
+                    rh[d] = ldw(u + (size_t)knc * 2048, voff, 0);
+                    rl[d] = ldw(u + (size_t)knc * 2048, voff, 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (more) {
+                    char *dst = lds + ((ch + 1) & 1) * BUF_BYTES;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(dst + l_off[i]) = stage[i];
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    if (!valid) return;
+    // epilogue: acc * oscale + bias -> fp32.  C fragment: lane holds column (l & 31), rows (reg&3) + 8 (reg>>2) + 4 (l>>5).
+    const float osc = p.oscale[(size_t)sel * p.osc_sel_stride];
+    const float *bsel = p.bias + (size_t)sel * p.bias_sel_stride;
+    const int col = ct * 32 + i32;
+    const float bshared = p.bias_env_stride == 0 ? bsel[col] : 0.f;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = row0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            float bv = bshared;
+            if (p.bias_env_stride != 0) bv = bsel[(size_t)(row / p.rows_per_env) * p.bias_env_stride + col];
+            p.out[(size_t)row * p.ldo + col] = fmaf(acc[rt][reg], osc, bv);
+        }
+}
+
+// ---------------------------------------------------------------- row kernels writing operand form
+__device__ __forceinline__ void put_split(_Float16 *rowp, int ld, int col, float v) {
+    const float vs = v * ACT_SCALE;
+    const _Float16 h = (_Float16)vs;
+    rowp[col] = h;
+    rowp[ld + col] = (_Float16)(vs - (float)h);
+}
+
+// In place, one wavefront per row: fp32 pre-activation row (width <= 4096 columns at the start of the row's ld * 4
+// bytes) -> ACT(LayerNorm(.)) -> operand form [hi | lo] of the same row.  The whole row is held in registers between
+// the read and the write (the two forms alias).
+template <int ACT>
+__global__ __launch_bounds__(RW_THREADS) void l_ln_act_s(LnActParams p) {
+    const int row = blockIdx.x * (RW_THREADS / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= p.rows) return;
+    const int sel = p.sel ? p.sel[(size_t)(row / p.rows_per_env) * p.sel_stride] : 0;
+    const float *g = p.g + (size_t)sel * p.gb_sel_stride, *bb = p.b + (size_t)sel * p.gb_sel_stride;
+    float *xr = p.x + (size_t)row * p.ld;
+    const int n4 = p.width / 4;
+    f32x4 v[16];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c4 = lane + 64 * q;
+        if (c4 < n4) {
+            v[q] = *reinterpret_cast<const f32x4 *>(xr + 4 * c4);
+            s += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
+        }
+    }
+    const float mean = group_sum<64>(s) / (float)p.width;
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        if (lane + 64 * q < n4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[q][e] - mean;
+                ss = fmaf(d, d, ss);
+            }
+        }
+    }
+    const float var = group_sum<64>(ss) / (float)p.width;
+    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+    _Float16 *hp = reinterpret_cast<_Float16 *>(xr);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int c4 = lane + 64 * q;
+        const bool ok = c4 < n4;
+        if (ACT == 0 && !ok) continue;
+        if (ACT == 1 && 64 * q >= n4) continue;  // whole wave out of range (uniform)
+        f32x4 y;
+        if (ok) {
+            const f32x4 gg = *reinterpret_cast<const f32x4 *>(g + 4 * c4);
+            const f32x4 be = *reinterpret_cast<const f32x4 *>(bb + 4 * c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = fmaf((v[q][e] - mean) * rstd, gg[e], be[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = -INFINITY;
+        }
+        if (ACT == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = mish_fast(y[e]);
+        } else {
+            float m = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
+            m = fmaxf(m, __shfl_xor(m, 1));
+            float es = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = ok ? __expf(y[e] - m) : 0.f;
+                es += y[e];
+            }
+            es += __shfl_xor(es, 1);
+            const float inv = 1.0f / es;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] *= inv;
+        }
+        if (ok) {
+            f16x4 hi, lo;
+            split4(y, hi, lo);
+            *reinterpret_cast<f16x4 *>(hp + 4 * c4) = hi;
+            *reinterpret_cast<f16x4 *>(hp + p.ld + 4 * c4) = lo;
+        }
+    }
+    // The fp32 pre-activation row aliased the hi / lo planes beyond `width` too (X: action and padding columns): leave
+    // zeros there, not fp32 bit patterns that read as f16 Inf / NaN (the action columns are set afterwards).
+    for (int c = p.width + lane; c < p.pad_to; c += 64) {
+        hp[c] = (_Float16)0.f;
+        hp[p.ld + c] = (_Float16)0.f;
+    }
+}
+
+// X[row] <- operand form of [z0[env] | zeros]; G, term <- 0.  One workgroup per row.
+__global__ void l_init_x_s(float *X, int ldx, int L, int rows_per_env, const float *z0, float *G, float *term) {
+    const int row = blockIdx.x;
+    const float *z = z0 + (size_t)(row / rows_per_env) * L;
+    _Float16 *xr = reinterpret_cast<_Float16 *>(X + (size_t)row * ldx);
+    for (int c = threadIdx.x; c < ldx; c += blockDim.x) put_split(xr, ldx, c, c < L ? z[c] : 0.f);
+    if (threadIdx.x == 0) {
+        if (G) G[row] = 0.f;
+        if (term) term[row] = 0.f;
+    }
+}
+
+__global__ void l_set_action_s(float *X, int ldx, int L, int A, int N, int H, int t, int rows, const float *actions) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * A) return;
+    const int row = idx / A, a = idx % A;
+    const int e = row / N, n = row % N;
+    put_split(reinterpret_cast<_Float16 *>(X + (size_t)row * ldx), ldx, L + a, actions[(((size_t)e * H + t) * N + n) * A + a]);
+}
+
+__global__ void l_pi_head_s(PiHeadParams p) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.rows * p.A) return;
+    const int row = idx / p.A, a = idx % p.A;
+    const int e = row / p.rows_per_env, n = row % p.rows_per_env;
+    const float *lr = p.lg + (size_t)row * p.ld;
+    float mu = lr[a];
+    float ls = p.lsmin + 0.5f * p.lsdif * (tanhf(lr[p.A + a]) + 1.f);
+    float eps = 0.f;
+    if (n < p.nvalid) {
+        const unsigned ridx = (unsigned)((size_t)n * p.A + a);
+        eps = p.eps ? p.eps[(size_t)e * p.eps_estride + ridx] : rng_normal(p.seed, p.call, p.site, p.iter, e, ridx);
+    }
+    if (p.mask) {
+        const float mk = p.mask[(size_t)e * p.A + a];
+        mu *= mk;
+        ls *= mk;
+        eps *= mk;
+    }
+    const float act = tanhf(mu + eps * expf(ls));
+    put_split(reinterpret_cast<_Float16 *>(p.X + (size_t)row * p.ldx), p.ldx, p.L + a, act);
+    if (p.actions && n < p.nvalid) p.actions[(((size_t)e * p.H + p.t) * p.N + n) * p.A + a] = act;
+    if (p.trace) p.trace[(size_t)row * (p.H + 2 + p.A) + p.H + 2 + a] = act;
+}

@@ -905,6 +905,7 @@ __global__ void k_copy_pad(const float *src, int n, int npad, float *dst) {
 
 #include "fused_split.cuh"
 #include "layered_kernels.cuh"
+#include "layered_split.cuh"
 
 // ================================================================ host side
 thread_local std::string g_err;
@@ -1210,10 +1211,10 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
                     "num_samples %% %d == 0 (got %d / %d / %d)", GBM, c.latent_dim, c.mlp_dim, c.num_samples);
     if (path != TDMPC2_PATH_FUSED && path != TDMPC2_PATH_LAYERED) return fail(TDMPC2_ERR_INVALID, "unknown path %d", c.path);
     int prec = c.precision;
-    if (prec == TDMPC2_PREC_AUTO) prec = path == TDMPC2_PATH_FUSED ? TDMPC2_PREC_SPLIT_F16 : TDMPC2_PREC_FP32;
+    if (prec == TDMPC2_PREC_AUTO) prec = TDMPC2_PREC_SPLIT_F16;
     if (prec != TDMPC2_PREC_FP32 && prec != TDMPC2_PREC_SPLIT_F16) return fail(TDMPC2_ERR_INVALID, "unknown precision %d", c.precision);
-    if (prec == TDMPC2_PREC_SPLIT_F16 && path != TDMPC2_PATH_FUSED)
-        return fail(TDMPC2_ERR_UNSUPPORTED, "the f16x2-split arithmetic is built for the fused kernel family only");
+    if (prec == TDMPC2_PREC_SPLIT_F16 && path == TDMPC2_PATH_LAYERED && (c.mlp_dim > 4096 || c.latent_dim > 4096))
+        return fail(TDMPC2_ERR_UNSUPPORTED, "the layered f16x2-split row kernels hold a row of at most 4096 columns in registers");
     if (hipSetDevice(c.device) != hipSuccess) return fail(TDMPC2_ERR_HIP, "hipSetDevice(%d) failed", c.device);
 
     tdmpc2_plan *h = new (std::nothrow) tdmpc2_plan();
@@ -1377,7 +1378,7 @@ int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *
     const int na = (layer == 0 && takes_action) ? c.action_dim : 0;
     // packed contraction length: FUSED pads the action columns to a multiple of 8 (one k-block), LAYERED pads the
     // whole row to a multiple of the GEMM k-chunk
-    const int Kp = h->lay.on ? (int)round_up((size_t)nz + na, GBK) : h->split ? nz + (na + 15) / 16 * 16 : nz + (na + 7) / 8 * 8;
+    const int Kp = h->lay.on ? (int)round_up((size_t)nz + na, GBK) : h->split ? nz + (na + 15) / 16 * 16 : nz + (na + 7) / 8 * 8;  // GBK = 32 is a multiple of both block sizes
     const int KB = h->split ? Kp / 16 : Kp / 8;
     const int CT = (out_features + 31) / 32;
     // one slab per tensor kind holding all ensemble members at a constant stride (the layered GEMM selects a member

@@ -15,28 +15,32 @@ pytestmark = pytest.mark.gpu
 
 PATH_FUSED, PATH_LAYERED = 1, 2
 LAYERED_CASES = ["small", "small_ep", "small_mt", "c1_ep", "c3", "c4"]
+# both arithmetic modes of the layered family: exact-fp32 MFMA GEMMs (1) and the f16x2 split (2)
+PRECS = pytest.mark.parametrize("prec", [1, 2], ids=["fp32", "split"])
 
 
+@PRECS
 @pytest.mark.parametrize("name", LAYERED_CASES)
-def test_layered_plan_matches_reference_golden(name):
+def test_layered_plan_matches_reference_golden(name, prec):
     """Whole plan() with the recorded noise tape against the outputs of the reference's own code."""
     from tests.gpu_common import case_on_gpu
 
-    c, model, planner = case_on_gpu(name)
-    assert planner.path == PATH_LAYERED
+    c, model, planner = case_on_gpu(name, 0, prec)
+    assert planner.path == PATH_LAYERED and planner.precision == prec
     g = load_golden(name)
     got = _run_native(c, model, planner)
     assert np.isfinite(got["action"]).all() and np.abs(got["action"]).max() <= 1.0
     _compare_stages(name, c, got, g, g["action"], g["prev_mean_out"])
 
 
+@PRECS
 @pytest.mark.parametrize("name", ["c1", "mt5", "c2"])
-def test_layered_family_on_fused_size_class(name):
+def test_layered_family_on_fused_size_class(name, prec):
     """The 512-wide cases run on BOTH kernel families: the layered one must also match the reference golden, and
     the two families' first-iteration values agree to fp32 round-off."""
     from tests.gpu_common import case_on_gpu
 
-    c, model, lay = case_on_gpu(name, PATH_LAYERED)
+    c, model, lay = case_on_gpu(name, PATH_LAYERED, prec)
     _, _, fus = case_on_gpu(name, PATH_FUSED, 1)
     assert lay.path == PATH_LAYERED and fus.path == PATH_FUSED
     g = load_golden(name)
@@ -48,12 +52,13 @@ def test_layered_family_on_fused_size_class(name):
     assert err < 2e-5
 
 
+@PRECS
 @pytest.mark.parametrize("name", ["small", "small_ep", "small_mt", "c1_ep", "c3"])
-def test_layered_estimate_value_matches_oracle(name):
+def test_layered_estimate_value_matches_oracle(name, prec):
     """_estimate_value (tdmpc2.py:122-136, incl. the termination head when episodic) on identical actions."""
     from tests.gpu_common import case_on_gpu, dev, plan_inputs
 
-    c, model, planner = case_on_gpu(name)
+    c, model, planner = case_on_gpu(name, 0, prec)
     inp = plan_inputs(c, model)
     E = c["n_envs"]
     for it in (0, c["iterations"] - 1):
@@ -79,7 +84,7 @@ def test_layered_trace_scalars_match_oracle():
     from oracle import planner_oracle as po
     from tests.gpu_common import case_on_gpu, dev, plan_inputs
 
-    c, model, planner = case_on_gpu("small")
+    c, model, planner = case_on_gpu("small", 0, 1)
     cfg = c["cfg"]
     inp = plan_inputs(c, model)
     E, H, N, A = c["n_envs"], cfg.horizon, cfg.num_samples, cfg.action_dim
