@@ -125,7 +125,7 @@ def main():
                     help="kernel family (auto: fused for 512-wide models, layered otherwise)")
     ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "split"],
                     help="contraction arithmetic: exact-fp32 MFMA or f16x2-split on the f16 matrix pipe (fp32-class "
-                         "accuracy); auto = split on the fused family, fp32 on the layered one")
+                         "accuracy); auto = split")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -267,7 +267,8 @@ def main():
     launch_s = (roll_ms / 1e3) / max(roll_n, 1)
     achieved = flops_rollout_launch(cfg, E) / launch_s / 1e12
     split = planner.precision == 2
-    kernel = ("ks_rollout" if split else "k_rollout") if family == "fused" else "g_gemm + row kernels of one _estimate_value"
+    kernel = (("ks_rollout" if split else "k_rollout") if family == "fused"
+              else ("g_gemm_s" if split else "g_gemm") + " + row kernels of one _estimate_value")
     traffic, traffic_src = pmc_traffic(E * cfg.num_samples // 64, kernel) if family == "fused" else (None, None)
     peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
     line = {

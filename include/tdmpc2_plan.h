@@ -68,8 +68,8 @@ enum tdmpc2_path { TDMPC2_PATH_AUTO = 0, TDMPC2_PATH_FUSED = 1, TDMPC2_PATH_LAYE
  *   FP32       v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation (bitwise an fmaf chain).
  *   SPLIT_F16  every fp32 operand is carried as hi + lo f16 pieces (22 significand bits) and a product is
  *              a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation: fp32-class
- *              error (checked against fp64 in the tests) at up to 16/3 of the fp32 matrix rate.  FUSED only.
- * AUTO = SPLIT_F16 where available (FUSED), FP32 otherwise. */
+ *              error (checked against fp64 in the tests) at up to 16/3 of the fp32 matrix rate.
+ * AUTO = SPLIT_F16. */
 enum tdmpc2_precision { TDMPC2_PREC_AUTO = 0, TDMPC2_PREC_FP32 = 1, TDMPC2_PREC_SPLIT_F16 = 2 };
 
 enum tdmpc2_net {

@@ -20,17 +20,17 @@
 // In-kernel phase timers (profiling builds only: -DSPLIT_TIMING, see tools/ablate.sh): wave 0 of every workgroup sums
 // the shader-clock cycles it spends in each phase class into p.timing[class].
 #ifdef SPLIT_TIMING
-#define TIMER_FIELDS mutable unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}; mutable unsigned long long t_last = 0, t_begin = 0;
+#define TIMER_FIELDS mutable unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; mutable unsigned long long t_last = 0, t_begin = 0;
 #define TIMER_START(c) { (c).t_last = (c).t_begin = __builtin_amdgcn_s_memtime(); }
 #define TIMER_MARK(c, cls) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); (c).t_acc[cls] += t_now - (c).t_last; (c).t_last = t_now; }
-#define TIMER_FLUSH(c, ptr) if ((ptr) && threadIdx.x == 0) { for (int i_ = 0; i_ < 6; ++i_) atomicAdd((ptr) + i_, (c).t_acc[i_]); atomicAdd((ptr) + 14, (c).t_last - (c).t_begin); atomicAdd((ptr) + 15, 1ull); }
+#define TIMER_FLUSH(c, ptr) if ((ptr) && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd((ptr) + i_, (c).t_acc[i_]); atomicAdd((ptr) + 14, (c).t_last - (c).t_begin); atomicAdd((ptr) + 15, 1ull); }
 #else
 #define TIMER_FIELDS
 #define TIMER_START(c)
 #define TIMER_MARK(c, cls)
 #define TIMER_FLUSH(c, ptr)
 #endif
-enum { T_KLOOP = 0, T_EPI = 1, T_HEAD = 2, T_ACT = 3, T_PARK = 4, T_TILE = 5 };
+enum { T_KLOOP = 0, T_EPI = 1, T_HEAD = 2, T_ACT = 3, T_PARK = 4, T_TILE = 5, T_EPI_PRE = 6, T_EPI_SYNC = 7 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -384,7 +384,9 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[2][2], float os
             c.stats[(c.wave * 64 + 32 * st + j) * 2 + 1] = m2;
         }
     }
+    TIMER_MARK(c, T_EPI_PRE)
     __syncthreads();
+    TIMER_MARK(c, T_EPI_SYNC)
     float rstd[2], shift[2];
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
