@@ -72,6 +72,33 @@ def pmc_traffic(workgroups, kernel="k_rollout"):
         return None, None
 
 
+def action_mse_vs_reference(device, path, prec):
+    """The second half of BASELINE.json's metric ("action MSE vs ref"): the planner replays the recorded noise tape of
+    the committed golden case for the benched model (c2: dog-run 5M, 2 envs, the reference's 8 iterations for A >= 20)
+    and its actions are compared with the actions the reference's OWN planner code produced on the same inputs
+    (tests/golden/c2.npz, made by oracle/make_golden.py).  Checker use of the test infrastructure, outside the timed
+    region; nothing here is measured for speed."""
+    import numpy as np
+    from oracle import cases
+    from tdmpc2_amd.native import NativePlanner
+
+    c = cases.build_case("c2")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "c2.npz"))
+    cfg, E = c["cfg"], c["n_envs"]
+    pl = NativePlanner(cfg, c["iterations"], device, max_envs=E, path=path, precision=prec)
+    pl.bind_state_dict({k: torch.as_tensor(v) for k, v in c["sd"].items()})
+    tape = {k: torch.as_tensor(v).to(device).contiguous() for k, v in c["tape"].items()}
+    z0 = torch.as_tensor(c["z0"]).to(device)
+    prev = torch.as_tensor(c["prev_mean"]).to(device).clone()
+    t0 = torch.as_tensor(c["t0"].astype(np.uint8)).to(device)
+    a = pl.plan(z0, disc_pow_rows(cfg, E, device), prev, t0, eval_mode=False, tape=tape).cpu().numpy()
+    pl.close()
+    d = a.astype(np.float64) - g["action"].astype(np.float64)
+    return {"action_mse_vs_reference": float((d ** 2).mean()), "action_max_abs_diff": float(np.abs(d).max()),
+            "case": "tests/golden/c2.npz: the reference's own planner code on the same weights, latents and noise tape "
+                    f"({E} envs x {c['iterations']} CEM iterations)"}
+
+
 def cpu_baseline(cfg, iterations, sd_np, budget_s=12.0):
     """The oracle (= the reference's planner math as plain torch CPU ops) timed on this box's host cores
     on a bounded sample of the same workload.  Test infrastructure used as a reported baseline only."""
@@ -232,6 +259,11 @@ def main():
         torch.cuda.synchronize(device)
         extra["latency_ms_single_env"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
 
+        if args.config == "c2":
+            try:
+                extra["parity"] = action_mse_vs_reference(device, path, prec)
+            except Exception as ex:
+                extra["parity"] = {"error": repr(ex)}
         if planner.precision == 2 and K >= 2:
             # companion measurement of the same workload with the exact-fp32 MFMA kernels (a few steps), so that one
             # bench line carries both arithmetic modes

@@ -774,15 +774,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
         }
         __syncthreads();
         TIMER_MARK(c, T_ACT)
-        // ---- first layers of dynamics and reward over the same [z_t | a_t] tile; the raw dynamics accumulators are
-        // parked in the workgroup's L2-resident scratch tile until the reward chain is done (64 VGPRs not held)
+        // ---- first layers of dynamics and reward over the same [z_t | a_t] tile.  The raw dynamics accumulators wait
+        // for the reward chain either in 64 held VGPRs (SPLIT_HOLD, needs the shallower weight ring) or parked in the
+        // workgroup's scratch tile (32 MB per round of workgroups: more than the L2s hold)
+#ifdef SPLIT_HOLD
+        f32x16 accd[2][2];
+        zero4(accd);
+        kloop_s(c, p.dyn.l[0], t == 0 ? ZKB16 : 0, KBA, accd);
+        TIMER_MARK(c, T_KLOOP)
+#endif
         {
             f32x16 acc[2][2];
+#ifndef SPLIT_HOLD
             zero4(acc);
             kloop_s(c, p.dyn.l[0], t == 0 ? ZKB16 : 0, KBA, acc);
             TIMER_MARK(c, T_KLOOP)
             park(c, acc, zs);
             TIMER_MARK(c, T_PARK)
+#endif
             zero4(acc);
             PFrag bf;
             load_pfrag(c, bf, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew);
@@ -800,14 +809,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
         TIMER_MARK(c, T_HEAD)
         if (tsc && (tid & 7) == 0) tsc[t] = r;
         G += disc[t] * r;
-        // ---- dynamics: pick the parked first layer up from L2, layers 2 and 3 (SimNorm)
+        // ---- dynamics: release the held / parked first layer, layers 2 and 3 (SimNorm)
         {
-            f32x16 acc[2][2];
             PFrag bf;
             load_pfrag(c, bf, t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn);
+#ifdef SPLIT_HOLD
+            epi_t<0>(c, accd, *p.dyn.l[0].oscale, bf, p.dyn.l[0].g, p.dyn.l[0].b, nullptr);
+#else
+            f32x16 acc[2][2];
             unpark(c, acc, zs);
             TIMER_MARK(c, T_PARK)
             epi_t<0>(c, acc, *p.dyn.l[0].oscale, bf, p.dyn.l[0].g, p.dyn.l[0].b, nullptr);
+#endif
         }
         __syncthreads();
         TIMER_MARK(c, T_EPI)
@@ -837,14 +850,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
     TIMER_MARK(c, T_TILE)
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 2);
     // ---- Q(z_H, a_H): the two selected heads, first layers in one pass (world_model.py:186-216)
+#ifdef SPLIT_HOLD
+    f32x16 accq[2][2];
+    zero4(accq);
+    kloop_s(c, p.q[q1].l[0], 0, KBA, accq);
+    TIMER_MARK(c, T_KLOOP)
+#endif
     {
-        // z_H has been read back from zs above: the scratch tile is free to park the second head's raw first layer
         f32x16 acc[2][2];
+#ifndef SPLIT_HOLD
+        // z_H has been read back from zs above: the scratch tile is free to park the second head's raw first layer
         zero4(acc);
         kloop_s(c, p.q[q1].l[0], 0, KBA, acc);
         TIMER_MARK(c, T_KLOOP)
         park(c, acc, zs);
         TIMER_MARK(c, T_PARK)
+#endif
         zero4(acc);
         PFrag bf;
         load_pfrag(c, bf, b_q0);
@@ -860,12 +881,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
     const float qa = head_twohot_s(c, p.q[q0].l[2], p.bins, p.num_bins);
     TIMER_MARK(c, T_HEAD)
     {
-        f32x16 acc[2][2];
         PFrag bf;
         load_pfrag(c, bf, b_q1);
+#ifdef SPLIT_HOLD
+        epi_t<0>(c, accq, *p.q[q1].l[0].oscale, bf, p.q[q1].l[0].g, p.q[q1].l[0].b, nullptr);
+#else
+        f32x16 acc[2][2];
         unpark(c, acc, zs);
         TIMER_MARK(c, T_PARK)
         epi_t<0>(c, acc, *p.q[q1].l[0].oscale, bf, p.q[q1].l[0].g, p.q[q1].l[0].b, nullptr);
+#endif
     }
     __syncthreads();
     TIMER_MARK(c, T_EPI)

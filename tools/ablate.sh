@@ -4,7 +4,11 @@
 # then `gpurun -- bash tools/ablate.sh run`.
 set -u
 R="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
-VARIANTS=("full:" "nomfma:-DSPLIT_ABL_NO_MFMA" "nobload:-DSPLIT_ABL_NO_BLOAD" "noepi:-DSPLIT_ABL_NO_EPI" "nomfma_nobload:-DSPLIT_ABL_NO_MFMA -DSPLIT_ABL_NO_BLOAD" "timing:-DSPLIT_TIMING" "${ABLATE_EXTRA:-full2:}")
+if [ -n "${ABLATE_VARIANTS:-}" ]; then
+  IFS=';' read -r -a VARIANTS <<< "$ABLATE_VARIANTS"
+else
+  VARIANTS=("full:" "nomfma:-DSPLIT_ABL_NO_MFMA" "nobload:-DSPLIT_ABL_NO_BLOAD" "noepi:-DSPLIT_ABL_NO_EPI" "nomfma_nobload:-DSPLIT_ABL_NO_MFMA -DSPLIT_ABL_NO_BLOAD" "timing:-DSPLIT_TIMING" "full2:")
+fi
 mkdir -p "$R/build/ablate"
 if [ "${1:-build}" = "build" ]; then
   for v in "${VARIANTS[@]}"; do
