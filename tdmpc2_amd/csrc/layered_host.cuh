@@ -147,7 +147,7 @@ int lay_setup(tdmpc2_plan *h, hipStream_t st, int E, const float *task_emb, cons
     for (int i = 0; i < c.num_q; ++i) { p.bias[BE_Q0 + i] = h->q[i].l[0].bias; p.wemb[BE_Q0 + i] = h->q[i].l[0].wemb; }
     p.task_emb = task_emb; p.prev_mean = prev_mean; p.t0 = t0; p.beff = h->beff;
     p.mean = init_dist ? h->mean : nullptr; p.std = h->std;
-    hipLaunchKernelGGL(l_setup, dim3(E), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(l_setup, dim3(E, c.multitask ? h->nnets : 1), dim3(256), 0, st, p);
     LAUNCH_CHECK();
     return 0;
 }

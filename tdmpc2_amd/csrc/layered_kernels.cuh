@@ -365,12 +365,14 @@ struct LSetupParams {
     float *beff, *mean, *std;
 };
 
+// grid (E, nnets): block (e, net) folds one net's task-embedding columns; block (e, 0) also initialises mean / std.
 __global__ void l_setup(LSetupParams p) {
     const int e = blockIdx.x, tid = threadIdx.x;
     if (p.multitask) {
         const float *emb = p.task_emb + (size_t)e * p.T;
-        for (int net = 0; net < p.nnets; ++net) {
-            if (!p.wemb[net]) continue;
+        {
+            const int net = blockIdx.y;
+            if (p.wemb[net])
             for (int c = tid; c < p.Mp; c += blockDim.x) {
                 float s = 0.f;
                 if (c < p.M) {
@@ -381,7 +383,7 @@ __global__ void l_setup(LSetupParams p) {
             }
         }
     }
-    if (p.mean) {
+    if (p.mean && blockIdx.y == 0) {
         for (int idx = tid; idx < p.H * p.A; idx += blockDim.x) {
             const int t = idx / p.A;
             float m = 0.f;
