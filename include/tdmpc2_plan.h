@@ -176,6 +176,12 @@ int tdmpc2_plan_refit(tdmpc2_plan_t *h, int n_envs, float *value, const float *a
                       const float *act_mask, float *mean, float *std, float *score,
                       int32_t *elite_idx, void *stream);
 
+/* Tuning knobs that never change results beyond fp32 round-off.  key TDMPC2_TUNE_ROWS_PER_WORKGROUP: sample rows a
+ * fused split-arithmetic rollout workgroup owns -- 0 = automatic (32 when a call brings too few plans to occupy the
+ * chip, i.e. single-environment latency; 64 otherwise), or 32 / 64 to force one. */
+enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0 };
+int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
+
 /* Live timing of the dominant (rollout) stage: after set_profiling(h, n > 0) every rollout launch
  * (FUSED: one k_rollout kernel; LAYERED: the GEMM / row-kernel sequence of one CEM iteration's
  * _estimate_value) is bracketed by HIP events recorded on the caller's stream (up to n are kept;

@@ -54,12 +54,16 @@ struct NetS {
 // The action padding (16, 32, 48 or 64 columns) is a template parameter: with compile-time row strides every LDS
 // address of the unrolled epilogues is base + immediate; with a run-time stride the compiler pre-computes hundreds of
 // addresses, hoists them out of the step loop and spills them.
-template <int APAD>
+// ST = 32-row sample tiles per workgroup: 2 (64 rows, throughput) or 1 (32 rows: twice the workgroups for the same plans,
+// used when a call has too few plans to fill the chip -- single-environment latency).
+template <int APAD, int ST = 2>
 struct CtxT {
+    static constexpr int NST = ST;
+    static constexpr int TROWS = 32 * ST;    // sample rows per workgroup
     static constexpr int SH = WIDTH + APAD;  // plane length in halfs
     static constexpr int RSH = 2 * SH + 8;   // row stride in halfs (row stride in dwords = SH + 4 = 4 x odd)
     _Float16 *act;  // LDS tile, operand form: row r at act + r * RSH: [hi: SH halfs | lo: SH halfs | 8 pad]
-    float *stats;   // LDS [8 waves][64 rows][2]: per-wave LayerNorm partials
+    float *stats;   // LDS [8 waves][TROWS][2]: per-wave LayerNorm partials
     int tid, wave, lane;
     TIMER_FIELDS
     __device__ __forceinline__ float *f32() const { return reinterpret_cast<float *>(act); }  // staging view [64][RSF]
@@ -137,25 +141,35 @@ __device__ __forceinline__ void load_b(BFrag &b, const char *u0, const char *u1,
     b.h[1] = ldw(u1, voff, 0);
     b.l[1] = ldw(u1, voff, 1024);
 }
-struct AFrag {
-    f16x8 h0, l0, h1, l1;  // hi / lo pieces of the two 32-row sample tiles
+template <int ST>
+__device__ __forceinline__ void zero_acc(f32x16 (&a)[ST][2]) {
+#pragma unroll
+    for (int r = 0; r < ST; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a[r][cc][e] = 0.f;
+}
+template <int ST>
+struct AFragT {
+    f16x8 h[ST], l[ST];  // hi / lo pieces of the 32-row sample tiles
 };
 template <class CT>
-__device__ __forceinline__ void load_a(AFrag &a, const _Float16 *a0p, const _Float16 *a1p, int kk) {
-    a.h0 = *reinterpret_cast<const f16x8 *>(a0p + kk * 16);
-    a.l0 = *reinterpret_cast<const f16x8 *>(a0p + CT::SH + kk * 16);
-    a.h1 = *reinterpret_cast<const f16x8 *>(a1p + kk * 16);
-    a.l1 = *reinterpret_cast<const f16x8 *>(a1p + CT::SH + kk * 16);
+__device__ __forceinline__ void load_a(AFragT<CT::NST> &a, const _Float16 *a0p, int kk) {
+#pragma unroll
+    for (int st = 0; st < CT::NST; ++st) {
+        a.h[st] = *reinterpret_cast<const f16x8 *>(a0p + st * 32 * CT::RSH + kk * 16);
+        a.l[st] = *reinterpret_cast<const f16x8 *>(a0p + st * 32 * CT::RSH + CT::SH + kk * 16);
+    }
 }
 // Software pipeline, per k-block: [read the NEXT block's activation fragments from LDS] [12 MFMAs on the current
 // block] [issue the weight loads for block + PF into the ring slot just consumed] [sched_barrier].  The barrier pins
 // the order: without it the machine scheduler sinks the prefetch loads to their first use (the next outer iteration)
 // and the loop runs load -> wait -> compute with no overlap.
 template <class CT>
-__device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, int kb1, f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, int kb1, f32x16 (&acc)[CT::NST][2]) {
     const int i = c.lane & 31, hh = c.lane >> 5;
     const _Float16 *a0p = c.act + i * c.RSH + 8 * hh + kb0 * 16;
-    const _Float16 *a1p = a0p + 32 * c.RSH;
     // one k-block of one column tile = 2 planes x 64 lanes x 16 B = 2048 B
     const char *u0 = reinterpret_cast<const char *>(ly.wp) + ((size_t)(2 * c.wave) * ly.KB + kb0) * 2048;
     const char *u1 = u0 + (size_t)ly.KB * 2048;
@@ -168,8 +182,8 @@ __device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, 
         const int kd = d < nk ? d : nk - 1;
         load_b(ring[d], u0 + (size_t)kd * 2048, u1 + (size_t)kd * 2048, voff);
     }
-    AFrag an;
-    load_a<CT>(an, a0p, a1p, 0);
+    AFragT<CT::NST> an;
+    load_a<CT>(an, a0p, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int k = 0; k < nk; k += PF) {
@@ -177,23 +191,20 @@ __device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, 
         for (int d = 0; d < PF; ++d) {
             const int kk = k + d;
             if (kk < nk) {  // wave-uniform
-                const AFrag a = an;
-                load_a<CT>(an, a0p, a1p, kk + 1 < nk ? kk + 1 : kk);
+                const AFragT<CT::NST> a = an;
+                load_a<CT>(an, a0p, kk + 1 < nk ? kk + 1 : kk);
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    acc[0][cc] = SPLIT_MFMA(ring[d].h[cc], a.h0, acc[0][cc]);
-                    acc[1][cc] = SPLIT_MFMA(ring[d].h[cc], a.h1, acc[1][cc]);
-                }
+                for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    acc[0][cc] = SPLIT_MFMA(ring[d].l[cc], a.h0, acc[0][cc]);
-                    acc[1][cc] = SPLIT_MFMA(ring[d].l[cc], a.h1, acc[1][cc]);
-                }
+                    for (int st = 0; st < CT::NST; ++st) acc[st][cc] = SPLIT_MFMA(ring[d].h[cc], a.h[st], acc[st][cc]);
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc) {
-                    acc[0][cc] = SPLIT_MFMA(ring[d].h[cc], a.l0, acc[0][cc]);
-                    acc[1][cc] = SPLIT_MFMA(ring[d].h[cc], a.l1, acc[1][cc]);
-                }
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int st = 0; st < CT::NST; ++st) acc[st][cc] = SPLIT_MFMA(ring[d].l[cc], a.h[st], acc[st][cc]);
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+                    for (int st = 0; st < CT::NST; ++st) acc[st][cc] = SPLIT_MFMA(ring[d].h[cc], a.l[st], acc[st][cc]);
                 const int kn = kk + PF < nk ? kk + PF : nk - 1;
                 load_b(ring[d], u0 + (size_t)kn * 2048, u1 + (size_t)kn * 2048, voff);
                 __builtin_amdgcn_sched_barrier(0);
@@ -206,21 +217,20 @@ __device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, 
 // weight fragment is fetched once per workgroup and feeds 6 MFMAs; six independent accumulators (row tile x product
 // kind) keep the matrix pipe issuing back to back.  Activations are the A operand here: C[sample][logit].
 template <class CT>
-__device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int ct, int kb0, int kb1, f32x16 (&out)[2]) {
+__device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int ct, int kb0, int kb1, f32x16 (&out)[CT::NST]) {
 #ifndef SPLIT_PFT
 #define SPLIT_PFT 6
 #endif
     constexpr int PFT = SPLIT_PFT;
     const int i = c.lane & 31, hh = c.lane >> 5;
     const _Float16 *a0p = c.act + i * c.RSH + 8 * hh + kb0 * 16;
-    const _Float16 *a1p = a0p + 32 * c.RSH;
     const char *u = reinterpret_cast<const char *>(ly.wp) + ((size_t)ct * ly.KB + kb0) * 2048;  // uniform
     unsigned voff = (unsigned)c.lane * 16u;
     asm volatile("" : "+v"(voff));
     const int nk = kb1 - kb0;
-    f32x16 acc[2][3];
+    f32x16 acc[CT::NST][3];
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < CT::NST; ++r)
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -232,8 +242,8 @@ __device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int 
         rh[d] = ldw(u + (size_t)kd * 2048, voff, 0);
         rl[d] = ldw(u + (size_t)kd * 2048, voff, 1024);
     }
-    AFrag an;
-    load_a<CT>(an, a0p, a1p, 0);
+    AFragT<CT::NST> an;
+    load_a<CT>(an, a0p, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int k = 0; k < nk; k += PFT) {
@@ -241,14 +251,14 @@ __device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int 
         for (int d = 0; d < PFT; ++d) {
             const int kk = k + d;
             if (kk < nk) {
-                const AFrag a = an;
-                load_a<CT>(an, a0p, a1p, kk + 1 < nk ? kk + 1 : kk);
-                acc[0][0] = SPLIT_MFMA(a.h0, rh[d], acc[0][0]);
-                acc[1][0] = SPLIT_MFMA(a.h1, rh[d], acc[1][0]);
-                acc[0][1] = SPLIT_MFMA(a.h0, rl[d], acc[0][1]);
-                acc[1][1] = SPLIT_MFMA(a.h1, rl[d], acc[1][1]);
-                acc[0][2] = SPLIT_MFMA(a.l0, rh[d], acc[0][2]);
-                acc[1][2] = SPLIT_MFMA(a.l1, rh[d], acc[1][2]);
+                const AFragT<CT::NST> a = an;
+                load_a<CT>(an, a0p, kk + 1 < nk ? kk + 1 : kk);
+#pragma unroll
+                for (int st = 0; st < CT::NST; ++st) acc[st][0] = SPLIT_MFMA(a.h[st], rh[d], acc[st][0]);
+#pragma unroll
+                for (int st = 0; st < CT::NST; ++st) acc[st][1] = SPLIT_MFMA(a.h[st], rl[d], acc[st][1]);
+#pragma unroll
+                for (int st = 0; st < CT::NST; ++st) acc[st][2] = SPLIT_MFMA(a.l[st], rh[d], acc[st][2]);
                 const int kn = kk + PFT < nk ? kk + PFT : nk - 1;
                 rh[d] = ldw(u + (size_t)kn * 2048, voff, 0);
                 rl[d] = ldw(u + (size_t)kn * 2048, voff, 1024);
@@ -257,7 +267,7 @@ __device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int 
         }
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < CT::NST; ++r)
 #pragma unroll
         for (int e = 0; e < 16; ++e) out[r][e] = acc[r][0][e] + (acc[r][1][e] + acc[r][2][e]);
 }
@@ -275,9 +285,9 @@ __device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int 
 
 // raw accumulators <-> a dense global tile in register order (coalesced 1 KiB per wave instruction)
 template <class CT>
-__device__ __forceinline__ void park(const CT &c, const f32x16 (&acc)[2][2], float *dst) {
+__device__ __forceinline__ void park(const CT &c, const f32x16 (&acc)[CT::NST][2], float *dst) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < CT::NST; ++st)
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -285,19 +295,19 @@ __device__ __forceinline__ void park(const CT &c, const f32x16 (&acc)[2][2], flo
                 f32x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[st][ft][4 * m + r];
-                const int idx4 = ((c.wave * 2 + st) * 2 + ft) * 4 + m;
+                const int idx4 = ((c.wave * CT::NST + st) * 2 + ft) * 4 + m;
                 *reinterpret_cast<f32x4 *>(dst + ((size_t)idx4 * 64 + c.lane) * 4) = v;
             }
 }
 template <class CT>
-__device__ __forceinline__ void unpark(const CT &c, f32x16 (&acc)[2][2], const float *src) {
+__device__ __forceinline__ void unpark(const CT &c, f32x16 (&acc)[CT::NST][2], const float *src) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st)
+    for (int st = 0; st < CT::NST; ++st)
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int idx4 = ((c.wave * 2 + st) * 2 + ft) * 4 + m;
+                const int idx4 = ((c.wave * CT::NST + st) * 2 + ft) * 4 + m;
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(src + ((size_t)idx4 * 64 + c.lane) * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = v[r];
@@ -306,10 +316,10 @@ __device__ __forceinline__ void unpark(const CT &c, f32x16 (&acc)[2][2], const f
 
 // values in register order -> operand form in the LDS tile (hi / lo planes), scaled by ACT_SCALE
 template <class CT>
-__device__ __forceinline__ void regs_to_tile(const CT &c, const f32x16 (&y)[2][2]) {
+__device__ __forceinline__ void regs_to_tile(const CT &c, const f32x16 (&y)[CT::NST][2]) {
     const int j = c.lane & 31, hh = c.lane >> 5;
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+    for (int st = 0; st < CT::NST; ++st) {
         _Float16 *hp = c.act + (32 * st + j) * c.RSH + 64 * c.wave + 4 * hh;
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft)
@@ -346,7 +356,7 @@ __device__ __forceinline__ void load_pfrag(const CT &c, PFrag &f, const float *v
 // exchange, which also orders every wave's last read of the operand tile before the first write of the new one);
 // the caller adds the one before the next contraction.
 template <int ACT, class CT>
-__device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[2][2], float osc, const PFrag &bias, const float *g, const float *b,
+__device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][2], float osc, const PFrag &bias, const float *g, const float *b,
                                       float *zcopy) {
     const int j = c.lane & 31, hh = c.lane >> 5;
     PFrag gf, bf;
@@ -357,12 +367,12 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[2][2], float os
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int st = 0; st < 2; ++st)
+            for (int st = 0; st < CT::NST; ++st)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = fmaf(acc[st][ft][4 * m + r], osc, bias.v[ft][m][r]);
     // per-wave partial statistics of the two sample rows this lane works on
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+    for (int st = 0; st < CT::NST; ++st) {
         float s = 0.f;
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft)
@@ -380,21 +390,21 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[2][2], float os
             }
         m2 += __shfl_xor(m2, 32);
         if (hh == 0) {
-            c.stats[(c.wave * 64 + 32 * st + j) * 2 + 0] = mw;
-            c.stats[(c.wave * 64 + 32 * st + j) * 2 + 1] = m2;
+            c.stats[(c.wave * CT::TROWS + 32 * st + j) * 2 + 0] = mw;
+            c.stats[(c.wave * CT::TROWS + 32 * st + j) * 2 + 1] = m2;
         }
     }
     TIMER_MARK(c, T_EPI_PRE)
     __syncthreads();
     TIMER_MARK(c, T_EPI_SYNC)
-    float rstd[2], shift[2];
+    float rstd[CT::NST], shift[CT::NST];
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+    for (int st = 0; st < CT::NST; ++st) {
         float pm[8], mean = 0.f, msum = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
-            pm[w] = c.stats[(w * 64 + 32 * st + j) * 2 + 0];
-            msum += c.stats[(w * 64 + 32 * st + j) * 2 + 1];
+            pm[w] = c.stats[(w * CT::TROWS + 32 * st + j) * 2 + 0];
+            msum += c.stats[(w * CT::TROWS + 32 * st + j) * 2 + 1];
             mean += pm[w];
         }
         mean *= 0.125f;
@@ -415,7 +425,7 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[2][2], float os
         for (int m = 0; m < 4; ++m) {
             const f32x4 g4 = gf.v[ft][m], b4 = bf.v[ft][m];
 #pragma unroll
-            for (int st = 0; st < 2; ++st) {
+            for (int st = 0; st < CT::NST; ++st) {
                 float y[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) y[r] = fmaf(fmaf(acc[st][ft][4 * m + r], rstd[st], shift[st]), g4[r], b4[r]);
@@ -464,7 +474,9 @@ __device__ __forceinline__ void store_tile_s(const CT &c, const f32x16 &acc, flo
 // softmax(logits) . bins -> symexp; the softmax normalisation is applied once to the weighted sum.
 template <class CT>
 __device__ __forceinline__ float twohot_rows_s(const CT &c, const float *bins, int num_bins) {
-    const int row = c.tid >> 3, part = c.tid & 7;
+    const int part = c.tid & 7;
+    const bool live = (c.tid >> 3) < CT::TROWS;  // ST = 1: the upper half of the workgroup has no row
+    const int row = live ? c.tid >> 3 : 0;
     const float *rp = c.f32() + row * c.RSF();
     float v[16];
     float m = -INFINITY;
@@ -491,8 +503,8 @@ __device__ __forceinline__ float twohot_rows_s(const CT &c, const float *bins, i
 template <int ACT, class CT>
 __device__ __forceinline__ void layer_full_s(const CT &c, const LayerS &ly, const float *bias, int kb0, int kb1,
                                              float *zcopy = nullptr) {
-    f32x16 acc[2][2];
-    zero4(acc);
+    f32x16 acc[CT::NST][2];
+    zero_acc(acc);
     PFrag bf;
     load_pfrag(c, bf, bias);
     kloop_s(c, ly, kb0, kb1, acc);
@@ -504,14 +516,14 @@ __device__ __forceinline__ void layer_full_s(const CT &c, const LayerS &ly, cons
 
 template <class CT>
 __device__ __forceinline__ float head_twohot_s(const CT &c, const LayerS &ly, const float *bins, int num_bins) {
-    f32x16 acc[2];
+    f32x16 acc[CT::NST];
     const int ct = c.wave;
     if (ct < ly.CT) kloop_tile_s(c, ly, ct, 0, ZKB16, acc);
     const float osc = *ly.oscale;
     __syncthreads();
     if (ct < ly.CT) {
-        store_tile_s(c, acc[0], osc, ly.bias, ct, 0);
-        store_tile_s(c, acc[1], osc, ly.bias, ct, 1);
+#pragma unroll
+        for (int rt = 0; rt < CT::NST; ++rt) store_tile_s(c, acc[rt], osc, ly.bias, ct, rt);
     }
     __syncthreads();
     const float r = twohot_rows_s(c, bins, num_bins);
@@ -534,19 +546,20 @@ __device__ __forceinline__ void put_action(const CT &c, int row, int a, float v)
 template <class CT, typename EpsFn>
 __device__ __forceinline__ void head_pi_s(const CT &c, const LayerS &ly, int A, int Apad, float lsmin, float lsdif,
                                           const float *mask, EpsFn eps, float *gdst, int nvalid, float *tsc) {
-    f32x16 acc[2];
+    f32x16 acc[CT::NST];
     const int ct = c.wave;
     if (ct < ly.CT) kloop_tile_s(c, ly, ct, 0, ZKB16, acc);
     const float osc = *ly.oscale;
     __syncthreads();
     if (ct < ly.CT) {
-        store_tile_s(c, acc[0], osc, ly.bias, ct, 0);
-        store_tile_s(c, acc[1], osc, ly.bias, ct, 1);
+#pragma unroll
+        for (int rt = 0; rt < CT::NST; ++rt) store_tile_s(c, acc[rt], osc, ly.bias, ct, rt);
     }
     __syncthreads();
     const int row = c.tid >> 3, part = c.tid & 7;
     const float *rp = c.f32() + row * c.RSF();
     // the logits (staging columns < 2A <= 128) do not alias the action columns (hi: floats 256.., lo: floats >= 512)
+    if (row < CT::TROWS)
     for (int a = part; a < Apad; a += 8) {
         float out = 0.f;
         if (a < A) {
@@ -571,13 +584,13 @@ __device__ __forceinline__ void head_pi_s(const CT &c, const LayerS &ly, int A, 
 // register-order fp32 tile in global (written by park / epi_t's zcopy) -> operand-form z columns
 template <class CT>
 __device__ __forceinline__ void tile_from_global_s(const CT &c, const float *src) {
-    f32x16 y[2][2];
+    f32x16 y[CT::NST][2];
     unpark(c, y, src);
     regs_to_tile(c, y);
 }
 template <class CT>
 __device__ __forceinline__ void tile_broadcast_row_s(const CT &c, const float *src_row) {
-    for (int idx = c.tid; idx < ROWS * (WIDTH / 4); idx += NTHREADS) {
+    for (int idx = c.tid; idx < CT::TROWS * (WIDTH / 4); idx += NTHREADS) {
         const int row = idx / (WIDTH / 4), c4 = idx % (WIDTH / 4);
         const f32x4 y = *reinterpret_cast<const f32x4 *>(src_row + 4 * c4);
         f16x4 hi, lo;
@@ -591,8 +604,8 @@ __device__ __forceinline__ void tile_broadcast_row_s(const CT &c, const float *s
 template <class CT>
 __device__ __forceinline__ void dump_tile_s(const CT &c, float *trace, int nslot, int slot) {
     if (!trace) return;
-    float *dst = trace + ((size_t)blockIdx.x * nslot + slot) * ROWS * WIDTH;
-    for (int idx = c.tid; idx < ROWS * WIDTH; idx += NTHREADS) {
+    float *dst = trace + ((size_t)blockIdx.x * nslot + slot) * CT::TROWS * WIDTH;
+    for (int idx = c.tid; idx < CT::TROWS * WIDTH; idx += NTHREADS) {
         const int row = idx / WIDTH, col = idx % WIDTH;
         const _Float16 *hp = c.act + row * c.RSH + col;
         dst[idx] = ((float)hp[0] + (float)hp[c.SH]) * (1.0f / ACT_SCALE);
@@ -627,8 +640,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
     tile_broadcast_row_s(c, p.z0 + (size_t)e * WIDTH);
     __syncthreads();
     f32x16 acc[2][2][2];
-    zero4(acc[0]);
-    zero4(acc[1]);
+    zero_acc(acc[0]);
+    zero_acc(acc[1]);
     kloop_s(c, p.rew.l[0], 0, ZKB16, acc[0]);
     kloop_s(c, p.dyn.l[0], 0, ZKB16, acc[1]);
     const float *b_rew = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_REW) * WIDTH : p.rew.l[0].bias;
@@ -648,12 +661,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
 }
 
 // ================================================================ kernel: policy-prior trajectories (cf. k_pitraj)
-template <int APAD>
+// ST = 1 (one 32-row tile) when num_pi_trajs <= 32 -- the reference's 24 -- else 2.
+template <int APAD, int ST>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x, tid = threadIdx.x;
-    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2, tid,
-                 __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    typedef CtxT<APAD, ST> CT;
+    CT c{reinterpret_cast<_Float16 *>(smem), smem + CT::TROWS * CT::RSH / 2, tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
     const float *b_pi = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_PI) * WIDTH : p.pi.l[0].bias;
     const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
@@ -661,7 +675,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) 
     const int KBA = ZKB16 + p.Apad / 16;
     tile_broadcast_row_s(c, p.z0 + (size_t)e * WIDTH);
     {  // zs <- z0 for every sample row, in register order (what tile_from_global_s reads back)
-        f32x16 y[2][2];
+        f32x16 y[ST][2];
         const int hh = c.lane >> 5;
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft)
@@ -669,7 +683,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) 
             for (int m = 0; m < 4; ++m) {
                 const f32x4 z = *reinterpret_cast<const f32x4 *>(p.z0 + (size_t)e * WIDTH + 64 * c.wave + 32 * ft + 8 * m + 4 * hh);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y[0][ft][4 * m + r] = y[1][ft][4 * m + r] = z[r];
+                for (int st = 0; st < ST; ++st)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[st][ft][4 * m + r] = z[r];
             }
         park(c, y, zs);
     }
@@ -695,22 +711,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) 
 }
 
 // ================================================================ kernel: one CEM iteration's rollouts (cf. k_rollout)
-template <int APAD>
+template <int APAD, int ST>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x / p.tiles, tile = blockIdx.x % p.tiles;
     const int tid = threadIdx.x;
-    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2, tid,
-                 __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
-    float *sm_mean = smem + ROWS * c.RSH / 2 + 1024;  // [H*A] after the tile and the LayerNorm partials
+    typedef CtxT<APAD, ST> CT;
+    constexpr int TROWS = CT::TROWS;
+    CT c{reinterpret_cast<_Float16 *>(smem), smem + TROWS * CT::RSH / 2, tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    float *sm_mean = smem + TROWS * c.RSH / 2 + 1024;  // [H*A] after the tile and the LayerNorm partials
     float *sm_std = sm_mean + p.H * p.A;
-    const int row0 = tile * ROWS;
+    const int row0 = tile * TROWS;
     const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
     const float *disc = p.disc_pow + (size_t)e * (p.H + 1);
     const int KBA = ZKB16 + p.Apad / 16;
-    float *zs = p.zscratch + (size_t)blockIdx.x * ROWS * WIDTH;
+    float *zs = p.zscratch + (size_t)blockIdx.x * TROWS * WIDTH;
     const int NSLOT = 5 * p.H + 7;
-    float *tsc = p.trace_scalars ? p.trace_scalars + ((size_t)e * p.N + row0 + (tid >> 3)) * (p.H + 2 + p.A) : nullptr;
+    const bool live = (tid >> 3) < TROWS;  // ST = 1: threads 256..511 own no sample row in the row-per-8-lanes phases
+    float *tsc = p.trace_scalars && live ? p.trace_scalars + ((size_t)e * p.N + row0 + (tid >> 3)) * (p.H + 2 + p.A) : nullptr;
 
     for (int idx = tid; idx < p.H * p.A; idx += NTHREADS) {
         sm_mean[idx] = p.mean[(size_t)e * p.H * p.A + idx];
@@ -741,7 +759,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
         {
             float *ag = p.actions + ((size_t)e * p.H + t) * p.N * p.A;
             const int hp = p.Apad / 2;
-            for (int idx = tid; idx < ROWS * hp; idx += NTHREADS) {
+            for (int idx = tid; idx < TROWS * hp; idx += NTHREADS) {
                 const int row = idx / hp, a0 = 2 * (idx % hp);
                 const int n = row0 + row;
                 float v[2] = {0.f, 0.f};
@@ -778,21 +796,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
         // for the reward chain either in 64 held VGPRs (SPLIT_HOLD, needs the shallower weight ring) or parked in the
         // workgroup's scratch tile (32 MB per round of workgroups: more than the L2s hold)
 #ifdef SPLIT_HOLD
-        f32x16 accd[2][2];
-        zero4(accd);
+        f32x16 accd[ST][2];
+        zero_acc(accd);
         kloop_s(c, p.dyn.l[0], t == 0 ? ZKB16 : 0, KBA, accd);
         TIMER_MARK(c, T_KLOOP)
 #endif
         {
-            f32x16 acc[2][2];
+            f32x16 acc[ST][2];
 #ifndef SPLIT_HOLD
-            zero4(acc);
+            zero_acc(acc);
             kloop_s(c, p.dyn.l[0], t == 0 ? ZKB16 : 0, KBA, acc);
             TIMER_MARK(c, T_KLOOP)
             park(c, acc, zs);
             TIMER_MARK(c, T_PARK)
 #endif
-            zero4(acc);
+            zero_acc(acc);
             PFrag bf;
             load_pfrag(c, bf, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew);
             kloop_s(c, p.rew.l[0], t == 0 ? ZKB16 : 0, KBA, acc);
@@ -816,7 +834,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
 #ifdef SPLIT_HOLD
             epi_t<0>(c, accd, *p.dyn.l[0].oscale, bf, p.dyn.l[0].g, p.dyn.l[0].b, nullptr);
 #else
-            f32x16 acc[2][2];
+            f32x16 acc[ST][2];
             unpark(c, acc, zs);
             TIMER_MARK(c, T_PARK)
             epi_t<0>(c, acc, *p.dyn.l[0].oscale, bf, p.dyn.l[0].g, p.dyn.l[0].b, nullptr);
@@ -851,22 +869,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 2);
     // ---- Q(z_H, a_H): the two selected heads, first layers in one pass (world_model.py:186-216)
 #ifdef SPLIT_HOLD
-    f32x16 accq[2][2];
-    zero4(accq);
+    f32x16 accq[ST][2];
+    zero_acc(accq);
     kloop_s(c, p.q[q1].l[0], 0, KBA, accq);
     TIMER_MARK(c, T_KLOOP)
 #endif
     {
-        f32x16 acc[2][2];
+        f32x16 acc[ST][2];
 #ifndef SPLIT_HOLD
         // z_H has been read back from zs above: the scratch tile is free to park the second head's raw first layer
-        zero4(acc);
+        zero_acc(acc);
         kloop_s(c, p.q[q1].l[0], 0, KBA, acc);
         TIMER_MARK(c, T_KLOOP)
         park(c, acc, zs);
         TIMER_MARK(c, T_PARK)
 #endif
-        zero4(acc);
+        zero_acc(acc);
         PFrag bf;
         load_pfrag(c, bf, b_q0);
         kloop_s(c, p.q[q0].l[0], 0, KBA, acc);
@@ -886,7 +904,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
 #ifdef SPLIT_HOLD
         epi_t<0>(c, accq, *p.q[q1].l[0].oscale, bf, p.q[q1].l[0].g, p.q[q1].l[0].b, nullptr);
 #else
-        f32x16 acc[2][2];
+        f32x16 acc[ST][2];
         unpark(c, acc, zs);
         TIMER_MARK(c, T_PARK)
         epi_t<0>(c, acc, *p.q[q1].l[0].oscale, bf, p.q[q1].l[0].g, p.q[q1].l[0].b, nullptr);
@@ -904,7 +922,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
         tsc[p.H] = qa;
         tsc[p.H + 1] = qb;
     }
-    if ((tid & 7) == 0) p.value[(size_t)e * p.N + row0 + (tid >> 3)] = G + disc[p.H] * ((qa + qb) / 2.f);
+    if ((tid & 7) == 0 && live) p.value[(size_t)e * p.N + row0 + (tid >> 3)] = G + disc[p.H] * ((qa + qb) / 2.f);
 }
 
 // ================================================================ weight scaling + packing

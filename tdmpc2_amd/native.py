@@ -23,7 +23,8 @@ ABI_VERSION = 2
 ABI_SYMBOLS = [
     "tdmpc2_plan_abi_version", "tdmpc2_last_error", "tdmpc2_plan_create", "tdmpc2_plan_destroy",
     "tdmpc2_plan_device_bytes", "tdmpc2_plan_path", "tdmpc2_plan_precision", "tdmpc2_plan_bind_weights", "tdmpc2_plan_run", "tdmpc2_plan_estimate_value",
-    "tdmpc2_plan_estimate_value_trace", "tdmpc2_plan_refit", "tdmpc2_plan_set_profiling", "tdmpc2_plan_profile_read",
+    "tdmpc2_plan_estimate_value_trace", "tdmpc2_plan_refit", "tdmpc2_plan_set_tuning", "tdmpc2_plan_set_profiling",
+    "tdmpc2_plan_profile_read",
 ]
 
 NET_DYNAMICS, NET_REWARD, NET_PI, NET_Q, NET_TERMINATION = range(5)
@@ -91,6 +92,8 @@ def load_library():
     lib.tdmpc2_plan_estimate_value_trace.restype = i32
     lib.tdmpc2_plan_refit.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tdmpc2_plan_refit.restype = i32
+    lib.tdmpc2_plan_set_tuning.argtypes = [vp, i32, i32]
+    lib.tdmpc2_plan_set_tuning.restype = i32
     lib.tdmpc2_plan_set_profiling.argtypes = [vp, i32]
     lib.tdmpc2_plan_set_profiling.restype = i32
     lib.tdmpc2_plan_profile_read.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
@@ -289,7 +292,11 @@ class NativePlanner:
                                                    _ptr(std), _ptr(score), _ptr(idx), self._stream()))
         return mean, std, score, idx
 
-    # ------------------------------------------------------------------ profiling
+    # ------------------------------------------------------------------ tuning / profiling
+    def set_rows_per_workgroup(self, rows: int):
+        """0 = automatic (32-row workgroups for calls with few plans: latency), or force 32 / 64."""
+        self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 0, int(rows)))
+
     def set_profiling(self, max_launches: int):
         """Bracket up to `max_launches` rollout-kernel launches with HIP events (0 = off)."""
         self._check(self.lib.tdmpc2_plan_set_profiling(self._h, int(max_launches)))

@@ -263,3 +263,20 @@ def test_errors_are_loud():
     with pytest.raises(NativeError):  # weights not bound
         p.plan(z, torch.ones(1, 4, device="cuda"), torch.zeros(1, 3, 6, device="cuda"),
                torch.ones(1, dtype=torch.uint8, device="cuda"))
+
+
+@pytest.mark.parametrize("rows", [32, 64])
+@pytest.mark.parametrize("name", ["c1", "c2", "mt5"])
+def test_split_workgroup_geometries_match_golden(name, rows):
+    """The split-arithmetic rollout runs with 64-row workgroups (throughput) or 32-row workgroups (few plans: latency);
+    both must reproduce the reference golden, and they agree with each other to fp32 round-off."""
+    from tests.gpu_common import case_on_gpu
+
+    c, model, planner = case_on_gpu(name, 1, 2)
+    g = load_golden(name)
+    planner.set_rows_per_workgroup(rows)
+    try:
+        got = _run_native(c, model, planner)
+    finally:
+        planner.set_rows_per_workgroup(0)
+    _compare_stages(f"{name}/rows{rows}", c, got, g, g["action"], g["prev_mean_out"])
