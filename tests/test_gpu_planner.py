@@ -280,3 +280,42 @@ def test_split_workgroup_geometries_match_golden(name, rows):
     finally:
         planner.set_rows_per_workgroup(0)
     _compare_stages(f"{name}/rows{rows}", c, got, g, g["action"], g["prev_mean_out"])
+
+
+@PRECS
+def test_action_statistics_over_32_seeds(prec):
+    """End-to-end action parity over 32 independently seeded plans: one batched call of 32 environments,
+    each with its own latent, warm-start mean and noise tape, against 32 sequential oracle plans.  top-k makes the
+    end-to-end map discontinuous, so plans whose oracle k-th / (k+1)-th values are closer than 1e-4 at some iteration
+    may legitimately diverge: they are counted, everything else must agree to 1e-4, and the MSE over all plans that
+    did not hit such a boundary is reported."""
+    from oracle import cases
+    from oracle import planner_oracle as po
+    from tdmpc2_amd.config import named_config
+    from tdmpc2_amd.native import NativePlanner
+    from tests.gpu_common import dev
+
+    E = 32
+    cfg = named_config("c1")
+    c = cases.build_custom(cfg, E)
+    model = po.OracleModel(cfg, {k: torch.as_tensor(v) for k, v in c["sd"].items()})
+    planner = NativePlanner(cfg, c["iterations"], dev(), max_envs=E, path=1, precision=prec)
+    planner.bind_state_dict(model.sd)
+    a, pm, st = po.plan_batch(model, c["z0"], c["tape"], c["prev_mean"], c["t0"], False, None, c["discounts"], c["iterations"])
+    got = _run_native(c, model, planner)
+    planner.close()
+    K = cfg.num_elites
+    clean, boundary = [], 0
+    for e in range(E):
+        same = all(elite_sets_equal(got["elite_idx"][e, it], st["elite_idx"][e, it].numpy()) for it in range(c["iterations"]))
+        if not same:
+            assert min(boundary_gap(st["value"][e, it].numpy(), K) for it in range(c["iterations"])) < 1e-4, e
+            boundary += 1
+            continue
+        clean.append(e)
+    d = got["action"][clean].astype(np.float64) - a.numpy()[clean].astype(np.float64)
+    mse, worst = float((d ** 2).mean()), float(np.abs(d).max())
+    print(f"[c1 x {E} seeds, precision {prec}] action MSE {mse:.3e}, max |diff| {worst:.3e}, "
+          f"{boundary} plans at an elite boundary")
+    assert len(clean) >= E - 4
+    assert worst < 1e-4 and mse < 1e-9
