@@ -10,10 +10,12 @@
 // each weight matrix by 2^kw with max|W| 2^kw in [2^13, 2^14) (k_wscale); the fp32 accumulator is multiplied back by
 // the exact 2^-(kw+5) in the epilogue.
 //
-// Same phase structure, work savings and reference citations as k_rollout / k_pitraj / k_setup in tdmpc2_plan.hip;
-// what differs is the LDS tile (operand form: per row [hi plane | lo plane], f16) and a leaner epilogue: the
-// pre-activation tile is staged once in fp32 (row-local alias of the same bytes), each thread then holds its 64-column
-// row slice in registers for LayerNorm statistics, activation and the hi/lo split, and writes the operand form back.
+// Same phase structure, work savings and reference citations as k_rollout / k_pitraj / k_setup in tdmpc2_plan.hip.
+// What differs: the LDS tile is in operand form (per row [hi plane | lo plane], f16, compile-time strides); the MFMAs
+// are issued with the weight fragment as the A operand so that each lane's accumulators belong to its own two sample
+// rows, which makes the LayerNorm / activation / hi-lo-split epilogue register resident (no fp32 staging pass, two
+// barriers per layer); weight fragments are prefetched through a register ring whose issue order is pinned with
+// sched_barrier; 32- or 64-row workgroups (ST).  DESIGN.md section 3.2 has the measured breakdown.
 // Included by tdmpc2_plan.hip inside its anonymous namespace.
 #pragma once
 

@@ -7,7 +7,12 @@
 //   NormedLinear / SimNorm                 tdmpc2/common/layers.py:74-118
 //   two_hot_inv / symexp / log_std / gumbel_softmax_sample   tdmpc2/common/math.py
 //
-// Design (see DESIGN.md for the full account):
+// This file: the C ABI, the handle, weight packing, the elite-refit kernel shared by every path, and the exact-fp32
+// fused kernels (k_setup / k_pitraj / k_rollout, v_mfma_f32_32x32x2_f32).  fused_split.cuh holds the same fused
+// kernels in the f16x2-split arithmetic (default), layered_kernels.cuh / layered_split.cuh / layered_host.cuh the
+// layer-at-a-time family for every other model size and for episodic planning.
+//
+// Design of the fused exact-fp32 kernels (see DESIGN.md for the full account):
 //   * One persistent "rollout" workgroup owns 64 sample rows of one plan for a
 //     whole CEM iteration: the H-step latent rollout (reward + dynamics MLPs),
 //     the policy prior and the two selected Q heads.  Activations never leave
