@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--precision", default="auto", choices=["auto", "fp32", "split"],
                     help="contraction arithmetic: exact-fp32 MFMA or f16x2-split on the f16 matrix pipe (fp32-class "
                          "accuracy); auto = split")
+    ap.add_argument("--rows-per-workgroup", type=int, default=0, help="fused split kernels: 0 auto, 32 or 64 sample rows")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
@@ -189,6 +190,8 @@ def main():
     family = {1: "fused", 2: "layered"}[planner.path]
     arith = {1: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 2: "f16x2 split (3x v_mfma_f32_32x32x16_f16, fp32 accumulate)"}[planner.precision]
     planner.bind_state_dict(sd)
+    if args.rows_per_workgroup:
+        planner.set_rows_per_workgroup(args.rows_per_workgroup)
 
     z0 = torch.as_tensor(synth.make_latents(cfg, E, seed=1000 + rank)).to(device)
     disc = disc_pow_rows(cfg, E, device)

@@ -58,14 +58,20 @@ struct NetS {
 // addresses, hoists them out of the step loop and spills them.
 // ST = 32-row sample tiles per workgroup: 2 (64 rows, throughput) or 1 (32 rows: twice the workgroups for the same plans,
 // used when a call has too few plans to fill the chip -- single-environment latency).
-template <int APAD, int ST = 2>
+// NW = wavefronts per workgroup: 8 (each owns 64 output features = 2 feature tiles) or 4 (128 features = 4 tiles).
+// The throughput geometry is (ST 1, NW 4): 32-row, 256-thread workgroups of 72 KB LDS, TWO per CU -- independent
+// barrier domains whose phases drift apart, so one workgroup's VALU epilogue overlaps the other's MFMA k-loop.
+template <int APAD, int ST = 2, int NW = 8>
 struct CtxT {
     static constexpr int NST = ST;
+    static constexpr int NWAVES = NW;
+    static constexpr int FT = 16 / NW;       // 32-wide output feature tiles per wave
+    static constexpr int NTHR = 64 * NW;     // threads per workgroup
     static constexpr int TROWS = 32 * ST;    // sample rows per workgroup
     static constexpr int SH = WIDTH + APAD;  // plane length in halfs
     static constexpr int RSH = 2 * SH + 8;   // row stride in halfs (row stride in dwords = SH + 4 = 4 x odd)
     _Float16 *act;  // LDS tile, operand form: row r at act + r * RSH: [hi: SH halfs | lo: SH halfs | 8 pad]
-    float *stats;   // LDS [8 waves][TROWS][2]: per-wave LayerNorm partials
+    float *stats;   // LDS [NW waves][TROWS][2]: per-wave LayerNorm partials
     int tid, wave, lane;
     TIMER_FIELDS
     __device__ __forceinline__ float *f32() const { return reinterpret_cast<float *>(act); }  // staging view [64][RSF]
@@ -110,8 +116,9 @@ __device__ __forceinline__ void rng_normal2(unsigned long long seed, unsigned ca
 #define SPLIT_PF 4
 #endif
 constexpr int PF = SPLIT_PF;
-struct BFrag {
-    f16x8 h[2], l[2];
+template <int FT>
+struct BFragT {
+    f16x8 h[FT], l[FT];
 };
 // B-fragment addressing: wave-uniform byte pointers (SGPR pairs, advanced by scalar arithmetic) + ONE 32-bit lane
 // offset, made opaque so that the compiler cannot fully unroll the k-loop into per-k-block 64-bit VGPR addresses and
@@ -137,18 +144,20 @@ __device__ __forceinline__ f32x16 fake_mfma(f16x8 a, f16x8 b, f32x16 c) {
 #else
 #define SPLIT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #endif
-__device__ __forceinline__ void load_b(BFrag &b, const char *u0, const char *u1, unsigned voff) {
-    b.h[0] = ldw(u0, voff, 0);
-    b.l[0] = ldw(u0, voff, 1024);
-    b.h[1] = ldw(u1, voff, 0);
-    b.l[1] = ldw(u1, voff, 1024);
+template <int FT>
+__device__ __forceinline__ void load_b(BFragT<FT> &b, const char *u0, size_t ct_stride, unsigned voff) {
+#pragma unroll
+    for (int cc = 0; cc < FT; ++cc) {
+        b.h[cc] = ldw(u0 + cc * ct_stride, voff, 0);
+        b.l[cc] = ldw(u0 + cc * ct_stride, voff, 1024);
+    }
 }
-template <int ST>
-__device__ __forceinline__ void zero_acc(f32x16 (&a)[ST][2]) {
+template <int ST, int FT>
+__device__ __forceinline__ void zero_acc(f32x16 (&a)[ST][FT]) {
 #pragma unroll
     for (int r = 0; r < ST; ++r)
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc)
+        for (int cc = 0; cc < FT; ++cc)
 #pragma unroll
             for (int e = 0; e < 16; ++e) a[r][cc][e] = 0.f;
 }
@@ -169,46 +178,48 @@ __device__ __forceinline__ void load_a(AFragT<CT::NST> &a, const _Float16 *a0p, 
 // the order: without it the machine scheduler sinks the prefetch loads to their first use (the next outer iteration)
 // and the loop runs load -> wait -> compute with no overlap.
 template <class CT>
-__device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, int kb1, f32x16 (&acc)[CT::NST][2]) {
+__device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, int kb1, f32x16 (&acc)[CT::NST][CT::FT]) {
+    constexpr int FT = CT::FT;
+    constexpr int PFD = FT == 2 ? PF : PF / 2;  // ring depth in k-blocks: FT x 8 VGPRs per block
     const int i = c.lane & 31, hh = c.lane >> 5;
     const _Float16 *a0p = c.act + i * c.RSH + 8 * hh + kb0 * 16;
     // one k-block of one column tile = 2 planes x 64 lanes x 16 B = 2048 B
-    const char *u0 = reinterpret_cast<const char *>(ly.wp) + ((size_t)(2 * c.wave) * ly.KB + kb0) * 2048;
-    const char *u1 = u0 + (size_t)ly.KB * 2048;
+    const char *u0 = reinterpret_cast<const char *>(ly.wp) + ((size_t)(FT * c.wave) * ly.KB + kb0) * 2048;
+    const size_t cts = (size_t)ly.KB * 2048;
     unsigned voff = (unsigned)c.lane * 16u;
     asm volatile("" : "+v"(voff));
     const int nk = kb1 - kb0;
-    BFrag ring[PF];
+    BFragT<FT> ring[PFD];
 #pragma unroll
-    for (int d = 0; d < PF; ++d) {
+    for (int d = 0; d < PFD; ++d) {
         const int kd = d < nk ? d : nk - 1;
-        load_b(ring[d], u0 + (size_t)kd * 2048, u1 + (size_t)kd * 2048, voff);
+        load_b(ring[d], u0 + (size_t)kd * 2048, cts, voff);
     }
     AFragT<CT::NST> an;
     load_a<CT>(an, a0p, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
-    for (int k = 0; k < nk; k += PF) {
+    for (int k = 0; k < nk; k += PFD) {
 #pragma unroll
-        for (int d = 0; d < PF; ++d) {
+        for (int d = 0; d < PFD; ++d) {
             const int kk = k + d;
             if (kk < nk) {  // wave-uniform
                 const AFragT<CT::NST> a = an;
                 load_a<CT>(an, a0p, kk + 1 < nk ? kk + 1 : kk);
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc)
+                for (int cc = 0; cc < FT; ++cc)
 #pragma unroll
                     for (int st = 0; st < CT::NST; ++st) acc[st][cc] = SPLIT_MFMA(ring[d].h[cc], a.h[st], acc[st][cc]);
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc)
+                for (int cc = 0; cc < FT; ++cc)
 #pragma unroll
                     for (int st = 0; st < CT::NST; ++st) acc[st][cc] = SPLIT_MFMA(ring[d].l[cc], a.h[st], acc[st][cc]);
 #pragma unroll
-                for (int cc = 0; cc < 2; ++cc)
+                for (int cc = 0; cc < FT; ++cc)
 #pragma unroll
                     for (int st = 0; st < CT::NST; ++st) acc[st][cc] = SPLIT_MFMA(ring[d].h[cc], a.l[st], acc[st][cc]);
-                const int kn = kk + PF < nk ? kk + PF : nk - 1;
-                load_b(ring[d], u0 + (size_t)kn * 2048, u1 + (size_t)kn * 2048, voff);
+                const int kn = kk + PFD < nk ? kk + PFD : nk - 1;
+                load_b(ring[d], u0 + (size_t)kn * 2048, cts, voff);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -287,29 +298,29 @@ __device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int 
 
 // raw accumulators <-> a dense global tile in register order (coalesced 1 KiB per wave instruction)
 template <class CT>
-__device__ __forceinline__ void park(const CT &c, const f32x16 (&acc)[CT::NST][2], float *dst) {
+__device__ __forceinline__ void park(const CT &c, const f32x16 (&acc)[CT::NST][CT::FT], float *dst) {
 #pragma unroll
     for (int st = 0; st < CT::NST; ++st)
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft)
+        for (int ft = 0; ft < CT::FT; ++ft)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 f32x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = acc[st][ft][4 * m + r];
-                const int idx4 = ((c.wave * CT::NST + st) * 2 + ft) * 4 + m;
+                const int idx4 = ((c.wave * CT::NST + st) * CT::FT + ft) * 4 + m;
                 *reinterpret_cast<f32x4 *>(dst + ((size_t)idx4 * 64 + c.lane) * 4) = v;
             }
 }
 template <class CT>
-__device__ __forceinline__ void unpark(const CT &c, f32x16 (&acc)[CT::NST][2], const float *src) {
+__device__ __forceinline__ void unpark(const CT &c, f32x16 (&acc)[CT::NST][CT::FT], const float *src) {
 #pragma unroll
     for (int st = 0; st < CT::NST; ++st)
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft)
+        for (int ft = 0; ft < CT::FT; ++ft)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int idx4 = ((c.wave * CT::NST + st) * 2 + ft) * 4 + m;
+                const int idx4 = ((c.wave * CT::NST + st) * CT::FT + ft) * 4 + m;
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(src + ((size_t)idx4 * 64 + c.lane) * 4);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = v[r];
@@ -318,13 +329,13 @@ __device__ __forceinline__ void unpark(const CT &c, f32x16 (&acc)[CT::NST][2], c
 
 // values in register order -> operand form in the LDS tile (hi / lo planes), scaled by ACT_SCALE
 template <class CT>
-__device__ __forceinline__ void regs_to_tile(const CT &c, const f32x16 (&y)[CT::NST][2]) {
+__device__ __forceinline__ void regs_to_tile(const CT &c, const f32x16 (&y)[CT::NST][CT::FT]) {
     const int j = c.lane & 31, hh = c.lane >> 5;
 #pragma unroll
     for (int st = 0; st < CT::NST; ++st) {
-        _Float16 *hp = c.act + (32 * st + j) * c.RSH + 64 * c.wave + 4 * hh;
+        _Float16 *hp = c.act + (32 * st + j) * c.RSH + 32 * CT::FT * c.wave + 4 * hh;
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft)
+        for (int ft = 0; ft < CT::FT; ++ft)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 f32x4 v;
@@ -338,53 +349,43 @@ __device__ __forceinline__ void regs_to_tile(const CT &c, const f32x16 (&y)[CT::
     }
 }
 
-// This lane's 32 parameter values (bias, or a LayerNorm affine vector) in accumulator order: eight float4 at
-// 64 wave + 32 ft + 8 m + 4 hh -- two distinct addresses per wave instruction, served from L1.
-struct PFrag {
-    f32x4 v[2][4];  // [ft][m]
-};
-template <class CT>
-__device__ __forceinline__ void load_pfrag(const CT &c, PFrag &f, const float *vec) {
-    const float *p = vec + 64 * c.wave + 4 * (c.lane >> 5);
-#pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) f.v[ft][m] = *reinterpret_cast<const f32x4 *>(p + 32 * ft + 8 * m);
-}
-
 // acc (raw MFMA sums) -> ACT(LayerNorm(acc * osc + bias)) -> operand form in the LDS tile (+ optional register-order
-// fp32 copy `zcopy` in global).  `bias` was loaded BEFORE the contraction (its latency hides behind the k-loop), the
-// affine vectors are loaded here and land while the statistics are exchanged.  One barrier inside (the statistics
-// exchange, which also orders every wave's last read of the operand tile before the first write of the new one);
-// the caller adds the one before the next contraction.
+// fp32 copy `zcopy` in global).  The bias / LayerNorm affine values of this lane's features are read as float4 at
+// 32 FT wave + 32 ft + 8 m + 4 hh (two distinct addresses per wave instruction, served from L1), one feature tile at a
+// time.  One barrier inside (the statistics exchange, which also orders every wave's last read of the operand tile
+// before the first write of the new one); the caller adds the one before the next contraction.
 template <int ACT, class CT>
-__device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][2], float osc, const PFrag &bias, const float *g, const float *b,
-                                      float *zcopy) {
+__device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][CT::FT], float osc, const float *bias, const float *g,
+                                      const float *b, float *zcopy) {
+    constexpr int FT = CT::FT, NW = CT::NWAVES;
+    constexpr float CNT = 32.f * FT;  // features of a row held by one wave
     const int j = c.lane & 31, hh = c.lane >> 5;
-    PFrag gf, bf;
-    load_pfrag(c, gf, g);
-    load_pfrag(c, bf, b);
+    const int poff = 32 * FT * c.wave + 4 * hh;
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
+    for (int ft = 0; ft < FT; ++ft) {
+        f32x4 b4[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) b4[m] = *reinterpret_cast<const f32x4 *>(bias + poff + 32 * ft + 8 * m);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int st = 0; st < CT::NST; ++st)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = fmaf(acc[st][ft][4 * m + r], osc, bias.v[ft][m][r]);
-    // per-wave partial statistics of the two sample rows this lane works on
+                for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = fmaf(acc[st][ft][4 * m + r], osc, b4[m][r]);
+    }
+    // per-wave partial statistics of the sample rows this lane works on
 #pragma unroll
     for (int st = 0; st < CT::NST; ++st) {
         float s = 0.f;
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft)
+        for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
             for (int e = 0; e < 16; ++e) s += acc[st][ft][e];
         s += __shfl_xor(s, 32);
-        const float mw = s * (1.0f / 64.f);
+        const float mw = s * (1.0f / CNT);
         float m2 = 0.f;
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft)
+        for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float d = acc[st][ft][e] - mw;
@@ -402,18 +403,18 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][2], fl
     float rstd[CT::NST], shift[CT::NST];
 #pragma unroll
     for (int st = 0; st < CT::NST; ++st) {
-        float pm[8], mean = 0.f, msum = 0.f;
+        float pm[NW], mean = 0.f, msum = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {
+        for (int w = 0; w < NW; ++w) {
             pm[w] = c.stats[(w * CT::TROWS + 32 * st + j) * 2 + 0];
             msum += c.stats[(w * CT::TROWS + 32 * st + j) * 2 + 1];
             mean += pm[w];
         }
-        mean *= 0.125f;
+        mean *= 1.0f / NW;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const float d = pm[w] - mean;
-            msum = fmaf(64.f * d, d, msum);
+            msum = fmaf(CNT * d, d, msum);  // Chan: M2 = sum M2_w + sum n_w (mean_w - mean)^2
         }
         rstd[st] = 1.0f / sqrtf(msum * (1.0f / WIDTH) + LN_EPS);
         shift[st] = -mean * rstd[st];
@@ -422,10 +423,16 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][2], fl
     if (rstd[0] == 12345.f)  // never true: the activation math below is skipped
 #endif
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft)
+    for (int ft = 0; ft < FT; ++ft) {
+        f32x4 gq[4], bq[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const f32x4 g4 = gf.v[ft][m], b4 = bf.v[ft][m];
+            gq[m] = *reinterpret_cast<const f32x4 *>(g + poff + 32 * ft + 8 * m);
+            bq[m] = *reinterpret_cast<const f32x4 *>(b + poff + 32 * ft + 8 * m);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 g4 = gq[m], b4 = bq[m];
 #pragma unroll
             for (int st = 0; st < CT::NST; ++st) {
                 float y[4];
@@ -452,6 +459,7 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][2], fl
                 for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = y[r];
             }
         }
+    }
     regs_to_tile(c, acc);
     if (zcopy) park(c, acc, zcopy);
 }
@@ -505,13 +513,11 @@ __device__ __forceinline__ float twohot_rows_s(const CT &c, const float *bins, i
 template <int ACT, class CT>
 __device__ __forceinline__ void layer_full_s(const CT &c, const LayerS &ly, const float *bias, int kb0, int kb1,
                                              float *zcopy = nullptr) {
-    f32x16 acc[CT::NST][2];
+    f32x16 acc[CT::NST][CT::FT];
     zero_acc(acc);
-    PFrag bf;
-    load_pfrag(c, bf, bias);
     kloop_s(c, ly, kb0, kb1, acc);
     TIMER_MARK(c, T_KLOOP)
-    epi_t<ACT>(c, acc, *ly.oscale, bf, ly.g, ly.b, zcopy);
+    epi_t<ACT>(c, acc, *ly.oscale, bias, ly.g, ly.b, zcopy);
     __syncthreads();
     TIMER_MARK(c, T_EPI)
 }
@@ -586,13 +592,13 @@ __device__ __forceinline__ void head_pi_s(const CT &c, const LayerS &ly, int A, 
 // register-order fp32 tile in global (written by park / epi_t's zcopy) -> operand-form z columns
 template <class CT>
 __device__ __forceinline__ void tile_from_global_s(const CT &c, const float *src) {
-    f32x16 y[CT::NST][2];
+    f32x16 y[CT::NST][CT::FT];
     unpark(c, y, src);
     regs_to_tile(c, y);
 }
 template <class CT>
 __device__ __forceinline__ void tile_broadcast_row_s(const CT &c, const float *src_row) {
-    for (int idx = c.tid; idx < CT::TROWS * (WIDTH / 4); idx += NTHREADS) {
+    for (int idx = c.tid; idx < CT::TROWS * (WIDTH / 4); idx += CT::NTHR) {
         const int row = idx / (WIDTH / 4), c4 = idx % (WIDTH / 4);
         const f32x4 y = *reinterpret_cast<const f32x4 *>(src_row + 4 * c4);
         f16x4 hi, lo;
@@ -607,7 +613,7 @@ template <class CT>
 __device__ __forceinline__ void dump_tile_s(const CT &c, float *trace, int nslot, int slot) {
     if (!trace) return;
     float *dst = trace + ((size_t)blockIdx.x * nslot + slot) * CT::TROWS * WIDTH;
-    for (int idx = c.tid; idx < CT::TROWS * WIDTH; idx += NTHREADS) {
+    for (int idx = c.tid; idx < CT::TROWS * WIDTH; idx += CT::NTHR) {
         const int row = idx / WIDTH, col = idx % WIDTH;
         const _Float16 *hp = c.act + row * c.RSH + col;
         dst[idx] = ((float)hp[0] + (float)hp[c.SH]) * (1.0f / ACT_SCALE);
@@ -619,8 +625,8 @@ template <int APAD>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x, tid = threadIdx.x;
-    CtxT<APAD> c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CtxT<APAD>::RSH / 2, tid,
-                 __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    typedef CtxT<APAD> CT;  // 64 rows, 8 waves
+    CT c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CT::RSH / 2, tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     if (p.multitask) {
         const float *emb = p.task_emb + (size_t)e * p.T;
         for (int net = 0; net < p.nnets; ++net) {
@@ -652,7 +658,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
     if ((c.lane & 31) == 0) {  // sample row 0 of the tile: lanes 0 (hh = 0) and 32 (hh = 1), sample tile 0
         const int hh = c.lane >> 5;
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft)
+        for (int ft = 0; ft < CT::FT; ++ft)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int col = 64 * c.wave + 32 * ft + 8 * (reg >> 2) + 4 * hh + (reg & 3);
@@ -680,7 +686,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) 
         f32x16 y[ST][2];
         const int hh = c.lane >> 5;
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft)
+        for (int ft = 0; ft < CT::FT; ++ft)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const f32x4 z = *reinterpret_cast<const f32x4 *>(p.z0 + (size_t)e * WIDTH + 64 * c.wave + 32 * ft + 8 * m + 4 * hh);
@@ -713,13 +719,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) 
 }
 
 // ================================================================ kernel: one CEM iteration's rollouts (cf. k_rollout)
-template <int APAD, int ST>
-__global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p) {
+template <int APAD, int ST, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x / p.tiles, tile = blockIdx.x % p.tiles;
     const int tid = threadIdx.x;
-    typedef CtxT<APAD, ST> CT;
-    constexpr int TROWS = CT::TROWS;
+    typedef CtxT<APAD, ST, NW> CT;
+    constexpr int TROWS = CT::TROWS, NTHR = CT::NTHR, FT = CT::FT;
     CT c{reinterpret_cast<_Float16 *>(smem), smem + TROWS * CT::RSH / 2, tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     float *sm_mean = smem + TROWS * c.RSH / 2 + 1024;  // [H*A] after the tile and the LayerNorm partials
     float *sm_std = sm_mean + p.H * p.A;
@@ -732,7 +738,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
     const bool live = (tid >> 3) < TROWS;  // ST = 1: threads 256..511 own no sample row in the row-per-8-lanes phases
     float *tsc = p.trace_scalars && live ? p.trace_scalars + ((size_t)e * p.N + row0 + (tid >> 3)) * (p.H + 2 + p.A) : nullptr;
 
-    for (int idx = tid; idx < p.H * p.A; idx += NTHREADS) {
+    for (int idx = tid; idx < p.H * p.A; idx += NTHR) {
         sm_mean[idx] = p.mean[(size_t)e * p.H * p.A + idx];
         sm_std[idx] = p.std[(size_t)e * p.H * p.A + idx];
     }
@@ -761,7 +767,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
         {
             float *ag = p.actions + ((size_t)e * p.H + t) * p.N * p.A;
             const int hp = p.Apad / 2;
-            for (int idx = tid; idx < TROWS * hp; idx += NTHREADS) {
+            for (int idx = tid; idx < TROWS * hp; idx += NTHR) {
                 const int row = idx / hp, a0 = 2 * (idx % hp);
                 const int n = row0 + row;
                 float v[2] = {0.f, 0.f};
@@ -798,13 +804,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
         // for the reward chain either in 64 held VGPRs (SPLIT_HOLD, needs the shallower weight ring) or parked in the
         // workgroup's scratch tile (32 MB per round of workgroups: more than the L2s hold)
 #ifdef SPLIT_HOLD
-        f32x16 accd[ST][2];
+        f32x16 accd[ST][FT];
         zero_acc(accd);
         kloop_s(c, p.dyn.l[0], t == 0 ? ZKB16 : 0, KBA, accd);
         TIMER_MARK(c, T_KLOOP)
 #endif
         {
-            f32x16 acc[ST][2];
+            f32x16 acc[ST][FT];
 #ifndef SPLIT_HOLD
             zero_acc(acc);
             kloop_s(c, p.dyn.l[0], t == 0 ? ZKB16 : 0, KBA, acc);
@@ -813,11 +819,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
             TIMER_MARK(c, T_PARK)
 #endif
             zero_acc(acc);
-            PFrag bf;
-            load_pfrag(c, bf, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew);
             kloop_s(c, p.rew.l[0], t == 0 ? ZKB16 : 0, KBA, acc);
             TIMER_MARK(c, T_KLOOP)
-            epi_t<0>(c, acc, *p.rew.l[0].oscale, bf, p.rew.l[0].g, p.rew.l[0].b, nullptr);
+            epi_t<0>(c, acc, *p.rew.l[0].oscale, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew, p.rew.l[0].g,
+                     p.rew.l[0].b, nullptr);
         }
         __syncthreads();
         TIMER_MARK(c, T_EPI)
@@ -831,15 +836,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
         G += disc[t] * r;
         // ---- dynamics: release the held / parked first layer, layers 2 and 3 (SimNorm)
         {
-            PFrag bf;
-            load_pfrag(c, bf, t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn);
+            const float *bd = t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn;
 #ifdef SPLIT_HOLD
-            epi_t<0>(c, accd, *p.dyn.l[0].oscale, bf, p.dyn.l[0].g, p.dyn.l[0].b, nullptr);
+            epi_t<0>(c, accd, *p.dyn.l[0].oscale, bd, p.dyn.l[0].g, p.dyn.l[0].b, nullptr);
 #else
-            f32x16 acc[ST][2];
+            f32x16 acc[ST][FT];
             unpark(c, acc, zs);
             TIMER_MARK(c, T_PARK)
-            epi_t<0>(c, acc, *p.dyn.l[0].oscale, bf, p.dyn.l[0].g, p.dyn.l[0].b, nullptr);
+            epi_t<0>(c, acc, *p.dyn.l[0].oscale, bd, p.dyn.l[0].g, p.dyn.l[0].b, nullptr);
 #endif
         }
         __syncthreads();
@@ -871,13 +875,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 2);
     // ---- Q(z_H, a_H): the two selected heads, first layers in one pass (world_model.py:186-216)
 #ifdef SPLIT_HOLD
-    f32x16 accq[ST][2];
+    f32x16 accq[ST][FT];
     zero_acc(accq);
     kloop_s(c, p.q[q1].l[0], 0, KBA, accq);
     TIMER_MARK(c, T_KLOOP)
 #endif
     {
-        f32x16 acc[ST][2];
+        f32x16 acc[ST][FT];
 #ifndef SPLIT_HOLD
         // z_H has been read back from zs above: the scratch tile is free to park the second head's raw first layer
         zero_acc(acc);
@@ -887,11 +891,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
         TIMER_MARK(c, T_PARK)
 #endif
         zero_acc(acc);
-        PFrag bf;
-        load_pfrag(c, bf, b_q0);
         kloop_s(c, p.q[q0].l[0], 0, KBA, acc);
         TIMER_MARK(c, T_KLOOP)
-        epi_t<0>(c, acc, *p.q[q0].l[0].oscale, bf, p.q[q0].l[0].g, p.q[q0].l[0].b, nullptr);
+        epi_t<0>(c, acc, *p.q[q0].l[0].oscale, b_q0, p.q[q0].l[0].g, p.q[q0].l[0].b, nullptr);
     }
     __syncthreads();
     TIMER_MARK(c, T_EPI)
@@ -901,15 +903,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout(RolloutParamsT<NetS> p
     const float qa = head_twohot_s(c, p.q[q0].l[2], p.bins, p.num_bins);
     TIMER_MARK(c, T_HEAD)
     {
-        PFrag bf;
-        load_pfrag(c, bf, b_q1);
 #ifdef SPLIT_HOLD
-        epi_t<0>(c, accq, *p.q[q1].l[0].oscale, bf, p.q[q1].l[0].g, p.q[q1].l[0].b, nullptr);
+        epi_t<0>(c, accq, *p.q[q1].l[0].oscale, b_q1, p.q[q1].l[0].g, p.q[q1].l[0].b, nullptr);
 #else
-        f32x16 acc[ST][2];
+        f32x16 acc[ST][FT];
         unpark(c, acc, zs);
         TIMER_MARK(c, T_PARK)
-        epi_t<0>(c, acc, *p.q[q1].l[0].oscale, bf, p.q[q1].l[0].g, p.q[q1].l[0].b, nullptr);
+        epi_t<0>(c, acc, *p.q[q1].l[0].oscale, b_q1, p.q[q1].l[0].g, p.q[q1].l[0].b, nullptr);
 #endif
     }
     __syncthreads();

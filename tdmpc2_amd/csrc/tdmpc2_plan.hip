@@ -1029,12 +1029,16 @@ int set_lds(K kernel, size_t bytes) {
 }
 
 // Kernel family of the fused path by operand form: NetW = exact fp32 MFMA, NetS = f16x2 split.
+#ifndef TDMPC2_DEFAULT_THROUGHPUT_ST
+#define TDMPC2_DEFAULT_THROUGHPUT_ST 2  // sample tiles per workgroup when a call has enough plans to fill the chip
+#endif
 template <class NET> struct Kern;
 template <> struct Kern<NetW> {
     static int sample_tiles(const tdmpc2_plan *, int, bool) { return 2; }
+    static int waves(const tdmpc2_plan *, int, int) { return 8; }
     static void setup(const SetupParamsT<NetW> &p, int E, size_t lds, hipStream_t st) { hipLaunchKernelGGL(k_setup, dim3(E), dim3(NTHREADS), lds, st, p); }
     static void pitraj(const PiTrajParamsT<NetW> &p, int E, size_t lds, hipStream_t st) { hipLaunchKernelGGL(k_pitraj, dim3(E), dim3(NTHREADS), lds, st, p); }
-    static void rollout(const RolloutParamsT<NetW> &p, int grid, size_t lds, hipStream_t st, int) { hipLaunchKernelGGL(k_rollout, dim3(grid), dim3(NTHREADS), lds, st, p); }
+    static void rollout(const RolloutParamsT<NetW> &p, int grid, size_t lds, hipStream_t st, int, int) { hipLaunchKernelGGL(k_rollout, dim3(grid), dim3(NTHREADS), lds, st, p); }
 };
 #define SPLIT_DISPATCH(KERNEL, APAD, GRID)                                                                       \
     switch (APAD) {                                                                                                \
@@ -1043,20 +1047,25 @@ template <> struct Kern<NetW> {
         case 48: hipLaunchKernelGGL(KERNEL<48>, dim3(GRID), dim3(NTHREADS), lds, st, p); break;                   \
         default: hipLaunchKernelGGL(KERNEL<64>, dim3(GRID), dim3(NTHREADS), lds, st, p); break;                   \
     }
-#define SPLIT_DISPATCH_ST(APAD, ST, GRID)                                                                        \
+#define SPLIT_DISPATCH_ST(APAD, ST, NW, GRID)                                                                    \
     switch (APAD) {                                                                                                \
-        case 16: hipLaunchKernelGGL((ks_rollout<16, ST>), dim3(GRID), dim3(NTHREADS), lds, st, p); break;         \
-        case 32: hipLaunchKernelGGL((ks_rollout<32, ST>), dim3(GRID), dim3(NTHREADS), lds, st, p); break;         \
-        case 48: hipLaunchKernelGGL((ks_rollout<48, ST>), dim3(GRID), dim3(NTHREADS), lds, st, p); break;         \
-        default: hipLaunchKernelGGL((ks_rollout<64, ST>), dim3(GRID), dim3(NTHREADS), lds, st, p); break;         \
+        case 16: hipLaunchKernelGGL((ks_rollout<16, ST, NW>), dim3(GRID), dim3(64 * NW), lds, st, p); break;      \
+        case 32: hipLaunchKernelGGL((ks_rollout<32, ST, NW>), dim3(GRID), dim3(64 * NW), lds, st, p); break;      \
+        case 48: hipLaunchKernelGGL((ks_rollout<48, ST, NW>), dim3(GRID), dim3(64 * NW), lds, st, p); break;      \
+        default: hipLaunchKernelGGL((ks_rollout<64, ST, NW>), dim3(GRID), dim3(64 * NW), lds, st, p); break;      \
     }
 template <> struct Kern<NetS> {  // the split kernels are instantiated per action padding (compile-time LDS strides)
     // 32-row workgroups (twice as many) when a call brings too few plans to occupy the chip: single-env latency
     static int sample_tiles(const tdmpc2_plan *h, int E, bool tracing) {
         if (tracing) return 2;  // the activation trace is laid out per 64-row tile
         if (h->force_rows) return h->force_rows / 32;
-        return E * h->tiles < 128 ? 1 : 2;
+        return E * h->tiles < 128 ? 1 : TDMPC2_DEFAULT_THROUGHPUT_ST;
     }
+    // Always 8 wavefronts per workgroup.  A 4-wave, 32-row geometry (two workgroups per CU, so that one's VALU epilogue
+    // overlaps the other's MFMA k-loop; the device code is templated for it: CtxT<APAD, 1, 4>) was measured and lost
+    // 5.83 vs 4.88 ms per launch: each weight fragment then feeds one row tile, the k-loop needs 85 B/clk/CU of
+    // fragment loads and becomes L1-bound.
+    static int waves(const tdmpc2_plan *, int, int) { return 8; }
     static void setup(const SetupParamsT<NetS> &p, int E, size_t lds, hipStream_t st) { SPLIT_DISPATCH(ks_setup, (p.stride - 8) / 2 - WIDTH, E) }
     static void pitraj(const PiTrajParamsT<NetS> &p, int E, size_t lds, hipStream_t st) {
         if (p.P <= 32) {  // one 32-row tile holds the policy-prior trajectories (the reference uses 24)
@@ -1076,8 +1085,10 @@ template <> struct Kern<NetS> {  // the split kernels are instantiated per actio
             }
         }
     }
-    static void rollout(const RolloutParamsT<NetS> &p, int grid, size_t lds, hipStream_t st, int nst) {
-        if (nst == 1) { SPLIT_DISPATCH_ST(p.Apad, 1, grid) } else { SPLIT_DISPATCH_ST(p.Apad, 2, grid) }
+    static void rollout(const RolloutParamsT<NetS> &p, int grid, size_t lds, hipStream_t st, int nst, int nw) {
+        (void)nw;
+        if (nst == 2) { SPLIT_DISPATCH_ST(p.Apad, 2, 8, grid) }
+        else { SPLIT_DISPATCH_ST(p.Apad, 1, 8, grid) }
     }
 };
 
@@ -1144,7 +1155,7 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
     RolloutParamsT<NET> rp{};
     fill_rollout<NET>(h, rp, E);
     rp.z0 = z0; rp.act_mask = act_mask; rp.disc_pow = disc_pow; rp.seed = seed; rp.call = call; rp.given_actions = 0;
-    const int nst = Kern<NET>::sample_tiles(h, E, false);
+    const int nst = Kern<NET>::sample_tiles(h, E, false), nw = Kern<NET>::waves(h, E, nst);
     rp.tiles = h->tiles * (2 / nst);
     const size_t roll_lds = nst == 2 ? h->lds_bytes : h->lds_bytes - (size_t)32 * h->stride * 2;
     const size_t refit_lds = ((size_t)N + 3 * K + 2 * H * A) * 4 + 64;
@@ -1159,7 +1170,7 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
             rp.qidx_estride = (long)I * 2;
         }
         if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
-        Kern<NET>::rollout(rp, E * rp.tiles, roll_lds, st, nst);
+        Kern<NET>::rollout(rp, E * rp.tiles, roll_lds, st, nst, nw);
         HIP_TRY(hipGetLastError());
         if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) {
             HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
@@ -1207,9 +1218,9 @@ int fused_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0,
     rp.pi_eps = pi_eps; rp.pi_eps_estride = (long)N * A;
     rp.qidx = qidx; rp.qidx_estride = 2;
     rp.trace_tiles = trace_tiles; rp.trace_scalars = trace_scalars;
-    const int nst = Kern<NET>::sample_tiles(h, E, trace_tiles != nullptr);
+    const int nst = Kern<NET>::sample_tiles(h, E, trace_tiles != nullptr), nw = Kern<NET>::waves(h, E, nst);
     rp.tiles = h->tiles * (2 / nst);
-    Kern<NET>::rollout(rp, E * rp.tiles, nst == 2 ? h->lds_bytes : h->lds_bytes - (size_t)32 * h->stride * 2, st, nst);
+    Kern<NET>::rollout(rp, E * rp.tiles, nst == 2 ? h->lds_bytes : h->lds_bytes - (size_t)32 * h->stride * 2, st, nst, nw);
     HIP_TRY(hipGetLastError());
     return TDMPC2_OK;
 }
@@ -1348,10 +1359,10 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
     }
     if (h->split) {
         switch (h->Apad) {
-            case 16: rc = set_lds(ks_setup<16>, h->lds_bytes) || set_lds(ks_pitraj<16, 2>, h->lds_bytes) || set_lds(ks_pitraj<16, 1>, h->lds_bytes) || set_lds(ks_rollout<16, 2>, h->lds_bytes) || set_lds(ks_rollout<16, 1>, h->lds_bytes); break;
-            case 32: rc = set_lds(ks_setup<32>, h->lds_bytes) || set_lds(ks_pitraj<32, 2>, h->lds_bytes) || set_lds(ks_pitraj<32, 1>, h->lds_bytes) || set_lds(ks_rollout<32, 2>, h->lds_bytes) || set_lds(ks_rollout<32, 1>, h->lds_bytes); break;
-            case 48: rc = set_lds(ks_setup<48>, h->lds_bytes) || set_lds(ks_pitraj<48, 2>, h->lds_bytes) || set_lds(ks_pitraj<48, 1>, h->lds_bytes) || set_lds(ks_rollout<48, 2>, h->lds_bytes) || set_lds(ks_rollout<48, 1>, h->lds_bytes); break;
-            default: rc = set_lds(ks_setup<64>, h->lds_bytes) || set_lds(ks_pitraj<64, 2>, h->lds_bytes) || set_lds(ks_pitraj<64, 1>, h->lds_bytes) || set_lds(ks_rollout<64, 2>, h->lds_bytes) || set_lds(ks_rollout<64, 1>, h->lds_bytes); break;
+            case 16: rc = set_lds(ks_setup<16>, h->lds_bytes) || set_lds(ks_pitraj<16, 2>, h->lds_bytes) || set_lds(ks_pitraj<16, 1>, h->lds_bytes) || set_lds(ks_rollout<16, 2, 8>, h->lds_bytes) || set_lds(ks_rollout<16, 1, 8>, h->lds_bytes); break;
+            case 32: rc = set_lds(ks_setup<32>, h->lds_bytes) || set_lds(ks_pitraj<32, 2>, h->lds_bytes) || set_lds(ks_pitraj<32, 1>, h->lds_bytes) || set_lds(ks_rollout<32, 2, 8>, h->lds_bytes) || set_lds(ks_rollout<32, 1, 8>, h->lds_bytes); break;
+            case 48: rc = set_lds(ks_setup<48>, h->lds_bytes) || set_lds(ks_pitraj<48, 2>, h->lds_bytes) || set_lds(ks_pitraj<48, 1>, h->lds_bytes) || set_lds(ks_rollout<48, 2, 8>, h->lds_bytes) || set_lds(ks_rollout<48, 1, 8>, h->lds_bytes); break;
+            default: rc = set_lds(ks_setup<64>, h->lds_bytes) || set_lds(ks_pitraj<64, 2>, h->lds_bytes) || set_lds(ks_pitraj<64, 1>, h->lds_bytes) || set_lds(ks_rollout<64, 2, 8>, h->lds_bytes) || set_lds(ks_rollout<64, 1, 8>, h->lds_bytes); break;
         }
         if (rc) {
             tdmpc2_plan_destroy(h);

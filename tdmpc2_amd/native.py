@@ -294,7 +294,7 @@ class NativePlanner:
 
     # ------------------------------------------------------------------ tuning / profiling
     def set_rows_per_workgroup(self, rows: int):
-        """0 = automatic (32-row workgroups for calls with few plans: latency), or force 32 / 64."""
+        """0 = automatic (32-row workgroups for calls with few plans: latency), or force 32 / 64 sample rows."""
         self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 0, int(rows)))
 
     def set_profiling(self, max_launches: int):
