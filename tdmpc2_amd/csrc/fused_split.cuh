@@ -110,10 +110,12 @@ __device__ __forceinline__ void rng_normal2(unsigned long long seed, unsigned ca
 // ---------------------------------------------------------------- contraction loops
 // v_mfma_f32_32x32x16_f16: lane l supplies A[i = l & 31][k = 8 (l >> 5) .. +7] and B[k = 8 (l >> 5) .. +7][j = l & 31].
 // Wave w of 8 owns output columns [64 w, 64 w + 64) for both 32-row tiles: acc[set][row tile][col tile].
-// B fragments are prefetched PF k-blocks ahead (PF x 16 VGPRs): at the f16 matrix rate one k-block is only
-// 12 MFMAs = 384 pipe cycles per wave, far shorter than an L2 round trip under load.
+// B fragments are prefetched PF k-blocks ahead (PF x 16 VGPRs) through a register ring.
 #ifndef SPLIT_PF
-#define SPLIT_PF 4
+#define SPLIT_PF 2  // measured: 2, 3 and 4 k-blocks of prefetch run within 1 % of each other; 6 spills
+#endif
+#ifndef SPLIT_PARK
+#define SPLIT_HOLD 1  // first-layer accumulators of the second chain stay in VGPRs (+4.6 % over parking them in L2/HBM)
 #endif
 constexpr int PF = SPLIT_PF;
 template <int FT>
@@ -180,7 +182,7 @@ __device__ __forceinline__ void load_a(AFragT<CT::NST> &a, const _Float16 *a0p, 
 template <class CT>
 __device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, int kb1, f32x16 (&acc)[CT::NST][CT::FT]) {
     constexpr int FT = CT::FT;
-    constexpr int PFD = FT == 2 ? PF : PF / 2;  // ring depth in k-blocks: FT x 8 VGPRs per block
+    constexpr int PFD = FT == 2 ? PF : (PF > 1 ? PF / 2 : 1);  // ring depth in k-blocks: FT x 8 VGPRs per block
     const int i = c.lane & 31, hh = c.lane >> 5;
     const _Float16 *a0p = c.act + i * c.RSH + 8 * hh + kb0 * 16;
     // one k-block of one column tile = 2 planes x 64 lanes x 16 B = 2048 B
@@ -232,7 +234,7 @@ __device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, 
 template <class CT>
 __device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int ct, int kb0, int kb1, f32x16 (&out)[CT::NST]) {
 #ifndef SPLIT_PFT
-#define SPLIT_PFT 6
+#define SPLIT_PFT 4
 #endif
     constexpr int PFT = SPLIT_PFT;
     const int i = c.lane & 31, hh = c.lane >> 5;
@@ -801,8 +803,8 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
         __syncthreads();
         TIMER_MARK(c, T_ACT)
         // ---- first layers of dynamics and reward over the same [z_t | a_t] tile.  The raw dynamics accumulators wait
-        // for the reward chain either in 64 held VGPRs (SPLIT_HOLD, needs the shallower weight ring) or parked in the
-        // workgroup's scratch tile (32 MB per round of workgroups: more than the L2s hold)
+        // for the reward chain in 64 held VGPRs (default) or, with -DSPLIT_PARK, parked in the workgroup's scratch
+        // tile (32 MB per round of workgroups: more than the L2s hold, measured 4.6 % slower)
 #ifdef SPLIT_HOLD
         f32x16 accd[ST][FT];
         zero_acc(accd);
