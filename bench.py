@@ -170,8 +170,12 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     import torch.distributed as dist
-    if world > 1:
+    # under torch.distributed.run (RANK set) the RCCL group is always initialised, also for one rank, so that the same
+    # collective calls run at every N
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from tdmpc2_amd.dist import broadcast_state_dict
@@ -213,7 +217,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -237,7 +241,7 @@ def main():
     log(f"timed region: {K} steps in {elapsed:.3f} s")
     roll_ms, roll_n = planner.profile_read()
     planner.set_profiling(0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -292,7 +296,7 @@ def main():
             ex.close()
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -353,7 +357,7 @@ def main():
         except Exception as ex:  # the baseline is a reported number, never a reason to lose the measurement
             line["cpu_baseline"] = {"value": None, "error": repr(ex)}
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

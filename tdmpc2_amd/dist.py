@@ -25,7 +25,7 @@ def shard_range(n_envs: int, world_size: int, rank: int) -> Tuple[int, int]:
 def broadcast_state_dict(sd: Dict[str, torch.Tensor], src: int = 0) -> Dict[str, torch.Tensor]:
     """In-place broadcast of every tensor of a (structurally identical) state dict from `src`.
     Tensors are flattened into one bucket per dtype so the 5M model moves in one collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return sd
     keys = sorted(k for k, v in sd.items() if torch.is_tensor(v))
     by_dtype: Dict[torch.dtype, list] = {}
