@@ -39,14 +39,13 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr float ACT_SCALE = 32.f;  // 2^5
 constexpr int ACT_SCALE_LOG2 = 5;
-constexpr int ZKB16 = WIDTH / 16;  // k16-blocks covering the latent columns
 
 struct LayerS {
-    const _Float16 *wp;  // packed [CT][KB][2 planes][64 lanes][8]
+    const _Float16 *wp;  // split: packed [CT][KB16][2 planes][64 lanes][8] f16; exact fp32: [CT][KB8][64 lanes][4] fp32
     const float *bias;   // [CT*32] zero padded
     const float *g, *b;  // LayerNorm affine (null for plain output layers)
-    const float *oscale; // device scalar: 2^-(kw + ACT_SCALE_LOG2)
-    int KB;              // k16-blocks
+    const float *oscale; // device scalar: 2^-(kw + ACT_SCALE_LOG2) (split) or 1 (exact fp32)
+    int KB;              // k-blocks: of 16 (split) or of 8 (exact fp32)
     int CT;
 };
 struct NetS {
@@ -61,21 +60,28 @@ struct NetS {
 // NW = wavefronts per workgroup: 8 (each owns 64 output features = 2 feature tiles) or 4 (128 features = 4 tiles).
 // The throughput geometry is (ST 1, NW 4): 32-row, 256-thread workgroups of 72 KB LDS, TWO per CU -- independent
 // barrier domains whose phases drift apart, so one workgroup's VALU epilogue overlaps the other's MFMA k-loop.
-template <int APAD, int ST = 2, int NW = 8>
+// ARITH: 0 = f16x2 split (operand tile = hi / lo f16 planes), 1 = exact fp32 (v_mfma_f32_32x32x2_f32; operand tile =
+// fp32 rows of WIDTH + APAD + 4 floats, stride / 4 odd).  Everything but the contraction loops and the tile writes is
+// shared between the two.
+template <int APAD, int ST = 2, int NW = 8, int AR = 0>
 struct CtxT {
     static constexpr int NST = ST;
     static constexpr int NWAVES = NW;
+    static constexpr int ARITH = AR;
     static constexpr int FT = 16 / NW;       // 32-wide output feature tiles per wave
     static constexpr int NTHR = 64 * NW;     // threads per workgroup
     static constexpr int TROWS = 32 * ST;    // sample rows per workgroup
-    static constexpr int SH = WIDTH + APAD;  // plane length in halfs
-    static constexpr int RSH = 2 * SH + 8;   // row stride in halfs (row stride in dwords = SH + 4 = 4 x odd)
-    _Float16 *act;  // LDS tile, operand form: row r at act + r * RSH: [hi: SH halfs | lo: SH halfs | 8 pad]
+    static constexpr int SH = WIDTH + APAD;  // split: plane length in halfs
+    static constexpr int RSH = 2 * SH + 8;   // split: row stride in halfs (row stride in dwords = SH + 4 = 4 x odd)
+    static constexpr int RSF_ = AR == 0 ? RSH / 2 : WIDTH + APAD + 4;  // row stride in floats of either form
+    static constexpr int KBLK = AR == 0 ? 16 : 8;                      // contraction block
+    static constexpr int ZKB = WIDTH / KBLK;                           // blocks covering the latent columns
+    _Float16 *act;  // LDS tile.  split: row r at act + r * RSH: [hi: SH halfs | lo: SH halfs | 8 pad]; fp32: actf() rows
     float *stats;   // LDS [NW waves][TROWS][2]: per-wave LayerNorm partials
     int tid, wave, lane;
     TIMER_FIELDS
-    __device__ __forceinline__ float *f32() const { return reinterpret_cast<float *>(act); }  // staging view [64][RSF]
-    static constexpr __device__ __forceinline__ int RSF() { return RSH / 2; }
+    __device__ __forceinline__ float *f32() const { return reinterpret_cast<float *>(act); }  // fp32 view [TROWS][RSF]
+    static constexpr __device__ __forceinline__ int RSF() { return RSF_; }
 };
 
 __device__ __forceinline__ float mish_fast(float x) {
@@ -84,6 +90,23 @@ __device__ __forceinline__ float mish_fast(float x) {
     const float e = __expf(fminf(x, 20.f));
     const float n = e * (e + 2.f);
     return x * (n * __builtin_amdgcn_rcpf(n + 2.f));  // v_rcp_f32: 1 ulp; __fdividef expands to the full division
+}
+
+// exact-arithmetic flavours of the transcendental pieces (ARITH 1 keeps libm-accurate expf and IEEE division)
+template <class CT>
+__device__ __forceinline__ float exp_a(float x) {
+    if constexpr (CT::ARITH == 1) return expf(x);
+    else return __expf(x);
+}
+template <class CT>
+__device__ __forceinline__ float mish_a(float x) {
+    if constexpr (CT::ARITH == 1) {
+        const float e = expf(fminf(x, 20.f));
+        const float n = e * (e + 2.f);
+        return x * (n / (n + 2.f));
+    } else {
+        return mish_fast(x);
+    }
 }
 
 __device__ __forceinline__ void split4(const f32x4 y, f16x4 &hi, f16x4 &lo) {
@@ -179,8 +202,66 @@ __device__ __forceinline__ void load_a(AFragT<CT::NST> &a, const _Float16 *a0p, 
 // block] [issue the weight loads for block + PF into the ring slot just consumed] [sched_barrier].  The barrier pins
 // the order: without it the machine scheduler sinks the prefetch loads to their first use (the next outer iteration)
 // and the loop runs load -> wait -> compute with no overlap.
+// exact-fp32 form of the same loop: v_mfma_f32_32x32x2_f32, weight fragment (one 16-byte read = 4 MFMAs' operands, k pairs
+// {8 kb + r, 8 kb + 4 + r}) as the A operand, activation fragment from the fp32 tile as the B operand.
+template <class CT>
+__device__ __forceinline__ void kloop_f32(const CT &c, const LayerS &ly, int kb0, int kb1, f32x16 (&acc)[CT::NST][CT::FT]) {
+    constexpr int FT = CT::FT, NST = CT::NST;
+    constexpr int PFD = 4;
+    const int i = c.lane & 31, hh = c.lane >> 5;
+    const float *a0p = c.f32() + i * CT::RSF() + 4 * hh + kb0 * 8;
+    const char *u0 = reinterpret_cast<const char *>(ly.wp) + ((size_t)(FT * c.wave) * ly.KB + kb0) * 1024;  // 64 lanes x 16 B
+    const size_t cts = (size_t)ly.KB * 1024;
+    unsigned voff = (unsigned)c.lane * 16u;
+    asm volatile("" : "+v"(voff));
+    const int nk = kb1 - kb0;
+    f32x4 ring[PFD][FT];
+#pragma unroll
+    for (int d = 0; d < PFD; ++d) {
+        const int kd = d < nk ? d : nk - 1;
+#pragma unroll
+        for (int cc = 0; cc < FT; ++cc) ring[d][cc] = *reinterpret_cast<const f32x4 *>(u0 + (size_t)kd * 1024 + cc * cts + voff);
+    }
+    f32x4 an[NST];
+#pragma unroll
+    for (int st = 0; st < NST; ++st) an[st] = *reinterpret_cast<const f32x4 *>(a0p + st * 32 * CT::RSF());
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int k = 0; k < nk; k += PFD) {
+#pragma unroll
+        for (int d = 0; d < PFD; ++d) {
+            const int kk = k + d;
+            if (kk < nk) {  // wave-uniform
+                f32x4 a[NST];
+                const int kx = kk + 1 < nk ? kk + 1 : kk;
+#pragma unroll
+                for (int st = 0; st < NST; ++st) {
+                    a[st] = an[st];
+                    an[st] = *reinterpret_cast<const f32x4 *>(a0p + st * 32 * CT::RSF() + kx * 8);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int cc = 0; cc < FT; ++cc)
+#pragma unroll
+                        for (int st = 0; st < NST; ++st)
+                            acc[st][cc] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[d][cc][r], a[st][r], acc[st][cc], 0, 0, 0);
+                const int kn = kk + PFD < nk ? kk + PFD : nk - 1;
+#pragma unroll
+                for (int cc = 0; cc < FT; ++cc)
+                    ring[d][cc] = *reinterpret_cast<const f32x4 *>(u0 + (size_t)kn * 1024 + cc * cts + voff);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
 template <class CT>
 __device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, int kb1, f32x16 (&acc)[CT::NST][CT::FT]) {
+    if constexpr (CT::ARITH == 1) {
+        kloop_f32(c, ly, kb0, kb1, acc);
+        return;
+    }
     constexpr int FT = CT::FT;
     constexpr int PFD = FT == 2 ? PF : (PF > 1 ? PF / 2 : 1);  // ring depth in k-blocks: FT x 8 VGPRs per block
     const int i = c.lane & 31, hh = c.lane >> 5;
@@ -233,6 +314,44 @@ __device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, 
 // kind) keep the matrix pipe issuing back to back.  Activations are the A operand here: C[sample][logit].
 template <class CT>
 __device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int ct, int kb0, int kb1, f32x16 (&out)[CT::NST]) {
+    if constexpr (CT::ARITH == 1) {  // exact fp32: activations as the A operand, one accumulator per row tile
+        constexpr int NST = CT::NST, PFD = 4;
+        const int i = c.lane & 31, hh = c.lane >> 5;
+        const float *a0p = c.f32() + i * CT::RSF() + 4 * hh + kb0 * 8;
+        const char *u = reinterpret_cast<const char *>(ly.wp) + ((size_t)ct * ly.KB + kb0) * 1024;
+        unsigned voff = (unsigned)c.lane * 16u;
+        asm volatile("" : "+v"(voff));
+        const int nk = kb1 - kb0;
+#pragma unroll
+        for (int r = 0; r < NST; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) out[r][e] = 0.f;
+        f32x4 ring[PFD];
+#pragma unroll
+        for (int d = 0; d < PFD; ++d) ring[d] = *reinterpret_cast<const f32x4 *>(u + (size_t)(d < nk ? d : nk - 1) * 1024 + voff);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int k = 0; k < nk; k += PFD) {
+#pragma unroll
+            for (int d = 0; d < PFD; ++d) {
+                const int kk = k + d;
+                if (kk < nk) {
+                    f32x4 a[NST];
+#pragma unroll
+                    for (int st = 0; st < NST; ++st) a[st] = *reinterpret_cast<const f32x4 *>(a0p + st * 32 * CT::RSF() + kk * 8);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int st = 0; st < NST; ++st)
+                            out[st] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st][r], ring[d][r], out[st], 0, 0, 0);
+                    const int kn = kk + PFD < nk ? kk + PFD : nk - 1;
+                    ring[d] = *reinterpret_cast<const f32x4 *>(u + (size_t)kn * 1024 + voff);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        return;
+    }
 #ifndef SPLIT_PFT
 #define SPLIT_PFT 4
 #endif
@@ -333,6 +452,22 @@ __device__ __forceinline__ void unpark(const CT &c, f32x16 (&acc)[CT::NST][CT::F
 template <class CT>
 __device__ __forceinline__ void regs_to_tile(const CT &c, const f32x16 (&y)[CT::NST][CT::FT]) {
     const int j = c.lane & 31, hh = c.lane >> 5;
+    if constexpr (CT::ARITH == 1) {
+#pragma unroll
+        for (int st = 0; st < CT::NST; ++st) {
+            float *fp = c.f32() + (32 * st + j) * CT::RSF() + 32 * CT::FT * c.wave + 4 * hh;
+#pragma unroll
+            for (int ft = 0; ft < CT::FT; ++ft)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = y[st][ft][4 * m + r];
+                    *reinterpret_cast<f32x4 *>(fp + 32 * ft + 8 * m) = v;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int st = 0; st < CT::NST; ++st) {
         _Float16 *hp = c.act + (32 * st + j) * c.RSH + 32 * CT::FT * c.wave + 4 * hh;
@@ -442,20 +577,25 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][CT::FT
                 for (int r = 0; r < 4; ++r) y[r] = fmaf(fmaf(acc[st][ft][4 * m + r], rstd[st], shift[st]), g4[r], b4[r]);
                 if (ACT == 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[r] = mish_fast(y[r]);
+                    for (int r = 0; r < 4; ++r) y[r] = mish_a<CT>(y[r]);
                 } else {
                     float mx = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
                     mx = fmaxf(mx, __shfl_xor(mx, 32));
                     float es = 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        y[r] = __expf(y[r] - mx);
+                        y[r] = exp_a<CT>(y[r] - mx);
                         es += y[r];
                     }
                     es += __shfl_xor(es, 32);
-                    const float inv = 1.0f / es;
+                    if constexpr (CT::ARITH == 1) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[r] *= inv;
+                        for (int r = 0; r < 4; ++r) y[r] = y[r] / es;
+                    } else {
+                        const float inv = 1.0f / es;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] *= inv;
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = y[r];
@@ -503,7 +643,7 @@ __device__ __forceinline__ float twohot_rows_s(const CT &c, const float *bins, i
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int jj = part + 8 * q;
-        const float ev = (jj < num_bins) ? __expf(v[q] - m) : 0.f;
+        const float ev = (jj < num_bins) ? expf(v[q] - m) : 0.f;  // libm-accurate in both arithmetics: feeds symexp
         es += ev;
         x = fmaf(ev, (jj < num_bins) ? bins[jj] : 0.f, x);
     }
@@ -528,7 +668,7 @@ template <class CT>
 __device__ __forceinline__ float head_twohot_s(const CT &c, const LayerS &ly, const float *bins, int num_bins) {
     f32x16 acc[CT::NST];
     const int ct = c.wave;
-    if (ct < ly.CT) kloop_tile_s(c, ly, ct, 0, ZKB16, acc);
+    if (ct < ly.CT) kloop_tile_s(c, ly, ct, 0, CT::ZKB, acc);
     const float osc = *ly.oscale;
     __syncthreads();
     if (ct < ly.CT) {
@@ -544,6 +684,10 @@ __device__ __forceinline__ float head_twohot_s(const CT &c, const LayerS &ly, co
 // write one action value into the operand-form action columns of a row
 template <class CT>
 __device__ __forceinline__ void put_action(const CT &c, int row, int a, float v) {
+    if constexpr (CT::ARITH == 1) {
+        c.f32()[row * CT::RSF() + WIDTH + a] = v;
+        return;
+    }
     const float vs = v * ACT_SCALE;
     const _Float16 h = (_Float16)vs;
     _Float16 *rp = c.act + row * c.RSH + WIDTH + a;
@@ -558,7 +702,7 @@ __device__ __forceinline__ void head_pi_s(const CT &c, const LayerS &ly, int A, 
                                           const float *mask, EpsFn eps, float *gdst, int nvalid, float *tsc) {
     f32x16 acc[CT::NST];
     const int ct = c.wave;
-    if (ct < ly.CT) kloop_tile_s(c, ly, ct, 0, ZKB16, acc);
+    if (ct < ly.CT) kloop_tile_s(c, ly, ct, 0, CT::ZKB, acc);
     const float osc = *ly.oscale;
     __syncthreads();
     if (ct < ly.CT) {
@@ -603,11 +747,15 @@ __device__ __forceinline__ void tile_broadcast_row_s(const CT &c, const float *s
     for (int idx = c.tid; idx < CT::TROWS * (WIDTH / 4); idx += CT::NTHR) {
         const int row = idx / (WIDTH / 4), c4 = idx % (WIDTH / 4);
         const f32x4 y = *reinterpret_cast<const f32x4 *>(src_row + 4 * c4);
-        f16x4 hi, lo;
-        split4(y, hi, lo);
-        _Float16 *hp = c.act + row * c.RSH + 4 * c4;
-        *reinterpret_cast<f16x4 *>(hp) = hi;
-        *reinterpret_cast<f16x4 *>(hp + c.SH) = lo;
+        if constexpr (CT::ARITH == 1) {
+            *reinterpret_cast<f32x4 *>(c.f32() + row * CT::RSF() + 4 * c4) = y;
+        } else {
+            f16x4 hi, lo;
+            split4(y, hi, lo);
+            _Float16 *hp = c.act + row * c.RSH + 4 * c4;
+            *reinterpret_cast<f16x4 *>(hp) = hi;
+            *reinterpret_cast<f16x4 *>(hp + c.SH) = lo;
+        }
     }
 }
 // operand form -> fp32 trace dump (hi + lo, unscaled)
@@ -617,18 +765,22 @@ __device__ __forceinline__ void dump_tile_s(const CT &c, float *trace, int nslot
     float *dst = trace + ((size_t)blockIdx.x * nslot + slot) * CT::TROWS * WIDTH;
     for (int idx = c.tid; idx < CT::TROWS * WIDTH; idx += CT::NTHR) {
         const int row = idx / WIDTH, col = idx % WIDTH;
-        const _Float16 *hp = c.act + row * c.RSH + col;
-        dst[idx] = ((float)hp[0] + (float)hp[c.SH]) * (1.0f / ACT_SCALE);
+        if constexpr (CT::ARITH == 1) {
+            dst[idx] = c.f32()[row * CT::RSF() + col];
+        } else {
+            const _Float16 *hp = c.act + row * c.RSH + col;
+            dst[idx] = ((float)hp[0] + (float)hp[c.SH]) * (1.0f / ACT_SCALE);
+        }
     }
 }
 
 // ================================================================ kernel: per-plan setup (cf. k_setup)
-template <int APAD>
+template <int APAD, int AR>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x, tid = threadIdx.x;
-    typedef CtxT<APAD> CT;  // 64 rows, 8 waves
-    CT c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CT::RSH / 2, tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    typedef CtxT<APAD, 2, 8, AR> CT;  // 64 rows, 8 waves
+    CT c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CT::RSF(), tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     if (p.multitask) {
         const float *emb = p.task_emb + (size_t)e * p.T;
         for (int net = 0; net < p.nnets; ++net) {
@@ -652,8 +804,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
     f32x16 acc[2][2][2];
     zero_acc(acc[0]);
     zero_acc(acc[1]);
-    kloop_s(c, p.rew.l[0], 0, ZKB16, acc[0]);
-    kloop_s(c, p.dyn.l[0], 0, ZKB16, acc[1]);
+    kloop_s(c, p.rew.l[0], 0, CT::ZKB, acc[0]);
+    kloop_s(c, p.dyn.l[0], 0, CT::ZKB, acc[1]);
     const float *b_rew = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_REW) * WIDTH : p.rew.l[0].bias;
     const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
     const float o_rew = *p.rew.l[0].oscale, o_dyn = *p.dyn.l[0].oscale;
@@ -672,17 +824,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
 
 // ================================================================ kernel: policy-prior trajectories (cf. k_pitraj)
 // ST = 1 (one 32-row tile) when num_pi_trajs <= 32 -- the reference's 24 -- else 2.
-template <int APAD, int ST>
+template <int APAD, int ST, int AR>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x, tid = threadIdx.x;
-    typedef CtxT<APAD, ST> CT;
-    CT c{reinterpret_cast<_Float16 *>(smem), smem + CT::TROWS * CT::RSH / 2, tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    typedef CtxT<APAD, ST, 8, AR> CT;
+    constexpr int ZKB16 = CT::ZKB;  // k-blocks of this arithmetic covering the latent columns
+    CT c{reinterpret_cast<_Float16 *>(smem), smem + CT::TROWS * CT::RSF(), tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
     const float *b_pi = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_PI) * WIDTH : p.pi.l[0].bias;
     const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
     float *zs = p.zscratch + (size_t)e * p.zscratch_estride;
-    const int KBA = ZKB16 + p.Apad / 16;
+    const int KBA = ZKB16 + p.Apad / CT::KBLK;
     tile_broadcast_row_s(c, p.z0 + (size_t)e * WIDTH);
     {  // zs <- z0 for every sample row, in register order (what tile_from_global_s reads back)
         f32x16 y[ST][2];
@@ -721,20 +874,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) 
 }
 
 // ================================================================ kernel: one CEM iteration's rollouts (cf. k_rollout)
-template <int APAD, int ST, int NW>
+template <int APAD, int ST, int NW, int AR>
 __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x / p.tiles, tile = blockIdx.x % p.tiles;
     const int tid = threadIdx.x;
-    typedef CtxT<APAD, ST, NW> CT;
+    typedef CtxT<APAD, ST, NW, AR> CT;
     constexpr int TROWS = CT::TROWS, NTHR = CT::NTHR, FT = CT::FT;
-    CT c{reinterpret_cast<_Float16 *>(smem), smem + TROWS * CT::RSH / 2, tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
-    float *sm_mean = smem + TROWS * c.RSH / 2 + 1024;  // [H*A] after the tile and the LayerNorm partials
+    constexpr int ZKB16 = CT::ZKB;  // k-blocks of this arithmetic covering the latent columns
+    CT c{reinterpret_cast<_Float16 *>(smem), smem + TROWS * CT::RSF(), tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    float *sm_mean = smem + TROWS * CT::RSF() + 1024;  // [H*A] after the tile and the LayerNorm partials
     float *sm_std = sm_mean + p.H * p.A;
     const int row0 = tile * TROWS;
     const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
     const float *disc = p.disc_pow + (size_t)e * (p.H + 1);
-    const int KBA = ZKB16 + p.Apad / 16;
+    const int KBA = ZKB16 + p.Apad / CT::KBLK;
     float *zs = p.zscratch + (size_t)blockIdx.x * TROWS * WIDTH;
     const int NSLOT = 5 * p.H + 7;
     const bool live = (tid >> 3) < TROWS;  // ST = 1: threads 256..511 own no sample row in the row-per-8-lanes phases

@@ -51,24 +51,11 @@ namespace {
 constexpr int ROWS = 64;        // sample rows per rollout workgroup
 constexpr int NTHREADS = 512;   // 8 wavefronts
 constexpr int WIDTH = 512;      // latent_dim == mlp_dim of the fused size class
-constexpr int ZKB = WIDTH / 8;  // k-blocks (of 8) covering the latent columns
 constexpr int MAXQ = 8;
 constexpr int MAXH = 8;
 constexpr float LN_EPS = 1e-5f;
 
-// ---------------------------------------------------------------- device-side descriptors
-struct LayerW {
-    const float *wp;    // packed [CT][KB][64 lanes][4]
-    const float *bias;  // [CT*32] zero padded
-    const float *g;     // LayerNorm weight [out] (null for plain output layers)
-    const float *b;     // LayerNorm bias   [out]
-    int KB;             // k-blocks in the packed matrix
-    int CT;             // column tiles (of 32 output features)
-};
-struct NetW {
-    LayerW l[3];
-};
-
+// ---------------------------------------------------------------- kernel parameter blocks (NET = NetS, fused_split.cuh)
 template <class NET>
 struct RolloutParamsT {
     int E, N, H, A, Apad, P, stride, tiles, nq, num_bins, multitask, given_actions, iter, iters_total;
@@ -99,7 +86,6 @@ struct RolloutParamsT {
     float *trace_scalars;  // optional [E, N, H+2+A]: r_0..r_{H-1}, Q_a, Q_b, a_H[A]
     unsigned long long *timing;  // profiling builds (-DSPLIT_TIMING): 16 cycle counters summed over workgroups, else null
 };
-using RolloutParams = RolloutParamsT<NetW>;
 
 // net slots inside `beff`
 enum { BE_DYN = 0, BE_REW = 1, BE_PI = 2, BE_Q0 = 3 };
@@ -164,304 +150,9 @@ __device__ __forceinline__ float rng_exponential(unsigned long long seed, unsign
     return -logf(u01(rng_raw(seed, call, site, iter, env, idx).x));
 }
 
-// ---------------------------------------------------------------- MFMA contraction loops
-// Per workgroup: A operand = activations act[64][stride] in LDS (k contiguous), B operand = packed
-// weights.  v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].
-// One 16-byte read per operand feeds 4 MFMAs: lane (i,h) holds k = kb*8 + 4h + r for r = 0..3, i.e.
-// MFMA r contracts the pair {kb*8 + r, kb*8 + 4 + r}; the same permutation on both operands.
-// Wave w of 8 owns output columns [64w, 64w+64) for both 32-row tiles: acc[set][row tile][col tile].
-template <int NS>
-__device__ __forceinline__ void kloop_full(const float *act, int stride, const float *const (&wp)[NS], const int (&KB)[NS],
-                                           int kb0, int kb1, int wave, int lane, f32x16 (&acc)[NS][2][2]) {
-    const int i = lane & 31, h = lane >> 5;
-    const float *a0p = act + i * stride + 4 * h;
-    const float *a1p = a0p + 32 * stride;
-    const f32x4 *w[NS][2];
-    f32x4 bn[NS][2];
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            w[s][c] = reinterpret_cast<const f32x4 *>(wp[s]) + (size_t)(2 * wave + c) * KB[s] * 64 + lane;
-            bn[s][c] = w[s][c][(size_t)kb0 * 64];
-        }
-#pragma unroll 2
-    for (int kb = kb0; kb < kb1; ++kb) {
-        f32x4 b[NS][2];
-        const int kn = (kb + 1 < kb1) ? kb + 1 : kb;
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                b[s][c] = bn[s][c];
-                bn[s][c] = w[s][c][(size_t)kn * 64];
-            }
-        const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p + kb * 8);
-        const f32x4 a1 = *reinterpret_cast<const f32x4 *>(a1p + kb * 8);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                acc[s][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b[s][0][r], acc[s][0][0], 0, 0, 0);
-                acc[s][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[r], b[s][1][r], acc[s][0][1], 0, 0, 0);
-                acc[s][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b[s][0][r], acc[s][1][0], 0, 0, 0);
-                acc[s][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[r], b[s][1][r], acc[s][1][1], 0, 0, 0);
-            }
-        }
-    }
-}
-
-// One 32x32 output tile (row tile rt, column tile ct) — the narrow output layers (two-hot / pi heads).
-__device__ __forceinline__ void kloop_tile(const float *act, int stride, const float *wp, int KB, int ct, int rt,
-                                           int kb0, int kb1, int lane, f32x16 &acc) {
-    const int i = lane & 31, h = lane >> 5;
-    const float *ap = act + (rt * 32 + i) * stride + 4 * h;
-    const f32x4 *w = reinterpret_cast<const f32x4 *>(wp) + (size_t)ct * KB * 64 + lane;
-    f32x4 bn = w[(size_t)kb0 * 64];
-#pragma unroll 2
-    for (int kb = kb0; kb < kb1; ++kb) {
-        const f32x4 b = bn;
-        const int kn = (kb + 1 < kb1) ? kb + 1 : kb;
-        bn = w[(size_t)kn * 64];
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(ap + kb * 8);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b[r], acc, 0, 0, 0);
-    }
-}
-
-__device__ __forceinline__ void zero4(f32x16 (&a)[2][2]) {
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) a[r][c][e] = 0.f;
-}
-
-// C/D fragment of a 32x32 tile: lane l holds column (l & 31), rows (reg&3) + 8*(reg>>2) + 4*(l>>5).
-__device__ __forceinline__ void store_full(float *act, int stride, const f32x16 (&acc)[2][2], const float *bias,
-                                           int wave, int lane) {
-    const int j = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int col = (2 * wave + c) * 32 + j;
-        const float bv = bias[col];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int row = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                act[row * stride + col] = acc[rt][c][reg] + bv;
-            }
-    }
-}
-__device__ __forceinline__ void store_tile(float *act, int stride, const f32x16 &acc, const float *bias, int ct,
-                                           int rt, int lane) {
-    const int j = lane & 31, h = lane >> 5;
-    const int col = ct * 32 + j;
-    const float bv = bias[col];
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        const int row = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        act[row * stride + col] = acc[reg] + bv;
-    }
-}
-
-// ---------------------------------------------------------------- row-wise epilogues (in place, in LDS)
-// Thread t owns row (t >> 3) and the sixteen 4-column chunks {part + 8q}, part = t & 7: the 8 owners
-// of a row are 8 adjacent lanes.  LayerNorm = biased variance, eps 1e-5 (nn.LayerNorm defaults,
-// tdmpc2/common/layers.py:101); ACT 0 = Mish, 1 = SimNorm over groups of 8 (layers.py:84-88).
-template <int ACT>
-__device__ __forceinline__ void ln_act_rows(float *act, int stride, const float *g, const float *b, int tid,
-                                            float *gcopy /* optional [64][WIDTH] global copy of the result */) {
-    const int row = tid >> 3, part = tid & 7;
-    float *rp = act + row * stride + 4 * part;
-    // three passes over the row slice in LDS (cheap) instead of 64 live registers per thread
-    float s = 0.f;
-#pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(rp + 32 * q);
-        s += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    const float mean = group_sum<8>(s) * (1.0f / WIDTH);
-    float ss = 0.f;
-#pragma unroll 4
-    for (int q = 0; q < 16; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(rp + 32 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float d = v[e] - mean;
-            ss += d * d;
-        }
-    }
-    const float var = group_sum<8>(ss) * (1.0f / WIDTH);
-    const float rstd = 1.0f / sqrtf(var + LN_EPS);
-#pragma unroll 2
-    for (int q = 0; q < 16; ++q) {
-        const int col = 4 * part + 32 * q;
-        const f32x4 v = *reinterpret_cast<const f32x4 *>(rp + 32 * q);
-        const f32x4 gg = *reinterpret_cast<const f32x4 *>(g + col);
-        const f32x4 bb = *reinterpret_cast<const f32x4 *>(b + col);
-        f32x4 y;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = (v[e] - mean) * rstd * gg[e] + bb[e];
-        if (ACT == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = mish_f(y[e]);
-        } else {
-            // group of 8 columns = this lane's chunk + the chunk of lane (part ^ 1)
-            float m = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
-            m = fmaxf(m, __shfl_xor(m, 1));
-            float es = 0.f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                y[e] = expf(y[e] - m);
-                es += y[e];
-            }
-            es += __shfl_xor(es, 1);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = y[e] / es;
-        }
-        *reinterpret_cast<f32x4 *>(rp + 32 * q) = y;
-        if (gcopy) *reinterpret_cast<f32x4 *>(gcopy + row * WIDTH + col) = y;
-    }
-}
-
-// two_hot_inv (tdmpc2/common/math.py:74-83) on logits in act[row][0..num_bins): softmax, expectation over
-// the bin centres, symexp.  Result valid in every thread of the row's 8-lane group.
-__device__ __forceinline__ float twohot_rows(const float *act, int stride, const float *bins, int num_bins, int tid) {
-    const int row = tid >> 3, part = tid & 7;
-    const float *rp = act + row * stride;
-    float v[16];
-    float m = -INFINITY;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int j = part + 8 * q;
-        v[q] = (j < num_bins) ? rp[j] : -INFINITY;
-        m = fmaxf(m, v[q]);
-    }
-    m = group_max<8>(m);
-    float es = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int j = part + 8 * q;
-        v[q] = (j < num_bins) ? expf(v[q] - m) : 0.f;
-        es += v[q];
-    }
-    es = group_sum<8>(es);
-    float x = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int j = part + 8 * q;
-        if (j < num_bins) x += (v[q] / es) * bins[j];
-    }
-    x = group_sum<8>(x);
-    return symexp_f(x);
-}
-
-// ---------------------------------------------------------------- composite phases
-struct Ctx {
-    float *act;
-    int stride, tid, wave, lane;
-};
-
-// out = ACT(LayerNorm(W x + bias)) for a WIDTH-wide layer; input and output in ctx.act.
-template <int ACT>
-__device__ __forceinline__ void layer_full(const Ctx &c, const LayerW &ly, const float *bias, int kb0, int kb1,
-                                           float *gcopy = nullptr) {
-    f32x16 acc[1][2][2];
-    zero4(acc[0]);
-    const float *const wp[1] = {ly.wp};
-    const int KB[1] = {ly.KB};
-    kloop_full<1>(c.act, c.stride, wp, KB, kb0, kb1, c.wave, c.lane, acc);
-    __syncthreads();
-    store_full(c.act, c.stride, acc[0], bias, c.wave, c.lane);
-    __syncthreads();
-    ln_act_rows<ACT>(c.act, c.stride, ly.g, ly.b, c.tid, gcopy);
-    __syncthreads();
-}
-
-// Two-hot output layer: logits -> scalar per row (returned to every thread of the row group).
-__device__ __forceinline__ float head_twohot(const Ctx &c, const LayerW &ly, const float *bins, int num_bins) {
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const int rt = c.wave & 1, ct = c.wave >> 1;
-    if (ct < ly.CT) kloop_tile(c.act, c.stride, ly.wp, ly.KB, ct, rt, 0, ZKB, c.lane, acc);
-    __syncthreads();
-    if (ct < ly.CT) store_tile(c.act, c.stride, acc, ly.bias, ct, rt, c.lane);
-    __syncthreads();
-    const float r = twohot_rows(c.act, c.stride, bins, num_bins, c.tid);
-    __syncthreads();
-    return r;
-}
-
-// Policy prior output layer + squashed Gaussian sample (tdmpc2/common/world_model.py:152-173).
-// eps(row, a) supplies the randn_like draw.  Writes the action into act[row][WIDTH + a] and, if
-// `gdst` is given, into gdst[row * A + a] for rows < nvalid.
-template <typename EpsFn>
-__device__ __forceinline__ void head_pi(const Ctx &c, const LayerW &ly, int A, int Apad, float lsmin, float lsdif,
-                                        const float *mask, EpsFn eps, float *gdst, int nvalid) {
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    const int rt = c.wave & 1, ct = c.wave >> 1;
-    if (ct < ly.CT) kloop_tile(c.act, c.stride, ly.wp, ly.KB, ct, rt, 0, ZKB, c.lane, acc);
-    __syncthreads();
-    if (ct < ly.CT) store_tile(c.act, c.stride, acc, ly.bias, ct, rt, c.lane);
-    __syncthreads();
-    const int row = c.tid >> 3, part = c.tid & 7;
-    float *rp = c.act + row * c.stride;
-    for (int a = part; a < Apad; a += 8) {
-        float out = 0.f;
-        if (a < A) {
-            float mu = rp[a];
-            float ls = lsmin + 0.5f * lsdif * (tanhf(rp[A + a]) + 1.f);  // math.log_std, math.py:12-13
-            float e = eps(row, a);
-            if (mask) {
-                const float mk = mask[a];
-                mu *= mk;
-                ls *= mk;
-                e *= mk;
-            }
-            out = tanhf(mu + e * expf(ls));  // reparameterisation + squash, world_model.py:173-174
-            if (gdst && row < nvalid) gdst[row * A + a] = out;
-        }
-        rp[WIDTH + a] = out;
-    }
-    __syncthreads();
-}
-
-// Copy a [64][WIDTH] tile between LDS rows and a dense global buffer.
-__device__ __forceinline__ void tile_from_global(const Ctx &c, const float *src) {
-    for (int idx = c.tid; idx < ROWS * (WIDTH / 4); idx += NTHREADS) {
-        const int row = idx / (WIDTH / 4), c4 = idx % (WIDTH / 4);
-        *reinterpret_cast<f32x4 *>(c.act + row * c.stride + 4 * c4) =
-            *reinterpret_cast<const f32x4 *>(src + row * WIDTH + 4 * c4);
-    }
-}
-__device__ __forceinline__ void tile_broadcast_row(const Ctx &c, const float *src_row) {
-    for (int idx = c.tid; idx < ROWS * (WIDTH / 4); idx += NTHREADS) {
-        const int row = idx / (WIDTH / 4), c4 = idx % (WIDTH / 4);
-        *reinterpret_cast<f32x4 *>(c.act + row * c.stride + 4 * c4) =
-            *reinterpret_cast<const f32x4 *>(src_row + 4 * c4);
-    }
-}
-
-__device__ __forceinline__ void dump_tile(const Ctx &c, float *trace, int nslot, int slot) {
-    if (!trace) return;
-    float *dst = trace + ((size_t)blockIdx.x * nslot + slot) * ROWS * WIDTH;
-    for (int idx = c.tid; idx < ROWS * (WIDTH / 4); idx += NTHREADS) {
-        const int row = idx / (WIDTH / 4), c4 = idx % (WIDTH / 4);
-        *reinterpret_cast<f32x4 *>(dst + row * WIDTH + 4 * c4) =
-            *reinterpret_cast<const f32x4 *>(c.act + row * c.stride + 4 * c4);
-    }
-}
-
-// ================================================================ kernel: per-plan setup
-// grid = E.  (1) effective first-layer biases b + W[:, L:L+T] . task_emb (multitask);
-// (2) cvec = z0-part (+ bias) of the reward / dynamics first layers (all rows share z0 at t = 0,
-//     tdmpc2/tdmpc2.py:163); (3) mean / std initialisation and warm start (tdmpc2.py:164-167).
+// per-plan setup: (1) effective first-layer biases b + W[:, L:L+T] . task_emb (multitask); (2) cvec = z0-part (+ bias) of
+// the reward / dynamics first layers (all rows share z0 at t = 0, tdmpc2/tdmpc2.py:163); (3) mean / std initialisation
+// and warm start (tdmpc2.py:164-167)
 template <class NET>
 struct SetupParamsT {
     int E, H, A, T, multitask, nq, nnets, stride;
@@ -473,54 +164,8 @@ struct SetupParamsT {
     const unsigned char *t0;
     float *beff, *cvec, *mean, *std;
 };
-using SetupParams = SetupParamsT<NetW>;
 
-__global__ __launch_bounds__(NTHREADS, 2) void k_setup(SetupParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int e = blockIdx.x, tid = threadIdx.x;
-    Ctx c{smem, p.stride, tid, tid >> 6, tid & 63};
-    if (p.multitask) {
-        // one thread per output column, one dot product of length T per net
-        const float *emb = p.task_emb + (size_t)e * p.T;
-        for (int net = 0; net < p.nnets; ++net) {
-            const LayerW &l1 = net == BE_DYN ? p.dyn.l[0] : net == BE_REW ? p.rew.l[0] : net == BE_PI ? p.pi.l[0]
-                                                                                                    : p.q[net - BE_Q0].l[0];
-            const float *w = p.wemb[net] + (size_t)tid * p.T;
-            float s = 0.f;
-            for (int k = 0; k < p.T; ++k) s = fmaf(w[k], emb[k], s);
-            p.beff[((size_t)e * p.nnets + net) * WIDTH + tid] = l1.bias[tid] + s;
-        }
-    }
-    for (int idx = tid; idx < p.H * p.A; idx += NTHREADS) {
-        const int t = idx / p.A;
-        float m = 0.f;
-        if (!p.t0[e] && t < p.H - 1) m = p.prev_mean[(size_t)e * p.H * p.A + idx + p.A];
-        p.mean[(size_t)e * p.H * p.A + idx] = m;
-        p.std[(size_t)e * p.H * p.A + idx] = p.max_std;
-    }
-    tile_broadcast_row(c, p.z0 + (size_t)e * WIDTH);
-    __syncthreads();  // also orders the beff stores above for this block's later reads
-    f32x16 acc[2][2][2];
-    zero4(acc[0]);
-    zero4(acc[1]);
-    const float *const wp[2] = {p.rew.l[0].wp, p.dyn.l[0].wp};
-    const int KB[2] = {p.rew.l[0].KB, p.dyn.l[0].KB};
-    kloop_full<2>(c.act, c.stride, wp, KB, 0, ZKB, c.wave, c.lane, acc);
-    const float *b_rew = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_REW) * WIDTH : p.rew.l[0].bias;
-    const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
-    // row 0 of the tile lives in lanes with (lane >> 5) == 0, register 0 of row tile 0
-    if ((c.lane >> 5) == 0) {
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-            const int col = (2 * c.wave + ct) * 32 + (c.lane & 31);
-            p.cvec[((size_t)e * 2 + 0) * WIDTH + col] = acc[0][0][ct][0] + b_rew[col];
-            p.cvec[((size_t)e * 2 + 1) * WIDTH + col] = acc[1][0][ct][0] + b_dyn[col];
-        }
-    }
-}
-
-// ================================================================ kernel: policy-prior trajectories
-// grid = E (rows < P of one tile are meaningful).  tdmpc2/tdmpc2.py:154-160.
+// policy-prior trajectories (tdmpc2/tdmpc2.py:154-160): rows < P of one tile per plan
 template <class NET>
 struct PiTrajParamsT {
     int E, N, H, A, Apad, P, stride, multitask, nnets;
@@ -534,197 +179,6 @@ struct PiTrajParamsT {
     float *zscratch;  // [E,64,WIDTH] (tile 0 of each plan)
     long zscratch_estride;
 };
-using PiTrajParams = PiTrajParamsT<NetW>;
-
-__global__ __launch_bounds__(NTHREADS, 2) void k_pitraj(PiTrajParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int e = blockIdx.x, tid = threadIdx.x;
-    Ctx c{smem, p.stride, tid, tid >> 6, tid & 63};
-    const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
-    const float *b_pi = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_PI) * WIDTH : p.pi.l[0].bias;
-    const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
-    float *zs = p.zscratch + (size_t)e * p.zscratch_estride;
-    const int KBA = ZKB + p.Apad / 8;
-    tile_broadcast_row(c, p.z0 + (size_t)e * WIDTH);
-    for (int idx = tid; idx < ROWS * WIDTH / 4; idx += NTHREADS)
-        *reinterpret_cast<f32x4 *>(zs + 4 * idx) =
-            *reinterpret_cast<const f32x4 *>(p.z0 + (size_t)e * WIDTH + 4 * (idx % (WIDTH / 4)));
-    __syncthreads();
-    for (int t = 0; t < p.H; ++t) {
-        // a_t = pi(z)
-        layer_full<0>(c, p.pi.l[0], b_pi, 0, ZKB);
-        layer_full<0>(c, p.pi.l[1], p.pi.l[1].bias, 0, ZKB);
-        const float *tape = p.pi_traj_eps ? p.pi_traj_eps + ((size_t)e * p.H + t) * p.P * p.A : nullptr;
-        auto eps = [&](int row, int a) -> float {
-            if (row >= p.P) return 0.f;
-            if (tape) return tape[row * p.A + a];
-            return rng_normal(p.seed, p.call, SITE_PITRAJ, t, e, (unsigned)(row * p.A + a));
-        };
-        head_pi(c, p.pi.l[2], p.A, p.Apad, p.log_std_min, p.log_std_dif, mask, eps,
-                p.actions + ((size_t)e * p.H + t) * p.N * p.A, p.P);
-        if (t == p.H - 1) break;
-        // z = next(z, a_t)
-        tile_from_global(c, zs);
-        __syncthreads();
-        layer_full<0>(c, p.dyn.l[0], b_dyn, 0, KBA);
-        layer_full<0>(c, p.dyn.l[1], p.dyn.l[1].bias, 0, ZKB);
-        layer_full<1>(c, p.dyn.l[2], p.dyn.l[2].bias, 0, ZKB, zs);
-    }
-}
-
-// ================================================================ kernel: one CEM iteration's rollouts
-// grid = E * N/64.  tdmpc2/tdmpc2.py:176-184 (sampling + _estimate_value).
-__global__ __launch_bounds__(NTHREADS, 2) void k_rollout(RolloutParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int e = blockIdx.x / p.tiles, tile = blockIdx.x % p.tiles;
-    const int tid = threadIdx.x;
-    Ctx c{smem, p.stride, tid, tid >> 6, tid & 63};
-    float *sm_mean = smem + ROWS * p.stride;  // [H*A]
-    float *sm_std = sm_mean + p.H * p.A;
-    const int row0 = tile * ROWS;
-    const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
-    const float *disc = p.disc_pow + (size_t)e * (p.H + 1);
-    const int KBA = ZKB + p.Apad / 8;
-    float *zs = p.zscratch + (size_t)blockIdx.x * ROWS * WIDTH;
-    const int NSLOT = 5 * p.H + 7;
-    float *tsc = p.trace_scalars ? p.trace_scalars + ((size_t)e * p.N + row0 + (tid >> 3)) * (p.H + 2 + p.A) : nullptr;
-
-    for (int idx = tid; idx < p.H * p.A; idx += NTHREADS) {
-        sm_mean[idx] = p.mean[(size_t)e * p.H * p.A + idx];
-        sm_std[idx] = p.std[(size_t)e * p.H * p.A + idx];
-    }
-    int q0, q1;
-    if (p.qidx) {
-        q0 = p.qidx[(size_t)e * p.qidx_estride + 0];
-        q1 = p.qidx[(size_t)e * p.qidx_estride + 1];
-    } else {  // two distinct heads, uniform over ordered pairs (randperm(nq)[:2], world_model.py:212)
-        const uint4 r = rng_raw(p.seed, p.call, SITE_QIDX, p.iter, e, 0);
-        q0 = (int)(r.x % (unsigned)p.nq);
-        q1 = (int)(r.y % (unsigned)(p.nq - 1));
-        if (q1 >= q0) ++q1;
-    }
-    const float *b_rew = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_REW) * WIDTH : p.rew.l[0].bias;
-    const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
-    const float *b_pi = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_PI) * WIDTH : p.pi.l[0].bias;
-    const float *b_q0 = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_Q0 + q0) * WIDTH : p.q[q0].l[0].bias;
-    const float *b_q1 = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_Q0 + q1) * WIDTH : p.q[q1].l[0].bias;
-    __syncthreads();
-
-    float G = 0.f;
-    for (int t = 0; t < p.H; ++t) {
-        // ---- actions of step t for this tile's rows (tdmpc2.py:176-181) -> LDS columns [WIDTH, WIDTH+Apad)
-        {
-            float *ag = p.actions + ((size_t)e * p.H + t) * p.N * p.A;
-            for (int idx = tid; idx < ROWS * p.Apad; idx += NTHREADS) {
-                const int row = idx / p.Apad, a = idx % p.Apad;
-                const int n = row0 + row;
-                float v = 0.f;
-                if (a < p.A) {
-                    if (p.given_actions || n < p.P) {
-                        v = ag[(size_t)n * p.A + a];
-                    } else {
-                        float r;
-                        const unsigned ridx = (unsigned)(((size_t)t * (p.N - p.P) + (n - p.P)) * p.A + a);
-                        if (p.sample_eps)
-                            r = p.sample_eps[(size_t)e * p.sample_eps_estride + ridx];
-                        else
-                            r = rng_normal(p.seed, p.call, SITE_SAMPLE, p.iter, e, ridx);
-                        v = sm_mean[t * p.A + a] + sm_std[t * p.A + a] * r;
-                        v = fminf(fmaxf(v, -1.f), 1.f);
-                    }
-                    if (mask && !p.given_actions) v *= mask[a];
-                    if (!p.given_actions) ag[(size_t)n * p.A + a] = v;
-                }
-                c.act[row * c.stride + WIDTH + a] = v;
-            }
-        }
-        __syncthreads();
-        // ---- first layers of reward and dynamics in one pass over [z_t | a_t]
-        f32x16 acc[2][2][2];
-        zero4(acc[0]);
-        zero4(acc[1]);
-        {
-            const float *const wp[2] = {p.rew.l[0].wp, p.dyn.l[0].wp};
-            const int KB[2] = {p.rew.l[0].KB, p.dyn.l[0].KB};
-            // t = 0: every row shares z0 -> z-part precomputed per plan in cvec, contract actions only
-            kloop_full<2>(c.act, c.stride, wp, KB, t == 0 ? ZKB : 0, KBA, c.wave, c.lane, acc);
-        }
-        __syncthreads();
-        store_full(c.act, c.stride, acc[0], t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew, c.wave, c.lane);
-        __syncthreads();
-        ln_act_rows<0>(c.act, c.stride, p.rew.l[0].g, p.rew.l[0].b, tid, nullptr);
-        __syncthreads();
-        dump_tile(c, p.trace_tiles, NSLOT, 5 * t + 0);
-        // ---- reward: layer 2, two-hot head
-        layer_full<0>(c, p.rew.l[1], p.rew.l[1].bias, 0, ZKB);
-        dump_tile(c, p.trace_tiles, NSLOT, 5 * t + 1);
-        const float r = head_twohot(c, p.rew.l[2], p.bins, p.num_bins);
-        if (tsc && (tid & 7) == 0) tsc[t] = r;
-        G += disc[t] * r;  // G + discount * (1 - termination) * reward, termination == 0 (tdmpc2.py:130)
-        // ---- dynamics: release the held first layer, layers 2 and 3 (SimNorm)
-        store_full(c.act, c.stride, acc[1], t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn, c.wave, c.lane);
-        __syncthreads();
-        ln_act_rows<0>(c.act, c.stride, p.dyn.l[0].g, p.dyn.l[0].b, tid, nullptr);
-        __syncthreads();
-        dump_tile(c, p.trace_tiles, NSLOT, 5 * t + 2);
-        layer_full<0>(c, p.dyn.l[1], p.dyn.l[1].bias, 0, ZKB);
-        dump_tile(c, p.trace_tiles, NSLOT, 5 * t + 3);
-        layer_full<1>(c, p.dyn.l[2], p.dyn.l[2].bias, 0, ZKB, t == p.H - 1 ? zs : nullptr);
-        dump_tile(c, p.trace_tiles, NSLOT, 5 * t + 4);
-    }
-    // ---- a_H = pi(z_H) (tdmpc2.py:135); z_H was also saved to zs
-    layer_full<0>(c, p.pi.l[0], b_pi, 0, ZKB);
-    dump_tile(c, p.trace_tiles, NSLOT, 5 * p.H + 0);
-    layer_full<0>(c, p.pi.l[1], p.pi.l[1].bias, 0, ZKB);
-    dump_tile(c, p.trace_tiles, NSLOT, 5 * p.H + 1);
-    {
-        auto eps = [&](int row, int a) -> float {
-            const unsigned ridx = (unsigned)((size_t)(row0 + row) * p.A + a);
-            if (p.pi_eps) return p.pi_eps[(size_t)e * p.pi_eps_estride + ridx];
-            return rng_normal(p.seed, p.call, SITE_PI, p.iter, e, ridx);
-        };
-        head_pi(c, p.pi.l[2], p.A, p.Apad, p.log_std_min, p.log_std_dif, mask, eps, nullptr, 0);
-    }
-    tile_from_global(c, zs);
-    __syncthreads();
-    dump_tile(c, p.trace_tiles, NSLOT, 5 * p.H + 2);
-    if (tsc) {
-        const int row = tid >> 3;
-        for (int a = tid & 7; a < p.A; a += 8) tsc[p.H + 2 + a] = c.act[row * c.stride + WIDTH + a];
-    }
-    // ---- Q(z_H, a_H): the two selected heads, first layers in one pass (world_model.py:186-216)
-    f32x16 acc[2][2][2];
-    zero4(acc[0]);
-    zero4(acc[1]);
-    {
-        const float *const wp[2] = {p.q[q0].l[0].wp, p.q[q1].l[0].wp};
-        const int KB[2] = {p.q[q0].l[0].KB, p.q[q1].l[0].KB};
-        kloop_full<2>(c.act, c.stride, wp, KB, 0, KBA, c.wave, c.lane, acc);
-    }
-    __syncthreads();
-    store_full(c.act, c.stride, acc[0], b_q0, c.wave, c.lane);
-    __syncthreads();
-    ln_act_rows<0>(c.act, c.stride, p.q[q0].l[0].g, p.q[q0].l[0].b, tid, nullptr);
-    __syncthreads();
-    dump_tile(c, p.trace_tiles, NSLOT, 5 * p.H + 3);
-    layer_full<0>(c, p.q[q0].l[1], p.q[q0].l[1].bias, 0, ZKB);
-    dump_tile(c, p.trace_tiles, NSLOT, 5 * p.H + 4);
-    const float qa = head_twohot(c, p.q[q0].l[2], p.bins, p.num_bins);
-    store_full(c.act, c.stride, acc[1], b_q1, c.wave, c.lane);
-    __syncthreads();
-    ln_act_rows<0>(c.act, c.stride, p.q[q1].l[0].g, p.q[q1].l[0].b, tid, nullptr);
-    __syncthreads();
-    dump_tile(c, p.trace_tiles, NSLOT, 5 * p.H + 5);
-    layer_full<0>(c, p.q[q1].l[1], p.q[q1].l[1].bias, 0, ZKB);
-    dump_tile(c, p.trace_tiles, NSLOT, 5 * p.H + 6);
-    const float qb = head_twohot(c, p.q[q1].l[2], p.bins, p.num_bins);
-    if (tsc && (tid & 7) == 0) {
-        tsc[p.H] = qa;
-        tsc[p.H + 1] = qb;
-    }
-    // G + discount * (1 - termination) * Q.sum(0) / 2   (tdmpc2.py:136, world_model.py:216)
-    if ((tid & 7) == 0) p.value[(size_t)e * p.N + row0 + (tid >> 3)] = G + disc[p.H] * ((qa + qb) / 2.f);
-}
 
 // ================================================================ kernel: elite select + refit
 // grid = E, block = N threads.  tdmpc2/tdmpc2.py:184-206.
@@ -960,6 +414,8 @@ struct tdmpc2_plan {
     Layered lay;
     bool split = false;  // fused kernels on the f16 matrix pipe with hi/lo operand split (fused_split.cuh)
     int force_rows = 0;  // TDMPC2_TUNE_ROWS_PER_WORKGROUP: 0 auto, 32, 64
+    size_t row_bytes = 0;  // bytes of one sample row of the fused kernels' LDS tile
+    float *one = nullptr;  // device scalar 1.0f: the output scale of the exact-fp32 arithmetic
     int Apad = 0, stride = 0, tiles = 0, nnets = 0;
     size_t lds_bytes = 0;
     HostNet dyn, rew, pi, term;
@@ -987,14 +443,11 @@ int dev_alloc(tdmpc2_plan *h, void **p, size_t bytes) {
 }
 
 template <class NET> NET to_dev(const HostNet &n);
-template <> NetW to_dev<NetW>(const HostNet &n) {
-    NetW w;
-    for (int i = 0; i < 3; ++i) w.l[i] = LayerW{n.l[i].wp, n.l[i].bias, n.l[i].g, n.l[i].b, n.l[i].KB, n.l[i].CT};
-    return w;
-}
-template <> NetS to_dev<NetS>(const HostNet &n) {
+template <> NetS to_dev<NetS>(const HostNet &n) {  // split: hi/lo f16 packing + per-matrix scale; exact fp32: fp32 packing, scale 1
     NetS w;
-    for (int i = 0; i < 3; ++i) w.l[i] = LayerS{n.l[i].wps, n.l[i].bias, n.l[i].g, n.l[i].b, n.l[i].oscale, n.l[i].KB, n.l[i].CT};
+    for (int i = 0; i < 3; ++i)
+        w.l[i] = LayerS{n.l[i].wps ? n.l[i].wps : reinterpret_cast<const _Float16 *>(n.l[i].wp), n.l[i].bias, n.l[i].g, n.l[i].b,
+                        n.l[i].oscale, n.l[i].KB, n.l[i].CT};
     return w;
 }
 
@@ -1028,33 +481,20 @@ int set_lds(K kernel, size_t bytes) {
     return 0;
 }
 
-// Kernel family of the fused path by operand form: NetW = exact fp32 MFMA, NetS = f16x2 split.
+// The fused kernels are instantiated per action padding (compile-time LDS strides) and arithmetic (AR 0 = f16x2 split,
+// 1 = exact fp32 MFMA); ks_rollout / ks_pitraj also per workgroup geometry.
 #ifndef TDMPC2_DEFAULT_THROUGHPUT_ST
 #define TDMPC2_DEFAULT_THROUGHPUT_ST 2  // sample tiles per workgroup when a call has enough plans to fill the chip
 #endif
+#define FUSED_DISPATCH(APAD_VALUE, AR_VALUE, CALL) \
+    switch (APAD_VALUE) {                          \
+        case 16: if (AR_VALUE) { CALL(16, 1) } else { CALL(16, 0) } break; \
+        case 32: if (AR_VALUE) { CALL(32, 1) } else { CALL(32, 0) } break; \
+        case 48: if (AR_VALUE) { CALL(48, 1) } else { CALL(48, 0) } break; \
+        default: if (AR_VALUE) { CALL(64, 1) } else { CALL(64, 0) } break; \
+    }
 template <class NET> struct Kern;
-template <> struct Kern<NetW> {
-    static int sample_tiles(const tdmpc2_plan *, int, bool) { return 2; }
-    static int waves(const tdmpc2_plan *, int, int) { return 8; }
-    static void setup(const SetupParamsT<NetW> &p, int E, size_t lds, hipStream_t st) { hipLaunchKernelGGL(k_setup, dim3(E), dim3(NTHREADS), lds, st, p); }
-    static void pitraj(const PiTrajParamsT<NetW> &p, int E, size_t lds, hipStream_t st) { hipLaunchKernelGGL(k_pitraj, dim3(E), dim3(NTHREADS), lds, st, p); }
-    static void rollout(const RolloutParamsT<NetW> &p, int grid, size_t lds, hipStream_t st, int, int) { hipLaunchKernelGGL(k_rollout, dim3(grid), dim3(NTHREADS), lds, st, p); }
-};
-#define SPLIT_DISPATCH(KERNEL, APAD, GRID)                                                                       \
-    switch (APAD) {                                                                                                \
-        case 16: hipLaunchKernelGGL(KERNEL<16>, dim3(GRID), dim3(NTHREADS), lds, st, p); break;                   \
-        case 32: hipLaunchKernelGGL(KERNEL<32>, dim3(GRID), dim3(NTHREADS), lds, st, p); break;                   \
-        case 48: hipLaunchKernelGGL(KERNEL<48>, dim3(GRID), dim3(NTHREADS), lds, st, p); break;                   \
-        default: hipLaunchKernelGGL(KERNEL<64>, dim3(GRID), dim3(NTHREADS), lds, st, p); break;                   \
-    }
-#define SPLIT_DISPATCH_ST(APAD, ST, NW, GRID)                                                                    \
-    switch (APAD) {                                                                                                \
-        case 16: hipLaunchKernelGGL((ks_rollout<16, ST, NW>), dim3(GRID), dim3(64 * NW), lds, st, p); break;      \
-        case 32: hipLaunchKernelGGL((ks_rollout<32, ST, NW>), dim3(GRID), dim3(64 * NW), lds, st, p); break;      \
-        case 48: hipLaunchKernelGGL((ks_rollout<48, ST, NW>), dim3(GRID), dim3(64 * NW), lds, st, p); break;      \
-        default: hipLaunchKernelGGL((ks_rollout<64, ST, NW>), dim3(GRID), dim3(64 * NW), lds, st, p); break;      \
-    }
-template <> struct Kern<NetS> {  // the split kernels are instantiated per action padding (compile-time LDS strides)
+template <> struct Kern<NetS> {
     // 32-row workgroups (twice as many) when a call brings too few plans to occupy the chip: single-env latency
     static int sample_tiles(const tdmpc2_plan *h, int E, bool tracing) {
         if (tracing) return 2;  // the activation trace is laid out per 64-row tile
@@ -1066,29 +506,41 @@ template <> struct Kern<NetS> {  // the split kernels are instantiated per actio
     // 5.83 vs 4.88 ms per launch: each weight fragment then feeds one row tile, the k-loop needs 85 B/clk/CU of
     // fragment loads and becomes L1-bound.
     static int waves(const tdmpc2_plan *, int, int) { return 8; }
-    static void setup(const SetupParamsT<NetS> &p, int E, size_t lds, hipStream_t st) { SPLIT_DISPATCH(ks_setup, (p.stride - 8) / 2 - WIDTH, E) }
-    static void pitraj(const PiTrajParamsT<NetS> &p, int E, size_t lds, hipStream_t st) {
+    static void setup(const tdmpc2_plan *h, const SetupParamsT<NetS> &p, int E, hipStream_t st) {
+        const size_t lds = h->lds_bytes;
+        const int ar = h->split ? 0 : 1;
+#define CALL_SETUP(AP, AR) hipLaunchKernelGGL((ks_setup<AP, AR>), dim3(E), dim3(NTHREADS), lds, st, p);
+        FUSED_DISPATCH(h->Apad, ar, CALL_SETUP)
+#undef CALL_SETUP
+    }
+    static void pitraj(const tdmpc2_plan *h, const PiTrajParamsT<NetS> &p, int E, hipStream_t st) {
+        const int ar = h->split ? 0 : 1;
         if (p.P <= 32) {  // one 32-row tile holds the policy-prior trajectories (the reference uses 24)
-            lds -= (size_t)32 * p.stride * 2;
-            switch (p.Apad) {
-                case 16: hipLaunchKernelGGL((ks_pitraj<16, 1>), dim3(E), dim3(NTHREADS), lds, st, p); break;
-                case 32: hipLaunchKernelGGL((ks_pitraj<32, 1>), dim3(E), dim3(NTHREADS), lds, st, p); break;
-                case 48: hipLaunchKernelGGL((ks_pitraj<48, 1>), dim3(E), dim3(NTHREADS), lds, st, p); break;
-                default: hipLaunchKernelGGL((ks_pitraj<64, 1>), dim3(E), dim3(NTHREADS), lds, st, p); break;
-            }
+            const size_t lds = h->lds_bytes - (size_t)32 * h->row_bytes;
+#define CALL_PITRAJ1(AP, AR) hipLaunchKernelGGL((ks_pitraj<AP, 1, AR>), dim3(E), dim3(NTHREADS), lds, st, p);
+            FUSED_DISPATCH(h->Apad, ar, CALL_PITRAJ1)
+#undef CALL_PITRAJ1
         } else {
-            switch (p.Apad) {
-                case 16: hipLaunchKernelGGL((ks_pitraj<16, 2>), dim3(E), dim3(NTHREADS), lds, st, p); break;
-                case 32: hipLaunchKernelGGL((ks_pitraj<32, 2>), dim3(E), dim3(NTHREADS), lds, st, p); break;
-                case 48: hipLaunchKernelGGL((ks_pitraj<48, 2>), dim3(E), dim3(NTHREADS), lds, st, p); break;
-                default: hipLaunchKernelGGL((ks_pitraj<64, 2>), dim3(E), dim3(NTHREADS), lds, st, p); break;
-            }
+            const size_t lds = h->lds_bytes;
+#define CALL_PITRAJ2(AP, AR) hipLaunchKernelGGL((ks_pitraj<AP, 2, AR>), dim3(E), dim3(NTHREADS), lds, st, p);
+            FUSED_DISPATCH(h->Apad, ar, CALL_PITRAJ2)
+#undef CALL_PITRAJ2
         }
     }
-    static void rollout(const RolloutParamsT<NetS> &p, int grid, size_t lds, hipStream_t st, int nst, int nw) {
+    static void rollout(const tdmpc2_plan *h, const RolloutParamsT<NetS> &p, int grid, hipStream_t st, int nst, int nw) {
         (void)nw;
-        if (nst == 2) { SPLIT_DISPATCH_ST(p.Apad, 2, 8, grid) }
-        else { SPLIT_DISPATCH_ST(p.Apad, 1, 8, grid) }
+        const int ar = h->split ? 0 : 1;
+        if (nst == 2) {
+            const size_t lds = h->lds_bytes;
+#define CALL_ROLL2(AP, AR) hipLaunchKernelGGL((ks_rollout<AP, 2, 8, AR>), dim3(grid), dim3(NTHREADS), lds, st, p);
+            FUSED_DISPATCH(h->Apad, ar, CALL_ROLL2)
+#undef CALL_ROLL2
+        } else {
+            const size_t lds = h->lds_bytes - (size_t)32 * h->row_bytes;
+#define CALL_ROLL1(AP, AR) hipLaunchKernelGGL((ks_rollout<AP, 1, 8, AR>), dim3(grid), dim3(NTHREADS), lds, st, p);
+            FUSED_DISPATCH(h->Apad, ar, CALL_ROLL1)
+#undef CALL_ROLL1
+        }
     }
 };
 
@@ -1104,7 +556,7 @@ int launch_setup(tdmpc2_plan *h, int E, const float *z0, const float *task_emb, 
     for (int i = 0; i < h->cfg.num_q; ++i) p.wemb[BE_Q0 + i] = h->q[i].l[0].wemb;
     p.z0 = z0; p.task_emb = task_emb; p.prev_mean = prev_mean; p.t0 = t0;
     p.beff = h->beff; p.cvec = h->cvec; p.mean = h->mean; p.std = h->std;
-    Kern<NET>::setup(p, E, h->lds_bytes, st);
+    Kern<NET>::setup(h, p, E, st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1149,7 +601,7 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
         p.z0 = z0; p.beff = h->beff; p.act_mask = act_mask; p.pi_traj_eps = tape ? tape->pi_traj_eps : nullptr;
         p.seed = seed; p.call = call; p.actions = h->actions; p.zscratch = h->zscratch;
         p.zscratch_estride = (long)h->tiles * ROWS * WIDTH;
-        Kern<NET>::pitraj(p, E, h->lds_bytes, st);
+        Kern<NET>::pitraj(h, p, E, st);
         HIP_TRY(hipGetLastError());
     }
     RolloutParamsT<NET> rp{};
@@ -1157,7 +609,6 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
     rp.z0 = z0; rp.act_mask = act_mask; rp.disc_pow = disc_pow; rp.seed = seed; rp.call = call; rp.given_actions = 0;
     const int nst = Kern<NET>::sample_tiles(h, E, false), nw = Kern<NET>::waves(h, E, nst);
     rp.tiles = h->tiles * (2 / nst);
-    const size_t roll_lds = nst == 2 ? h->lds_bytes : h->lds_bytes - (size_t)32 * h->stride * 2;
     const size_t refit_lds = ((size_t)N + 3 * K + 2 * H * A) * 4 + 64;
     for (int it = 0; it < I; ++it) {
         rp.iter = it;
@@ -1170,7 +621,7 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
             rp.qidx_estride = (long)I * 2;
         }
         if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
-        Kern<NET>::rollout(rp, E * rp.tiles, roll_lds, st, nst, nw);
+        Kern<NET>::rollout(h, rp, E * rp.tiles, st, nst, nw);
         HIP_TRY(hipGetLastError());
         if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) {
             HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
@@ -1220,7 +671,7 @@ int fused_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0,
     rp.trace_tiles = trace_tiles; rp.trace_scalars = trace_scalars;
     const int nst = Kern<NET>::sample_tiles(h, E, trace_tiles != nullptr), nw = Kern<NET>::waves(h, E, nst);
     rp.tiles = h->tiles * (2 / nst);
-    Kern<NET>::rollout(rp, E * rp.tiles, nst == 2 ? h->lds_bytes : h->lds_bytes - (size_t)32 * h->stride * 2, st, nst, nw);
+    Kern<NET>::rollout(h, rp, E * rp.tiles, st, nst, nw);
     HIP_TRY(hipGetLastError());
     return TDMPC2_OK;
 }
@@ -1279,7 +730,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
     h->cfg.precision = prec;
     h->lay.on = (path == TDMPC2_PATH_LAYERED);
     h->split = (prec == TDMPC2_PREC_SPLIT_F16);
-    h->Apad = h->split ? (c.action_dim + 15) / 16 * 16 : (c.action_dim + 7) / 8 * 8;
+    h->Apad = (c.action_dim + 15) / 16 * 16;  // the fused kernels are instantiated for action paddings 16 / 32 / 48 / 64
     h->tiles = c.num_samples / ROWS;
     h->nnets = BE_Q0 + c.num_q;
     int rc = 0;
@@ -1289,13 +740,13 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             // operand form: row = [hi: SH halfs | lo: SH halfs | 8 pad]; row stride in dwords SH + 4 = 4 x odd
             const int SH = WIDTH + h->Apad;
             h->stride = 2 * SH + 8;  // in halfs
-            h->lds_bytes = (size_t)ROWS * h->stride * 2 + 4096 /* LayerNorm partials */ + (size_t)2 * c.horizon * c.action_dim * 4 + 64;
+            h->row_bytes = (size_t)h->stride * 2;
         } else {
-            // row stride: [z (512) | a (Apad) | pad] with stride/4 odd: conflict-free ds_read_b128 across 16 rows
-            h->stride = WIDTH + h->Apad + 4;
-            if ((h->stride / 4) % 2 == 0) h->stride += 4;
-            h->lds_bytes = (size_t)ROWS * h->stride * 4 + (size_t)2 * c.horizon * c.action_dim * 4 + 64;
+            // fp32 rows [z (512) | a (Apad) | 4 pad]: stride / 4 odd -> conflict-free ds_read_b128 across 16 rows
+            h->stride = WIDTH + h->Apad + 4;  // in floats
+            h->row_bytes = (size_t)h->stride * 4;
         }
+        h->lds_bytes = (size_t)ROWS * h->row_bytes + 4096 /* LayerNorm partials */ + (size_t)2 * c.horizon * c.action_dim * 4 + 64;
         if (h->lds_bytes > 160 * 1024) {
             const size_t need = h->lds_bytes;
             delete h;
@@ -1352,21 +803,24 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
         tdmpc2_plan_destroy(h);
         return fail(TDMPC2_ERR_HIP, "hipMemcpy(bins) failed");
     }
-    if (!h->lay.on && !h->split && ((rc = set_lds(k_setup, h->lds_bytes)) || (rc = set_lds(k_pitraj, h->lds_bytes)) ||
-                                    (rc = set_lds(k_rollout, h->lds_bytes)))) {
-        tdmpc2_plan_destroy(h);
-        return rc;
-    }
-    if (h->split) {
-        switch (h->Apad) {
-            case 16: rc = set_lds(ks_setup<16>, h->lds_bytes) || set_lds(ks_pitraj<16, 2>, h->lds_bytes) || set_lds(ks_pitraj<16, 1>, h->lds_bytes) || set_lds(ks_rollout<16, 2, 8>, h->lds_bytes) || set_lds(ks_rollout<16, 1, 8>, h->lds_bytes); break;
-            case 32: rc = set_lds(ks_setup<32>, h->lds_bytes) || set_lds(ks_pitraj<32, 2>, h->lds_bytes) || set_lds(ks_pitraj<32, 1>, h->lds_bytes) || set_lds(ks_rollout<32, 2, 8>, h->lds_bytes) || set_lds(ks_rollout<32, 1, 8>, h->lds_bytes); break;
-            case 48: rc = set_lds(ks_setup<48>, h->lds_bytes) || set_lds(ks_pitraj<48, 2>, h->lds_bytes) || set_lds(ks_pitraj<48, 1>, h->lds_bytes) || set_lds(ks_rollout<48, 2, 8>, h->lds_bytes) || set_lds(ks_rollout<48, 1, 8>, h->lds_bytes); break;
-            default: rc = set_lds(ks_setup<64>, h->lds_bytes) || set_lds(ks_pitraj<64, 2>, h->lds_bytes) || set_lds(ks_pitraj<64, 1>, h->lds_bytes) || set_lds(ks_rollout<64, 2, 8>, h->lds_bytes) || set_lds(ks_rollout<64, 1, 8>, h->lds_bytes); break;
-        }
+    if (!h->lay.on) {
+        const int ar = h->split ? 0 : 1;
+#define CALL_SETLDS(AP, AR)                                                                                          \
+    rc = set_lds(ks_setup<AP, AR>, h->lds_bytes) || set_lds(ks_pitraj<AP, 2, AR>, h->lds_bytes) ||                   \
+         set_lds(ks_pitraj<AP, 1, AR>, h->lds_bytes) || set_lds(ks_rollout<AP, 2, 8, AR>, h->lds_bytes) ||            \
+         set_lds(ks_rollout<AP, 1, 8, AR>, h->lds_bytes);
+        FUSED_DISPATCH(h->Apad, ar, CALL_SETLDS)
+#undef CALL_SETLDS
         if (rc) {
             tdmpc2_plan_destroy(h);
             return TDMPC2_ERR_HIP;
+        }
+        if (!h->split) {  // output scale of the exact arithmetic
+            const float one = 1.f;
+            if ((rc = dev_alloc(h, (void **)&h->one, 4)) || hipMemcpy(h->one, &one, 4, hipMemcpyHostToDevice) != hipSuccess) {
+                tdmpc2_plan_destroy(h);
+                return fail(TDMPC2_ERR_HIP, "allocating the unit output scale failed");
+            }
         }
     }
     if (getenv("TDMPC2_TIMING")) {
@@ -1431,9 +885,8 @@ int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *
     const int nz = (layer == 0) ? c.latent_dim : c.mlp_dim;
     const int nt = (layer == 0) ? c.task_dim : 0;
     const int na = (layer == 0 && takes_action) ? c.action_dim : 0;
-    // packed contraction length: FUSED pads the action columns to a multiple of 8 (one k-block), LAYERED pads the
-    // whole row to a multiple of the GEMM k-chunk
-    const int Kp = h->lay.on ? (int)round_up((size_t)nz + na, GBK) : h->split ? nz + (na + 15) / 16 * 16 : nz + (na + 7) / 8 * 8;  // GBK = 32 is a multiple of both block sizes
+    // packed contraction length: the fused kernels pad the action columns to 16, the layered GEMMs the whole row to GBK
+    const int Kp = h->lay.on ? (int)round_up((size_t)nz + na, GBK) : nz + (na + 15) / 16 * 16;
     const int KB = h->split ? Kp / 16 : Kp / 8;
     const int CT = (out_features + 31) / 32;
     // one slab per tensor kind holding all ensemble members at a constant stride (the layered GEMM selects a member
@@ -1463,6 +916,7 @@ int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *
                 L.maxbits = reinterpret_cast<unsigned int *>(sslab + hd * 4 + 2);
             } else {
                 L.wp = wslab + hd * wsz;
+                L.oscale = h->one;  // null on the layered fp32 path, which has no output scale
             }
             L.bias = bslab + hd * bsz;
             L.g = has_ln ? gslab + hd * gsz : nullptr;
@@ -1549,9 +1003,7 @@ int tdmpc2_plan_run(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *
     hipStream_t st = (hipStream_t)stream;
     if (h->lay.on)
         return lay_run(h, st, n_envs, z0, task_emb, act_mask, disc_pow, prev_mean, t0, eval_mode, tape, seed, action, dbg);
-    if (h->split)
-        return fused_run<NetS>(h, st, n_envs, z0, task_emb, act_mask, disc_pow, prev_mean, t0, eval_mode, tape, seed, action, dbg);
-    return fused_run<NetW>(h, st, n_envs, z0, task_emb, act_mask, disc_pow, prev_mean, t0, eval_mode, tape, seed, action, dbg);
+    return fused_run<NetS>(h, st, n_envs, z0, task_emb, act_mask, disc_pow, prev_mean, t0, eval_mode, tape, seed, action, dbg);
 }
 
 int tdmpc2_plan_estimate_value(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *task_emb,
@@ -1581,10 +1033,7 @@ int tdmpc2_plan_estimate_value_trace(tdmpc2_plan_t *h, int n_envs, const float *
         return lay_estimate_value(h, st, E, z0, act_mask, disc_pow, actions, pi_eps, (long)N * A, h->lay.qidx, 0, 0, 0, value,
                                   trace_scalars);
     }
-    if (h->split)
-        return fused_estimate_value<NetS>(h, st, E, z0, task_emb, act_mask, disc_pow, actions, pi_eps, qidx, value, trace_tiles,
-                                          trace_scalars);
-    return fused_estimate_value<NetW>(h, st, E, z0, task_emb, act_mask, disc_pow, actions, pi_eps, qidx, value, trace_tiles,
+    return fused_estimate_value<NetS>(h, st, E, z0, task_emb, act_mask, disc_pow, actions, pi_eps, qidx, value, trace_tiles,
                                       trace_scalars);
 }
 
