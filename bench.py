@@ -306,7 +306,7 @@ def main():
     launch_s = (roll_ms / 1e3) / max(roll_n, 1)
     achieved = flops_rollout_launch(cfg, E) / launch_s / 1e12
     split = planner.precision == 2
-    kernel = (("ks_rollout" if split else "k_rollout") if family == "fused"
+    kernel = ("ks_rollout" if family == "fused"
               else ("g_gemm_s" if split else "g_gemm") + " + row kernels of one _estimate_value")
     traffic, traffic_src = pmc_traffic(E * cfg.num_samples // 64, kernel) if family == "fused" else (None, None)
     peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS

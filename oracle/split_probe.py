@@ -5,7 +5,7 @@
 Each fp32 product of every nn.Linear in `_estimate_value` is replaced by an emulation of a split-precision
 matrix-pipe scheme (operands rounded to f16 / bf16 pieces exactly as the HIP kernels do, partial products
 accumulated in fp32 by torch's sgemm) and the resulting trajectory values are compared with an fp64
-evaluation of the same network.  This is how the f16x2-split mode of `fused_split.cuh` was chosen:
+evaluation of the same network.  This is how the f16x2-split mode of `fused_kernels.cuh` was chosen:
 
     fp32        plain torch fp32                                   error vs fp64 ~ 4e-6 (c1)
     f16x2_3     x = hi + lo in f16, 3 products (hh, hl, lh)        ~ 4e-6   <- same class as fp32: CHOSEN

@@ -1,5 +1,7 @@
-// Fused 512-wide planner kernels on the f16 matrix pipe with fp32-class accuracy ("f16x2 split").
+// Fused 512-wide planner kernels: the f16 matrix pipe with fp32-class accuracy ("f16x2 split", ARITH 0, the default)
+// and exact fp32 MFMA (ARITH 1) share every phase; only the contraction loops and the LDS tile form differ.
 //
+// The f16x2 split:
 // Every fp32 operand x is carried as two f16 pieces, x ~ hi + lo with hi = f16(x), lo = f16(x - hi): 22 significand
 // bits.  A product a.b is formed from THREE v_mfma_f32_32x32x16_f16 instructions
 //         a_hi.b_hi + a_hi.b_lo + a_lo.b_hi                       (the dropped a_lo.b_lo term is ~2^-22 relative)
@@ -10,8 +12,9 @@
 // each weight matrix by 2^kw with max|W| 2^kw in [2^13, 2^14) (k_wscale); the fp32 accumulator is multiplied back by
 // the exact 2^-(kw+5) in the epilogue.
 //
-// Same phase structure, work savings and reference citations as k_rollout / k_pitraj / k_setup in tdmpc2_plan.hip.
-// What differs: the LDS tile is in operand form (per row [hi plane | lo plane], f16, compile-time strides); the MFMAs
+// Structure (reference: TDMPC2._plan / _estimate_value, tdmpc2/tdmpc2.py:122-206; WorldModel.next / reward / pi / Q,
+// tdmpc2/common/world_model.py:114-216; NormedLinear / SimNorm, tdmpc2/common/layers.py:74-118; math.py:12-94):
+// the LDS tile is in operand form (per row [hi plane | lo plane], f16, compile-time strides); the MFMAs
 // are issued with the weight fragment as the A operand so that each lane's accumulators belong to its own two sample
 // rows, which makes the LayerNorm / activation / hi-lo-split epilogue register resident (no fp32 staging pass, two
 // barriers per layer); weight fragments are prefetched through a register ring whose issue order is pinned with

@@ -1,4 +1,4 @@
-// f16x2-split arithmetic (see fused_split.cuh) for the layer-at-a-time family: the 19M / 48M / 317M world models.
+// f16x2-split arithmetic (see fused_kernels.cuh) for the layer-at-a-time family: the 19M / 48M / 317M world models.
 //
 // Activations that feed a GEMM are stored in HBM in OPERAND FORM: a row of `ld` columns occupies the same ld * 4
 // bytes as an fp32 row, laid out [hi: ld halfs | lo: ld halfs] with hi = f16(32 x), lo = f16(32 x - hi).  The row
@@ -8,7 +8,7 @@
 // g_gemm_s: 128 x 128 output tile per 256-thread workgroup; wave w owns the 32 output columns [32 w, 32 w + 32) for all
 // 128 rows (4 row tiles x 1 column tile): every weight fragment (2 KB per k16-block, from L2) feeds 12 MFMAs and the
 // row fragments come from LDS (8 ds_read_b128 per block) -- weight bytes per MFMA are half of the fused kernel's.
-// Included by tdmpc2_plan.hip inside its anonymous namespace, after fused_split.cuh and layered_kernels.cuh.
+// Included by tdmpc2_plan.hip inside its anonymous namespace, after fused_kernels.cuh and layered_kernels.cuh.
 #pragma once
 
 constexpr int GS_LDH = GBK + 8;  // LDS row stride of one plane in halfs: 80 B = 20 dwords = 4 x odd -> conflict-free b128
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     const int KB = p.K / 16;
     const int ct = cb * 4 + wave;
     const bool valid = ct < p.CT;
-    // weight fragments: wave-uniform byte pointer + opaque 32-bit lane offset (see fused_split.cuh)
+    // weight fragments: wave-uniform byte pointer + opaque 32-bit lane offset (see fused_kernels.cuh)
     const char *u = reinterpret_cast<const char *>(p.wp + (size_t)sel * p.w_sel_stride) + (size_t)(valid ? ct : p.CT - 1) * KB * 2048;
     unsigned voff = (unsigned)lane * 16u;
     asm volatile("" : "+v"(voff));

@@ -7,28 +7,17 @@
 //   NormedLinear / SimNorm                 tdmpc2/common/layers.py:74-118
 //   two_hot_inv / symexp / log_std / gumbel_softmax_sample   tdmpc2/common/math.py
 //
-// This file: the C ABI, the handle, weight packing, the elite-refit kernel shared by every path, and the exact-fp32
-// fused kernels (k_setup / k_pitraj / k_rollout, v_mfma_f32_32x32x2_f32).  fused_split.cuh holds the same fused
-// kernels in the f16x2-split arithmetic (default), layered_kernels.cuh / layered_split.cuh / layered_host.cuh the
-// layer-at-a-time family for every other model size and for episodic planning.
-//
-// Design of the fused exact-fp32 kernels (see DESIGN.md for the full account):
-//   * One persistent "rollout" workgroup owns 64 sample rows of one plan for a
-//     whole CEM iteration: the H-step latent rollout (reward + dynamics MLPs),
-//     the policy prior and the two selected Q heads.  Activations never leave
-//     the CU: the current layer's input [64 x 512(+A)] fp32 lives in LDS, the
-//     layer's output accumulates in MFMA accumulators (v_mfma_f32_32x32x2_f32,
-//     exact fp32), LayerNorm/Mish/SimNorm/two-hot run on the tile in place.
-//   * Weights are re-packed once (bind) into MFMA B-fragment order so that a
-//     wave's global_load_dwordx4 reads 1 KiB contiguous; each workgroup streams
-//     every layer exactly once per use (32 FLOP per weight byte), from L2/MALL.
-//   * Reward and dynamics share their first-layer input, so both first layers
-//     are computed in one pass over the LDS tile (two accumulator sets); the
-//     same trick is used for the two Q heads.  At t = 0 every row shares z0, so
-//     the z-part of both first layers is computed once per plan (setup kernel)
-//     and only the action columns are contracted per row.
-//   * One small workgroup per plan does nan_to_num + top-k + score + mean/std
-//     refit (+ the final Gumbel pick) between rollout launches.
+// This file: the C ABI, the handle, weight packing, the elite-refit kernel shared by every path, and the host side of
+// the fused family.  Kernels:
+//   fused_kernels.cuh    fused 512-wide family (ks_setup / ks_pitraj / ks_rollout): one persistent workgroup keeps 32 or
+//                        64 sample rows of one plan in LDS for a whole CEM iteration; templated on the arithmetic
+//                        (f16x2 split on the f16 matrix pipe -- the default -- or exact fp32 MFMA), the action padding
+//                        and the workgroup geometry
+//   layered_kernels.cuh, layered_split.cuh, layered_host.cuh
+//                        layer-at-a-time family for every other model size and for episodic planning
+// Weights are re-packed once (bind) into MFMA fragment order so that a wave's global_load_dwordx4 reads 1 KiB
+// contiguous; one small workgroup per plan does nan_to_num + top-k + score + mean/std refit (+ the final Gumbel pick)
+// between rollout launches (k_refit below).  DESIGN.md has the full account.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -55,7 +44,7 @@ constexpr int MAXQ = 8;
 constexpr int MAXH = 8;
 constexpr float LN_EPS = 1e-5f;
 
-// ---------------------------------------------------------------- kernel parameter blocks (NET = NetS, fused_split.cuh)
+// ---------------------------------------------------------------- kernel parameter blocks (NET = NetS, fused_kernels.cuh)
 template <class NET>
 struct RolloutParamsT {
     int E, N, H, A, Apad, P, stride, tiles, nq, num_bins, multitask, given_actions, iter, iters_total;
@@ -362,7 +351,7 @@ __global__ void k_copy_pad(const float *src, int n, int npad, float *dst) {
         dst[idx] = idx < n ? src[idx] : 0.f;
 }
 
-#include "fused_split.cuh"
+#include "fused_kernels.cuh"
 #include "layered_kernels.cuh"
 #include "layered_split.cuh"
 
@@ -385,7 +374,7 @@ int fail(int code, const char *fmt, ...) {
 
 struct HostLayer {
     float *wp = nullptr, *bias = nullptr, *g = nullptr, *b = nullptr, *wemb = nullptr;
-    // f16x2-split form (fused_split.cuh): hi/lo packed weights, per-matrix power-of-two scales (device scalars)
+    // f16x2-split form (fused_kernels.cuh): hi/lo packed weights, per-matrix power-of-two scales (device scalars)
     _Float16 *wps = nullptr;
     float *wscale = nullptr, *oscale = nullptr;
     unsigned int *maxbits = nullptr;
@@ -412,7 +401,7 @@ struct Layered {
 struct tdmpc2_plan {
     tdmpc2_plan_cfg cfg;
     Layered lay;
-    bool split = false;  // fused kernels on the f16 matrix pipe with hi/lo operand split (fused_split.cuh)
+    bool split = false;  // fused kernels on the f16 matrix pipe with hi/lo operand split (fused_kernels.cuh)
     int force_rows = 0;  // TDMPC2_TUNE_ROWS_PER_WORKGROUP: 0 auto, 32, 64
     size_t row_bytes = 0;  // bytes of one sample row of the fused kernels' LDS tile
     float *one = nullptr;  // device scalar 1.0f: the output scale of the exact-fp32 arithmetic

@@ -1,4 +1,4 @@
-"""CPU: the arithmetic of the f16x2-split MFMA mode (fused_split.cuh), emulated on the oracle network with the
+"""CPU: the arithmetic of the f16x2-split MFMA mode (fused_kernels.cuh), emulated on the oracle network with the
 kernels' operand scaling, is in the fp32 round-off class; the cheaper bf16x2 split is not (why it was rejected)."""
 import pytest
 
