@@ -308,7 +308,8 @@ def main():
     split = planner.precision == 2
     kernel = ("ks_rollout" if family == "fused"
               else ("g_gemm_s" if split else "g_gemm") + " + row kernels of one _estimate_value")
-    traffic, traffic_src = pmc_traffic(E * cfg.num_samples // 64, kernel) if family == "fused" else (None, None)
+    # the committed PMC passes are of the default (split-arithmetic) rollout kernel at 64 rows per workgroup
+    traffic, traffic_src = pmc_traffic(E * cfg.num_samples // 64, kernel) if (family == "fused" and split) else (None, None)
     peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
     line = {
         "metric": "plan() calls/sec (H=3, 512 samples, 6 iters)",
