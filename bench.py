@@ -99,6 +99,34 @@ def action_mse_vs_reference(device, path, prec):
                     f"({E} envs x {c['iterations']} CEM iterations)"}
 
 
+def torch_eager_gpu_baseline(cfg, iterations, sd_np, device, n_plans=5):
+    """The same restatement of the reference's planner math, run as stock PyTorch-ROCm eager ops on the SAME MI355X
+    (what `python evaluate.py compile=false` does with the reference): a reported reference point, like cpu_baseline."""
+    from oracle import planner_oracle as po
+
+    model = po.OracleModel(cfg, {k: torch.as_tensor(v) for k, v in sd_np.items()}, device=device)
+    z0 = torch.as_tensor(synth.make_latents(cfg, 1, seed=1)).to(device)
+    tape = {k: v.to(device) for k, v in po.env_tape(synth.make_noise_tape(cfg, 1, iterations, seed=2), 0).items()}
+    disc = get_discount(cfg, cfg.episode_length)
+    prev = torch.zeros(cfg.horizon, cfg.action_dim, device=device)
+    task = 0 if cfg.multitask else None
+    disc = torch.tensor(disc, device=device) if cfg.multitask else disc
+    with torch.no_grad():
+        for _ in range(2):
+            a, prev, _ = po.plan(model, z0=z0, tape=tape, prev_mean=prev, t0=False, eval_mode=False, task=task, discount=disc,
+                                 iterations=iterations)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(n_plans):
+            a, prev, _ = po.plan(model, z0=z0, tape=tape, prev_mean=prev, t0=False, eval_mode=False, task=task, discount=disc,
+                                 iterations=iterations)
+        torch.cuda.synchronize(device)
+        el = time.perf_counter() - t0
+    return {"value": round(n_plans / el, 2), "unit": "plans/s", "ms_per_plan": round(1e3 * el / n_plans, 2),
+            "what": f"oracle restatement of the reference planner as PyTorch-ROCm {torch.__version__} eager ops on this GPU, "
+                    f"1 env, {n_plans} sequential plans"}
+
+
 def cpu_baseline(cfg, iterations, sd_np, budget_s=12.0):
     """The oracle (= the reference's planner math as plain torch CPU ops) timed on this box's host cores
     on a bounded sample of the same workload.  Test infrastructure used as a reported baseline only."""
@@ -353,6 +381,10 @@ def main():
         "extra": extra,
     }
     if world == 1 and not args.skip_cpu_baseline:
+        try:
+            line["extra"]["torch_rocm_eager_same_gpu"] = torch_eager_gpu_baseline(cfg, I, sd_np, device)
+        except Exception as ex:
+            line["extra"]["torch_rocm_eager_same_gpu"] = {"error": repr(ex)}
         try:
             line["cpu_baseline"] = cpu_baseline(cfg, I, sd_np, args.cpu_budget)
         except Exception as ex:  # the baseline is a reported number, never a reason to lose the measurement

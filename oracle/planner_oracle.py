@@ -81,7 +81,7 @@ def two_hot_inv(x, cfg):
         return x
     if cfg.num_bins == 1:
         return symexp(x)
-    bins = torch.linspace(cfg.vmin, cfg.vmax, cfg.num_bins, dtype=x.dtype)
+    bins = torch.linspace(cfg.vmin, cfg.vmax, cfg.num_bins, dtype=x.dtype, device=x.device)
     x = F.softmax(x, dim=-1)
     x = torch.sum(x * bins, dim=-1, keepdim=True)
     return symexp(x)
@@ -98,11 +98,15 @@ class OracleModel:
     (tdmpc2/common/world_model.py:88-216) over a state dict in the reference's
     checkpoint key layout."""
 
-    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], dtype=torch.float32):
+    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], dtype=torch.float32, device=None):
+        """`device` (default: where the tensors are, i.e. CPU) lets bench.py time the same restatement as stock
+        PyTorch-ROCm eager ops on the GPU."""
         self.cfg = cfg
         self.dtype = dtype
         self.sd = {k: (v.to(dtype) if torch.is_tensor(v) and v.is_floating_point() else v)
                    for k, v in state_dict.items() if torch.is_tensor(v)}
+        if device is not None:
+            self.sd = {k: v.to(device) for k, v in self.sd.items()}
 
     def task_emb(self, x, task: int):
         """world_model.py:88-101; nn.Embedding(max_norm=1) (world_model.py:21)
@@ -168,7 +172,7 @@ def estimate_value(model: OracleModel, z, actions, task, discount, pi_eps, qidx)
     or the 0-dim fp32 tensor discount[task] (multitask)."""
     cfg = model.cfg
     G, disc = 0, 1
-    termination = torch.zeros(cfg.num_samples, 1, dtype=z.dtype)
+    termination = torch.zeros(cfg.num_samples, 1, dtype=z.dtype, device=z.device)
     for t in range(cfg.horizon):
         reward = two_hot_inv(model.reward(z, actions[t], task), cfg)
         z = model.next(z, actions[t], task)
@@ -221,7 +225,7 @@ def plan(model: OracleModel, *, z0=None, obs=None, tape: Dict[str, torch.Tensor]
     z = model.encode(obs.to(dt), task) if z0 is None else z0.to(dt)
     mask = model.sd["_action_masks"][task].unsqueeze(0) if cfg.multitask else None
     # policy trajectories, tdmpc2.py:154-160
-    pi_actions = torch.empty(H, P, A, dtype=dt)
+    pi_actions = torch.empty(H, P, A, dtype=dt, device=z.device)
     if P > 0:
         _z = z.repeat(P, 1)
         for t in range(H - 1):
@@ -230,11 +234,11 @@ def plan(model: OracleModel, *, z0=None, obs=None, tape: Dict[str, torch.Tensor]
         pi_actions[-1] = model.pi(_z, task, tape["pi_traj_eps"][H - 1].to(dt))
     # init, tdmpc2.py:163-170
     z = z.repeat(N, 1)
-    mean = torch.zeros(H, A, dtype=dt)
-    std = torch.full((H, A), cfg.max_std, dtype=dt)
+    mean = torch.zeros(H, A, dtype=dt, device=z.device)
+    std = torch.full((H, A), cfg.max_std, dtype=dt, device=z.device)
     if not t0:
         mean[:-1] = prev_mean[1:].to(dt)
-    actions = torch.empty(H, N, A, dtype=dt)
+    actions = torch.empty(H, N, A, dtype=dt, device=z.device)
     if P > 0:
         actions[:, :P] = pi_actions
     stages = {"value": [], "elite_idx": [], "score": [], "mean": [], "std": [], "actions": []}
