@@ -43,6 +43,18 @@ def flops_rollout_launch(cfg, n_envs):
     return n_envs * 2 * cfg.num_samples * (cfg.horizon * (rew + dyn) + pi + cfg.num_q * rew)
 
 
+def flops_rollout_executed(cfg, n_envs, fused):
+    """FLOPs the kernels actually issue for the same launch: 2 of the num_q Q heads (the two the reference's
+    `Q(..., return_type='avg')` keeps, world_model.py:175-178, are drawn before the launch), and in the fused family
+    the z0 half of both first layers at t = 0 is computed once per environment instead of once per sample."""
+    dyn, rew, pi = per_row_macs(cfg)
+    per_row = cfg.horizon * (rew + dyn) + pi + 2 * rew
+    f = n_envs * 2 * cfg.num_samples * per_row
+    if fused:
+        f -= n_envs * 2 * (cfg.num_samples - 1) * 2 * (cfg.latent_dim + cfg.task_dim) * cfg.mlp_dim
+    return f
+
+
 def flops_plan(cfg, iterations):
     dyn, rew, pi = per_row_macs(cfg)
     pitraj = cfg.num_pi_trajs * (cfg.horizon * pi + (cfg.horizon - 1) * dyn)
@@ -316,11 +328,14 @@ def main():
             el = time.perf_counter() - t1
             ms, n = ex.profile_read()
             ach = flops_rollout_launch(cfg, E) / (ms / 1e3 / max(n, 1)) / 1e12
+            ach_x = flops_rollout_executed(cfg, E, family == "fused") / (ms / 1e3 / max(n, 1)) / 1e12
             extra["exact_fp32_mode"] = {
                 "value": round(3 * E / el, 2), "unit": "plans/s (this rank)", "steps": 3,
                 "arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32): bitwise an fmaf chain",
                 "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "avg_launch_ms": round(ms / max(n, 1), 4)}}
+                             "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "achieved_executed": round(ach_x, 2),
+                             "frac_executed": round(ach_x / FP32_MFMA_PEAK_TFLOPS, 4),
+                             "avg_launch_ms": round(ms / max(n, 1), 4)}}
             ex.close()
 
     if rank != 0:
@@ -333,6 +348,7 @@ def main():
     value = plans / elapsed
     launch_s = (roll_ms / 1e3) / max(roll_n, 1)
     achieved = flops_rollout_launch(cfg, E) / launch_s / 1e12
+    executed = flops_rollout_executed(cfg, E, family == "fused") / launch_s / 1e12
     split = planner.precision == 2
     kernel = ("ks_rollout" if family == "fused"
               else ("g_gemm_s" if split else "g_gemm") + " + row kernels of one _estimate_value")
@@ -363,13 +379,18 @@ def main():
         "roofline": {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic,
+            "achieved_executed": round(executed, 2),
+            "mfma_issue_executed": round(executed * (3 if split else 1), 2),
+            "frac_mfma_issue_executed": round(executed * (3 if split else 1) / peak, 4),
             "traffic_unit": "bytes per launch (HBM/fabric side of L2: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
             "traffic_source": traffic_src,
             "kernel": kernel,
             "launches_timed": roll_n, "avg_launch_ms": round(1e3 * launch_s, 4),
             "note": "achieved = ALGORITHMIC (as-written) FLOPs of one CEM iteration (all num_q Q heads, SURVEY 8(d)) x envs / "
                     "mean duration of that iteration's rollout stage (HIP events on the launch stream); the kernels "
-                    "execute fewer algorithmic FLOPs (2 of num_q heads; fused: shared z0 product at t=0)"
+                    "execute fewer algorithmic FLOPs (2 of num_q heads; fused: shared z0 product at t=0): achieved_executed; "
+                    "mfma_issue_executed = executed x MFMA products per algorithmic product, the figure to hold against "
+                    "the PMC matrix-pipe utilisation in profiles/"
                     + ("; peak = dense f16 MFMA; the f16x2-split arithmetic spends 3 MFMA FLOPs per algorithmic FLOP "
                        "(a_hi.b_hi + a_hi.b_lo + a_lo.b_hi, fp32 accumulate, fp32-class error), so the ceiling of this "
                        "arithmetic in algorithmic FLOPs is peak/3" if split else "; peak = fp32-input MFMA (exact fp32)"),
