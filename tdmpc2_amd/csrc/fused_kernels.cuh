@@ -25,17 +25,23 @@
 // In-kernel phase timers (profiling builds only: -DSPLIT_TIMING, see tools/ablate.sh): wave 0 of every workgroup sums
 // the shader-clock cycles it spends in each phase class into p.timing[class].
 #ifdef SPLIT_TIMING
-#define TIMER_FIELDS mutable unsigned long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; mutable unsigned long long t_last = 0, t_begin = 0;
+#define TIMER_FIELDS mutable unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; mutable unsigned long long t_last = 0, t_begin = 0;
 #define TIMER_START(c) { (c).t_last = (c).t_begin = __builtin_amdgcn_s_memtime(); }
-#define TIMER_MARK(c, cls) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); (c).t_acc[cls] += t_now - (c).t_last; (c).t_last = t_now; }
-#define TIMER_FLUSH(c, ptr) if ((ptr) && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) atomicAdd((ptr) + i_, (c).t_acc[i_]); atomicAdd((ptr) + 14, (c).t_last - (c).t_begin); atomicAdd((ptr) + 15, 1ull); }
+#define TIMER_MARK(c, cls) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); (c).t_acc[cls] += t_now - (c).t_last; (c).t_last = t_now; }
+// the wave whose clock is read: 0-3 are the first-dispatched (older) wave of their SIMD, 4-7 the younger one, which loses
+// the MFMA arbitration and is the critical path of every k-loop
+#ifndef SPLIT_TIMING_WAVE
+#define SPLIT_TIMING_WAVE 4
+#endif
+#define TIMER_FLUSH(c, ptr) if ((ptr) && threadIdx.x == 64 * SPLIT_TIMING_WAVE) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd((ptr) + i_, (c).t_acc[i_]); atomicAdd((ptr) + 14, (c).t_last - (c).t_begin); atomicAdd((ptr) + 15, 1ull); }
 #else
 #define TIMER_FIELDS
 #define TIMER_START(c)
 #define TIMER_MARK(c, cls)
 #define TIMER_FLUSH(c, ptr)
 #endif
-enum { T_KLOOP = 0, T_EPI = 1, T_HEAD = 2, T_ACT = 3, T_PARK = 4, T_TILE = 5, T_EPI_PRE = 6, T_EPI_SYNC = 7 };
+enum { T_KLOOP = 0, T_EPI = 1, T_HEAD = 2, T_ACT = 3, T_PARK = 4, T_TILE = 5, T_EPI_PRE = 6, T_EPI_SYNC = 7, T_EPI_BIAS = 8,
+       T_EPI_COMB = 9, T_EPI_MATH = 10 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -513,6 +519,7 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][CT::FT
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = fmaf(acc[st][ft][4 * m + r], osc, b4[m][r]);
     }
+    TIMER_MARK(c, T_EPI_BIAS)
     // per-wave partial statistics of the sample rows this lane works on
 #pragma unroll
     for (int st = 0; st < CT::NST; ++st) {
@@ -559,6 +566,7 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][CT::FT
         rstd[st] = 1.0f / sqrtf(msum * (1.0f / WIDTH) + LN_EPS);
         shift[st] = -mean * rstd[st];
     }
+    TIMER_MARK(c, T_EPI_COMB)
 #ifdef SPLIT_ABL_NO_EPI
     if (rstd[0] == 12345.f)  // never true: the activation math below is skipped
 #endif
@@ -606,6 +614,7 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][CT::FT
         }
     }
     regs_to_tile(c, acc);
+    TIMER_MARK(c, T_EPI_MATH)  // LayerNorm affine + activation + split + tile store (the compiler merges them)
     if (zcopy) park(c, acc, zcopy);
 }
 

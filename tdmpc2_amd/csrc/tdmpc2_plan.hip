@@ -824,9 +824,9 @@ void tdmpc2_plan_destroy(tdmpc2_plan_t *h) {
     if (h->timing) {  // in-kernel phase timers of a -DSPLIT_TIMING build (tools/ablate.sh)
         unsigned long long t[16];
         if (hipMemcpy(t, h->timing, sizeof t, hipMemcpyDeviceToHost) == hipSuccess && t[15] > 0) {
-            static const char *names[16] = {"kloop", "epi_post", "head", "actions", "park/unpark", "tile_from_global", "epi_pre", "epi_sync",
-                                            "", "", "", "", "", "", "total", "workgroups"};
-            fprintf(stderr, "[tdmpc2_plan timing max_envs=%d] mean cycles per workgroup (wave 0):", h->cfg.max_envs);
+            static const char *names[16] = {"kloop", "epi_post", "head", "actions", "park/unpark", "tile_from_global", "epi_stats", "epi_sync",
+                                            "epi_bias", "epi_combine", "epi_math_store", "", "", "", "total", "workgroups"};
+            fprintf(stderr, "[tdmpc2_plan timing max_envs=%d] mean cycles per workgroup (one wave, SPLIT_TIMING_WAVE):", h->cfg.max_envs);
             for (int i = 0; i < 15; ++i)
                 if (names[i][0]) fprintf(stderr, " %s=%.0f", names[i], (double)t[i] / (double)t[15]);
             fprintf(stderr, "\n");
