@@ -305,6 +305,28 @@ def main():
             one.plan(z1, d1, p1, warm[:1], seed=10 + i, out=o1, task_emb=e1, act_mask=m1)
         torch.cuda.synchronize(device)
         extra["latency_ms_single_env"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+        # the same from the observation on (WorldModel.encode in the library, tdmpc2_plan_run_obs): what one
+        # TDMPC2.act() costs on the device
+        try:
+            one.bind_encoder({k: v for k, v in sd.items() if k.startswith("_encoder.state.")})
+            ob = torch.as_tensor(synth.make_obs(cfg, 1, seed=3)).to(device)
+            for i in range(2):
+                one.plan_obs(ob, d1, p1, warm[:1], seed=i, out=o1, task_emb=e1, act_mask=m1)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for i in range(5):
+                one.plan_obs(ob, d1, p1, warm[:1], seed=20 + i, out=o1, task_emb=e1, act_mask=m1)
+            torch.cuda.synchronize(device)
+            extra["latency_ms_single_env_from_obs"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+            zb = torch.empty(1, cfg.latent_dim, device=device)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for i in range(20):
+                one.encode(ob, e1, out=zb)
+            torch.cuda.synchronize(device)
+            extra["encode_us_single_env"] = round((time.perf_counter() - t1) / 20 * 1e6, 1)
+        except Exception as ex:
+            extra["latency_ms_single_env_from_obs"] = {"error": repr(ex)}
 
         if args.config == "c2":
             try:

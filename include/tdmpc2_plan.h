@@ -14,6 +14,9 @@
  *   tdmpc2_plan_run           <- TDMPC2._plan after encode()            tdmpc2/tdmpc2.py:154-206
  *   tdmpc2_plan_estimate_value<- TDMPC2._estimate_value                 tdmpc2/tdmpc2.py:122-136
  *   tdmpc2_plan_refit         <- the elite select + refit block         tdmpc2/tdmpc2.py:184-197
+ *   tdmpc2_plan_bind_encoder  <- the state encoder's parameters         tdmpc2/common/layers.py:153-164
+ *   tdmpc2_plan_encode        <- WorldModel.encode (state observations) tdmpc2/common/world_model.py:103-112
+ *   tdmpc2_plan_run_obs       <- TDMPC2._plan including encode()        tdmpc2/tdmpc2.py:152-206
  *
  * Conventions
  *   - plain C types only; every tensor is a DEVICE pointer to fp32 (or int32 /
@@ -37,7 +40,7 @@
 extern "C" {
 #endif
 
-#define TDMPC2_PLAN_ABI_VERSION 2
+#define TDMPC2_PLAN_ABI_VERSION 3
 
 typedef struct tdmpc2_plan tdmpc2_plan_t;
 
@@ -151,6 +154,25 @@ int tdmpc2_plan_run(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *
                     const float *act_mask, const float *disc_pow, float *prev_mean, const uint8_t *t0,
                     int eval_mode, const tdmpc2_noise *tape, uint64_t seed, float *action,
                     const tdmpc2_debug *dbg, void *stream);
+
+/* State-observation encoder: WorldModel.encode for cfg.obs == 'state'
+ * (tdmpc2/common/world_model.py:103-112) with the network of layers.enc (tdmpc2/common/layers.py:153-164):
+ * n_layers NormedLinear blocks, Mish after all but the last, SimNorm after the last.  Pixel observations stay with the
+ * host framework.  bind_encoder takes one nn.Linear (`W` [out, in] row-major, `b` [out]) and its LayerNorm (`ln_g`,
+ * `ln_b` [out]) per call, DEVICE pointers, copied (weights transposed) into library memory; layer 0 takes
+ * obs_dim + task_dim inputs, the last layer has latent_dim outputs; widths up to 4096. */
+int tdmpc2_plan_bind_encoder(tdmpc2_plan_t *h, int layer, int n_layers, const float *W, const float *b,
+                             const float *ln_g, const float *ln_b, int out_features, int in_features,
+                             void *stream);
+/*   obs [E, obs_dim], task_emb [E, T] (NULL if !multitask; the rows the reference concatenates in
+ *   WorldModel.task_emb, world_model.py:88-101) -> z_out [E, L].  n_envs is not limited by max_envs. */
+int tdmpc2_plan_encode(tdmpc2_plan_t *h, int n_envs, const float *obs, int obs_dim, const float *task_emb,
+                       float *z_out, void *stream);
+/* TDMPC2._plan from the observation on (tdmpc2/tdmpc2.py:152-206): encode into library memory, then exactly
+ * tdmpc2_plan_run.  One call per environment step, no framework kernel in between. */
+int tdmpc2_plan_run_obs(tdmpc2_plan_t *h, int n_envs, const float *obs, int obs_dim, const float *task_emb,
+                        const float *act_mask, const float *disc_pow, float *prev_mean, const uint8_t *t0,
+                        int eval_mode, const tdmpc2_noise *tape, uint64_t seed, float *action, void *stream);
 
 /* TDMPC2._estimate_value on given action sequences (stage-wise parity).
  *   actions [E,H,N,A], pi_eps [E,N,A], qidx [E,2] -> value [E,N] (before nan_to_num). */

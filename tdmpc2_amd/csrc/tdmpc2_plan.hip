@@ -354,6 +354,7 @@ __global__ void k_copy_pad(const float *src, int n, int npad, float *dst) {
 #include "fused_kernels.cuh"
 #include "layered_kernels.cuh"
 #include "layered_split.cuh"
+#include "encoder_kernels.cuh"
 
 // ================================================================ host side
 thread_local std::string g_err;
@@ -414,6 +415,14 @@ struct tdmpc2_plan {
     // workspace
     float *bins = nullptr, *actions = nullptr, *value = nullptr, *mean = nullptr, *std = nullptr, *cvec = nullptr,
           *beff = nullptr, *zscratch = nullptr;
+    // state-observation encoder (optional: bound with tdmpc2_plan_bind_encoder)
+    struct Enc {
+        float *wt = nullptr, *bias = nullptr, *g = nullptr, *b = nullptr;
+        int in = 0, out = 0;
+        bool bound = false;
+    } enc[6];
+    int enc_layers = 0;
+    float *zenc = nullptr;  // [max_envs, L]: latents of tdmpc2_plan_run_obs
     unsigned int call = 0;
     unsigned long long *timing = nullptr;  // TDMPC2_TIMING=1 with a -DSPLIT_TIMING build: in-kernel phase cycle counters
     // profiling
@@ -938,6 +947,89 @@ int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *
         L.bound = true;
     }
     return TDMPC2_OK;
+}
+
+int tdmpc2_plan_bind_encoder(tdmpc2_plan_t *h, int layer, int n_layers, const float *W, const float *b, const float *ln_g,
+                             const float *ln_b, int out_features, int in_features, void *stream) {
+    if (!h || !W || !b || !ln_g || !ln_b) return fail(TDMPC2_ERR_INVALID, "null argument");
+    if (n_layers < 1 || n_layers > ENC_MAX_LAYERS) return fail(TDMPC2_ERR_INVALID, "encoder depth %d outside [1, %d]", n_layers, ENC_MAX_LAYERS);
+    if (layer < 0 || layer >= n_layers) return fail(TDMPC2_ERR_INVALID, "encoder layer %d outside [0, %d)", layer, n_layers);
+    if (out_features < 1 || out_features > ENC_THREADS * ENC_MAX_PER_THREAD || in_features < 1)
+        return fail(TDMPC2_ERR_UNSUPPORTED, "encoder layer %d: width %d outside [1, %d]", layer, out_features, ENC_THREADS * ENC_MAX_PER_THREAD);
+    const tdmpc2_plan_cfg &c = h->cfg;
+    if (layer == n_layers - 1 && out_features != c.latent_dim)
+        return fail(TDMPC2_ERR_INVALID, "the last encoder layer has %d outputs, latent_dim is %d", out_features, c.latent_dim);
+    if (layer == n_layers - 1 && (c.latent_dim % c.simnorm_dim || (c.simnorm_dim & (c.simnorm_dim - 1)) || c.simnorm_dim > 64))
+        return fail(TDMPC2_ERR_UNSUPPORTED, "SimNorm groups of %d over %d latents", c.simnorm_dim, c.latent_dim);
+    if (h->enc_layers && h->enc_layers != n_layers) return fail(TDMPC2_ERR_STATE, "encoder depth changed from %d to %d", h->enc_layers, n_layers);
+    HIP_TRY(hipSetDevice(c.device));
+    tdmpc2_plan::Enc &L = h->enc[layer];
+    if (L.wt && (L.in != in_features || L.out != out_features))
+        return fail(TDMPC2_ERR_STATE, "encoder layer %d re-bound with a different shape", layer);
+    int rc;
+    if (!L.wt) {
+        if ((rc = dev_alloc(h, (void **)&L.wt, (size_t)in_features * out_features * 4))) return rc;
+        if ((rc = dev_alloc(h, (void **)&L.bias, (size_t)out_features * 4))) return rc;
+        if ((rc = dev_alloc(h, (void **)&L.g, (size_t)out_features * 4))) return rc;
+        if ((rc = dev_alloc(h, (void **)&L.b, (size_t)out_features * 4))) return rc;
+        L.in = in_features;
+        L.out = out_features;
+    }
+    if (!h->zenc && (rc = dev_alloc(h, (void **)&h->zenc, (size_t)c.max_envs * c.latent_dim * 4))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t n = (size_t)in_features * out_features;
+    hipLaunchKernelGGL(k_transpose, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, W, L.wt, out_features, in_features);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(L.bias, b, (size_t)out_features * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(L.g, ln_g, (size_t)out_features * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(L.b, ln_b, (size_t)out_features * 4, hipMemcpyDeviceToDevice, st));
+    L.bound = true;
+    h->enc_layers = n_layers;
+    return TDMPC2_OK;
+}
+
+namespace {
+int launch_encode(tdmpc2_plan *h, int E, const float *obs, int obs_dim, const float *task_emb, float *z, hipStream_t st) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    if (!h->enc_layers) return fail(TDMPC2_ERR_STATE, "no encoder bound (tdmpc2_plan_bind_encoder)");
+    EncodeParams p{};
+    int maxw = 0;
+    for (int l = 0; l < h->enc_layers; ++l) {
+        const tdmpc2_plan::Enc &L = h->enc[l];
+        if (!L.bound) return fail(TDMPC2_ERR_STATE, "encoder layer %d of %d is not bound", l, h->enc_layers);
+        const int exp_in = l == 0 ? obs_dim + c.task_dim : h->enc[l - 1].out;
+        if (L.in != exp_in) return fail(TDMPC2_ERR_INVALID, "encoder layer %d takes %d inputs, the data brings %d", l, L.in, exp_in);
+        p.l[l] = EncLayerDev{L.wt, L.bias, L.g, L.b, L.in, L.out};
+        maxw = std::max(maxw, std::max(L.in, L.out));
+    }
+    if (c.task_dim > 0 && !task_emb) return fail(TDMPC2_ERR_INVALID, "multitask encoder needs task_emb");
+    p.nl = h->enc_layers; p.obs_dim = obs_dim; p.T = c.task_dim; p.maxw = maxw; p.simnorm_dim = c.simnorm_dim;
+    p.obs = obs; p.task_emb = task_emb; p.z = z;
+    const size_t lds = ((size_t)2 * maxw + ENC_THREADS / 64) * 4;
+    hipLaunchKernelGGL(k_encode, dim3(E), dim3(ENC_THREADS), lds, st, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+}  // namespace
+
+int tdmpc2_plan_encode(tdmpc2_plan_t *h, int n_envs, const float *obs, int obs_dim, const float *task_emb, float *z_out,
+                       void *stream) {
+    if (!h || !obs || !z_out) return fail(TDMPC2_ERR_INVALID, "null argument");
+    if (n_envs < 1) return fail(TDMPC2_ERR_INVALID, "n_envs %d < 1", n_envs);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    return launch_encode(h, n_envs, obs, obs_dim, task_emb, z_out, (hipStream_t)stream);
+}
+
+int tdmpc2_plan_run_obs(tdmpc2_plan_t *h, int n_envs, const float *obs, int obs_dim, const float *task_emb,
+                        const float *act_mask, const float *discount_pow, float *prev_mean, const uint8_t *t0, int eval_mode,
+                        const tdmpc2_noise *tape, uint64_t seed, float *action, void *stream) {
+    if (!h || !obs) return fail(TDMPC2_ERR_INVALID, "null argument");
+    if (n_envs < 1 || n_envs > h->cfg.max_envs) return fail(TDMPC2_ERR_INVALID, "n_envs %d outside [1, %d]", n_envs, h->cfg.max_envs);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    int rc = launch_encode(h, n_envs, obs, obs_dim, task_emb, h->zenc, (hipStream_t)stream);
+    if (rc) return rc;
+    return tdmpc2_plan_run(h, n_envs, h->zenc, task_emb, act_mask, discount_pow, prev_mean, t0, eval_mode, tape, seed, action,
+                           nullptr, stream);
 }
 
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value) {

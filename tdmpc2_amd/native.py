@@ -17,14 +17,14 @@ import torch
 _LIB_PATH = os.environ.get("TDMPC2_PLAN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtdmpc2_plan.so")
 _lib = None
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/tdmpc2_plan.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
     "tdmpc2_plan_abi_version", "tdmpc2_last_error", "tdmpc2_plan_create", "tdmpc2_plan_destroy",
     "tdmpc2_plan_device_bytes", "tdmpc2_plan_path", "tdmpc2_plan_precision", "tdmpc2_plan_bind_weights", "tdmpc2_plan_run", "tdmpc2_plan_estimate_value",
     "tdmpc2_plan_estimate_value_trace", "tdmpc2_plan_refit", "tdmpc2_plan_set_tuning", "tdmpc2_plan_set_profiling",
-    "tdmpc2_plan_profile_read",
+    "tdmpc2_plan_profile_read", "tdmpc2_plan_bind_encoder", "tdmpc2_plan_encode", "tdmpc2_plan_run_obs",
 ]
 
 NET_DYNAMICS, NET_REWARD, NET_PI, NET_Q, NET_TERMINATION = range(5)
@@ -86,6 +86,12 @@ def load_library():
     lib.tdmpc2_plan_run.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, i32, C.POINTER(Noise), u64, vp,
                                     C.POINTER(Debug), vp]
     lib.tdmpc2_plan_run.restype = i32
+    lib.tdmpc2_plan_bind_encoder.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, vp]
+    lib.tdmpc2_plan_bind_encoder.restype = i32
+    lib.tdmpc2_plan_encode.argtypes = [vp, i32, vp, i32, vp, vp, vp]
+    lib.tdmpc2_plan_encode.restype = i32
+    lib.tdmpc2_plan_run_obs.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, C.POINTER(Noise), u64, vp, vp]
+    lib.tdmpc2_plan_run_obs.restype = i32
     lib.tdmpc2_plan_estimate_value.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tdmpc2_plan_estimate_value.restype = i32
     lib.tdmpc2_plan_estimate_value_trace.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -156,6 +162,8 @@ class NativePlanner:
         self.path = int(self.lib.tdmpc2_plan_path(h))  # PATH_FUSED or PATH_LAYERED
         self.precision = int(self.lib.tdmpc2_plan_precision(h))  # PREC_FP32 or PREC_SPLIT_F16
         self._seed_calls = 0
+        self.encoder_layers = 0
+        self.obs_dim = None
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, rc: int):
@@ -208,6 +216,83 @@ class NativePlanner:
                                                                   _ptr(beta), out_f, in_f, self._stream()))
             torch.cuda.current_stream(self.device).synchronize()  # sources may now be freed
 
+    def bind_encoder(self, sd: Dict[str, torch.Tensor], prefix: str = "_encoder.state"):
+        """Bind the state encoder (tdmpc2/common/layers.py:153-164) from checkpoint keys
+        `_encoder.state.{i}.{weight,bias,ln.weight,ln.bias}`; afterwards `encode` / `plan_obs` run it in HIP."""
+        n = 0
+        while f"{prefix}.{n}.weight" in sd:
+            n += 1
+        if n == 0:
+            raise KeyError(f"state dict has no {prefix}.0.weight")
+        keep = []
+        with torch.cuda.device(self.device):
+            for layer in range(n):
+                ts = []
+                for name in ("weight", "bias", "ln.weight", "ln.bias"):
+                    t = sd[f"{prefix}.{layer}.{name}"].detach().to(self.device, torch.float32).contiguous()
+                    keep.append(t)
+                    ts.append(t)
+                W = ts[0]
+                self._check(self.lib.tdmpc2_plan_bind_encoder(self._h, layer, n, _ptr(W), _ptr(ts[1]), _ptr(ts[2]), _ptr(ts[3]),
+                                                              int(W.shape[0]), int(W.shape[1]), self._stream()))
+            torch.cuda.current_stream(self.device).synchronize()
+        self.encoder_layers = n
+        self.obs_dim = int(sd[f"{prefix}.0.weight"].shape[1]) - int(self.cfg.task_dim)
+
+    def encode(self, obs, task_emb=None, out: Optional[torch.Tensor] = None):
+        """WorldModel.encode for state observations (world_model.py:103-112): obs [E, obs_dim] -> z [E, L]."""
+        cfg, dev = self.cfg, self.device
+        E = int(obs.shape[0])
+        _chk_tensor("obs", obs, torch.float32, (E, self.obs_dim), dev)
+        if cfg.multitask:
+            if task_emb is None:
+                raise ValueError("multitask encoding needs task_emb")
+            _chk_tensor("task_emb", task_emb, torch.float32, (E, cfg.task_dim), dev)
+        else:
+            task_emb = None
+        z = out if out is not None else torch.empty(E, cfg.latent_dim, device=dev, dtype=torch.float32)
+        _chk_tensor("z", z, torch.float32, (E, cfg.latent_dim), dev)
+        with torch.cuda.device(dev):
+            self._check(self.lib.tdmpc2_plan_encode(self._h, E, _ptr(obs), self.obs_dim, _ptr(task_emb), _ptr(z), self._stream()))
+        return z
+
+    def plan_obs(self, obs, disc_pow, prev_mean, t0, eval_mode=False, task_emb=None, act_mask=None,
+                 tape: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0, out: Optional[torch.Tensor] = None):
+        """TDMPC2._plan from the observation on (tdmpc2.py:152-206): encode + plan in one library call."""
+        cfg, dev = self.cfg, self.device
+        E = int(obs.shape[0])
+        H, N, K, P, A, I = cfg.horizon, cfg.num_samples, cfg.num_elites, cfg.num_pi_trajs, cfg.action_dim, self.iterations
+        _chk_tensor("obs", obs, torch.float32, (E, self.obs_dim), dev)
+        _chk_tensor("disc_pow", disc_pow, torch.float32, (E, H + 1), dev)
+        if cfg.multitask:
+            if task_emb is None or act_mask is None:
+                raise ValueError("multitask planning needs task_emb and act_mask")
+            _chk_tensor("task_emb", task_emb, torch.float32, (E, cfg.task_dim), dev)
+            _chk_tensor("act_mask", act_mask, torch.float32, (E, A), dev)
+        _chk_tensor("prev_mean", prev_mean, torch.float32, (E, H, A), dev)
+        _chk_tensor("t0", t0, torch.uint8, (E,), dev)
+        action = out if out is not None else torch.empty(E, A, device=dev, dtype=torch.float32)
+        _chk_tensor("action", action, torch.float32, (E, A), dev)
+        noise_p = None
+        if tape is not None:
+            noise = self._noise(tape, E)
+            noise_p = C.byref(noise)
+        with torch.cuda.device(dev):
+            self._check(self.lib.tdmpc2_plan_run_obs(self._h, E, _ptr(obs), self.obs_dim, _ptr(task_emb), _ptr(act_mask),
+                                                     _ptr(disc_pow), _ptr(prev_mean), _ptr(t0), int(bool(eval_mode)), noise_p,
+                                                     C.c_uint64(int(seed) & (2**64 - 1)), _ptr(action), self._stream()))
+        return action
+
+    def _noise(self, tape, E):
+        cfg, dev = self.cfg, self.device
+        H, N, K, P, A, I = cfg.horizon, cfg.num_samples, cfg.num_elites, cfg.num_pi_trajs, cfg.action_dim, self.iterations
+        shapes = {"pi_traj_eps": ((E, H, P, A), torch.float32), "sample_eps": ((E, I, H, N - P, A), torch.float32),
+                  "pi_eps": ((E, I, N, A), torch.float32), "qidx": ((E, I, 2), torch.int32),
+                  "gumbel_exp": ((E, K), torch.float32), "final_eps": ((E, A), torch.float32)}
+        for k, (shp, dt) in shapes.items():
+            _chk_tensor(f"tape[{k}]", tape[k], dt, shp, dev)
+        return Noise(**{k: tape[k].data_ptr() for k in shapes})
+
     # ------------------------------------------------------------------ planning
     def _common_inputs(self, E, z0, task_emb, act_mask, disc_pow):
         cfg, dev = self.cfg, self.device
@@ -234,12 +319,7 @@ class NativePlanner:
         _chk_tensor("action", action, torch.float32, (E, A), dev)
         noise_p = None
         if tape is not None:
-            shapes = {"pi_traj_eps": ((E, H, P, A), torch.float32), "sample_eps": ((E, I, H, N - P, A), torch.float32),
-                      "pi_eps": ((E, I, N, A), torch.float32), "qidx": ((E, I, 2), torch.int32),
-                      "gumbel_exp": ((E, K), torch.float32), "final_eps": ((E, A), torch.float32)}
-            for k, (shp, dt) in shapes.items():
-                _chk_tensor(f"tape[{k}]", tape[k], dt, shp, dev)
-            noise = Noise(**{k: tape[k].data_ptr() for k in shapes})
+            noise = self._noise(tape, E)
             noise_p = C.byref(noise)
         dbg_p, stages = None, None
         if debug:

@@ -41,6 +41,7 @@ class TDMPC2(torch.nn.Module):
             self.discount = get_discount(cfg, cfg.episode_length)
         self._prev_mean = torch.nn.Buffer(torch.zeros(cfg.horizon, cfg.action_dim, device=self.device))
         self.max_envs = int(max_envs)
+        self.native_encoder = True  # False: encode with the PyTorch-ROCm module (the parity tests compare both)
         self._planner: Optional[NativePlanner] = None
         self._prev_mean_batch = None
         self._seed = int(getattr(cfg, "seed", 0))
@@ -71,12 +72,21 @@ class TDMPC2(torch.nn.Module):
                                           log_std_min=float(self.model.log_std_min),
                                           log_std_dif=float(self.model.log_std_dif))
             self._planner.bind_state_dict(self.model.planner_state_dict())
+            self._bind_encoder()
         return self._planner
+
+    def _bind_encoder(self):
+        # state observations: WorldModel.encode runs inside the library as well (include/tdmpc2_plan.h,
+        # tdmpc2_plan_run_obs); pixel observations keep the PyTorch-ROCm encoder
+        if self.native_encoder and self.cfg.obs == "state":
+            sd = {k: v for k, v in self.model.state_dict().items() if torch.is_tensor(v) and k.startswith("_encoder.state.")}
+            self._planner.bind_encoder(sd)
 
     def sync_planner_weights(self):
         """Re-pack the model's current weights into the planner (after load / a training step)."""
         if self._planner is not None:
             self._planner.bind_state_dict(self.model.planner_state_dict())
+            self._bind_encoder()
 
     def _disc_pow(self, tasks):
         """discount^0..discount^H exactly as tdmpc2.py:126,130-132 accumulates it: python-float
@@ -117,10 +127,12 @@ class TDMPC2(torch.nn.Module):
     @torch.no_grad()
     def _plan(self, obs, t0=False, eval_mode=False, task=None):
         """reference tdmpc2.py:138-206.  obs [1, obs_dim] on device; task int64[1] or None."""
-        z = self.model.encode(obs, task)  # host-side PyTorch-ROCm, as in the reference
-        a = self._plan_latent(z.contiguous(), self._one if t0 else self._zero, eval_mode, task,
-                              self._prev_mean.view(1, *self._prev_mean.shape))
-        return a[0]
+        t0 = self._one if t0 else self._zero
+        prev = self._prev_mean.view(1, *self._prev_mean.shape)
+        if self.native_encoder and self.cfg.obs == "state":
+            return self._plan_obs(obs.to(torch.float32).contiguous(), t0, eval_mode, task, prev)[0]
+        z = self.model.encode(obs, task)  # PyTorch-ROCm encoder (pixels, or native_encoder = False)
+        return self._plan_latent(z.contiguous(), t0, eval_mode, task, prev)[0]
 
     # ------------------------------------------------------------------ vectorised extension
     @torch.no_grad()
@@ -128,27 +140,27 @@ class TDMPC2(torch.nn.Module):
         """E environments at once.  obs [E, obs_dim]; t0 bool[E] (or bool); tasks int64[E] or None."""
         obs = obs.to(self.device)
         E = obs.shape[0]
-        if self.cfg.multitask:
-            tasks = torch.as_tensor(tasks, device=self.device).long()
-            emb = self.model._task_emb(tasks)  # max_norm renorm happens inside the lookup
-            z = self.model._encoder[self.cfg.obs](torch.cat([obs, emb], dim=-1))
-        else:
-            tasks = None
-            z = self.model._encoder[self.cfg.obs](obs)
+        tasks = torch.as_tensor(tasks, device=self.device).long() if self.cfg.multitask else None
         if self._prev_mean_batch is None or self._prev_mean_batch.shape[0] != E:
             self._prev_mean_batch = torch.zeros(E, self.cfg.horizon, self.cfg.action_dim, device=self.device)
         if isinstance(t0, bool):
             t0 = torch.full((E,), int(t0), dtype=torch.uint8, device=self.device)
         else:
             t0 = torch.as_tensor(t0, device=self.device).to(torch.uint8)
+        if self.native_encoder and self.cfg.obs == "state":
+            return self._plan_obs(obs.to(torch.float32).contiguous(), t0, eval_mode, tasks, self._prev_mean_batch)
+        if self.cfg.multitask:
+            emb = self.model._task_emb(tasks)  # max_norm renorm happens inside the lookup
+            z = self.model._encoder[self.cfg.obs](torch.cat([obs, emb], dim=-1))
+        else:
+            z = self.model._encoder[self.cfg.obs](obs)
         return self._plan_latent(z.contiguous(), t0, eval_mode, tasks, self._prev_mean_batch)
 
     @torch.no_grad()
     def act_batch(self, obs, t0, eval_mode=False, tasks=None):
         return self.plan_batch(obs, t0, eval_mode, tasks).cpu()
 
-    def _plan_latent(self, z, t0, eval_mode, tasks, prev_mean):
-        E = z.shape[0]
+    def _plan_inputs(self, E, tasks):
         planner = self.planner()
         if E > planner.max_envs:
             raise ValueError(f"{E} environments exceed max_envs={planner.max_envs} given at construction")
@@ -160,5 +172,15 @@ class TDMPC2(torch.nn.Module):
         else:
             disc = self._disc_pow(None).unsqueeze(0).repeat(E, 1).contiguous()
         self._seed += 1
+        return planner, emb, mask, disc
+
+    def _plan_obs(self, obs, t0, eval_mode, tasks, prev_mean):
+        """encode + plan inside the library (tdmpc2_plan_run_obs)."""
+        planner, emb, mask, disc = self._plan_inputs(obs.shape[0], tasks)
+        return planner.plan_obs(obs, disc, prev_mean, t0, eval_mode=eval_mode, task_emb=emb, act_mask=mask,
+                                tape=self.noise_tape, seed=self._seed)
+
+    def _plan_latent(self, z, t0, eval_mode, tasks, prev_mean):
+        planner, emb, mask, disc = self._plan_inputs(z.shape[0], tasks)
         return planner.plan(z.to(torch.float32), disc, prev_mean, t0, eval_mode=eval_mode, task_emb=emb,
                             act_mask=mask, tape=self.noise_tape, seed=self._seed)
