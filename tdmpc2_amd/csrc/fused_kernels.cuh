@@ -87,7 +87,9 @@ struct CtxT {
     static constexpr int ZKB = WIDTH / KBLK;                           // blocks covering the latent columns
     _Float16 *act;  // LDS tile.  split: row r at act + r * RSH: [hi: SH halfs | lo: SH halfs | 8 pad]; fp32: actf() rows
     float *stats;   // LDS [NW waves][TROWS][2]: per-wave LayerNorm partials
+    float *gb;      // LDS [2][WIDTH]: LayerNorm weight / bias of the layer whose epilogue comes next (see gb_prefetch)
     int tid, wave, lane;
+    mutable float pg[(WIDTH + NTHR - 1) / NTHR], pb[(WIDTH + NTHR - 1) / NTHR];  // the successor layer's values in flight
     TIMER_FIELDS
     __device__ __forceinline__ float *f32() const { return reinterpret_cast<float *>(act); }  // fp32 view [TROWS][RSF]
     static constexpr __device__ __forceinline__ int RSF() { return RSF_; }
@@ -495,14 +497,53 @@ __device__ __forceinline__ void regs_to_tile(const CT &c, const f32x16 (&y)[CT::
     }
 }
 
+// LayerNorm affine parameters travel through LDS.  A lane needs the values of its 16 features per feature tile, the
+// same for all 32 sample columns: read from global that is 16 broadcast `global_load_dwordx4` per wave and layer, each
+// costing the L1 its full 1 KiB / 16 cycles of address processing behind a weight stream that leaves nothing cached
+// (measured: 62 k of 1 150 k cycles per launch).  Instead every thread fetches ONE value of the NEXT epilogue's g and b
+// at the top of the current epilogue (gb_prefetch: latency hidden behind the epilogue), stores it after the barrier
+// that ends the epilogue (gb_commit: every wave is past its reads of the previous values), and the next epilogue reads
+// float4s from LDS after its own statistics barrier.  Protocol: every epi_t names its successor's parameters and is
+// followed by epi_barrier().
+struct GB {  // LayerNorm weight / bias pointers of one layer, by value (no address of a kernel argument is taken)
+    const float *g = nullptr, *b = nullptr;
+};
+__device__ __forceinline__ GB gb_of(const LayerS &ly) { return GB{ly.g, ly.b}; }
+
+template <class CT>
+__device__ __forceinline__ void gb_prefetch(const CT &c, const float *g, const float *b) {
+#pragma unroll
+    for (int u = 0; u < (WIDTH + CT::NTHR - 1) / CT::NTHR; ++u) {
+        const int f = c.tid + u * CT::NTHR;
+        c.pg[u] = f < WIDTH ? g[f] : 0.f;
+        c.pb[u] = f < WIDTH ? b[f] : 0.f;
+    }
+}
+template <class CT>
+__device__ __forceinline__ void gb_commit(const CT &c) {
+#pragma unroll
+    for (int u = 0; u < (WIDTH + CT::NTHR - 1) / CT::NTHR; ++u) {
+        const int f = c.tid + u * CT::NTHR;
+        if (f < WIDTH) {
+            c.gb[f] = c.pg[u];
+            c.gb[WIDTH + f] = c.pb[u];
+        }
+    }
+}
+template <class CT>
+__device__ __forceinline__ void epi_barrier(const CT &c) {
+    __syncthreads();
+    gb_commit(c);
+}
+
 // acc (raw MFMA sums) -> ACT(LayerNorm(acc * osc + bias)) -> operand form in the LDS tile (+ optional register-order
-// fp32 copy `zcopy` in global).  The bias / LayerNorm affine values of this lane's features are read as float4 at
-// 32 FT wave + 32 ft + 8 m + 4 hh (two distinct addresses per wave instruction, served from L1), one feature tile at a
-// time.  One barrier inside (the statistics exchange, which also orders every wave's last read of the operand tile
+// fp32 copy `zcopy` in global).  The bias values of this lane's features are read from global as float4 at
+// 32 FT wave + 32 ft + 8 m + 4 hh (two distinct addresses per wave instruction), the LayerNorm affine values from
+// c.gb at the same offsets; `next` = the layer whose epilogue follows this one in program order (null: none).  One barrier inside (the statistics exchange, which also orders every wave's last read of the operand tile
 // before the first write of the new one); the caller adds the one before the next contraction.
 template <int ACT, class CT>
-__device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][CT::FT], float osc, const float *bias, const float *g,
-                                      const float *b, float *zcopy) {
+__device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][CT::FT], float osc, const float *bias,
+                                      GB next, float *zcopy) {
     constexpr int FT = CT::FT, NW = CT::NWAVES;
     constexpr float CNT = 32.f * FT;  // features of a row held by one wave
     const int j = c.lane & 31, hh = c.lane >> 5;
@@ -520,6 +561,8 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][CT::FT
                 for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = fmaf(acc[st][ft][4 * m + r], osc, b4[m][r]);
     }
     TIMER_MARK(c, T_EPI_BIAS)
+    // the successor's g / b (this layer's own are in c.gb already); behind the bias loads, which are needed first
+    if (next.g) gb_prefetch(c, next.g, next.b);
     // per-wave partial statistics of the sample rows this lane works on
 #pragma unroll
     for (int st = 0; st < CT::NST; ++st) {
@@ -575,8 +618,8 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][CT::FT
         f32x4 gq[4], bq[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            gq[m] = *reinterpret_cast<const f32x4 *>(g + poff + 32 * ft + 8 * m);
-            bq[m] = *reinterpret_cast<const f32x4 *>(b + poff + 32 * ft + 8 * m);
+            gq[m] = *reinterpret_cast<const f32x4 *>(c.gb + poff + 32 * ft + 8 * m);
+            bq[m] = *reinterpret_cast<const f32x4 *>(c.gb + WIDTH + poff + 32 * ft + 8 * m);
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -666,13 +709,13 @@ __device__ __forceinline__ float twohot_rows_s(const CT &c, const float *bins, i
 
 template <int ACT, class CT>
 __device__ __forceinline__ void layer_full_s(const CT &c, const LayerS &ly, const float *bias, int kb0, int kb1,
-                                             float *zcopy = nullptr) {
+                                             GB next, float *zcopy = nullptr) {
     f32x16 acc[CT::NST][CT::FT];
     zero_acc(acc);
     kloop_s(c, ly, kb0, kb1, acc);
     TIMER_MARK(c, T_KLOOP)
-    epi_t<ACT>(c, acc, *ly.oscale, bias, ly.g, ly.b, zcopy);
-    __syncthreads();
+    epi_t<ACT>(c, acc, *ly.oscale, bias, next, zcopy);
+    epi_barrier(c);
     TIMER_MARK(c, T_EPI)
 }
 
@@ -792,7 +835,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int e = blockIdx.x, tid = threadIdx.x;
     typedef CtxT<APAD, 2, 8, AR> CT;  // 64 rows, 8 waves
-    CT c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CT::RSF(), tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    CT c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CT::RSF(), smem + ROWS * CT::RSF() + 1024, tid,
+         __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     if (p.multitask) {
         const float *emb = p.task_emb + (size_t)e * p.T;
         for (int net = 0; net < p.nnets; ++net) {
@@ -842,7 +886,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) 
     const int e = blockIdx.x, tid = threadIdx.x;
     typedef CtxT<APAD, ST, 8, AR> CT;
     constexpr int ZKB16 = CT::ZKB;  // k-blocks of this arithmetic covering the latent columns
-    CT c{reinterpret_cast<_Float16 *>(smem), smem + CT::TROWS * CT::RSF(), tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    CT c{reinterpret_cast<_Float16 *>(smem), smem + CT::TROWS * CT::RSF(), smem + CT::TROWS * CT::RSF() + 1024, tid,
+         __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
     const float *b_pi = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_PI) * WIDTH : p.pi.l[0].bias;
     const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
@@ -864,10 +909,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) 
             }
         park(c, y, zs);
     }
-    __syncthreads();
+    gb_prefetch(c, p.pi.l[0].g, p.pi.l[0].b);
+    epi_barrier(c);
     for (int t = 0; t < p.H; ++t) {
-        layer_full_s<0>(c, p.pi.l[0], b_pi, 0, ZKB16);
-        layer_full_s<0>(c, p.pi.l[1], p.pi.l[1].bias, 0, ZKB16);
+        layer_full_s<0>(c, p.pi.l[0], b_pi, 0, ZKB16, gb_of(p.pi.l[1]));
+        layer_full_s<0>(c, p.pi.l[1], p.pi.l[1].bias, 0, ZKB16, t == p.H - 1 ? GB{} : gb_of(p.dyn.l[0]));
         const float *tape = p.pi_traj_eps ? p.pi_traj_eps + ((size_t)e * p.H + t) * p.P * p.A : nullptr;
         auto eps = [&](int row, int a) -> float {
             if (row >= p.P) return 0.f;
@@ -879,9 +925,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) 
         if (t == p.H - 1) break;
         tile_from_global_s(c, zs);
         __syncthreads();
-        layer_full_s<0>(c, p.dyn.l[0], b_dyn, 0, KBA);
-        layer_full_s<0>(c, p.dyn.l[1], p.dyn.l[1].bias, 0, ZKB16);
-        layer_full_s<1>(c, p.dyn.l[2], p.dyn.l[2].bias, 0, ZKB16, zs);
+        layer_full_s<0>(c, p.dyn.l[0], b_dyn, 0, KBA, gb_of(p.dyn.l[1]));
+        layer_full_s<0>(c, p.dyn.l[1], p.dyn.l[1].bias, 0, ZKB16, gb_of(p.dyn.l[2]));
+        layer_full_s<1>(c, p.dyn.l[2], p.dyn.l[2].bias, 0, ZKB16, gb_of(p.pi.l[0]), zs);
     }
 }
 
@@ -894,8 +940,9 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
     typedef CtxT<APAD, ST, NW, AR> CT;
     constexpr int TROWS = CT::TROWS, NTHR = CT::NTHR, FT = CT::FT;
     constexpr int ZKB16 = CT::ZKB;  // k-blocks of this arithmetic covering the latent columns
-    CT c{reinterpret_cast<_Float16 *>(smem), smem + TROWS * CT::RSF(), tid, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
-    float *sm_mean = smem + TROWS * CT::RSF() + 1024;  // [H*A] after the tile and the LayerNorm partials
+    CT c{reinterpret_cast<_Float16 *>(smem), smem + TROWS * CT::RSF(), smem + TROWS * CT::RSF() + 1024, tid,
+         __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    float *sm_mean = smem + TROWS * CT::RSF() + 2048;  // [H*A] after the tile, the LayerNorm partials and c.gb
     float *sm_std = sm_mean + p.H * p.A;
     const int row0 = tile * TROWS;
     const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
@@ -925,7 +972,8 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
     const float *b_pi = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_PI) * WIDTH : p.pi.l[0].bias;
     const float *b_q0 = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_Q0 + q0) * WIDTH : p.q[q0].l[0].bias;
     const float *b_q1 = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_Q0 + q1) * WIDTH : p.q[q1].l[0].bias;
-    __syncthreads();
+    gb_prefetch(c, p.rew.l[0].g, p.rew.l[0].b);  // the first epilogue's LayerNorm parameters
+    epi_barrier(c);
 
     float G = 0.f;
     TIMER_START(c)
@@ -989,14 +1037,13 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
             zero_acc(acc);
             kloop_s(c, p.rew.l[0], t == 0 ? ZKB16 : 0, KBA, acc);
             TIMER_MARK(c, T_KLOOP)
-            epi_t<0>(c, acc, *p.rew.l[0].oscale, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew, p.rew.l[0].g,
-                     p.rew.l[0].b, nullptr);
+            epi_t<0>(c, acc, *p.rew.l[0].oscale, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew, gb_of(p.rew.l[1]), nullptr);
         }
-        __syncthreads();
+        epi_barrier(c);
         TIMER_MARK(c, T_EPI)
         dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 0);
         // ---- reward: layer 2, two-hot head
-        layer_full_s<0>(c, p.rew.l[1], p.rew.l[1].bias, 0, ZKB16);
+        layer_full_s<0>(c, p.rew.l[1], p.rew.l[1].bias, 0, ZKB16, gb_of(p.dyn.l[0]));
         dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 1);
         const float r = head_twohot_s(c, p.rew.l[2], p.bins, p.num_bins);
         TIMER_MARK(c, T_HEAD)
@@ -1006,26 +1053,27 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
         {
             const float *bd = t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn;
 #ifdef SPLIT_HOLD
-            epi_t<0>(c, accd, *p.dyn.l[0].oscale, bd, p.dyn.l[0].g, p.dyn.l[0].b, nullptr);
+            epi_t<0>(c, accd, *p.dyn.l[0].oscale, bd, gb_of(p.dyn.l[1]), nullptr);
 #else
             f32x16 acc[ST][FT];
             unpark(c, acc, zs);
             TIMER_MARK(c, T_PARK)
-            epi_t<0>(c, acc, *p.dyn.l[0].oscale, bd, p.dyn.l[0].g, p.dyn.l[0].b, nullptr);
+            epi_t<0>(c, acc, *p.dyn.l[0].oscale, bd, gb_of(p.dyn.l[1]), nullptr);
 #endif
         }
-        __syncthreads();
+        epi_barrier(c);
         TIMER_MARK(c, T_EPI)
         dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 2);
-        layer_full_s<0>(c, p.dyn.l[1], p.dyn.l[1].bias, 0, ZKB16);
+        layer_full_s<0>(c, p.dyn.l[1], p.dyn.l[1].bias, 0, ZKB16, gb_of(p.dyn.l[2]));
         dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 3);
-        layer_full_s<1>(c, p.dyn.l[2], p.dyn.l[2].bias, 0, ZKB16, t == p.H - 1 ? zs : nullptr);
+        layer_full_s<1>(c, p.dyn.l[2], p.dyn.l[2].bias, 0, ZKB16, t == p.H - 1 ? gb_of(p.pi.l[0]) : gb_of(p.rew.l[0]),
+                        t == p.H - 1 ? zs : nullptr);
         dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 4);
     }
     // ---- a_H = pi(z_H) (tdmpc2.py:135); z_H was also saved to zs
-    layer_full_s<0>(c, p.pi.l[0], b_pi, 0, ZKB16);
+    layer_full_s<0>(c, p.pi.l[0], b_pi, 0, ZKB16, gb_of(p.pi.l[1]));
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 0);
-    layer_full_s<0>(c, p.pi.l[1], p.pi.l[1].bias, 0, ZKB16);
+    layer_full_s<0>(c, p.pi.l[1], p.pi.l[1].bias, 0, ZKB16, gb_of(p.q[q0].l[0]));
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 1);
     {
         auto eps = [&](int row, int a) -> float {
@@ -1061,29 +1109,29 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
         zero_acc(acc);
         kloop_s(c, p.q[q0].l[0], 0, KBA, acc);
         TIMER_MARK(c, T_KLOOP)
-        epi_t<0>(c, acc, *p.q[q0].l[0].oscale, b_q0, p.q[q0].l[0].g, p.q[q0].l[0].b, nullptr);
+        epi_t<0>(c, acc, *p.q[q0].l[0].oscale, b_q0, gb_of(p.q[q0].l[1]), nullptr);
     }
-    __syncthreads();
+    epi_barrier(c);
     TIMER_MARK(c, T_EPI)
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 3);
-    layer_full_s<0>(c, p.q[q0].l[1], p.q[q0].l[1].bias, 0, ZKB16);
+    layer_full_s<0>(c, p.q[q0].l[1], p.q[q0].l[1].bias, 0, ZKB16, gb_of(p.q[q1].l[0]));
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 4);
     const float qa = head_twohot_s(c, p.q[q0].l[2], p.bins, p.num_bins);
     TIMER_MARK(c, T_HEAD)
     {
 #ifdef SPLIT_HOLD
-        epi_t<0>(c, accq, *p.q[q1].l[0].oscale, b_q1, p.q[q1].l[0].g, p.q[q1].l[0].b, nullptr);
+        epi_t<0>(c, accq, *p.q[q1].l[0].oscale, b_q1, gb_of(p.q[q1].l[1]), nullptr);
 #else
         f32x16 acc[ST][FT];
         unpark(c, acc, zs);
         TIMER_MARK(c, T_PARK)
-        epi_t<0>(c, acc, *p.q[q1].l[0].oscale, b_q1, p.q[q1].l[0].g, p.q[q1].l[0].b, nullptr);
+        epi_t<0>(c, acc, *p.q[q1].l[0].oscale, b_q1, gb_of(p.q[q1].l[1]), nullptr);
 #endif
     }
-    __syncthreads();
+    epi_barrier(c);
     TIMER_MARK(c, T_EPI)
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 5);
-    layer_full_s<0>(c, p.q[q1].l[1], p.q[q1].l[1].bias, 0, ZKB16);
+    layer_full_s<0>(c, p.q[q1].l[1], p.q[q1].l[1].bias, 0, ZKB16, GB{});
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 6);
     const float qb = head_twohot_s(c, p.q[q1].l[2], p.bins, p.num_bins);
     TIMER_MARK(c, T_HEAD)

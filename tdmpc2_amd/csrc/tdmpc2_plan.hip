@@ -744,7 +744,8 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             h->stride = WIDTH + h->Apad + 4;  // in floats
             h->row_bytes = (size_t)h->stride * 4;
         }
-        h->lds_bytes = (size_t)ROWS * h->row_bytes + 4096 /* LayerNorm partials */ + (size_t)2 * c.horizon * c.action_dim * 4 + 64;
+        h->lds_bytes = (size_t)ROWS * h->row_bytes + 4096 /* LayerNorm partials */ + 4096 /* LayerNorm affine, CtxT::gb */ +
+                       (size_t)2 * c.horizon * c.action_dim * 4 + 64;
         if (h->lds_bytes > 160 * 1024) {
             const size_t need = h->lds_bytes;
             delete h;
