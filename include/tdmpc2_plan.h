@@ -165,7 +165,8 @@ int tdmpc2_plan_bind_encoder(tdmpc2_plan_t *h, int layer, int n_layers, const fl
                              const float *ln_g, const float *ln_b, int out_features, int in_features,
                              void *stream);
 /*   obs [E, obs_dim], task_emb [E, T] (NULL if !multitask; the rows the reference concatenates in
- *   WorldModel.task_emb, world_model.py:88-101) -> z_out [E, L].  n_envs is not limited by max_envs. */
+ *   WorldModel.task_emb, world_model.py:88-101) -> z_out [E, L].  n_envs is not limited by max_envs unless a layer
+ *   is wider than 1024 (those encoders run layer by layer through a workspace sized for max_envs rows). */
 int tdmpc2_plan_encode(tdmpc2_plan_t *h, int n_envs, const float *obs, int obs_dim, const float *task_emb,
                        float *z_out, void *stream);
 /* TDMPC2._plan from the observation on (tdmpc2/tdmpc2.py:152-206): encode into library memory, then exactly

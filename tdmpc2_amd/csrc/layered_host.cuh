@@ -17,7 +17,9 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         GemmSParams q{};
         q.A = reinterpret_cast<const _Float16 *>(A); q.lda = lda; q.K = ly.KB * 16; q.wp = ly.wps;
         q.w_sel_stride = sel ? w_sel_stride : 0; q.oscale = ly.oscale; q.osc_sel_stride = sel ? 4 : 0;  // slab of 4 floats per head
-        q.CT = ly.CT; q.ncolblk = (ly.CT + 3) / 4;
+        // wide outputs (>= 256 columns) take the 128 x 256 tile as long as that still leaves the chip two waves of workgroups
+        const bool wide = ly.CT >= 8 && (rows_p / GBM) * ((ly.CT + 7) / 8) >= (size_t)(getenv("TDMPC2_GEMM_NCT1") ? (1 << 30) : 512);
+        q.CT = ly.CT; q.ncolblk = wide ? (ly.CT + 7) / 8 : (ly.CT + 3) / 4;
         if (slot >= 0 && h->cfg.multitask) {
             q.bias = h->beff + (size_t)slot * h->lay.Mp;
             q.bias_env_stride = (long)h->nnets * h->lay.Mp;
@@ -29,7 +31,8 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         }
         q.sel = sel; q.sel_stride = 2; q.rows_per_env = rows_per_env; q.out = out; q.ldo = ldo;
         const int nblk = (int)(rows_p / GBM) * q.ncolblk;
-        hipLaunchKernelGGL(g_gemm_s, dim3(nblk), dim3(GTHREADS), 0, st, q);
+        if (wide) hipLaunchKernelGGL(g_gemm_s<2>, dim3(nblk), dim3(GTHREADS), 0, st, q);
+        else hipLaunchKernelGGL(g_gemm_s<1>, dim3(nblk), dim3(GTHREADS), 0, st, q);
         LAUNCH_CHECK();
         return 0;
     }

@@ -5,9 +5,9 @@
 // kernels that produce an activation (l_ln_act_s, l_init_x_s, l_set_action_s, l_pi_head_s) write that form once, so the
 // GEMM stages plain copies; GEMM outputs (pre-activations, head logits) stay fp32 and are converted in place, one
 // wavefront per row, by the LayerNorm kernel.
-// g_gemm_s: 128 x 128 output tile per 256-thread workgroup; wave w owns the 32 output columns [32 w, 32 w + 32) for all
-// 128 rows (4 row tiles x 1 column tile): every weight fragment (2 KB per k16-block, from L2) feeds 12 MFMAs and the
-// row fragments come from LDS (8 ds_read_b128 per block) -- weight bytes per MFMA are half of the fused kernel's.
+// g_gemm_s<NCT>: 128 x (128 NCT) output tile per 256-thread workgroup; wave w owns 32 NCT output columns for all 128 rows
+// (4 row tiles x NCT column tiles): every weight fragment (2 KB per k16-block, from L2) feeds 12 MFMAs and the row
+// fragments come from LDS (8 ds_read_b128 per block, shared by the NCT column tiles).
 // Included by tdmpc2_plan.hip inside its anonymous namespace, after fused_kernels.cuh and layered_kernels.cuh.
 #pragma once
 
@@ -31,6 +31,11 @@ struct GemmSParams {
     int ldo;
 };
 
+// NCT = 32-wide output column tiles per wave: 1 -> 128 x 128 workgroup tile (narrow outputs: heads, small models),
+// 2 -> 128 x 256 (a wave owns 64 columns x 128 rows = 8 accumulators: per k16-block 4 KB of weight fragments and 8 KB of
+// row fragments feed 24 MFMAs, 512 operand bytes per MFMA against 853 with NCT = 1 -- operand delivery, not MFMA issue,
+// is what bounds these loops, profiles/README.md).
+template <int NCT>
 __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     __shared__ __attribute__((aligned(16))) _Float16 As[2][2][GBM * GS_LDH];  // [buffer][plane][row][k]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -41,10 +46,15 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     const int row0 = rb * GBM;
     const int sel = p.sel ? p.sel[(size_t)(row0 / p.rows_per_env) * p.sel_stride] : 0;
     const int KB = p.K / 16;
-    const int ct = cb * 4 + wave;
-    const bool valid = ct < p.CT;
-    // weight fragments: wave-uniform byte pointer + opaque 32-bit lane offset (see fused_kernels.cuh)
-    const char *u = reinterpret_cast<const char *>(p.wp + (size_t)sel * p.w_sel_stride) + (size_t)(valid ? ct : p.CT - 1) * KB * 2048;
+    const int ct0 = (cb * 4 + wave) * NCT;
+    // weight fragments: wave-uniform byte pointers + opaque 32-bit lane offset (see fused_kernels.cuh); a column tile past
+    // the matrix re-reads the last one and is dropped in the epilogue
+    const char *u[NCT];
+#pragma unroll
+    for (int n = 0; n < NCT; ++n) {
+        const int ct = ct0 + n < p.CT ? ct0 + n : p.CT - 1;
+        u[n] = reinterpret_cast<const char *>(p.wp + (size_t)sel * p.w_sel_stride) + (size_t)ct * KB * 2048;
+    }
     unsigned voff = (unsigned)lane * 16u;
     asm volatile("" : "+v"(voff));
 
@@ -67,24 +77,29 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(lds + l_off[i]) = stage[i];
     __syncthreads();
 
-    f32x16 acc[4];
+    f32x16 acc[NCT][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int n = 0; n < NCT; ++n)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[n][r][e] = 0.f;
 
     const int i32 = lane & 31, hh = lane >> 5;
     const int nchunks = p.K / GBK;
-    constexpr int PFB = 4;
-    f16x8 rh[PFB], rl[PFB];
+    constexpr int PFB = NCT == 1 ? 4 : 2;  // weight ring in k16-blocks (NCT x 8 VGPRs each)
+    f16x8 rh[PFB][NCT], rl[PFB][NCT];
 #pragma unroll
     for (int d = 0; d < PFB; ++d) {
         const int kd = d < KB ? d : KB - 1;
-        rh[d] = ldw(u + (size_t)kd * 2048, voff, 0);
-        rl[d] = ldw(u + (size_t)kd * 2048, voff, 1024);
+#pragma unroll
+        for (int n = 0; n < NCT; ++n) {
+            rh[d][n] = ldw(u[n] + (size_t)kd * 2048, voff, 0);
+            rl[d][n] = ldw(u[n] + (size_t)kd * 2048, voff, 1024);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
-    for (int c = 0; c < nchunks; c += 2) {  // two chunks (4 k16-blocks = one turn of the weight ring) per iteration
+    for (int c = 0; c < nchunks; c += 2) {  // two chunks (4 k16-blocks) per iteration: a whole number of ring turns
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const int ch = c + cc;
@@ -99,7 +114,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
                 const _Float16 *al = &As[ch & 1][1][0] + i32 * GS_LDH + 8 * hh;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
-                    const int d = cc * 2 + kb;
+                    const int d = (cc * 2 + kb) % PFB;
                     f16x8 fh[4], fl[4];
 #pragma unroll
                     for (int rt = 0; rt < 4; ++rt) {
@@ -107,15 +122,24 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
                         fl[rt] = *reinterpret_cast<const f16x8 *>(al + rt * 32 * GS_LDH + kb * 16);
                     }
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) acc[rt] = SPLIT_MFMA(fh[rt], rh[d], acc[rt]);
+                    for (int n = 0; n < NCT; ++n)
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) acc[rt] = SPLIT_MFMA(fh[rt], rl[d], acc[rt]);
+                        for (int rt = 0; rt < 4; ++rt) acc[n][rt] = SPLIT_MFMA(fh[rt], rh[d][n], acc[n][rt]);
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) acc[rt] = SPLIT_MFMA(fl[rt], rh[d], acc[rt]);
+                    for (int n = 0; n < NCT; ++n)
+#pragma unroll
+                        for (int rt = 0; rt < 4; ++rt) acc[n][rt] = SPLIT_MFMA(fh[rt], rl[d][n], acc[n][rt]);
+#pragma unroll
+                    for (int n = 0; n < NCT; ++n)
+#pragma unroll
+                        for (int rt = 0; rt < 4; ++rt) acc[n][rt] = SPLIT_MFMA(fl[rt], rh[d][n], acc[n][rt]);
                     const int kn = ch * 2 + kb + PFB;
                     const int knc = kn < KB ? kn : KB - 1;
-                    rh[d] = ldw(u + (size_t)knc * 2048, voff, 0);
-                    rl[d] = ldw(u + (size_t)knc * 2048, voff, 1024);
+#pragma unroll
+                    for (int n = 0; n < NCT; ++n) {
+                        rh[d][n] = ldw(u[n] + (size_t)knc * 2048, voff, 0);
+                        rl[d][n] = ldw(u[n] + (size_t)knc * 2048, voff, 1024);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (more) {
@@ -128,21 +152,24 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
         }
     }
 
-    if (!valid) return;
     // epilogue: acc * oscale + bias -> fp32.  C fragment: lane holds column (l & 31), rows (reg&3) + 8 (reg>>2) + 4 (l>>5).
     const float osc = p.oscale[(size_t)sel * p.osc_sel_stride];
     const float *bsel = p.bias + (size_t)sel * p.bias_sel_stride;
-    const int col = ct * 32 + i32;
-    const float bshared = p.bias_env_stride == 0 ? bsel[col] : 0.f;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int n = 0; n < NCT; ++n) {
+        if (ct0 + n >= p.CT) continue;
+        const int col = (ct0 + n) * 32 + i32;
+        const float bshared = p.bias_env_stride == 0 ? bsel[col] : 0.f;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = row0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-            float bv = bshared;
-            if (p.bias_env_stride != 0) bv = bsel[(size_t)(row / p.rows_per_env) * p.bias_env_stride + col];
-            p.out[(size_t)row * p.ldo + col] = fmaf(acc[rt][reg], osc, bv);
-        }
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = row0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                float bv = bshared;
+                if (p.bias_env_stride != 0) bv = bsel[(size_t)(row / p.rows_per_env) * p.bias_env_stride + col];
+                p.out[(size_t)row * p.ldo + col] = fmaf(acc[n][rt][reg], osc, bv);
+            }
+    }
 }
 
 // ---------------------------------------------------------------- row kernels writing operand form

@@ -423,6 +423,8 @@ struct tdmpc2_plan {
     } enc[6];
     int enc_layers = 0;
     float *zenc = nullptr;  // [max_envs, L]: latents of tdmpc2_plan_run_obs
+    float *enc_y = nullptr, *enc_x = nullptr;  // wide encoders: [max_envs, widest layer] pre-activations / activations
+    int enc_ws_width = 0;
     unsigned int call = 0;
     unsigned long long *timing = nullptr;  // TDMPC2_TIMING=1 with a -DSPLIT_TIMING build: in-kernel phase cycle counters
     // profiling
@@ -977,6 +979,12 @@ int tdmpc2_plan_bind_encoder(tdmpc2_plan_t *h, int layer, int n_layers, const fl
         L.out = out_features;
     }
     if (!h->zenc && (rc = dev_alloc(h, (void **)&h->zenc, (size_t)c.max_envs * c.latent_dim * 4))) return rc;
+    const int w = std::max(in_features, out_features);
+    if (w > ENC_WIDE && w > h->enc_ws_width) {  // workspace of the layer-at-a-time encoder path (grows with the widest layer)
+        if ((rc = dev_alloc(h, (void **)&h->enc_y, (size_t)c.max_envs * w * 4))) return rc;
+        if ((rc = dev_alloc(h, (void **)&h->enc_x, (size_t)c.max_envs * w * 4))) return rc;
+        h->enc_ws_width = w;
+    }
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)in_features * out_features;
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, W, L.wt, out_features, in_features);
@@ -1004,6 +1012,24 @@ int launch_encode(tdmpc2_plan *h, int E, const float *obs, int obs_dim, const fl
         maxw = std::max(maxw, std::max(L.in, L.out));
     }
     if (c.task_dim > 0 && !task_emb) return fail(TDMPC2_ERR_INVALID, "multitask encoder needs task_emb");
+    if (maxw > ENC_WIDE) {  // layer-at-a-time across the chip (encoder_kernels.cuh)
+        if (E > c.max_envs) return fail(TDMPC2_ERR_INVALID, "encoders wider than %d take at most max_envs = %d rows per call (got %d)", ENC_WIDE, c.max_envs, E);
+        if (!h->enc_y || h->enc_ws_width < maxw) return fail(TDMPC2_ERR_STATE, "encoder workspace missing (bind every layer first)");
+        for (int l = 0; l < h->enc_layers; ++l) {
+            const tdmpc2_plan::Enc &L = h->enc[l];
+            EncGemvParams g{};
+            g.wt = L.wt; g.bias = L.bias; g.in = L.in; g.out = L.out; g.y = h->enc_y;
+            if (l == 0) { g.obs = obs; g.emb = task_emb; g.obs_dim = obs_dim; g.T = c.task_dim; }
+            else { g.x = h->enc_x; g.ldx = h->enc[l - 1].out; }
+            hipLaunchKernelGGL(k_enc_gemv, dim3((L.out + 63) / 64, E), dim3(256), ((size_t)L.in + 256) * 4, st, g);
+            EncNormParams n{};
+            const bool last = l == h->enc_layers - 1;
+            n.y = h->enc_y; n.g = L.g; n.b = L.b; n.out = last ? z : h->enc_x; n.width = L.out; n.last = last; n.simnorm_dim = c.simnorm_dim;
+            hipLaunchKernelGGL(k_enc_norm, dim3(E), dim3(ENC_THREADS), 0, st, n);
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     p.nl = h->enc_layers; p.obs_dim = obs_dim; p.T = c.task_dim; p.maxw = maxw; p.simnorm_dim = c.simnorm_dim;
     p.obs = obs; p.task_emb = task_emb; p.z = z;
     const size_t lds = ((size_t)2 * maxw + ENC_THREADS / 64) * 4;
