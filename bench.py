@@ -328,6 +328,23 @@ def main():
         except Exception as ex:
             extra["latency_ms_single_env_from_obs"] = {"error": repr(ex)}
 
+        if family == "fused" and not cfg.multitask:
+            # the training-side forward piece on the same kernels: TDMPC2._td_target at the reference's batch
+            # (horizon 3 x batch_size 256 rows, config.yaml)
+            try:
+                R = cfg.horizon * 256
+                nz = torch.as_tensor(synth.make_latents(cfg, R, seed=5)).to(device)
+                rw, tm = torch.randn(R, device=device), torch.zeros(R, device=device)
+                for i in range(3):
+                    planner.td_target(nz, rw, tm, 0.99, seed=i)
+                torch.cuda.synchronize(device)
+                t1 = time.perf_counter()
+                for i in range(20):
+                    planner.td_target(nz, rw, tm, 0.99, seed=10 + i)
+                torch.cuda.synchronize(device)
+                extra["td_target_us_768_rows"] = round((time.perf_counter() - t1) / 20 * 1e6, 1)
+            except Exception as ex:
+                extra["td_target_us_768_rows"] = {"error": repr(ex)}
         if args.config == "c2":
             try:
                 extra["parity"] = action_mse_vs_reference(device, path, prec)

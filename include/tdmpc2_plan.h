@@ -17,6 +17,8 @@
  *   tdmpc2_plan_bind_encoder  <- the state encoder's parameters         tdmpc2/common/layers.py:153-164
  *   tdmpc2_plan_encode        <- WorldModel.encode (state observations) tdmpc2/common/world_model.py:103-112
  *   tdmpc2_plan_run_obs       <- TDMPC2._plan including encode()        tdmpc2/tdmpc2.py:152-206
+ *   tdmpc2_plan_td_target     <- TDMPC2._td_target                      tdmpc2/tdmpc2.py:239-254
+ *   tdmpc2_plan_policy_value  <- forward half of TDMPC2.update_pi       tdmpc2/tdmpc2.py:208-225
  *
  * Conventions
  *   - plain C types only; every tensor is a DEVICE pointer to fp32 (or int32 /
@@ -40,7 +42,7 @@
 extern "C" {
 #endif
 
-#define TDMPC2_PLAN_ABI_VERSION 3
+#define TDMPC2_PLAN_ABI_VERSION 4
 
 typedef struct tdmpc2_plan tdmpc2_plan_t;
 
@@ -80,7 +82,8 @@ enum tdmpc2_net {
     TDMPC2_NET_REWARD = 1,      /* WorldModel._reward       world_model.py:27 */
     TDMPC2_NET_PI = 2,          /* WorldModel._pi           world_model.py:29 */
     TDMPC2_NET_Q = 3,           /* WorldModel._Qs (stacked) world_model.py:30 */
-    TDMPC2_NET_TERMINATION = 4  /* WorldModel._termination  world_model.py:28 */
+    TDMPC2_NET_TERMINATION = 4, /* WorldModel._termination  world_model.py:28 */
+    TDMPC2_NET_TARGET_Q = 5     /* WorldModel._target_Qs (stacked, optional)  world_model.py:38-53 */
 };
 
 enum tdmpc2_status {
@@ -174,6 +177,23 @@ int tdmpc2_plan_encode(tdmpc2_plan_t *h, int n_envs, const float *obs, int obs_d
 int tdmpc2_plan_run_obs(tdmpc2_plan_t *h, int n_envs, const float *obs, int obs_dim, const float *task_emb,
                         const float *act_mask, const float *disc_pow, float *prev_mean, const uint8_t *t0,
                         int eval_mode, const tdmpc2_noise *tape, uint64_t seed, float *action, void *stream);
+
+/* Training-side consumers of the planner's layer code, forward only, no gradients.  Fused kernel
+ * family (latent_dim = mlp_dim = 512), single-task models; TDMPC2_ERR_UNSUPPORTED otherwise.
+ *
+ * policy_value: a = pi(z) (world_model.py:144-184, sampled with pi_eps [n_rows, A] or Philox(seed) when NULL), then the
+ * two heads qidx[0..1] (device int32[2]; NULL: drawn like randperm(num_q)[:2], world_model.py:212) of the online ensemble
+ * (use_target = 0: what update_pi evaluates, tdmpc2.py:220-221) or of the target ensemble (use_target = 1: bind net
+ * TDMPC2_NET_TARGET_Q first), reduced 'avg' (reduce_min = 0) or 'min' (1), world_model.py:213-216.
+ *   z [n_rows, L] -> action [n_rows, A] (may be NULL), q [n_rows]. */
+int tdmpc2_plan_policy_value(tdmpc2_plan_t *h, int n_rows, const float *z, int use_target, int reduce_min,
+                             const float *pi_eps, const int32_t *qidx, uint64_t seed, float *action, float *q,
+                             void *stream);
+/* TDMPC2._td_target (tdmpc2.py:239-254): td = reward + discount (1 - terminated) min_{2 target heads} Q(next_z, pi(next_z)).
+ *   next_z [n_rows, L] (the reference's [H, B, L] flattened), reward, terminated [n_rows] -> td [n_rows]. */
+int tdmpc2_plan_td_target(tdmpc2_plan_t *h, int n_rows, const float *next_z, const float *reward,
+                          const float *terminated, float discount, const float *pi_eps, const int32_t *qidx,
+                          uint64_t seed, float *td, void *stream);
 
 /* TDMPC2._estimate_value on given action sequences (stage-wise parity).
  *   actions [E,H,N,A], pi_eps [E,N,A], qidx [E,2] -> value [E,N] (before nan_to_num). */

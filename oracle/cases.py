@@ -63,3 +63,15 @@ def build_custom(cfg, E: int, eval_mode: bool = False, head_std: float = 0.06, n
         discounts = [get_discount(cfg, cfg.episode_length)] * E
     return dict(cfg=cfg, iterations=I, sd=sd, z0=z0, tape=tape, prev_mean=prev, t0=t0, tasks=tasks,
                 discounts=discounts, eval_mode=eval_mode, n_envs=E)
+
+
+def td_batch(cfg, B: int = 40, seed: int = 5):
+    """Synthetic inputs of one `TDMPC2._td_target` call (tdmpc2/tdmpc2.py:239-254): next_z [H, B, L] SimNorm latents,
+    reward [H, B, 1], terminated [H, B, 1] in {0, 1}, the policy's noise and the two Q heads."""
+    rng = np.random.default_rng(seed)
+    H = cfg.horizon
+    z = synth.make_latents(cfg, H * B, seed=seed).reshape(H, B, cfg.latent_dim)
+    return {"next_z": z, "reward": rng.standard_normal((H, B, 1)).astype(np.float32),
+            "terminated": (rng.random((H, B, 1)) < 0.2).astype(np.float32),
+            "pi_eps": rng.standard_normal((H, B, cfg.action_dim)).astype(np.float32),
+            "qidx": np.array([min(3, cfg.num_q - 1), 1], np.int32) if cfg.num_q > 2 else np.array([1, 0], np.int32)}

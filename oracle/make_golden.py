@@ -49,11 +49,32 @@ def generate(name: str):
               for e in range(c["n_envs"])]
     arrs = {k: np.stack(v) for k, v in out.items()}
     arrs["encode_z"] = np.stack(zs)
+    if not cfg.multitask:  # TDMPC2._td_target on a synthetic [H, B] batch (inputs rebuilt by cases.td_batch)
+        tb = cases.td_batch(cfg)
+        td = ref_runner.run_reference_td_target(cfg, sd, next_z=tb["next_z"], reward=tb["reward"], terminated=tb["terminated"],
+                                                task=None, discount=_ref_discount(c, 0), pi_eps=tb["pi_eps"], qidx=tb["qidx"])
+        arrs["td_target"] = td.numpy()
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     path = os.path.join(GOLDEN_DIR, f"{name}.npz")
     np.savez_compressed(path, **arrs)
     print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.1f} KiB)  value range "
           f"[{arrs['value'].min():.3f}, {arrs['value'].max():.3f}]")
+
+
+def add_td_target(name: str):
+    """Add the `td_target` array (reference `TDMPC2._td_target` on cases.td_batch) to an existing fixture."""
+    c = cases.build_case(name)
+    cfg = c["cfg"]
+    assert not cfg.multitask
+    sd = {k: torch.as_tensor(v) for k, v in c["sd"].items()}
+    path = os.path.join(GOLDEN_DIR, f"{name}.npz")
+    arrs = dict(np.load(path))
+    tb = cases.td_batch(cfg)
+    arrs["td_target"] = ref_runner.run_reference_td_target(
+        cfg, sd, next_z=tb["next_z"], reward=tb["reward"], terminated=tb["terminated"], task=None,
+        discount=_ref_discount(c, 0), pi_eps=tb["pi_eps"], qidx=tb["qidx"]).numpy()
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: td_target {arrs['td_target'].shape} range [{arrs['td_target'].min():.3f}, {arrs['td_target'].max():.3f}]")
 
 
 def _ref_discount(c, e):
@@ -65,6 +86,11 @@ def _ref_discount(c, e):
         return torch.tensor([get_discount(cfg, L) for L in cfg.episode_lengths])
     return c["discounts"][e]
 
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--td-only":
+    for n in sys.argv[2:]:
+        add_td_target(n)
+    sys.exit(0)
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(cases.CASES)

@@ -165,6 +165,15 @@ class OracleModel:
         Q = two_hot_inv(out[qidx.long()], self.cfg)
         return Q.sum(0) / 2
 
+    def Q_pair(self, z, a, task, qidx, return_type="min", target=False):
+        """world_model.py:186-216 for return_type 'min' / 'avg' on the online (`_Qs.params`), or with `target` the
+        target (`_target_Qs_params`, world_model.py:38-53) ensemble; `qidx` = randperm(num_q)[:2] (line 212)."""
+        if self.cfg.multitask:
+            z = self.task_emb(z, task)
+        out = ensemble_forward(self.sd, "_target_Qs_params" if target else "_Qs.params", torch.cat([z, a], dim=-1))
+        Q = two_hot_inv(out[qidx.long()], self.cfg)
+        return Q.min(0).values if return_type == "min" else Q.sum(0) / 2
+
 
 # --------------------------------------------------------------------------- planner
 def estimate_value(model: OracleModel, z, actions, task, discount, pi_eps, qidx):
@@ -182,6 +191,26 @@ def estimate_value(model: OracleModel, z, actions, task, discount, pi_eps, qidx)
             termination = torch.clip(termination + (model.termination(z, task) > 0.5).to(z.dtype), max=1.0)
     action = model.pi(z, task, pi_eps)
     return G + disc * (1 - termination) * model.Q_avg(z, action, task, qidx)
+
+
+def td_target(model: OracleModel, next_z, reward, terminated, task, discount, pi_eps, qidx):
+    """tdmpc2/tdmpc2.py:239-254 (`TDMPC2._td_target`): next_z [..., L], reward / terminated [..., 1]; the randn_like draw
+    of `pi` and the randperm of `Q` are supplied."""
+    lead = next_z.shape[:-1]
+    z2, e2 = next_z.reshape(-1, next_z.shape[-1]), pi_eps.reshape(-1, pi_eps.shape[-1])
+    action = model.pi(z2, task, e2)
+    q = model.Q_pair(z2, action, task, qidx, "min", target=True).reshape(*lead, 1)
+    return reward + discount * (1 - terminated) * q
+
+
+def policy_value(model: OracleModel, zs, task, pi_eps, qidx):
+    """The forward half of tdmpc2/tdmpc2.py:208-225 (`TDMPC2.update_pi`): action = pi(zs), qs = Q(zs, action, 'avg') on
+    the online (detached) ensemble, before the running-scale normalisation."""
+    lead = zs.shape[:-1]
+    z2, e2 = zs.reshape(-1, zs.shape[-1]), pi_eps.reshape(-1, pi_eps.shape[-1])
+    action = model.pi(z2, task, e2)
+    q = model.Q_pair(z2, action, task, qidx, "avg", target=False)
+    return action.reshape(*lead, -1), q.reshape(*lead, 1)
 
 
 def refit(cfg, value, actions, action_mask=None):

@@ -115,6 +115,11 @@ def build_agent(cfg, state_dict: Dict[str, torch.Tensor], discount):
             s._pi = layers.mlp(cfg.latent_dim + cfg.task_dim, 2 * [cfg.mlp_dim], 2 * cfg.action_dim)
             s._Qs = _Ens([layers.mlp(D, 2 * [cfg.mlp_dim], max(cfg.num_bins, 1), dropout=cfg.dropout)
                           for _ in range(cfg.num_q)])
+            # the target / detached ensembles of world_model.py:38-53 (there: deep copies of _Qs holding separate
+            # parameter sets); WorldModel.Q picks one by its `target` / `detach` flags (world_model.py:201-206)
+            s._target_Qs = _Ens([layers.mlp(D, 2 * [cfg.mlp_dim], max(cfg.num_bins, 1), dropout=cfg.dropout)
+                                 for _ in range(cfg.num_q)])
+            s._detach_Qs = s._Qs
             s.register_buffer("log_std_min", torch.tensor(float(cfg.log_std_min)))
             s.register_buffer("log_std_dif", torch.tensor(float(cfg.log_std_max)) - s.log_std_min)
 
@@ -132,6 +137,7 @@ def build_agent(cfg, state_dict: Dict[str, torch.Tensor], discount):
 
     Agent._plan = TDMPC2._plan
     Agent._estimate_value = TDMPC2._estimate_value
+    Agent._td_target = TDMPC2._td_target
     agent = Agent()
     # load weights (checkpoint keys -> host modules)
     own = agent.model.state_dict()
@@ -139,6 +145,10 @@ def build_agent(cfg, state_dict: Dict[str, torch.Tensor], discount):
         for k, v in state_dict.items():
             if k.startswith("_Qs.params."):
                 kk = "_Qs.p." + k[len("_Qs.params."):].replace(".", "__")
+            elif k.startswith("_target_Qs_params."):
+                kk = "_target_Qs.p." + k[len("_target_Qs_params."):].replace(".", "__")
+            elif k.startswith("_detach_Qs_params."):
+                continue  # an alias of _Qs.params in the reference (world_model.py:40)
             else:
                 kk = k
             if kk not in own:
@@ -204,6 +214,31 @@ class TapePlayer:
         if exc[0] is None:
             assert self.pos == len(self.q), f"reference consumed {self.pos} of {len(self.q)} tape entries"
         return False
+
+
+def run_reference_td_target(cfg, state_dict, *, next_z, reward, terminated, task, discount, pi_eps, qidx):
+    """Call the reference's `TDMPC2._td_target` (tdmpc2/tdmpc2.py:239-254) once with its two RNG draws (the policy's
+    randn_like, world_model.py:156, and Q's randperm, world_model.py:212) served from the arguments.
+    next_z [H, B, L], reward / terminated [H, B, 1]; `discount` = what the reference holds in self.discount."""
+    agent = build_agent(cfg, state_dict, discount)
+    saved = (torch.randn_like, torch.randperm)
+
+    def randn_like(x, **kw):
+        assert tuple(x.shape) == tuple(pi_eps.shape)
+        return torch.as_tensor(pi_eps).to(x.dtype).clone()
+
+    def randperm(n, **kw):
+        first = torch.as_tensor(qidx).long()
+        rest = torch.tensor([i for i in range(n) if i not in first.tolist()], dtype=torch.long)
+        return torch.cat([first, rest])
+
+    torch.randn_like, torch.randperm = randn_like, randperm
+    try:
+        with torch.no_grad():
+            task_t = None if task is None else torch.as_tensor(task)
+            return agent._td_target(torch.as_tensor(next_z), torch.as_tensor(reward), torch.as_tensor(terminated), task_t)
+    finally:
+        torch.randn_like, torch.randperm = saved
 
 
 def run_reference_plan(cfg, state_dict, *, obs=None, z0=None, tape, prev_mean, t0, eval_mode, task, discount,

@@ -813,6 +813,24 @@ __device__ __forceinline__ void tile_broadcast_row_s(const CT &c, const float *s
         }
     }
 }
+// row-major fp32 rows in global -> operand-form z columns (rows >= nvalid are zero)
+template <class CT>
+__device__ __forceinline__ void tile_from_rows_s(const CT &c, const float *src, int nvalid) {
+    for (int idx = c.tid; idx < CT::TROWS * (WIDTH / 4); idx += CT::NTHR) {
+        const int row = idx / (WIDTH / 4), c4 = idx % (WIDTH / 4);
+        f32x4 y = {0.f, 0.f, 0.f, 0.f};
+        if (row < nvalid) y = *reinterpret_cast<const f32x4 *>(src + (size_t)row * WIDTH + 4 * c4);
+        if constexpr (CT::ARITH == 1) {
+            *reinterpret_cast<f32x4 *>(c.f32() + row * CT::RSF() + 4 * c4) = y;
+        } else {
+            f16x4 hi, lo;
+            split4(y, hi, lo);
+            _Float16 *hp = c.act + row * c.RSH + 4 * c4;
+            *reinterpret_cast<f16x4 *>(hp) = hi;
+            *reinterpret_cast<f16x4 *>(hp + c.SH) = lo;
+        }
+    }
+}
 // operand form -> fp32 trace dump (hi + lo, unscaled)
 template <class CT>
 __device__ __forceinline__ void dump_tile_s(const CT &c, float *trace, int nslot, int slot) {
@@ -1141,6 +1159,65 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
         tsc[p.H + 1] = qb;
     }
     if ((tid & 7) == 0 && live) p.value[(size_t)e * p.N + row0 + (tid >> 3)] = G + disc[p.H] * ((qa + qb) / 2.f);
+}
+
+// ================================================================ kernel: pi + two Q heads on a batch of latent rows
+// The forward halves of TDMPC2._td_target (tdmpc2/tdmpc2.py:239-254: a = pi(z'), min of two target heads, then
+// r + discount (1 - terminated) Q) and of TDMPC2.update_pi (tdmpc2.py:208-225: a = pi(z), mean of two online heads) on the
+// planner's layer code: one workgroup per 64 rows, the same three chains the rollout kernel ends with.  Single-task
+// models (the first-layer bias is per workgroup, not per row).
+template <int APAD, int AR>
+__global__ __launch_bounds__(NTHREADS, 2) void ks_value(ValueParamsT<NetS> p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    typedef CtxT<APAD, 2, 8, AR> CT;
+    constexpr int TROWS = CT::TROWS, ZKB16 = CT::ZKB;
+    CT c{reinterpret_cast<_Float16 *>(smem), smem + TROWS * CT::RSF(), smem + TROWS * CT::RSF() + 1024, tid,
+         __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    const int row0 = blockIdx.x * TROWS;
+    const int nvalid = min(TROWS, p.rows - row0);
+    const float *zsrc = p.z + (size_t)row0 * WIDTH;
+    const int KBA = ZKB16 + p.Apad / CT::KBLK;
+    int q0, q1;
+    if (p.qidx) {
+        q0 = p.qidx[0];
+        q1 = p.qidx[1];
+    } else {  // randperm(num_q)[:2] (world_model.py:212), one draw per call
+        const uint4 r = rng_raw(p.seed, p.call, SITE_QIDX, 0, 0, 0);
+        q0 = (int)(r.x % (unsigned)p.nq);
+        q1 = (int)(r.y % (unsigned)(p.nq - 1));
+        if (q1 >= q0) ++q1;
+    }
+    tile_from_rows_s(c, zsrc, nvalid);
+    gb_prefetch(c, p.pi.l[0].g, p.pi.l[0].b);
+    epi_barrier(c);
+    layer_full_s<0>(c, p.pi.l[0], p.pi.l[0].bias, 0, ZKB16, gb_of(p.pi.l[1]));
+    layer_full_s<0>(c, p.pi.l[1], p.pi.l[1].bias, 0, ZKB16, gb_of(p.q[q0].l[0]));
+    {
+        auto eps = [&](int row, int a) -> float {
+            const unsigned ridx = (unsigned)((size_t)(row0 + row) * p.A + a);
+            if (p.pi_eps) return row < nvalid ? p.pi_eps[ridx] : 0.f;
+            return rng_normal(p.seed, p.call, SITE_PI, 0, 0, ridx);
+        };
+        head_pi_s(c, p.pi.l[2], p.A, p.Apad, p.log_std_min, p.log_std_dif, nullptr, eps,
+                  p.action ? p.action + (size_t)row0 * p.A : nullptr, nvalid, nullptr);
+    }
+    tile_from_rows_s(c, zsrc, nvalid);  // the hidden layers overwrote the z columns; the action columns stay
+    __syncthreads();
+    layer_full_s<0>(c, p.q[q0].l[0], p.q[q0].l[0].bias, 0, KBA, gb_of(p.q[q0].l[1]));
+    layer_full_s<0>(c, p.q[q0].l[1], p.q[q0].l[1].bias, 0, ZKB16, gb_of(p.q[q1].l[0]));
+    const float qa = head_twohot_s(c, p.q[q0].l[2], p.bins, p.num_bins);
+    tile_from_rows_s(c, zsrc, nvalid);
+    __syncthreads();
+    layer_full_s<0>(c, p.q[q1].l[0], p.q[q1].l[0].bias, 0, KBA, gb_of(p.q[q1].l[1]));
+    layer_full_s<0>(c, p.q[q1].l[1], p.q[q1].l[1].bias, 0, ZKB16, GB{});
+    const float qb = head_twohot_s(c, p.q[q1].l[2], p.bins, p.num_bins);
+    const int row = tid >> 3;
+    if ((tid & 7) == 0 && row < nvalid) {
+        float v = p.reduce_min ? fminf(qa, qb) : (qa + qb) / 2.f;
+        if (p.reward) v = p.reward[row0 + row] + p.discount * (1.f - p.terminated[row0 + row]) * v;
+        p.out[row0 + row] = v;
+    }
 }
 
 // ================================================================ weight scaling + packing

@@ -76,6 +76,24 @@ struct RolloutParamsT {
     unsigned long long *timing;  // profiling builds (-DSPLIT_TIMING): 16 cycle counters summed over workgroups, else null
 };
 
+// pi + two Q heads on a batch of latent rows (fused_kernels.cuh: ks_value)
+template <class NET>
+struct ValueParamsT {
+    int rows, A, Apad, nq, num_bins, reduce_min;
+    float log_std_min, log_std_dif, discount;
+    NET pi;
+    NET q[MAXQ];
+    const float *bins;
+    const float *z;        // [rows, L]
+    const float *pi_eps;   // [rows, A] or null (Philox)
+    const int *qidx;       // [2] or null (Philox)
+    unsigned long long seed;
+    unsigned int call;
+    const float *reward, *terminated;  // [rows] or null
+    float *action;         // [rows, A] or null
+    float *out;            // [rows]
+};
+
 // net slots inside `beff`
 enum { BE_DYN = 0, BE_REW = 1, BE_PI = 2, BE_Q0 = 3 };
 
@@ -410,6 +428,7 @@ struct tdmpc2_plan {
     size_t lds_bytes = 0;
     HostNet dyn, rew, pi, term;
     HostNet q[MAXQ];
+    HostNet tq[MAXQ];  // target ensemble (optional: tdmpc2_plan_td_target)
     std::vector<void *> allocs;
     uint64_t bytes = 0;
     // workspace
@@ -458,6 +477,7 @@ HostNet *net_of(tdmpc2_plan *h, int net, int head) {
         case TDMPC2_NET_PI: return &h->pi;
         case TDMPC2_NET_Q: return &h->q[head];
         case TDMPC2_NET_TERMINATION: return &h->term;
+        case TDMPC2_NET_TARGET_Q: return &h->tq[head];
     }
     return nullptr;
 }
@@ -809,7 +829,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
 #define CALL_SETLDS(AP, AR)                                                                                          \
     rc = set_lds(ks_setup<AP, AR>, h->lds_bytes) || set_lds(ks_pitraj<AP, 2, AR>, h->lds_bytes) ||                   \
          set_lds(ks_pitraj<AP, 1, AR>, h->lds_bytes) || set_lds(ks_rollout<AP, 2, 8, AR>, h->lds_bytes) ||            \
-         set_lds(ks_rollout<AP, 1, 8, AR>, h->lds_bytes);
+         set_lds(ks_rollout<AP, 1, 8, AR>, h->lds_bytes) || set_lds(ks_value<AP, AR>, h->lds_bytes);
         FUSED_DISPATCH(h->Apad, ar, CALL_SETLDS)
 #undef CALL_SETLDS
         if (rc) {
@@ -857,13 +877,14 @@ int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *
                              const float *ln_b, int out_features, int in_features, void *stream) {
     if (!h || !W || !b) return fail(TDMPC2_ERR_INVALID, "null argument");
     if (layer < 0 || layer > 2) return fail(TDMPC2_ERR_INVALID, "layer %d outside [0, 2]", layer);
-    if (net < TDMPC2_NET_DYNAMICS || net > TDMPC2_NET_TERMINATION) return fail(TDMPC2_ERR_INVALID, "unknown net %d", net);
+    if (net < TDMPC2_NET_DYNAMICS || net > TDMPC2_NET_TARGET_Q) return fail(TDMPC2_ERR_INVALID, "unknown net %d", net);
     const tdmpc2_plan_cfg &c = h->cfg;
     if (net == TDMPC2_NET_TERMINATION && !c.episodic)
         return fail(TDMPC2_ERR_INVALID, "termination head bound on a non-episodic planner");
     hipStream_t st = (hipStream_t)stream;
-    const int heads = net == TDMPC2_NET_Q ? c.num_q : 1;
-    const bool takes_action = (net == TDMPC2_NET_DYNAMICS || net == TDMPC2_NET_REWARD || net == TDMPC2_NET_Q);
+    const bool is_q = net == TDMPC2_NET_Q || net == TDMPC2_NET_TARGET_Q;
+    const int heads = is_q ? c.num_q : 1;
+    const bool takes_action = (net == TDMPC2_NET_DYNAMICS || net == TDMPC2_NET_REWARD || is_q);
     // expected shapes (tdmpc2/common/world_model.py:26-30)
     int exp_in, exp_out;
     if (layer == 0) {
@@ -1057,6 +1078,57 @@ int tdmpc2_plan_run_obs(tdmpc2_plan_t *h, int n_envs, const float *obs, int obs_
     if (rc) return rc;
     return tdmpc2_plan_run(h, n_envs, h->zenc, task_emb, act_mask, discount_pow, prev_mean, t0, eval_mode, tape, seed, action,
                            nullptr, stream);
+}
+
+namespace {
+int launch_value(tdmpc2_plan *h, int rows, const float *z, bool target, bool reduce_min, const float *pi_eps, const int32_t *qidx,
+                 uint64_t seed, const float *reward, const float *terminated, float discount, float *action, float *out,
+                 hipStream_t st) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    if (h->lay.on)
+        return fail(TDMPC2_ERR_UNSUPPORTED, "policy_value / td_target run on the fused kernel family (latent_dim = mlp_dim = 512)");
+    if (c.multitask) return fail(TDMPC2_ERR_UNSUPPORTED, "policy_value / td_target: single-task models only");
+    int rc = check_ready(h);
+    if (rc) return rc;
+    if (target)
+        for (int i = 0; i < 3; ++i)
+            for (int qh = 0; qh < c.num_q; ++qh)
+                if (!h->tq[qh].l[i].bound)
+                    return fail(TDMPC2_ERR_STATE, "layer %d of target Q head %d is not bound (net TDMPC2_NET_TARGET_Q)", i, qh);
+    ValueParamsT<NetS> p{};
+    p.rows = rows; p.A = c.action_dim; p.Apad = h->Apad; p.nq = c.num_q; p.num_bins = c.num_bins; p.reduce_min = reduce_min ? 1 : 0;
+    p.log_std_min = c.log_std_min; p.log_std_dif = c.log_std_dif; p.discount = discount;
+    p.pi = to_dev<NetS>(h->pi);
+    for (int i = 0; i < c.num_q; ++i) p.q[i] = to_dev<NetS>(target ? h->tq[i] : h->q[i]);
+    p.bins = h->bins; p.z = z; p.pi_eps = pi_eps; p.qidx = qidx; p.seed = seed; p.call = ++h->call;
+    p.reward = reward; p.terminated = terminated; p.action = action; p.out = out;
+    const int grid = (rows + ROWS - 1) / ROWS;
+    const size_t lds = h->lds_bytes;
+    const int ar = h->split ? 0 : 1;
+#define CALL_VALUE(AP, AR) hipLaunchKernelGGL((ks_value<AP, AR>), dim3(grid), dim3(NTHREADS), lds, st, p);
+    FUSED_DISPATCH(h->Apad, ar, CALL_VALUE)
+#undef CALL_VALUE
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+}  // namespace
+
+int tdmpc2_plan_policy_value(tdmpc2_plan_t *h, int n_rows, const float *z, int use_target, int reduce_min, const float *pi_eps,
+                             const int32_t *qidx, uint64_t seed, float *action, float *q, void *stream) {
+    if (!h || !z || !q) return fail(TDMPC2_ERR_INVALID, "null argument");
+    if (n_rows < 1) return fail(TDMPC2_ERR_INVALID, "n_rows %d < 1", n_rows);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    return launch_value(h, n_rows, z, use_target != 0, reduce_min != 0, pi_eps, qidx, seed, nullptr, nullptr, 0.f, action, q,
+                        (hipStream_t)stream);
+}
+
+int tdmpc2_plan_td_target(tdmpc2_plan_t *h, int n_rows, const float *next_z, const float *reward, const float *terminated,
+                          float discount, const float *pi_eps, const int32_t *qidx, uint64_t seed, float *td, void *stream) {
+    if (!h || !next_z || !reward || !terminated || !td) return fail(TDMPC2_ERR_INVALID, "null argument");
+    if (n_rows < 1) return fail(TDMPC2_ERR_INVALID, "n_rows %d < 1", n_rows);
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    return launch_value(h, n_rows, next_z, true, true, pi_eps, qidx, seed, reward, terminated, discount, nullptr, td,
+                        (hipStream_t)stream);
 }
 
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value) {

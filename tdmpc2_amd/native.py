@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("TDMPC2_PLAN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtdmpc2_plan.so")
 _lib = None
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/tdmpc2_plan.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
@@ -25,9 +25,10 @@ ABI_SYMBOLS = [
     "tdmpc2_plan_device_bytes", "tdmpc2_plan_path", "tdmpc2_plan_precision", "tdmpc2_plan_bind_weights", "tdmpc2_plan_run", "tdmpc2_plan_estimate_value",
     "tdmpc2_plan_estimate_value_trace", "tdmpc2_plan_refit", "tdmpc2_plan_set_tuning", "tdmpc2_plan_set_profiling",
     "tdmpc2_plan_profile_read", "tdmpc2_plan_bind_encoder", "tdmpc2_plan_encode", "tdmpc2_plan_run_obs",
+    "tdmpc2_plan_policy_value", "tdmpc2_plan_td_target",
 ]
 
-NET_DYNAMICS, NET_REWARD, NET_PI, NET_Q, NET_TERMINATION = range(5)
+NET_DYNAMICS, NET_REWARD, NET_PI, NET_Q, NET_TERMINATION, NET_TARGET_Q = range(6)
 PATH_AUTO, PATH_FUSED, PATH_LAYERED = range(3)  # enum tdmpc2_path
 PREC_AUTO, PREC_FP32, PREC_SPLIT_F16 = range(3)  # enum tdmpc2_precision
 
@@ -92,6 +93,10 @@ def load_library():
     lib.tdmpc2_plan_encode.restype = i32
     lib.tdmpc2_plan_run_obs.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, C.POINTER(Noise), u64, vp, vp]
     lib.tdmpc2_plan_run_obs.restype = i32
+    lib.tdmpc2_plan_policy_value.argtypes = [vp, i32, vp, i32, i32, vp, vp, u64, vp, vp, vp]
+    lib.tdmpc2_plan_policy_value.restype = i32
+    lib.tdmpc2_plan_td_target.argtypes = [vp, i32, vp, vp, vp, C.c_float, vp, vp, u64, vp, vp]
+    lib.tdmpc2_plan_td_target.restype = i32
     lib.tdmpc2_plan_estimate_value.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tdmpc2_plan_estimate_value.restype = i32
     lib.tdmpc2_plan_estimate_value_trace.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -196,6 +201,8 @@ class NativePlanner:
         nets = [(NET_DYNAMICS, "_dynamics"), (NET_REWARD, "_reward"), (NET_PI, "_pi"), (NET_Q, "_Qs.params")]
         if self.cfg.episodic:
             nets.append((NET_TERMINATION, "_termination"))
+        if "_target_Qs_params.0.weight" in sd and self.path == PATH_FUSED and not self.cfg.multitask:
+            nets.append((NET_TARGET_Q, "_target_Qs_params"))  # optional: td_target (tdmpc2.py:239-254)
         keep = []
         with torch.cuda.device(self.device):
             for net, prefix in nets:
@@ -292,6 +299,43 @@ class NativePlanner:
         for k, (shp, dt) in shapes.items():
             _chk_tensor(f"tape[{k}]", tape[k], dt, shp, dev)
         return Noise(**{k: tape[k].data_ptr() for k in shapes})
+
+    # ------------------------------------------------------------------ training-side forward pieces
+    def policy_value(self, z, use_target=False, reduce="avg", pi_eps=None, qidx=None, seed: int = 0, return_action=True):
+        """a = pi(z), then two Q heads of the online / target ensemble, 'avg' or 'min' (the forward half of
+        TDMPC2.update_pi, tdmpc2.py:208-225).  z [R, L] -> (action [R, A] or None, q [R])."""
+        cfg, dev = self.cfg, self.device
+        R = int(z.shape[0])
+        _chk_tensor("z", z, torch.float32, (R, cfg.latent_dim), dev)
+        if pi_eps is not None:
+            _chk_tensor("pi_eps", pi_eps, torch.float32, (R, cfg.action_dim), dev)
+        if qidx is not None:
+            _chk_tensor("qidx", qidx, torch.int32, (2,), dev)
+        action = torch.empty(R, cfg.action_dim, device=dev) if return_action else None
+        q = torch.empty(R, device=dev)
+        with torch.cuda.device(dev):
+            self._check(self.lib.tdmpc2_plan_policy_value(self._h, R, _ptr(z), int(bool(use_target)), int(reduce == "min"),
+                                                          _ptr(pi_eps), _ptr(qidx), C.c_uint64(int(seed) & (2**64 - 1)),
+                                                          _ptr(action), _ptr(q), self._stream()))
+        return action, q
+
+    def td_target(self, next_z, reward, terminated, discount: float, pi_eps=None, qidx=None, seed: int = 0):
+        """TDMPC2._td_target (tdmpc2.py:239-254) on flattened rows: next_z [R, L], reward / terminated [R] -> td [R]."""
+        cfg, dev = self.cfg, self.device
+        R = int(next_z.shape[0])
+        _chk_tensor("next_z", next_z, torch.float32, (R, cfg.latent_dim), dev)
+        _chk_tensor("reward", reward, torch.float32, (R,), dev)
+        _chk_tensor("terminated", terminated, torch.float32, (R,), dev)
+        if pi_eps is not None:
+            _chk_tensor("pi_eps", pi_eps, torch.float32, (R, cfg.action_dim), dev)
+        if qidx is not None:
+            _chk_tensor("qidx", qidx, torch.int32, (2,), dev)
+        td = torch.empty(R, device=dev)
+        with torch.cuda.device(dev):
+            self._check(self.lib.tdmpc2_plan_td_target(self._h, R, _ptr(next_z), _ptr(reward), _ptr(terminated),
+                                                       C.c_float(float(discount)), _ptr(pi_eps), _ptr(qidx),
+                                                       C.c_uint64(int(seed) & (2**64 - 1)), _ptr(td), self._stream()))
+        return td
 
     # ------------------------------------------------------------------ planning
     def _common_inputs(self, E, z0, task_emb, act_mask, disc_pow):

@@ -85,6 +85,10 @@ def make_state_dict(cfg: Config, seed: int = 0, head_std: float = 0.06) -> Dict[
     _mlp(rng, sd, "_pi", L + T, 2 * [M], 2 * A, last_ln=False, out_std=0.05)
     _mlp(rng, sd, "_Qs.params", L + A + T, 2 * [M], max(cfg.num_bins, 1), last_ln=False, out_std=head_std,
          stack=cfg.num_q)
+    # target ensemble (world_model.py:38-53): an EMA copy in training; here independently drawn so that a test can tell
+    # the two apart.  Drawn last so the other tensors keep their values for a given seed.
+    _mlp(np.random.default_rng(seed + 7919), sd, "_target_Qs_params", L + A + T, 2 * [M], max(cfg.num_bins, 1), last_ln=False,
+         out_std=head_std, stack=cfg.num_q)
     sd["log_std_min"] = np.asarray(cfg.log_std_min, np.float32)
     sd["log_std_dif"] = np.asarray(np.float32(cfg.log_std_max) - np.float32(cfg.log_std_min), np.float32)
     return sd

@@ -88,7 +88,8 @@ class WorldModel(nn.Module):
     def planner_state_dict(self):
         """The tensors the HIP planner binds (new-format keys)."""
         sd = {k: v for k, v in self.state_dict().items() if torch.is_tensor(v)}
-        return {k: v for k, v in sd.items() if k.startswith(("_dynamics.", "_reward.", "_pi.", "_Qs.params.", "_termination."))}
+        return {k: v for k, v in sd.items()
+                if k.startswith(("_dynamics.", "_reward.", "_pi.", "_Qs.params.", "_termination.", "_target_Qs_params."))}
 
     # ---- forward pieces (reference world_model.py:88-216) ------------------------------
     def task_emb(self, x, task):

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(lib):
     for sym in _declared_symbols():
         assert hasattr(lib, sym), sym
     lib.tdmpc2_plan_abi_version.restype = ctypes.c_int
-    assert lib.tdmpc2_plan_abi_version() == 3
+    assert lib.tdmpc2_plan_abi_version() == 4
 
 
 def test_cfg_struct_matches_header_layout():

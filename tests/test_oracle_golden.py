@@ -58,6 +58,19 @@ def test_oracle_encode_matches_reference(name):
         np.testing.assert_allclose(z, g["encode_z"][e], atol=1e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("name", ["tiny", "small", "c1", "c1_wide"])
+def test_oracle_td_target_matches_reference(name):
+    """oracle.td_target (restating tdmpc2.py:239-254) vs the fixture minted by the reference's own `_td_target`."""
+    g = load_golden(name)
+    c = cases.build_case(name)
+    model = po.OracleModel(c["cfg"], {k: torch.as_tensor(v) for k, v in c["sd"].items()})
+    tb = cases.td_batch(c["cfg"])
+    td = po.td_target(model, torch.as_tensor(tb["next_z"]), torch.as_tensor(tb["reward"]), torch.as_tensor(tb["terminated"]),
+                      None, c["discounts"][0], torch.as_tensor(tb["pi_eps"]), torch.as_tensor(tb["qidx"])).numpy()
+    assert td.shape == g["td_target"].shape
+    np.testing.assert_allclose(td, g["td_target"], atol=2e-5, rtol=2e-5)
+
+
 def test_tiny_is_bit_exact():
     """On the tiny config both implementations take identical kernels: exact."""
     g = load_golden("tiny")
