@@ -80,3 +80,30 @@ def test_plan_batch_vectorised_envs():
     assert a.shape == (8, c["cfg"].action_dim) and torch.isfinite(a).all() and a.abs().max() <= 1
     b = agent.act_batch(obs, t0=False)
     assert not torch.equal(a, b)
+
+
+def test_plan_is_hip_graph_capturable():
+    """`run` allocates nothing and launches only on the caller's stream: a whole plan (setup, policy prior, I x (rollout, refit))
+    captures into a hipGraph (what the reference obtains with torch.compile's reduce-overhead mode, tdmpc2.py:52) and the
+    replay reproduces the eager result bit for bit on the same noise tape."""
+    from tests.gpu_common import case_on_gpu, plan_inputs
+
+    c, model, planner = case_on_gpu("c1")
+    inp = plan_inputs(c, model)
+    kw = dict(task_emb=inp["task_emb"], act_mask=inp["act_mask"], tape=inp["tape"])
+    pm_eager = inp["prev_mean"].clone()
+    a_eager = planner.plan(inp["z0"], inp["disc_pow"], pm_eager, inp["t0"], **kw).clone()
+    pm_static, out = inp["prev_mean"].clone(), torch.empty_like(a_eager)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):  # warm-up on the side stream, then capture
+        planner.plan(inp["z0"], inp["disc_pow"], pm_static.clone(), inp["t0"], out=out, **kw)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        planner.plan(inp["z0"], inp["disc_pow"], pm_static, inp["t0"], out=out, **kw)
+    for _ in range(2):
+        pm_static.copy_(inp["prev_mean"])
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, a_eager) and torch.equal(pm_static, pm_eager)
