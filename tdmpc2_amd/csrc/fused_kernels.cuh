@@ -561,8 +561,10 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][CT::FT
                 for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = fmaf(acc[st][ft][4 * m + r], osc, b4[m][r]);
     }
     TIMER_MARK(c, T_EPI_BIAS)
+#ifdef SPLIT_GB_IN_EPI
     // the successor's g / b (this layer's own are in c.gb already); behind the bias loads, which are needed first
     if (next.g) gb_prefetch(c, next.g, next.b);
+#endif
     // per-wave partial statistics of the sample rows this lane works on
 #pragma unroll
     for (int st = 0; st < CT::NST; ++st) {
@@ -712,6 +714,9 @@ __device__ __forceinline__ void layer_full_s(const CT &c, const LayerS &ly, cons
                                              GB next, float *zcopy = nullptr) {
     f32x16 acc[CT::NST][CT::FT];
     zero_acc(acc);
+#ifndef SPLIT_GB_IN_EPI
+    if (next.g) gb_prefetch(c, next.g, next.b);  // in flight behind the whole contraction
+#endif
     kloop_s(c, ly, kb0, kb1, acc);
     TIMER_MARK(c, T_KLOOP)
     epi_t<ACT>(c, acc, *ly.oscale, bias, next, zcopy);
@@ -1053,6 +1058,9 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
             TIMER_MARK(c, T_PARK)
 #endif
             zero_acc(acc);
+#ifndef SPLIT_GB_IN_EPI
+            gb_prefetch(c, p.rew.l[1].g, p.rew.l[1].b);
+#endif
             kloop_s(c, p.rew.l[0], t == 0 ? ZKB16 : 0, KBA, acc);
             TIMER_MARK(c, T_KLOOP)
             epi_t<0>(c, acc, *p.rew.l[0].oscale, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew, gb_of(p.rew.l[1]), nullptr);
@@ -1063,6 +1071,9 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
         // ---- reward: layer 2, two-hot head
         layer_full_s<0>(c, p.rew.l[1], p.rew.l[1].bias, 0, ZKB16, gb_of(p.dyn.l[0]));
         dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 1);
+#ifndef SPLIT_GB_IN_EPI
+        gb_prefetch(c, p.dyn.l[1].g, p.dyn.l[1].b);  // for the held dynamics epilogue below; in flight behind the head
+#endif
         const float r = head_twohot_s(c, p.rew.l[2], p.bins, p.num_bins);
         TIMER_MARK(c, T_HEAD)
         if (tsc && (tid & 7) == 0) tsc[t] = r;
@@ -1125,6 +1136,9 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
         TIMER_MARK(c, T_PARK)
 #endif
         zero_acc(acc);
+#ifndef SPLIT_GB_IN_EPI
+        gb_prefetch(c, p.q[q0].l[1].g, p.q[q0].l[1].b);
+#endif
         kloop_s(c, p.q[q0].l[0], 0, KBA, acc);
         TIMER_MARK(c, T_KLOOP)
         epi_t<0>(c, acc, *p.q[q0].l[0].oscale, b_q0, gb_of(p.q[q0].l[1]), nullptr);
@@ -1134,6 +1148,9 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 3);
     layer_full_s<0>(c, p.q[q0].l[1], p.q[q0].l[1].bias, 0, ZKB16, gb_of(p.q[q1].l[0]));
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 4);
+#ifndef SPLIT_GB_IN_EPI
+    gb_prefetch(c, p.q[q1].l[1].g, p.q[q1].l[1].b);  // for the held second-head epilogue below
+#endif
     const float qa = head_twohot_s(c, p.q[q0].l[2], p.bins, p.num_bins);
     TIMER_MARK(c, T_HEAD)
     {
