@@ -107,3 +107,46 @@ def test_plan_is_hip_graph_capturable():
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, a_eager) and torch.equal(pm_static, pm_eager)
+
+
+def test_rebinding_weights_and_concurrent_handles():
+    """`load()` / a training step re-binds weights into a live handle (tdmpc2.py:81-95 semantics); two handles on two
+    streams share no mutable state: both reproduce their own single-handle results when run concurrently."""
+    from oracle import cases
+    from tests.gpu_common import dev, plan_inputs
+    from oracle import planner_oracle as po
+    from tdmpc2_amd.native import NativePlanner
+
+    c1 = cases.build_case("c1")
+    sd_a = {k: torch.as_tensor(v) for k, v in c1["sd"].items()}
+    from tdmpc2_amd import synth
+    sd_b = {k: torch.as_tensor(v) for k, v in synth.make_state_dict(c1["cfg"], seed=123).items()}
+    model = po.OracleModel(c1["cfg"], sd_a)
+    inp = plan_inputs(c1, model)
+    kw = dict(task_emb=None, act_mask=None, tape=inp["tape"])
+
+    def run(pl, stream=None):
+        if stream is None:
+            return pl.plan(inp["z0"], inp["disc_pow"], inp["prev_mean"].clone(), inp["t0"], **kw).clone()
+        with torch.cuda.stream(stream):  # every op of this plan, the prev_mean copy included, on that stream
+            return pl.plan(inp["z0"], inp["disc_pow"], inp["prev_mean"].clone(), inp["t0"], **kw)
+
+    pa = NativePlanner(c1["cfg"], c1["iterations"], dev(), max_envs=c1["n_envs"])
+    pb = NativePlanner(c1["cfg"], c1["iterations"], dev(), max_envs=c1["n_envs"])
+    pa.bind_state_dict(sd_a)
+    pb.bind_state_dict(sd_b)
+    ra, rb = run(pa), run(pb)
+    assert (ra - rb).abs().max() > 1e-3  # different weights, different plans
+    # re-bind: handle b takes a's weights and must now reproduce a's plan exactly
+    pb.bind_state_dict(sd_a)
+    assert torch.equal(run(pb), ra)
+    pb.bind_state_dict(sd_b)
+    # concurrently on two streams
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(3):
+        outs.append((run(pa, s1), run(pb, s2)))
+    torch.cuda.synchronize()
+    for oa, ob in outs:
+        assert torch.equal(oa, ra) and torch.equal(ob, rb)
