@@ -425,6 +425,7 @@ struct tdmpc2_plan {
     size_t row_bytes = 0;  // bytes of one sample row of the fused kernels' LDS tile
     float *one = nullptr;  // device scalar 1.0f: the output scale of the exact-fp32 arithmetic
     int Apad = 0, stride = 0, tiles = 0, nnets = 0;
+    int num_cus = 0;  // compute units of cfg.device
     size_t lds_bytes = 0;
     HostNet dyn, rew, pi, term;
     HostNet q[MAXQ];
@@ -515,11 +516,17 @@ int set_lds(K kernel, size_t bytes) {
     }
 template <class NET> struct Kern;
 template <> struct Kern<NetS> {
-    // 32-row workgroups (twice as many) when a call brings too few plans to occupy the chip: single-env latency
+    // 32- or 64-row workgroups.  A 64-row workgroup reuses every weight fragment for two row tiles and is the
+    // efficient one when the chip is full; a call with few plans is better served by twice as many 32-row workgroups.
+    // Model: one workgroup per CU at a time, a round of 32-row workgroups takes 0.61 of a round of 64-row ones
+    // (measured, c1: 0.34 vs 0.556 ms); pick the geometry with the shorter sum of rounds (E = 16: +30 %).
     static int sample_tiles(const tdmpc2_plan *h, int E, bool tracing) {
         if (tracing) return 2;  // the activation trace is laid out per 64-row tile
         if (h->force_rows) return h->force_rows / 32;
-        return E * h->tiles < 128 ? 1 : TDMPC2_DEFAULT_THROUGHPUT_ST;
+        const long cus = h->num_cus > 0 ? h->num_cus : 256;
+        const long w2 = (long)E * h->tiles, w1 = 2 * w2;
+        const long r2 = (w2 + cus - 1) / cus, r1 = (w1 + cus - 1) / cus;
+        return 0.61 * (double)r1 < (double)r2 ? 1 : TDMPC2_DEFAULT_THROUGHPUT_ST;
     }
     // Always 8 wavefronts per workgroup.  A 4-wave, 32-row geometry (two workgroups per CU, so that one's VALU epilogue
     // overlaps the other's MFMA k-loop; the device code is templated for it: CtxT<APAD, 1, 4>) was measured and lost
@@ -750,6 +757,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
     h->cfg.precision = prec;
     h->lay.on = (path == TDMPC2_PATH_LAYERED);
     h->split = (prec == TDMPC2_PREC_SPLIT_F16);
+    if (hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess) h->num_cus = 0;
     h->Apad = (c.action_dim + 15) / 16 * 16;  // the fused kernels are instantiated for action paddings 16 / 32 / 48 / 64
     h->tiles = c.num_samples / ROWS;
     h->nnets = BE_Q0 + c.num_q;
