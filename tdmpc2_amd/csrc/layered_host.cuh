@@ -237,7 +237,8 @@ int lay_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float 
     int rc;
     if ((rc = lay_setup(h, st, E, task_emb, prev_mean, t0, true))) return rc;
     if (P > 0 && (rc = lay_pitraj(h, st, E, z0, act_mask, tape ? tape->pi_traj_eps : nullptr, seed, call))) return rc;
-    const size_t refit_lds = ((size_t)N + 3 * K + 2 * H * A) * 4 + 64;
+    int refit_stage = 0;
+    const size_t refit_lds = refit_lds_bytes(N, K, H, A, &refit_stage);
     for (int it = 0; it < I; ++it) {
         SampleParams sp{};
         sp.E = E; sp.H = H; sp.N = N; sp.A = A; sp.P = P; sp.iter = it; sp.mean = h->mean; sp.std = h->std; sp.mask = act_mask;
@@ -261,7 +262,7 @@ int lay_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float 
             HIP_TRY(hipMemcpy2DAsync(dbg->actions + (size_t)it * H * N * A, (size_t)I * H * N * A * 4, h->actions,
                                      (size_t)H * N * A * 4, (size_t)H * N * A * 4, E, hipMemcpyDeviceToDevice, st));
         RefitParams fp{};
-        fp.E = E; fp.N = N; fp.H = H; fp.A = A; fp.K = K; fp.iter = it; fp.last = (it == I - 1); fp.eval_mode = eval_mode;
+        fp.E = E; fp.N = N; fp.H = H; fp.A = A; fp.K = K; fp.iter = it; fp.last = (it == I - 1); fp.eval_mode = eval_mode; fp.stage = refit_stage;
         fp.temperature = c.temperature; fp.min_std = c.min_std; fp.max_std = c.max_std;
         fp.value = h->value; fp.actions = h->actions; fp.act_mask = act_mask; fp.mean = h->mean; fp.std = h->std;
         fp.gumbel_exp = tape ? tape->gumbel_exp : nullptr; fp.final_eps = tape ? tape->final_eps : nullptr;
