@@ -70,8 +70,8 @@ def disc_pow_rows(cfg, n_envs, device):
     return torch.tensor(vals, dtype=torch.float32, device=device).repeat(n_envs, 1).contiguous()
 
 
-def pmc_traffic(workgroups, kernel="k_rollout"):
-    """HBM-side bytes per k_rollout launch from the committed rocprofv3 --pmc passes (FETCH_SIZE with the gfx950
+def pmc_traffic(workgroups, kernel="ks_rollout"):
+    """HBM-side bytes per rollout-kernel launch from the committed rocprofv3 --pmc passes (FETCH_SIZE with the gfx950
     x2 correction + WRITE_SIZE; tools/gpu_pmc.sh -> tools/pmc_summary.py --json).  bench.py cannot read PMC
     counters from inside its own process, so the figure comes from the profile of the same launch geometry;
     None if no profile of that geometry is committed."""

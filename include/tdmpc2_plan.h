@@ -226,7 +226,7 @@ enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0 };
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
 
 /* Live timing of the dominant (rollout) stage: after set_profiling(h, n > 0) every rollout launch
- * (FUSED: one k_rollout kernel; LAYERED: the GEMM / row-kernel sequence of one CEM iteration's
+ * (FUSED: one ks_rollout kernel; LAYERED: the GEMM / row-kernel sequence of one CEM iteration's
  * _estimate_value) is bracketed by HIP events recorded on the caller's stream (up to n are kept;
  * n = 0 turns it off).  profile_read synchronises those events, returns their summed duration and the number of
  * launches measured, and rewinds the buffer. */

@@ -66,9 +66,9 @@ struct NetS {
 // addresses, hoists them out of the step loop and spills them.
 // ST = 32-row sample tiles per workgroup: 2 (64 rows, throughput) or 1 (32 rows: twice the workgroups for the same plans,
 // used when a call has too few plans to fill the chip -- single-environment latency).
-// NW = wavefronts per workgroup: 8 (each owns 64 output features = 2 feature tiles) or 4 (128 features = 4 tiles).
-// The throughput geometry is (ST 1, NW 4): 32-row, 256-thread workgroups of 72 KB LDS, TWO per CU -- independent
-// barrier domains whose phases drift apart, so one workgroup's VALU epilogue overlaps the other's MFMA k-loop.
+// NW = wavefronts per workgroup: 8 (each owns 64 output features = 2 feature tiles); the code is written for 4 as well
+// (128 features = 4 tiles per wave), a geometry that was measured and lost both as two 32-row workgroups per CU and
+// as one 64-row workgroup per CU (profiles/README.md).
 // ARITH: 0 = f16x2 split (operand tile = hi / lo f16 planes), 1 = exact fp32 (v_mfma_f32_32x32x2_f32; operand tile =
 // fp32 rows of WIDTH + APAD + 4 floats, stride / 4 odd).  Everything but the contraction loops and the tile writes is
 // shared between the two.
@@ -852,7 +852,7 @@ __device__ __forceinline__ void dump_tile_s(const CT &c, float *trace, int nslot
     }
 }
 
-// ================================================================ kernel: per-plan setup (cf. k_setup)
+// ================================================================ kernel: per-plan setup
 template <int APAD, int AR>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
     }
 }
 
-// ================================================================ kernel: policy-prior trajectories (cf. k_pitraj)
+// ================================================================ kernel: policy-prior trajectories
 // ST = 1 (one 32-row tile) when num_pi_trajs <= 32 -- the reference's 24 -- else 2.
 template <int APAD, int ST, int AR>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) {
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) 
     }
 }
 
-// ================================================================ kernel: one CEM iteration's rollouts (cf. k_rollout)
+// ================================================================ kernel: one CEM iteration's rollouts
 template <int APAD, int ST, int NW, int AR>
 __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];

@@ -1,7 +1,7 @@
 // Layer-at-a-time planner kernels for ANY (latent_dim, mlp_dim): the 19M / 48M / 317M world models
 // (c3, c4, c5) and episodic (termination-head) planning at every size.
 //
-// The fused kernel (k_rollout) keeps a 64-row activation tile in LDS across a whole CEM iteration, which only
+// The fused kernel (ks_rollout) keeps a 64-row activation tile in LDS across a whole CEM iteration, which only
 // fits for 512-wide layers.  Here activations live in HBM (288 GB: [E*N, mlp_dim] fp32 per buffer) and every
 // nn.Linear of the reference becomes one LDS-tiled fp32-MFMA GEMM launch over all E*N sample rows of all
 // plans, followed by one row-wise kernel for the LayerNorm / Mish / SimNorm / two-hot / policy-head math

@@ -13,8 +13,11 @@
 //                        64 sample rows of one plan in LDS for a whole CEM iteration; templated on the arithmetic
 //                        (f16x2 split on the f16 matrix pipe -- the default -- or exact fp32 MFMA), the action padding
 //                        and the workgroup geometry
+//                        + ks_value: pi + two Q heads on a batch of latent rows (TDMPC2._td_target, tdmpc2.py:239-254,
+//                        and the forward half of update_pi, tdmpc2.py:208-225)
 //   layered_kernels.cuh, layered_split.cuh, layered_host.cuh
 //                        layer-at-a-time family for every other model size and for episodic planning
+//   encoder_kernels.cuh  WorldModel.encode for state observations (world_model.py:103-112)
 // Weights are re-packed once (bind) into MFMA fragment order so that a wave's global_load_dwordx4 reads 1 KiB
 // contiguous; one small workgroup per plan does nan_to_num + top-k + score + mean/std refit (+ the final Gumbel pick)
 // between rollout launches (k_refit below).  DESIGN.md has the full account.
