@@ -40,9 +40,8 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     __shared__ __attribute__((aligned(16))) _Float16 As[2][2][GBM * GS_LDH];  // [buffer][plane][row][k]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nb = gridDim.x, b = blockIdx.x;
-    const int tile = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
-    const int rb = tile / p.ncolblk, cb = tile % p.ncolblk;
+    int rb, cb;
+    gemm_tile_of_block(blockIdx.x, gridDim.x, p.ncolblk, rb, cb);
     const int row0 = rb * GBM;
     const int sel = p.sel ? p.sel[(size_t)(row0 / p.rows_per_env) * p.sel_stride] : 0;
     const int KB = p.K / 16;
