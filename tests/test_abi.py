@@ -73,3 +73,20 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "/root/reference" not in txt, f
+
+
+def test_new_entry_points_reject_null_arguments(lib):
+    """No GPU needed: argument validation comes first in every entry point."""
+    lib.tdmpc2_last_error.restype = ctypes.c_char_p
+    for name, nargs in [("tdmpc2_plan_encode", 7), ("tdmpc2_plan_run_obs", 14), ("tdmpc2_plan_bind_encoder", 10),
+                        ("tdmpc2_plan_policy_value", 11), ("tdmpc2_plan_td_target", 11)]:
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_int
+        if name == "tdmpc2_plan_td_target":
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float,
+                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]
+            rc = fn(None, 1, None, None, None, 0.99, None, None, 0, None, None)
+        else:
+            rc = fn(*([None] + [0] * (nargs - 1))) if name != "tdmpc2_plan_run_obs" else fn(*([None] * nargs))
+        assert rc == 1, name  # TDMPC2_ERR_INVALID
+        assert b"null" in lib.tdmpc2_last_error()
