@@ -71,7 +71,8 @@ def td_batch(cfg, B: int = 40, seed: int = 5):
     rng = np.random.default_rng(seed)
     H = cfg.horizon
     z = synth.make_latents(cfg, H * B, seed=seed).reshape(H, B, cfg.latent_dim)
-    return {"next_z": z, "reward": rng.standard_normal((H, B, 1)).astype(np.float32),
+    tasks = (np.arange(B) % len(cfg.tasks)).astype(np.int64) if cfg.multitask else None  # task [B] as in tdmpc2.py:249
+    return {"tasks": tasks, "next_z": z, "reward": rng.standard_normal((H, B, 1)).astype(np.float32),
             "terminated": (rng.random((H, B, 1)) < 0.2).astype(np.float32),
             "pi_eps": rng.standard_normal((H, B, cfg.action_dim)).astype(np.float32),
             "qidx": np.array([min(3, cfg.num_q - 1), 1], np.int32) if cfg.num_q > 2 else np.array([1, 0], np.int32)}

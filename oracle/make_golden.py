@@ -49,11 +49,8 @@ def generate(name: str):
               for e in range(c["n_envs"])]
     arrs = {k: np.stack(v) for k, v in out.items()}
     arrs["encode_z"] = np.stack(zs)
-    if not cfg.multitask:  # TDMPC2._td_target on a synthetic [H, B] batch (inputs rebuilt by cases.td_batch)
-        tb = cases.td_batch(cfg)
-        td = ref_runner.run_reference_td_target(cfg, sd, next_z=tb["next_z"], reward=tb["reward"], terminated=tb["terminated"],
-                                                task=None, discount=_ref_discount(c, 0), pi_eps=tb["pi_eps"], qidx=tb["qidx"])
-        arrs["td_target"] = td.numpy()
+    # TDMPC2._td_target on a synthetic [H, B] batch (inputs rebuilt by cases.td_batch)
+    arrs["td_target"] = _td_target_reference(c, cfg, sd)
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     path = os.path.join(GOLDEN_DIR, f"{name}.npz")
     np.savez_compressed(path, **arrs)
@@ -65,16 +62,27 @@ def add_td_target(name: str):
     """Add the `td_target` array (reference `TDMPC2._td_target` on cases.td_batch) to an existing fixture."""
     c = cases.build_case(name)
     cfg = c["cfg"]
-    assert not cfg.multitask
     sd = {k: torch.as_tensor(v) for k, v in c["sd"].items()}
     path = os.path.join(GOLDEN_DIR, f"{name}.npz")
     arrs = dict(np.load(path))
-    tb = cases.td_batch(cfg)
-    arrs["td_target"] = ref_runner.run_reference_td_target(
-        cfg, sd, next_z=tb["next_z"], reward=tb["reward"], terminated=tb["terminated"], task=None,
-        discount=_ref_discount(c, 0), pi_eps=tb["pi_eps"], qidx=tb["qidx"]).numpy()
+    arrs["td_target"] = _td_target_reference(c, cfg, sd)
     np.savez_compressed(path, **arrs)
     print(f"{name}: td_target {arrs['td_target'].shape} range [{arrs['td_target'].min():.3f}, {arrs['td_target'].max():.3f}]")
+
+
+def _td_target_reference(c, cfg, sd):
+    """The reference's `_td_target` (tdmpc2.py:239-254) on cases.td_batch; multitask: one task per batch column and the
+    per-task discount vector the reference holds in self.discount (tdmpc2.py:35-37)."""
+    from tdmpc2_amd.config import get_discount
+
+    tb = cases.td_batch(cfg)
+    if cfg.multitask:
+        task = torch.as_tensor(tb["tasks"])
+        discount = torch.tensor([get_discount(cfg, ln) for ln in cfg.episode_lengths])
+    else:
+        task, discount = None, _ref_discount(c, 0)
+    return ref_runner.run_reference_td_target(cfg, sd, next_z=tb["next_z"], reward=tb["reward"], terminated=tb["terminated"],
+                                              task=task, discount=discount, pi_eps=tb["pi_eps"], qidx=tb["qidx"]).numpy()
 
 
 def _ref_discount(c, e):

@@ -111,6 +111,12 @@ class OracleModel:
     def task_emb(self, x, task: int):
         """world_model.py:88-101; nn.Embedding(max_norm=1) (world_model.py:21)
         rescales a looked-up row with ||row|| > 1 by 1/(||row|| + 1e-7)."""
+        if torch.is_tensor(task) and task.numel() > 1:  # one task per row (training batches, world_model.py:95-97)
+            emb = self.sd["_task_emb.weight"][task.long()]
+            norm = emb.norm(2, dim=-1, keepdim=True)
+            emb = torch.where(norm > 1.0, emb * (1.0 / (norm + 1e-7)), emb)
+            return torch.cat([x, emb], dim=-1)
+        task = int(task)
         emb = self.sd["_task_emb.weight"][task]
         norm = emb.norm(2)
         if norm > 1.0:
@@ -149,7 +155,7 @@ class OracleModel:
         mean, log_std = mlp_forward(self.sd, "_pi", z).chunk(2, dim=-1)
         log_std = log_std_fn(log_std, self.sd["log_std_min"], self.sd["log_std_dif"])
         if self.cfg.multitask:
-            mask = self.sd["_action_masks"][task]
+            mask = self.sd["_action_masks"][task.long() if torch.is_tensor(task) else task]
             mean = mean * mask
             log_std = log_std * mask
             eps = eps * mask
@@ -198,6 +204,8 @@ def td_target(model: OracleModel, next_z, reward, terminated, task, discount, pi
     of `pi` and the randperm of `Q` are supplied."""
     lead = next_z.shape[:-1]
     z2, e2 = next_z.reshape(-1, next_z.shape[-1]), pi_eps.reshape(-1, pi_eps.shape[-1])
+    if torch.is_tensor(task) and task.numel() > 1:  # task [B] for next_z [H, B, L]: one task per row of the flattened batch
+        task = task.repeat(next_z.shape[0]) if next_z.dim() == 3 else task
     action = model.pi(z2, task, e2)
     q = model.Q_pair(z2, action, task, qidx, "min", target=True).reshape(*lead, 1)
     return reward + discount * (1 - terminated) * q

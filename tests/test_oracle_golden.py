@@ -58,15 +58,24 @@ def test_oracle_encode_matches_reference(name):
         np.testing.assert_allclose(z, g["encode_z"][e], atol=1e-6, rtol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["tiny", "small", "c1", "c1_wide"])
+@pytest.mark.parametrize("name", ["tiny", "small", "c1", "c1_wide", "tiny_mt", "small_mt", "mt5"])
 def test_oracle_td_target_matches_reference(name):
-    """oracle.td_target (restating tdmpc2.py:239-254) vs the fixture minted by the reference's own `_td_target`."""
+    """oracle.td_target (restating tdmpc2.py:239-254) vs the fixture minted by the reference's own `_td_target`
+    (multitask cases: one task per batch column, per-task discounts)."""
+    from tdmpc2_amd.config import get_discount
+
     g = load_golden(name)
     c = cases.build_case(name)
-    model = po.OracleModel(c["cfg"], {k: torch.as_tensor(v) for k, v in c["sd"].items()})
-    tb = cases.td_batch(c["cfg"])
+    cfg = c["cfg"]
+    model = po.OracleModel(cfg, {k: torch.as_tensor(v) for k, v in c["sd"].items()})
+    tb = cases.td_batch(cfg)
+    if cfg.multitask:
+        task = torch.as_tensor(tb["tasks"])
+        discount = torch.tensor([get_discount(cfg, ln) for ln in cfg.episode_lengths])[task].unsqueeze(-1)
+    else:
+        task, discount = None, c["discounts"][0]
     td = po.td_target(model, torch.as_tensor(tb["next_z"]), torch.as_tensor(tb["reward"]), torch.as_tensor(tb["terminated"]),
-                      None, c["discounts"][0], torch.as_tensor(tb["pi_eps"]), torch.as_tensor(tb["qidx"])).numpy()
+                      task, discount, torch.as_tensor(tb["pi_eps"]), torch.as_tensor(tb["qidx"])).numpy()
     assert td.shape == g["td_target"].shape
     np.testing.assert_allclose(td, g["td_target"], atol=2e-5, rtol=2e-5)
 
