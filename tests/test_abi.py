@@ -90,3 +90,41 @@ def test_new_entry_points_reject_null_arguments(lib):
             rc = fn(*([None] + [0] * (nargs - 1))) if name != "tdmpc2_plan_run_obs" else fn(*([None] * nargs))
         assert rc == 1, name  # TDMPC2_ERR_INVALID
         assert b"null" in lib.tdmpc2_last_error()
+
+
+def test_create_validates_the_configuration_before_touching_the_device(lib):
+    """Configuration errors are reported with their own codes and messages (no GPU needed: validation comes first)."""
+    from tdmpc2_amd import native
+    from tdmpc2_amd.config import named_config
+
+    lib.tdmpc2_plan_create.restype = ctypes.c_int
+    lib.tdmpc2_plan_create.argtypes = [ctypes.POINTER(native.PlanCfg), ctypes.POINTER(ctypes.c_void_p)]
+    lib.tdmpc2_last_error.restype = ctypes.c_char_p
+
+    def make(**over):
+        cfg = named_config("c1")
+        f = dict(horizon=cfg.horizon, num_samples=cfg.num_samples, num_elites=cfg.num_elites, num_pi_trajs=cfg.num_pi_trajs,
+                 iterations=6, action_dim=cfg.action_dim, latent_dim=cfg.latent_dim, mlp_dim=cfg.mlp_dim, task_dim=0,
+                 num_bins=cfg.num_bins, num_q=cfg.num_q, simnorm_dim=8, vmin=-10.0, vmax=10.0, min_std=0.05, max_std=2.0,
+                 temperature=0.5, log_std_min=-10.0, log_std_dif=12.0, multitask=0, episodic=0, max_envs=1, device=0, path=0,
+                 precision=0)
+        f.update(over)
+        h = ctypes.c_void_p()
+        rc = lib.tdmpc2_plan_create(ctypes.byref(native.PlanCfg(**f)), ctypes.byref(h))
+        return rc, lib.tdmpc2_last_error().decode()
+
+    INVALID, UNSUPPORTED = 1, 2
+    rc, msg = make(path=1, latent_dim=768)  # fused family asked for a 768-wide model
+    assert rc == UNSUPPORTED and "fused planner kernels" in msg
+    rc, msg = make(path=2, num_samples=500)  # layered family: rows per plan must be a multiple of the GEMM tile
+    assert rc == UNSUPPORTED and "num_samples" in msg
+    rc, msg = make(multitask=1, task_dim=0)
+    assert rc == INVALID and "task_dim" in msg
+    rc, msg = make(multitask=1, task_dim=64, episodic=1)
+    assert rc == UNSUPPORTED and "termination" in msg
+    rc, msg = make(iterations=0)
+    assert rc == INVALID
+    rc, msg = make(precision=7)
+    assert rc == INVALID and "precision" in msg
+    rc, msg = make(path=9)
+    assert rc == INVALID and "path" in msg
