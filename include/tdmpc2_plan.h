@@ -17,8 +17,9 @@
  *   tdmpc2_plan_bind_encoder  <- the state encoder's parameters         tdmpc2/common/layers.py:153-164
  *   tdmpc2_plan_encode        <- WorldModel.encode (state observations) tdmpc2/common/world_model.py:103-112
  *   tdmpc2_plan_run_obs       <- TDMPC2._plan including encode()        tdmpc2/tdmpc2.py:152-206
- *   tdmpc2_plan_td_target     <- TDMPC2._td_target                      tdmpc2/tdmpc2.py:239-254
- *   tdmpc2_plan_policy_value  <- forward half of TDMPC2.update_pi       tdmpc2/tdmpc2.py:208-225
+ *   tdmpc2_plan_td_target[_mt]    <- TDMPC2._td_target                  tdmpc2/tdmpc2.py:239-254
+ *   tdmpc2_plan_policy_value[_mt] <- forward half of TDMPC2.update_pi   tdmpc2/tdmpc2.py:208-225
+ *   tdmpc2_plan_export_packed / import_packed <- TDMPC2.save / load of the planner's weights  tdmpc2/tdmpc2.py:72-95
  *
  * Conventions
  *   - plain C types only; every tensor is a DEVICE pointer to fp32 (or int32 /
@@ -26,7 +27,10 @@
  *   - the caller owns every buffer it passes; the library owns only what it
  *     allocates in create/bind and frees in destroy.  `run` allocates nothing.
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
- *     a handle is not re-entrant.  Return value 0 = ok, otherwise an error code
+ *     a handle is not re-entrant: a call entered while another thread is inside
+ *     the same handle returns TDMPC2_ERR_STATE (use one handle per thread; handles
+ *     share nothing).  Every call runs on the handle's device (cfg.device) and
+ *     restores the caller's current device.  Return value 0 = ok, otherwise an error code
  *     (no C++ exception crosses the ABI); `tdmpc2_last_error()` has the text.
  *   - E = number of independent environments planned in one call (the reference
  *     is E = 1: tdmpc2/tdmpc2.py:111,163).  H horizon, N num_samples,
@@ -42,7 +46,7 @@
 extern "C" {
 #endif
 
-#define TDMPC2_PLAN_ABI_VERSION 4
+#define TDMPC2_PLAN_ABI_VERSION 5
 
 typedef struct tdmpc2_plan tdmpc2_plan_t;
 
@@ -63,7 +67,7 @@ typedef struct tdmpc2_plan_cfg {
 
 /* Two kernel families implement the same math (results agree to fp32 round-off):
  *   FUSED   one persistent workgroup per 64 sample rows keeps activations in LDS for a whole CEM
- *           iteration; built for latent_dim == mlp_dim == 512 (every 5M model), non-episodic.
+ *           iteration; built for latent_dim == mlp_dim == 512 (every 5M model), episodic or not.
  *   LAYERED one MFMA GEMM launch per nn.Linear over all E*N rows, activations in HBM; any
  *           latent_dim / mlp_dim that are multiples of 32 (1M ... 317M models), episodic or not.
  * AUTO picks FUSED when the configuration fits it, else LAYERED. */
@@ -160,8 +164,8 @@ int tdmpc2_plan_run(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *
 
 /* State-observation encoder: WorldModel.encode for cfg.obs == 'state'
  * (tdmpc2/common/world_model.py:103-112) with the network of layers.enc (tdmpc2/common/layers.py:153-164):
- * n_layers NormedLinear blocks, Mish after all but the last, SimNorm after the last.  Pixel observations stay with the
- * host framework.  bind_encoder takes one nn.Linear (`W` [out, in] row-major, `b` [out]) and its LayerNorm (`ln_g`,
+ * n_layers NormedLinear blocks, Mish after all but the last, SimNorm after the last.  Pixel observations are encoded
+ * by the host framework's conv module (tdmpc2_amd/layers.py: conv) and enter through tdmpc2_plan_run as latents.  bind_encoder takes one nn.Linear (`W` [out, in] row-major, `b` [out]) and its LayerNorm (`ln_g`,
  * `ln_b` [out]) per call, DEVICE pointers, copied (weights transposed) into library memory; layer 0 takes
  * obs_dim + task_dim inputs, the last layer has latent_dim outputs; widths up to 4096. */
 int tdmpc2_plan_bind_encoder(tdmpc2_plan_t *h, int layer, int n_layers, const float *W, const float *b,
@@ -178,8 +182,10 @@ int tdmpc2_plan_run_obs(tdmpc2_plan_t *h, int n_envs, const float *obs, int obs_
                         const float *act_mask, const float *disc_pow, float *prev_mean, const uint8_t *t0,
                         int eval_mode, const tdmpc2_noise *tape, uint64_t seed, float *action, void *stream);
 
-/* Training-side consumers of the planner's layer code, forward only, no gradients.  Fused kernel
- * family (latent_dim = mlp_dim = 512), single-task models; TDMPC2_ERR_UNSUPPORTED otherwise.
+/* Training-side consumers of the planner's layer code, forward only, no gradients.  Both kernel
+ * families, single-task and multitask models.  The fused family takes any number of rows; the layered family at most
+ * max_envs * num_samples rows per call (its activation workspace).  Multitask tables are (re)built inside the call and
+ * their storage grows on demand (the first such call allocates: keep it outside a hipGraph capture).
  *
  * policy_value: a = pi(z) (world_model.py:144-184, sampled with pi_eps [n_rows, A] or Philox(seed) when NULL), then the
  * two heads qidx[0..1] (device int32[2]; NULL: drawn like randperm(num_q)[:2], world_model.py:212) of the online ensemble
@@ -194,6 +200,36 @@ int tdmpc2_plan_policy_value(tdmpc2_plan_t *h, int n_rows, const float *z, int u
 int tdmpc2_plan_td_target(tdmpc2_plan_t *h, int n_rows, const float *next_z, const float *reward,
                           const float *terminated, float discount, const float *pi_eps, const int32_t *qidx,
                           uint64_t seed, float *td, void *stream);
+
+/* The same on multitask models, where a training batch carries ONE TASK PER ROW (WorldModel.task_emb with a task
+ * vector, world_model.py:88-101; the reference repeats task [B] over the H leading rows of next_z [H, B, L]):
+ * the row -> task map plus the per-task tables the reference indexes with it.  All DEVICE pointers. */
+typedef struct tdmpc2_task_tables {
+    const int32_t *task_ids;  /* [n_rows]            task of each row */
+    const float *task_emb;    /* [n_tasks, T]        WorldModel._task_emb rows, max_norm renorm applied (world_model.py:21) */
+    const float *act_mask;    /* [n_tasks, A]        WorldModel._action_masks (world_model.py:22-24) */
+    const float *discount;    /* [n_tasks] or NULL   TDMPC2.discount (tdmpc2.py:35-37); td_target only */
+    int32_t n_tasks;
+} tdmpc2_task_tables;
+/* `tasks` must be NULL for single-task handles and non-NULL for multitask ones. */
+int tdmpc2_plan_policy_value_mt(tdmpc2_plan_t *h, int n_rows, const float *z, const tdmpc2_task_tables *tasks,
+                                int use_target, int reduce_min, const float *pi_eps, const int32_t *qidx, uint64_t seed,
+                                float *action, float *q, void *stream);
+/* `discount` is used by single-task handles; multitask handles take tasks->discount[task of the row]. */
+int tdmpc2_plan_td_target_mt(tdmpc2_plan_t *h, int n_rows, const float *next_z, const float *reward,
+                             const float *terminated, float discount, const tdmpc2_task_tables *tasks,
+                             const float *pi_eps, const int32_t *qidx, uint64_t seed, float *td, void *stream);
+
+/* Packed weight file (the native counterpart of TDMPC2.save / load, tdmpc2.py:72-95).
+ * export_packed copies everything the binds produced -- weights in MFMA fragment order (hi / lo split and scaled for the
+ * SPLIT_F16 arithmetic), padded biases, LayerNorm parameters, task-embedding columns, per-layer scale records, the
+ * transposed encoder, the target ensemble when bound -- into ONE host buffer of packed_size bytes; import_packed
+ * restores a handle created with the same model dimensions, kernel family and arithmetic from such a buffer with plain
+ * host-to-device copies (no packing kernels, no fp32 checkpoint on the device).  The blob is specific to (path, precision);
+ * TDMPC2_ERR_INVALID on any mismatch.  Both synchronise `stream`. */
+int tdmpc2_plan_packed_size(tdmpc2_plan_t *h, uint64_t *bytes);
+int tdmpc2_plan_export_packed(tdmpc2_plan_t *h, void *host_buf, uint64_t bytes, void *stream);
+int tdmpc2_plan_import_packed(tdmpc2_plan_t *h, const void *host_buf, uint64_t bytes, void *stream);
 
 /* TDMPC2._estimate_value on given action sequences (stage-wise parity).
  *   actions [E,H,N,A], pi_eps [E,N,A], qidx [E,2] -> value [E,N] (before nan_to_num). */
@@ -221,8 +257,10 @@ int tdmpc2_plan_refit(tdmpc2_plan_t *h, int n_envs, float *value, const float *a
 
 /* Tuning knobs that never change results beyond fp32 round-off.  key TDMPC2_TUNE_ROWS_PER_WORKGROUP: sample rows a
  * fused split-arithmetic rollout workgroup owns -- 0 = automatic (32 when a call brings too few plans to occupy the
- * chip, i.e. single-environment latency; 64 otherwise), or 32 / 64 to force one. */
-enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0 };
+ * chip, i.e. single-environment latency; 64 otherwise), or 32 / 64 to force one.  key TDMPC2_TUNE_FOLD_REFIT (fused
+ * family): 1 (default) = the last workgroup of a plan to finish its rollouts does the elite selection + refit
+ * (tdmpc2.py:184-206) inside the rollout launch, one launch per CEM iteration; 0 = a launch of its own (k_refit). */
+enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0, TDMPC2_TUNE_FOLD_REFIT = 1 };
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
 
 /* Live timing of the dominant (rollout) stage: after set_profiling(h, n > 0) every rollout launch

@@ -29,6 +29,13 @@ CASES = {
     "c1_ep": ("c1", dict(episodic=True), 1, False, 0.06),
     "c3": ("c3", {}, 2, False, 0.03),                   # mt30 48M: L768 M1792 T64
     "c4": ("c4", dict(iterations=2), 1, False, 0.02),   # mt80 317M: L1376 M4096 nq8 T96, H5 N1024 (2 CEM iterations)
+    # BASELINE.json's configs[3] as literally written: latent_dim=1024 (the reference's 317M uses 1376), H5 N1024
+    "c4_l1024": ("c4_l1024", dict(iterations=2), 1, False, 0.02),
+    # the benched setting of configs[1]: I = 6 CEM iterations (BASELINE.json metric text; the reference's own rule gives
+    # 8 for action_dim >= 20, tdmpc2.py:34, which is what "c2" pins): base iterations 4 + 2
+    "c2_i6": ("c2", dict(iterations=4), 2, False, 0.06),
+    # episodic (termination head) at the dog-run dims: A = 38 exercises the 48-column action padding of the fused family
+    "c2_ep": ("c2", dict(iterations=2, episodic=True), 1, False, 0.06),
 }
 
 
@@ -39,7 +46,7 @@ def build_case(name: str):
 
 def build_custom(cfg, E: int, eval_mode: bool = False, head_std: float = 0.06, name: str = "", t0=None):
     """A case from an arbitrary config (edge-case tests build these on the fly; no golden fixture)."""
-    if cfg.multitask and name in ("tiny_mt", "small_mt", "c3", "c4"):
+    if cfg.multitask and name in ("tiny_mt", "small_mt", "c3", "c4", "c4_l1024"):
         # heterogeneous action dims / episode lengths to exercise masks and per-task discounts
         n = len(cfg.tasks)
         cfg.action_dims = [cfg.action_dim - (i % 3) for i in range(n)]

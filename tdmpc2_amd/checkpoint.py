@@ -23,6 +23,14 @@ def is_meta_key(k: str) -> bool:
     return k.endswith(META_SUFFIXES)
 
 
+def is_old_format(sd: Dict[str, torch.Tensor]) -> bool:
+    """The reference's test (layers.py:172): a new-format dict carries `_detach_Qs_params.0.weight`; anything else that
+    has flat-numbered Q keys is the old API."""
+    if "_detach_Qs_params.0.weight" in sd:
+        return False
+    return any(k.startswith("_Qs.params.") and k[len("_Qs.params."):].isdigit() for k in sd)
+
+
 def convert_state_dict(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Return a new-format state dict without tensordict meta entries."""
     out = {}

@@ -46,6 +46,11 @@ enum { T_KLOOP = 0, T_EPI = 1, T_HEAD = 2, T_ACT = 3, T_PARK = 4, T_TILE = 5, T_
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+// Scale of bounded operands (SimNorm latents in [0, 1], actions in [-1, 1]) and the LARGEST scale of a hidden activation.
+// A hidden layer's own scale is chosen at bind time from its LayerNorm affine parameters (k_ascale: the largest power
+// of two <= 2^5 that keeps |Mish(LayerNorm(.))| * scale below the f16 maximum for ANY input), so that a checkpoint with a
+// huge LayerNorm gain cannot overflow the hi piece into Inf -> NaN -> nan_to_num(0).  The consuming layer's output
+// scale (LayerS::oscale) carries the matching 2^-(kw + log2 scale_in).
 constexpr float ACT_SCALE = 32.f;  // 2^5
 constexpr int ACT_SCALE_LOG2 = 5;
 
@@ -53,7 +58,8 @@ struct LayerS {
     const _Float16 *wp;  // split: packed [CT][KB16][2 planes][64 lanes][8] f16; exact fp32: [CT][KB8][64 lanes][4] fp32
     const float *bias;   // [CT*32] zero padded
     const float *g, *b;  // LayerNorm affine (null for plain output layers)
-    const float *oscale; // device scalar: 2^-(kw + ACT_SCALE_LOG2) (split) or 1 (exact fp32)
+    const float *oscale; // device scalar: 2^-(kw + log2 of the input's scale) (split) or 1 (exact fp32)
+    const float *ascale; // device scalar: scale of THIS layer's output in operand form (split: 2^ka <= 32; exact fp32: 1)
     int KB;              // k-blocks: of 16 (split) or of 8 (exact fp32)
     int CT;
 };
@@ -120,10 +126,10 @@ __device__ __forceinline__ float mish_a(float x) {
     }
 }
 
-__device__ __forceinline__ void split4(const f32x4 y, f16x4 &hi, f16x4 &lo) {
+__device__ __forceinline__ void split4(const f32x4 y, f16x4 &hi, f16x4 &lo, const float scale = ACT_SCALE) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float ys = y[e] * ACT_SCALE;
+        const float ys = y[e] * scale;
         const _Float16 h = (_Float16)ys;
         hi[e] = h;
         lo[e] = (_Float16)(ys - (float)h);
@@ -147,9 +153,6 @@ __device__ __forceinline__ void rng_normal2(unsigned long long seed, unsigned ca
 // B fragments are prefetched PF k-blocks ahead (PF x 16 VGPRs) through a register ring.
 #ifndef SPLIT_PF
 #define SPLIT_PF 2  // measured: 2, 3 and 4 k-blocks of prefetch run within 1 % of each other; 6 spills
-#endif
-#ifndef SPLIT_PARK
-#define SPLIT_HOLD 1  // first-layer accumulators of the second chain stay in VGPRs (+4.6 % over parking them in L2/HBM)
 #endif
 constexpr int PF = SPLIT_PF;
 template <int FT>
@@ -461,7 +464,7 @@ __device__ __forceinline__ void unpark(const CT &c, f32x16 (&acc)[CT::NST][CT::F
 
 // values in register order -> operand form in the LDS tile (hi / lo planes), scaled by ACT_SCALE
 template <class CT>
-__device__ __forceinline__ void regs_to_tile(const CT &c, const f32x16 (&y)[CT::NST][CT::FT]) {
+__device__ __forceinline__ void regs_to_tile(const CT &c, const f32x16 (&y)[CT::NST][CT::FT], const float scale = ACT_SCALE) {
     const int j = c.lane & 31, hh = c.lane >> 5;
     if constexpr (CT::ARITH == 1) {
 #pragma unroll
@@ -490,7 +493,7 @@ __device__ __forceinline__ void regs_to_tile(const CT &c, const f32x16 (&y)[CT::
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = y[st][ft][4 * m + r];
                 f16x4 hi, lo;
-                split4(v, hi, lo);
+                split4(v, hi, lo, scale);
                 *reinterpret_cast<f16x4 *>(hp + 32 * ft + 8 * m) = hi;
                 *reinterpret_cast<f16x4 *>(hp + c.SH + 32 * ft + 8 * m) = lo;
             }
@@ -541,24 +544,26 @@ __device__ __forceinline__ void epi_barrier(const CT &c) {
 // 32 FT wave + 32 ft + 8 m + 4 hh (two distinct addresses per wave instruction), the LayerNorm affine values from
 // c.gb at the same offsets; `next` = the layer whose epilogue follows this one in program order (null: none).  One barrier inside (the statistics exchange, which also orders every wave's last read of the operand tile
 // before the first write of the new one); the caller adds the one before the next contraction.
-template <int ACT, class CT>
-__device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][CT::FT], float osc, const float *bias,
+template <int ACT, class CT, bool HASBIAS = true>
+__device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][CT::FT], float osc, float asc, const float *bias,
                                       GB next, float *zcopy) {
     constexpr int FT = CT::FT, NW = CT::NWAVES;
     constexpr float CNT = 32.f * FT;  // features of a row held by one wave
     const int j = c.lane & 31, hh = c.lane >> 5;
     const int poff = 32 * FT * c.wave + 4 * hh;
+    if constexpr (HASBIAS) {  // else: the caller applied scale and bias already (add_row_bias)
 #pragma unroll
-    for (int ft = 0; ft < FT; ++ft) {
-        f32x4 b4[4];
+        for (int ft = 0; ft < FT; ++ft) {
+            f32x4 b4[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) b4[m] = *reinterpret_cast<const f32x4 *>(bias + poff + 32 * ft + 8 * m);
+            for (int m = 0; m < 4; ++m) b4[m] = *reinterpret_cast<const f32x4 *>(bias + poff + 32 * ft + 8 * m);
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int st = 0; st < CT::NST; ++st)
+                for (int st = 0; st < CT::NST; ++st)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = fmaf(acc[st][ft][4 * m + r], osc, b4[m][r]);
+                    for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = fmaf(acc[st][ft][4 * m + r], osc, b4[m][r]);
+        }
     }
     TIMER_MARK(c, T_EPI_BIAS)
 #ifdef SPLIT_GB_IN_EPI
@@ -658,9 +663,27 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][CT::FT
             }
         }
     }
-    regs_to_tile(c, acc);
+    regs_to_tile(c, acc, ACT == 0 ? asc : ACT_SCALE);  // SimNorm outputs lie in [0, 1]: fixed scale
     TIMER_MARK(c, T_EPI_MATH)  // LayerNorm affine + activation + split + tile store (the compiler merges them)
     if (zcopy) park(c, acc, zcopy);
+}
+
+// acc * osc + bias of the lane's OWN sample rows: brow[st] = the first-layer bias vector of row 32 st + (lane & 31)
+// (training batches carry one task per row: world_model.py:95-97).  16-byte loads, two rows per lane.
+template <class CT>
+__device__ __forceinline__ void add_row_bias(const CT &c, f32x16 (&acc)[CT::NST][CT::FT], float osc, const float *const (&brow)[CT::NST]) {
+    const int hh = c.lane >> 5;
+    const int poff = 32 * CT::FT * c.wave + 4 * hh;
+#pragma unroll
+    for (int st = 0; st < CT::NST; ++st)
+#pragma unroll
+        for (int ft = 0; ft < CT::FT; ++ft)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(brow[st] + poff + 32 * ft + 8 * m);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[st][ft][4 * m + r] = fmaf(acc[st][ft][4 * m + r], osc, b4[r]);
+            }
 }
 
 // Narrow output layers (two-hot / policy heads): acc * oscale + bias -> fp32 logits in the staging view of the tile.
@@ -719,7 +742,7 @@ __device__ __forceinline__ void layer_full_s(const CT &c, const LayerS &ly, cons
 #endif
     kloop_s(c, ly, kb0, kb1, acc);
     TIMER_MARK(c, T_KLOOP)
-    epi_t<ACT>(c, acc, *ly.oscale, bias, next, zcopy);
+    epi_t<ACT>(c, acc, *ly.oscale, *ly.ascale, bias, next, zcopy);
     epi_barrier(c);
     TIMER_MARK(c, T_EPI)
 }
@@ -759,7 +782,8 @@ __device__ __forceinline__ void put_action(const CT &c, int row, int a, float v)
 // (zero for padded columns) and optionally gdst[row * A + a] for rows < nvalid.
 template <class CT, typename EpsFn>
 __device__ __forceinline__ void head_pi_s(const CT &c, const LayerS &ly, int A, int Apad, float lsmin, float lsdif,
-                                          const float *mask, EpsFn eps, float *gdst, int nvalid, float *tsc) {
+                                          const float *mask_wg, EpsFn eps, float *gdst, int nvalid, float *tsc,
+                                          const float *mask_tab = nullptr, const int *row_task = nullptr) {
     f32x16 acc[CT::NST];
     const int ct = c.wave;
     if (ct < ly.CT) kloop_tile_s(c, ly, ct, 0, CT::ZKB, acc);
@@ -772,6 +796,9 @@ __device__ __forceinline__ void head_pi_s(const CT &c, const LayerS &ly, int A, 
     __syncthreads();
     const int row = c.tid >> 3, part = c.tid & 7;
     const float *rp = c.f32() + row * c.RSF();
+    // action mask: one per workgroup (planning: the plan's task) or one per row (training batches: mask_tab[task of row])
+    const float *mask = mask_wg;
+    if (mask_tab && row < CT::TROWS) mask = mask_tab + (size_t)row_task[row] * A;
     // the logits (staging columns < 2A <= 128) do not alias the action columns (hi: floats 256.., lo: floats >= 512)
     if (row < CT::TROWS)
     for (int a = part; a < Apad; a += 8) {
@@ -838,8 +865,9 @@ __device__ __forceinline__ void tile_from_rows_s(const CT &c, const float *src, 
 }
 // operand form -> fp32 trace dump (hi + lo, unscaled)
 template <class CT>
-__device__ __forceinline__ void dump_tile_s(const CT &c, float *trace, int nslot, int slot) {
+__device__ __forceinline__ void dump_tile_s(const CT &c, float *trace, int nslot, int slot, const float *scale_ptr = nullptr) {
     if (!trace) return;
+    const float inv_scale = 1.0f / (scale_ptr ? *scale_ptr : ACT_SCALE);
     float *dst = trace + ((size_t)blockIdx.x * nslot + slot) * CT::TROWS * WIDTH;
     for (int idx = c.tid; idx < CT::TROWS * WIDTH; idx += CT::NTHR) {
         const int row = idx / WIDTH, col = idx % WIDTH;
@@ -847,7 +875,7 @@ __device__ __forceinline__ void dump_tile_s(const CT &c, float *trace, int nslot
             dst[idx] = c.f32()[row * CT::RSF() + col];
         } else {
             const _Float16 *hp = c.act + row * c.RSH + col;
-            dst[idx] = ((float)hp[0] + (float)hp[c.SH]) * (1.0f / ACT_SCALE);
+            dst[idx] = ((float)hp[0] + (float)hp[c.SH]) * inv_scale;
         }
     }
 }
@@ -954,10 +982,111 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_pitraj(PiTrajParamsT<NetS> p) 
     }
 }
 
+// Termination head output (world_model.py:132-141; tdmpc2.py:133-134): 1 logit per row -> (sigmoid(logit) > 0.5) in
+// every lane of the row's 8-lane group.  Column tile 0 only: one wave runs the contraction.
+template <class CT>
+__device__ __forceinline__ float head_term_s(const CT &c, const LayerS &ly) {
+    f32x16 acc[CT::NST];
+    if (c.wave == 0) kloop_tile_s(c, ly, 0, 0, CT::ZKB, acc);
+    const float osc = *ly.oscale;
+    __syncthreads();
+    if (c.wave == 0) {
+#pragma unroll
+        for (int rt = 0; rt < CT::NST; ++rt) store_tile_s(c, acc[rt], osc, ly.bias, 0, rt);
+    }
+    __syncthreads();
+    const bool live = (c.tid >> 3) < CT::TROWS;
+    const float x = c.f32()[(live ? c.tid >> 3 : 0) * c.RSF()];
+    const float pr = 1.f / (1.f + expf(-x));
+    __syncthreads();
+    return pr > 0.5f ? 1.f : 0.f;
+}
+
+// Two first layers over the same [z | a] operand tile in ONE pass (dynamics + reward, or the two selected Q heads): the
+// activation fragments are read from LDS once per k-block and feed both nets' feature tiles (24 MFMAs per k-block per
+// wave instead of 2 x 12 with two reads of the same fragments).  -DSPLIT_PAIR; weight ring one k-block deep per net.
+#ifdef SPLIT_PAIR
+template <class CT>
+__device__ __forceinline__ void kloop_pair_s(const CT &c, const LayerS &la, const LayerS &lb, int kb0, int kb1,
+                                             f32x16 (&acca)[CT::NST][CT::FT], f32x16 (&accb)[CT::NST][CT::FT]) {
+    static_assert(CT::ARITH == 0, "paired first layers exist for the split arithmetic");
+    constexpr int FT = CT::FT;
+    const int i = c.lane & 31, hh = c.lane >> 5;
+    const _Float16 *a0p = c.act + i * c.RSH + 8 * hh + kb0 * 16;
+    const char *ua = reinterpret_cast<const char *>(la.wp) + ((size_t)(FT * c.wave) * la.KB + kb0) * 2048;
+    const char *ub = reinterpret_cast<const char *>(lb.wp) + ((size_t)(FT * c.wave) * lb.KB + kb0) * 2048;
+    const size_t cts = (size_t)la.KB * 2048;  // both nets have the same first-layer shape
+    unsigned voff = (unsigned)c.lane * 16u;
+    asm volatile("" : "+v"(voff));
+    const int nk = kb1 - kb0;
+    BFragT<FT> ra, rb;
+    load_b(ra, ua, cts, voff);
+    load_b(rb, ub, cts, voff);
+    AFragT<CT::NST> an;
+    load_a<CT>(an, a0p, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int kk = 0; kk < nk; ++kk) {
+        const AFragT<CT::NST> a = an;
+        load_a<CT>(an, a0p, kk + 1 < nk ? kk + 1 : kk);
+        const int kn = kk + 1 < nk ? kk + 1 : nk - 1;
+#pragma unroll
+        for (int cc = 0; cc < FT; ++cc)
+#pragma unroll
+            for (int st = 0; st < CT::NST; ++st) acca[st][cc] = SPLIT_MFMA(ra.h[cc], a.h[st], acca[st][cc]);
+#pragma unroll
+        for (int cc = 0; cc < FT; ++cc)
+#pragma unroll
+            for (int st = 0; st < CT::NST; ++st) acca[st][cc] = SPLIT_MFMA(ra.l[cc], a.h[st], acca[st][cc]);
+#pragma unroll
+        for (int cc = 0; cc < FT; ++cc)
+#pragma unroll
+            for (int st = 0; st < CT::NST; ++st) acca[st][cc] = SPLIT_MFMA(ra.h[cc], a.l[st], acca[st][cc]);
+        load_b(ra, ua + (size_t)kn * 2048, cts, voff);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cc = 0; cc < FT; ++cc)
+#pragma unroll
+            for (int st = 0; st < CT::NST; ++st) accb[st][cc] = SPLIT_MFMA(rb.h[cc], a.h[st], accb[st][cc]);
+#pragma unroll
+        for (int cc = 0; cc < FT; ++cc)
+#pragma unroll
+            for (int st = 0; st < CT::NST; ++st) accb[st][cc] = SPLIT_MFMA(rb.l[cc], a.h[st], accb[st][cc]);
+#pragma unroll
+        for (int cc = 0; cc < FT; ++cc)
+#pragma unroll
+            for (int st = 0; st < CT::NST; ++st) accb[st][cc] = SPLIT_MFMA(rb.h[cc], a.l[st], accb[st][cc]);
+        load_b(rb, ub + (size_t)kn * 2048, cts, voff);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+#endif
+
+// first layers of two nets over the same tile: acca <- la, accb <- lb (raw sums)
+template <class CT>
+__device__ __forceinline__ void first_layers_s(const CT &c, const LayerS &la, const LayerS &lb, int kb0, int kb1,
+                                               f32x16 (&acca)[CT::NST][CT::FT], f32x16 (&accb)[CT::NST][CT::FT]) {
+    zero_acc(acca);
+    zero_acc(accb);
+#ifdef SPLIT_PAIR
+    if constexpr (CT::ARITH == 0) {
+        kloop_pair_s(c, la, lb, kb0, kb1, acca, accb);
+        return;
+    }
+#endif
+    kloop_s(c, la, kb0, kb1, acca);
+    kloop_s(c, lb, kb0, kb1, accb);
+}
+
 // ================================================================ kernel: one CEM iteration's rollouts
-template <int APAD, int ST, int NW, int AR>
+// EP = 1: episodic planning -- the termination head (world_model.py:132-141) is evaluated on every new latent and masks
+// the later rewards and the terminal value (tdmpc2.py:128-136).  Its first layer reads the same z_t columns as the step's
+// reward / dynamics first layers, so it runs at the top of step t (t >= 1; after the loop next to the policy prior's):
+// the raw dynamics sums wait in the workgroup's L2 scratch tile, the raw termination sums in the held registers.
+template <int APAD, int ST, int NW, int AR, int EP>
 __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int s_is_last;
     const int e = blockIdx.x / p.tiles, tile = blockIdx.x % p.tiles;
     const int tid = threadIdx.x;
     typedef CtxT<APAD, ST, NW, AR> CT;
@@ -999,6 +1128,7 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
     epi_barrier(c);
 
     float G = 0.f;
+    float termv = 0.f;  // EP: 1 once any latent of this row's trajectory was classified terminal (tdmpc2.py:133-134)
     TIMER_START(c)
     for (int t = 0; t < p.H; ++t) {
         // ---- actions of step t (tdmpc2.py:176-181) -> operand-form action columns; a thread handles PAIRS of action
@@ -1039,71 +1169,71 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
         }
         __syncthreads();
         TIMER_MARK(c, T_ACT)
-        // ---- first layers of dynamics and reward over the same [z_t | a_t] tile.  The raw dynamics accumulators wait
-        // for the reward chain in 64 held VGPRs (default) or, with -DSPLIT_PARK, parked in the workgroup's scratch
-        // tile (32 MB per round of workgroups: more than the L2s hold, measured 4.6 % slower)
-#ifdef SPLIT_HOLD
+        // ---- first layers of dynamics and reward over the same [z_t | a_t] tile; the raw dynamics accumulators wait for
+        // the reward chain in 64 held VGPRs (parking them in L2 instead measured 4.6 % slower)
+        const bool term_step = EP && t > 0;
         f32x16 accd[ST][FT];
-        zero_acc(accd);
-        kloop_s(c, p.dyn.l[0], t == 0 ? ZKB16 : 0, KBA, accd);
-        TIMER_MARK(c, T_KLOOP)
-#endif
         {
             f32x16 acc[ST][FT];
-#ifndef SPLIT_HOLD
-            zero_acc(acc);
-            kloop_s(c, p.dyn.l[0], t == 0 ? ZKB16 : 0, KBA, acc);
-            TIMER_MARK(c, T_KLOOP)
-            park(c, acc, zs);
-            TIMER_MARK(c, T_PARK)
-#endif
-            zero_acc(acc);
-#ifndef SPLIT_GB_IN_EPI
             gb_prefetch(c, p.rew.l[1].g, p.rew.l[1].b);
-#endif
-            kloop_s(c, p.rew.l[0], t == 0 ? ZKB16 : 0, KBA, acc);
+            first_layers_s(c, p.dyn.l[0], p.rew.l[0], t == 0 ? ZKB16 : 0, KBA, accd, acc);
             TIMER_MARK(c, T_KLOOP)
-            epi_t<0>(c, acc, *p.rew.l[0].oscale, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew, gb_of(p.rew.l[1]), nullptr);
+            if constexpr (EP) {
+                if (term_step) {  // the held registers now take the termination head's first layer on z_t
+                    park(c, accd, zs);
+                    zero_acc(accd);
+                    kloop_s(c, p.term.l[0], 0, ZKB16, accd);
+                }
+            }
+            epi_t<0>(c, acc, *p.rew.l[0].oscale, *p.rew.l[0].ascale, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew,
+                     gb_of(p.rew.l[1]), nullptr);
         }
         epi_barrier(c);
         TIMER_MARK(c, T_EPI)
-        dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 0);
+        dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 0, p.rew.l[0].ascale);
         // ---- reward: layer 2, two-hot head
-        layer_full_s<0>(c, p.rew.l[1], p.rew.l[1].bias, 0, ZKB16, gb_of(p.dyn.l[0]));
-        dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 1);
-#ifndef SPLIT_GB_IN_EPI
-        gb_prefetch(c, p.dyn.l[1].g, p.dyn.l[1].b);  // for the held dynamics epilogue below; in flight behind the head
-#endif
+        layer_full_s<0>(c, p.rew.l[1], p.rew.l[1].bias, 0, ZKB16, term_step ? gb_of(p.term.l[0]) : gb_of(p.dyn.l[0]));
+        dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 1, p.rew.l[1].ascale);
+        // for the held epilogue below; in flight behind the head
+        if (term_step) gb_prefetch(c, p.term.l[1].g, p.term.l[1].b);
+        else gb_prefetch(c, p.dyn.l[1].g, p.dyn.l[1].b);
         const float r = head_twohot_s(c, p.rew.l[2], p.bins, p.num_bins);
         TIMER_MARK(c, T_HEAD)
         if (tsc && (tid & 7) == 0) tsc[t] = r;
-        G += disc[t] * r;
-        // ---- dynamics: release the held / parked first layer, layers 2 and 3 (SimNorm)
-        {
-            const float *bd = t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn;
-#ifdef SPLIT_HOLD
-            epi_t<0>(c, accd, *p.dyn.l[0].oscale, bd, gb_of(p.dyn.l[1]), nullptr);
-#else
-            f32x16 acc[ST][FT];
-            unpark(c, acc, zs);
-            TIMER_MARK(c, T_PARK)
-            epi_t<0>(c, acc, *p.dyn.l[0].oscale, bd, gb_of(p.dyn.l[1]), nullptr);
-#endif
+        if constexpr (EP) {
+            if (term_step) {  // termination(z_t): layers 1 (held), 2, logit
+                epi_t<0>(c, accd, *p.term.l[0].oscale, *p.term.l[0].ascale, p.term.l[0].bias, gb_of(p.term.l[1]), nullptr);
+                epi_barrier(c);
+                layer_full_s<0>(c, p.term.l[1], p.term.l[1].bias, 0, ZKB16, gb_of(p.dyn.l[0]));
+                gb_prefetch(c, p.dyn.l[1].g, p.dyn.l[1].b);
+                termv = fminf(termv + head_term_s(c, p.term.l[2]), 1.f);
+                unpark(c, accd, zs);
+            }
         }
+        G += disc[t] * (1.f - termv) * r;
+        // ---- dynamics: release the held first layer, layers 2 and 3 (SimNorm)
+        epi_t<0>(c, accd, *p.dyn.l[0].oscale, *p.dyn.l[0].ascale, t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn,
+                 gb_of(p.dyn.l[1]), nullptr);
         epi_barrier(c);
         TIMER_MARK(c, T_EPI)
-        dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 2);
+        dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 2, p.dyn.l[0].ascale);
         layer_full_s<0>(c, p.dyn.l[1], p.dyn.l[1].bias, 0, ZKB16, gb_of(p.dyn.l[2]));
-        dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 3);
+        dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 3, p.dyn.l[1].ascale);
         layer_full_s<1>(c, p.dyn.l[2], p.dyn.l[2].bias, 0, ZKB16, t == p.H - 1 ? gb_of(p.pi.l[0]) : gb_of(p.rew.l[0]),
                         t == p.H - 1 ? zs : nullptr);
         dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 4);
     }
-    // ---- a_H = pi(z_H) (tdmpc2.py:135); z_H was also saved to zs
+    // ---- a_H = pi(z_H) (tdmpc2.py:135); z_H was also saved to zs.  EP: termination(z_H) first layer from the same tile.
+    f32x16 acch[ST][FT];  // held raw sums: termination first layer (EP), then the second Q head's
+    if constexpr (EP) {
+        zero_acc(acch);
+        kloop_s(c, p.term.l[0], 0, ZKB16, acch);
+    }
     layer_full_s<0>(c, p.pi.l[0], b_pi, 0, ZKB16, gb_of(p.pi.l[1]));
-    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 0);
-    layer_full_s<0>(c, p.pi.l[1], p.pi.l[1].bias, 0, ZKB16, gb_of(p.q[q0].l[0]));
-    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 1);
+    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 0, p.pi.l[0].ascale);
+    layer_full_s<0>(c, p.pi.l[1], p.pi.l[1].bias, 0, ZKB16, EP ? gb_of(p.term.l[0]) : gb_of(p.q[q0].l[0]));
+    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 1, p.pi.l[1].ascale);
+    if constexpr (EP) gb_prefetch(c, p.term.l[1].g, p.term.l[1].b);
     {
         auto eps = [&](int row, int a) -> float {
             const unsigned ridx = (unsigned)((size_t)(row0 + row) * p.A + a);
@@ -1114,60 +1244,38 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
                   tsc ? tsc + p.H + 2 : nullptr);
     }
     TIMER_MARK(c, T_HEAD)
+    if constexpr (EP) {  // termination(z_H) (tdmpc2.py:133-134, last loop iteration): the hidden layers overwrite z columns only
+        epi_t<0>(c, acch, *p.term.l[0].oscale, *p.term.l[0].ascale, p.term.l[0].bias, gb_of(p.term.l[1]), nullptr);
+        epi_barrier(c);
+        layer_full_s<0>(c, p.term.l[1], p.term.l[1].bias, 0, ZKB16, gb_of(p.q[q0].l[0]));
+        termv = fminf(termv + head_term_s(c, p.term.l[2]), 1.f);
+    }
     tile_from_global_s(c, zs);
     __syncthreads();
     TIMER_MARK(c, T_TILE)
     dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 2);
     // ---- Q(z_H, a_H): the two selected heads, first layers in one pass (world_model.py:186-216)
-#ifdef SPLIT_HOLD
-    f32x16 accq[ST][FT];
-    zero_acc(accq);
-    kloop_s(c, p.q[q1].l[0], 0, KBA, accq);
-    TIMER_MARK(c, T_KLOOP)
-#endif
     {
         f32x16 acc[ST][FT];
-#ifndef SPLIT_HOLD
-        // z_H has been read back from zs above: the scratch tile is free to park the second head's raw first layer
-        zero_acc(acc);
-        kloop_s(c, p.q[q1].l[0], 0, KBA, acc);
-        TIMER_MARK(c, T_KLOOP)
-        park(c, acc, zs);
-        TIMER_MARK(c, T_PARK)
-#endif
-        zero_acc(acc);
-#ifndef SPLIT_GB_IN_EPI
         gb_prefetch(c, p.q[q0].l[1].g, p.q[q0].l[1].b);
-#endif
-        kloop_s(c, p.q[q0].l[0], 0, KBA, acc);
+        first_layers_s(c, p.q[q1].l[0], p.q[q0].l[0], 0, KBA, acch, acc);
         TIMER_MARK(c, T_KLOOP)
-        epi_t<0>(c, acc, *p.q[q0].l[0].oscale, b_q0, gb_of(p.q[q0].l[1]), nullptr);
+        epi_t<0>(c, acc, *p.q[q0].l[0].oscale, *p.q[q0].l[0].ascale, b_q0, gb_of(p.q[q0].l[1]), nullptr);
     }
     epi_barrier(c);
     TIMER_MARK(c, T_EPI)
-    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 3);
+    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 3, p.q[q0].l[0].ascale);
     layer_full_s<0>(c, p.q[q0].l[1], p.q[q0].l[1].bias, 0, ZKB16, gb_of(p.q[q1].l[0]));
-    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 4);
-#ifndef SPLIT_GB_IN_EPI
+    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 4, p.q[q0].l[1].ascale);
     gb_prefetch(c, p.q[q1].l[1].g, p.q[q1].l[1].b);  // for the held second-head epilogue below
-#endif
     const float qa = head_twohot_s(c, p.q[q0].l[2], p.bins, p.num_bins);
     TIMER_MARK(c, T_HEAD)
-    {
-#ifdef SPLIT_HOLD
-        epi_t<0>(c, accq, *p.q[q1].l[0].oscale, b_q1, gb_of(p.q[q1].l[1]), nullptr);
-#else
-        f32x16 acc[ST][FT];
-        unpark(c, acc, zs);
-        TIMER_MARK(c, T_PARK)
-        epi_t<0>(c, acc, *p.q[q1].l[0].oscale, b_q1, gb_of(p.q[q1].l[1]), nullptr);
-#endif
-    }
+    epi_t<0>(c, acch, *p.q[q1].l[0].oscale, *p.q[q1].l[0].ascale, b_q1, gb_of(p.q[q1].l[1]), nullptr);
     epi_barrier(c);
     TIMER_MARK(c, T_EPI)
-    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 5);
+    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 5, p.q[q1].l[0].ascale);
     layer_full_s<0>(c, p.q[q1].l[1], p.q[q1].l[1].bias, 0, ZKB16, GB{});
-    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 6);
+    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 6, p.q[q1].l[1].ascale);
     const float qb = head_twohot_s(c, p.q[q1].l[2], p.bins, p.num_bins);
     TIMER_MARK(c, T_HEAD)
     TIMER_FLUSH(c, p.timing)
@@ -1175,14 +1283,31 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
         tsc[p.H] = qa;
         tsc[p.H + 1] = qb;
     }
-    if ((tid & 7) == 0 && live) p.value[(size_t)e * p.N + row0 + (tid >> 3)] = G + disc[p.H] * ((qa + qb) / 2.f);
+    if ((tid & 7) == 0 && live) p.value[(size_t)e * p.N + row0 + (tid >> 3)] = G + disc[p.H] * (1.f - termv) * ((qa + qb) / 2.f);
+    if (!p.fold_refit) return;
+    // ---- elite selection + refit by the LAST workgroup of this plan to get here (tdmpc2.py:184-206): one launch per CEM
+    // iteration.  Release: every thread's value[] / actions[] stores are made visible device-wide before the ticket is
+    // taken; acquire: the last arriver invalidates its CU's L1 before reading the other workgroups' values and actions.
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(p.ticket + e, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == (unsigned)(p.tiles - 1);
+        if (last) __hip_atomic_store(p.ticket + e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch starts at 0
+        s_is_last = last;
+    }
+    __syncthreads();
+    if (!s_is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    refit_plan(p.rf, e, smem, tid, NTHR);
 }
 
 // ================================================================ kernel: pi + two Q heads on a batch of latent rows
 // The forward halves of TDMPC2._td_target (tdmpc2/tdmpc2.py:239-254: a = pi(z'), min of two target heads, then
 // r + discount (1 - terminated) Q) and of TDMPC2.update_pi (tdmpc2.py:208-225: a = pi(z), mean of two online heads) on the
-// planner's layer code: one workgroup per 64 rows, the same three chains the rollout kernel ends with.  Single-task
-// models (the first-layer bias is per workgroup, not per row).
+// planner's layer code: one workgroup per 64 rows, the same three chains the rollout kernel ends with.  Multitask
+// batches carry one task per row (world_model.py:95-97): the first-layer biases b + W[:, L:L+T] . task_emb come from a
+// per-task table (`beff_tab`, built by ks_task_bias) indexed with the row's task, and so do the action mask and discount.
 template <int APAD, int AR>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_value(ValueParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1191,6 +1316,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_value(ValueParamsT<NetS> p) {
     constexpr int TROWS = CT::TROWS, ZKB16 = CT::ZKB;
     CT c{reinterpret_cast<_Float16 *>(smem), smem + TROWS * CT::RSF(), smem + TROWS * CT::RSF() + 1024, tid,
          __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    int *s_task = reinterpret_cast<int *>(smem + TROWS * CT::RSF() + 2048);  // [TROWS] task of each row (multitask)
     const int row0 = blockIdx.x * TROWS;
     const int nvalid = min(TROWS, p.rows - row0);
     const float *zsrc = p.z + (size_t)row0 * WIDTH;
@@ -1205,10 +1331,29 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_value(ValueParamsT<NetS> p) {
         q1 = (int)(r.y % (unsigned)(p.nq - 1));
         if (q1 >= q0) ++q1;
     }
+    if (p.task_ids && tid < TROWS) s_task[tid] = tid < nvalid ? p.task_ids[row0 + tid] : 0;
     tile_from_rows_s(c, zsrc, nvalid);
     gb_prefetch(c, p.pi.l[0].g, p.pi.l[0].b);
     epi_barrier(c);
-    layer_full_s<0>(c, p.pi.l[0], p.pi.l[0].bias, 0, ZKB16, gb_of(p.pi.l[1]));
+    // first-layer bias vectors of this lane's two sample rows
+    const int j = c.lane & 31;
+    auto first_layer = [&](const LayerS &ly, int slot, int kb1, GB next) {
+        if (!p.task_ids) {
+            layer_full_s<0>(c, ly, ly.bias, 0, kb1, next);
+            return;
+        }
+        const float *brow[CT::NST];
+#pragma unroll
+        for (int st = 0; st < CT::NST; ++st) brow[st] = p.beff_tab + ((size_t)s_task[32 * st + j] * p.nnets + slot) * WIDTH;
+        f32x16 acc[CT::NST][CT::FT];
+        zero_acc(acc);
+        if (next.g) gb_prefetch(c, next.g, next.b);
+        kloop_s(c, ly, 0, kb1, acc);
+        add_row_bias(c, acc, *ly.oscale, brow);
+        epi_t<0, CT, false>(c, acc, 1.f, *ly.ascale, nullptr, next, nullptr);
+        epi_barrier(c);
+    };
+    first_layer(p.pi.l[0], BE_PI, ZKB16, gb_of(p.pi.l[1]));
     layer_full_s<0>(c, p.pi.l[1], p.pi.l[1].bias, 0, ZKB16, gb_of(p.q[q0].l[0]));
     {
         auto eps = [&](int row, int a) -> float {
@@ -1217,23 +1362,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_value(ValueParamsT<NetS> p) {
             return rng_normal(p.seed, p.call, SITE_PI, 0, 0, ridx);
         };
         head_pi_s(c, p.pi.l[2], p.A, p.Apad, p.log_std_min, p.log_std_dif, nullptr, eps,
-                  p.action ? p.action + (size_t)row0 * p.A : nullptr, nvalid, nullptr);
+                  p.action ? p.action + (size_t)row0 * p.A : nullptr, nvalid, nullptr, p.task_ids ? p.mask_tab : nullptr, s_task);
     }
     tile_from_rows_s(c, zsrc, nvalid);  // the hidden layers overwrote the z columns; the action columns stay
     __syncthreads();
-    layer_full_s<0>(c, p.q[q0].l[0], p.q[q0].l[0].bias, 0, KBA, gb_of(p.q[q0].l[1]));
+    first_layer(p.q[q0].l[0], BE_Q0 + q0, KBA, gb_of(p.q[q0].l[1]));
     layer_full_s<0>(c, p.q[q0].l[1], p.q[q0].l[1].bias, 0, ZKB16, gb_of(p.q[q1].l[0]));
     const float qa = head_twohot_s(c, p.q[q0].l[2], p.bins, p.num_bins);
     tile_from_rows_s(c, zsrc, nvalid);
     __syncthreads();
-    layer_full_s<0>(c, p.q[q1].l[0], p.q[q1].l[0].bias, 0, KBA, gb_of(p.q[q1].l[1]));
+    first_layer(p.q[q1].l[0], BE_Q0 + q1, KBA, gb_of(p.q[q1].l[1]));
     layer_full_s<0>(c, p.q[q1].l[1], p.q[q1].l[1].bias, 0, ZKB16, GB{});
     const float qb = head_twohot_s(c, p.q[q1].l[2], p.bins, p.num_bins);
     const int row = tid >> 3;
     if ((tid & 7) == 0 && row < nvalid) {
         float v = p.reduce_min ? fminf(qa, qb) : (qa + qb) / 2.f;
-        if (p.reward) v = p.reward[row0 + row] + p.discount * (1.f - p.terminated[row0 + row]) * v;
+        if (p.reward) {
+            const float disc = p.disc_tab ? p.disc_tab[s_task[row]] : p.discount;
+            v = p.reward[row0 + row] + disc * (1.f - p.terminated[row0 + row]) * v;
+        }
         p.out[row0 + row] = v;
+    }
+}
+
+// beff_tab[task][net][WIDTH] = b + W[:, L:L+T] . task_emb[task] for the policy and the Q heads (online or target):
+// the per-task effective first-layer biases ks_value indexes per row.  grid = n_tasks, block = WIDTH threads.
+struct TaskBiasParams {
+    int T, nq, nnets;
+    const float *task_emb;            // [n_tasks, T] (max_norm renorm applied by the caller, world_model.py:21)
+    const float *wemb[3 + MAXQ];      // [WIDTH][T] per net slot (null: skipped)
+    const float *bias[3 + MAXQ];      // [WIDTH]
+    float *beff_tab;
+};
+__global__ void ks_task_bias(TaskBiasParams p) {
+    const int task = blockIdx.x, f = threadIdx.x;
+    const float *emb = p.task_emb + (size_t)task * p.T;
+    for (int net = 0; net < p.nnets; ++net) {
+        if (!p.wemb[net]) continue;
+        const float *w = p.wemb[net] + (size_t)f * p.T;
+        float sacc = 0.f;
+        for (int k = 0; k < p.T; ++k) sacc = fmaf(w[k], emb[k], sacc);
+        p.beff_tab[((size_t)task * p.nnets + net) * WIDTH + f] = p.bias[net][f] + sacc;
     }
 }
 
@@ -1248,15 +1417,49 @@ __global__ void k_absmax(const float *W, size_t n, unsigned int *out) {
     m = group_max<64>(m);
     if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
 }
-// kw such that max|W| 2^kw in [2^13, 2^14); wscale = 2^kw (for packing), oscale = 2^-(kw + ACT_SCALE_LOG2)
-__global__ void k_wscale(const unsigned int *maxbits, float *wscale, float *oscale) {
-    const float m = __uint_as_float(*maxbits);
+// Per-layer scalars of the split arithmetic, device resident (one record per layer and ensemble member).
+struct LayerScal {
+    float wscale;          // 2^kw: applied to the weights when they are packed
+    float oscale;          // 2^-(kw + log2 of the INPUT's operand scale): applied to the fp32 accumulator
+    unsigned int maxbits;  // max |W| as bits (k_absmax)
+    int kw;
+    float ascale;          // 2^ka: operand scale of this layer's OUTPUT (hidden layers; <= ACT_SCALE)
+    int ka;
+    unsigned int gmax, bmax;  // max |LayerNorm weight|, max |LayerNorm bias| as bits
+};
+// kw such that max|W| 2^kw in [2^13, 2^14); wscale = 2^kw (for packing)
+__global__ void k_wscale(LayerScal *s) {
+    const float m = __uint_as_float(s->maxbits);
     int ex = 0;
     if (m > 0.f) frexpf(m, &ex);  // m = f 2^ex, f in [0.5, 1)
     int kw = 14 - ex;
     kw = kw > 40 ? 40 : (kw < -40 ? -40 : kw);
-    *wscale = ldexpf(1.f, kw);
-    *oscale = ldexpf(1.f, -(kw + ACT_SCALE_LOG2));
+    s->kw = kw;
+    s->wscale = ldexpf(1.f, kw);
+}
+// Output scale of a LayerNorm + Mish layer of `width` features: |LayerNorm(x)_i| <= sqrt(width - 1) for any x, so
+// |Mish(g x + b)| <= sqrt(width - 1) max|g| + max|b| =: B.  ka = the largest exponent <= 5 with B 2^ka < 2^15 (half of
+// the f16 maximum: rounding of the hi piece cannot reach Inf).  Trained checkpoints (g ~ 1) keep ka = 5.
+__global__ void k_ascale(LayerScal *s, int width, int has_ln) {
+    int ka = ACT_SCALE_LOG2;
+    if (has_ln) {
+        const float bound = sqrtf((float)(width > 1 ? width - 1 : 1)) * __uint_as_float(s->gmax) + __uint_as_float(s->bmax);
+        if (bound > 0.f) {
+            int ex = 0;
+            frexpf(bound, &ex);  // bound < 2^ex
+            ka = 15 - ex < ka ? 15 - ex : ka;
+        }
+        ka = ka < -24 ? -24 : ka;
+    }
+    s->ka = ka;
+    s->ascale = ldexpf(1.f, ka);
+}
+// oscale of the three layers of one net: layer 0 reads [z | a] (scale 2^5), layer l > 0 reads layer l - 1's output
+__global__ void k_net_scales(LayerScal *s3) {
+    for (int l = 0; l < 3; ++l) {
+        const int kin = l == 0 ? ACT_SCALE_LOG2 : s3[l - 1].ka;
+        s3[l].oscale = ldexpf(1.f, -(s3[l].kw + kin));
+    }
 }
 // dst[ct][kb][plane][lane][e]: W[row = ct*32 + (lane & 31)][k = kb*16 + 8 (lane >> 5) + e] * wscale, hi / lo pieces;
 // packed k axis [z columns (nz) | action columns (na, zero padded)], source columns [z | task_emb (nt) | action].

@@ -16,12 +16,14 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
     if (h->split) {
         GemmSParams q{};
         q.A = reinterpret_cast<const _Float16 *>(A); q.lda = lda; q.K = ly.KB * 16; q.wp = ly.wps;
-        q.w_sel_stride = sel ? w_sel_stride : 0; q.oscale = ly.oscale; q.osc_sel_stride = sel ? 4 : 0;  // slab of 4 floats per head
+        q.w_sel_stride = sel ? w_sel_stride : 0; q.oscale = ly.oscale;
+        q.osc_sel_stride = sel ? (long)(3 * sizeof(LayerScal) / sizeof(float)) : 0;  // the net's [heads][3] scalar table
+        q.row_env = h->lay.row_env;
         // wide outputs (>= 256 columns) take the 128 x 256 tile as long as that still leaves the chip two waves of workgroups
         const bool wide = ly.CT >= 8 && (rows_p / GBM) * ((ly.CT + 7) / 8) >= (size_t)(getenv("TDMPC2_GEMM_NCT1") ? (1 << 30) : 512);
         q.CT = ly.CT; q.ncolblk = wide ? (ly.CT + 7) / 8 : (ly.CT + 3) / 4;
         if (slot >= 0 && h->cfg.multitask) {
-            q.bias = h->beff + (size_t)slot * h->lay.Mp;
+            q.bias = h->lay.bias_tab + (size_t)slot * h->lay.Mp;
             q.bias_env_stride = (long)h->nnets * h->lay.Mp;
             q.bias_sel_stride = sel ? h->lay.Mp : 0;
         } else {
@@ -39,8 +41,9 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
     GemmParams p{};
     p.A = A; p.lda = lda; p.K = ly.KB * 8; p.wp = ly.wp; p.w_sel_stride = sel ? w_sel_stride : 0;
     p.CT = ly.CT; p.ncolblk = (ly.CT + 3) / 4;
+    p.row_env = h->lay.row_env;
     if (slot >= 0 && h->cfg.multitask) {
-        p.bias = h->beff + (size_t)slot * h->lay.Mp;
+        p.bias = h->lay.bias_tab + (size_t)slot * h->lay.Mp;
         p.bias_env_stride = (long)h->nnets * h->lay.Mp;
         p.bias_sel_stride = sel ? h->lay.Mp : 0;
     } else {
@@ -61,6 +64,7 @@ int lay_ln(tdmpc2_plan *h, hipStream_t st, int act, float *x, int ld, int width,
     p.x = x; p.ld = ld; p.width = width; p.rows = (int)rows; p.rows_per_env = rows_per_env;
     p.g = ly.g; p.b = ly.b; p.gb_sel_stride = sel ? gb_sel_stride : 0; p.sel = sel; p.sel_stride = 2;
     p.pad_to = ld;  // whole row: only X has columns beyond `width`
+    p.ascale = ly.ascale; p.asc_sel_stride = sel ? (long)(3 * sizeof(LayerScal) / sizeof(float)) : 0;
     const int grid = (int)((rows + RW_THREADS / 64 - 1) / (RW_THREADS / 64));
     if (h->split) {
         if (act == 0) hipLaunchKernelGGL(l_ln_act_s<0>, dim3(grid), dim3(RW_THREADS), 0, st, p);
@@ -74,12 +78,14 @@ int lay_ln(tdmpc2_plan *h, hipStream_t st, int act, float *x, int ld, int width,
 }
 
 // strides between consecutive Q heads of layer `l` (slab allocation in bind_weights)
+// (h->lay.qarr: the online ensemble h->q, or the target ensemble h->tq inside lay_value)
 inline long q_wstride(const tdmpc2_plan *h, int l) {
     if (h->cfg.num_q < 2) return 0;
-    return h->split ? (long)(h->q[1].l[l].wps - h->q[0].l[l].wps) : (long)(h->q[1].l[l].wp - h->q[0].l[l].wp);
+    const HostNet *q = h->lay.qarr;
+    return h->split ? (long)(q[1].l[l].wps - q[0].l[l].wps) : (long)(q[1].l[l].wp - q[0].l[l].wp);
 }
-inline long q_bstride(const tdmpc2_plan *h, int l) { return h->cfg.num_q > 1 ? (long)(h->q[1].l[l].bias - h->q[0].l[l].bias) : 0; }
-inline long q_gstride(const tdmpc2_plan *h, int l) { return h->cfg.num_q > 1 ? (long)(h->q[1].l[l].g - h->q[0].l[l].g) : 0; }
+inline long q_bstride(const tdmpc2_plan *h, int l) { return h->cfg.num_q > 1 ? (long)(h->lay.qarr[1].l[l].bias - h->lay.qarr[0].l[l].bias) : 0; }
+inline long q_gstride(const tdmpc2_plan *h, int l) { return h->cfg.num_q > 1 ? (long)(h->lay.qarr[1].l[l].g - h->lay.qarr[0].l[l].g) : 0; }
 
 // X -> hidden 1 (HA) -> hidden 2 (HB): the two NormedLinear(Mish) layers of a reference `mlp` (layers.py:121-133).
 int lay_hidden(tdmpc2_plan *h, hipStream_t st, const HostNet &net, int slot, size_t rows, size_t rows_p, int rpe,
@@ -117,6 +123,8 @@ int lay_policy(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int r
     p.L = c.latent_dim; p.ldx = L.Kin; p.lsmin = c.log_std_min; p.lsdif = c.log_std_dif; p.mask = mask;
     p.eps = eps; p.eps_estride = eps_estride; p.seed = seed; p.call = call; p.site = site; p.iter = iter;
     p.X = L.X; p.actions = actions; p.t = t; p.H = c.horizon; p.N = c.num_samples; p.trace = trace;
+    p.row_env = L.row_env;
+    if (L.row_env) { p.H = 1; p.N = (int)rows; }  // value mode: actions is a flat [rows, A] output
     const int total = (int)rows * c.action_dim;
     if (h->split) hipLaunchKernelGGL(l_pi_head_s, dim3((total + 255) / 256), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(l_pi_head, dim3((total + 255) / 256), dim3(256), 0, st, p);
@@ -138,17 +146,18 @@ int lay_twohot(tdmpc2_plan *h, hipStream_t st, size_t rows, int rpe, int mode, i
 }
 
 int lay_setup(tdmpc2_plan *h, hipStream_t st, int E, const float *task_emb, const float *prev_mean, const unsigned char *t0,
-              bool init_dist) {
+              bool init_dist, float *beff_out = nullptr, const HostNet *qarr = nullptr) {
     const tdmpc2_plan_cfg &c = h->cfg;
     if (!c.multitask && !init_dist) return 0;
+    if (!qarr) qarr = h->q;
     LSetupParams p{};
     p.E = E; p.H = c.horizon; p.A = c.action_dim; p.T = c.task_dim; p.M = c.mlp_dim; p.Mp = h->lay.Mp; p.nnets = h->nnets;
     p.multitask = c.multitask; p.max_std = c.max_std;
     p.bias[BE_DYN] = h->dyn.l[0].bias; p.wemb[BE_DYN] = h->dyn.l[0].wemb;
     p.bias[BE_REW] = h->rew.l[0].bias; p.wemb[BE_REW] = h->rew.l[0].wemb;
     p.bias[BE_PI] = h->pi.l[0].bias; p.wemb[BE_PI] = h->pi.l[0].wemb;
-    for (int i = 0; i < c.num_q; ++i) { p.bias[BE_Q0 + i] = h->q[i].l[0].bias; p.wemb[BE_Q0 + i] = h->q[i].l[0].wemb; }
-    p.task_emb = task_emb; p.prev_mean = prev_mean; p.t0 = t0; p.beff = h->beff;
+    for (int i = 0; i < c.num_q; ++i) { p.bias[BE_Q0 + i] = qarr[i].l[0].bias; p.wemb[BE_Q0 + i] = qarr[i].l[0].wemb; }
+    p.task_emb = task_emb; p.prev_mean = prev_mean; p.t0 = t0; p.beff = beff_out ? beff_out : h->beff;
     p.mean = init_dist ? h->mean : nullptr; p.std = h->std;
     hipLaunchKernelGGL(l_setup, dim3(E, c.multitask ? h->nnets : 1), dim3(256), 0, st, p);
     LAUNCH_CHECK();
@@ -278,4 +287,41 @@ int lay_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float 
         LAUNCH_CHECK();
     }
     return TDMPC2_OK;
+}
+
+// pi + two Q heads on `rows` latent rows (TDMPC2._td_target, tdmpc2/tdmpc2.py:239-254, and the forward half of update_pi,
+// tdmpc2.py:208-225) on the layered family: the same GEMM / row kernels as a planning step, the row -> task map (multitask)
+// selecting the first-layer bias, action mask and discount of each row.
+int lay_value(tdmpc2_plan *h, hipStream_t st, int rows, const float *z, bool target, bool reduce_min, const float *pi_eps,
+              const int *qidx_dev /* [2] */, unsigned long long seed, unsigned call, const float *reward, const float *terminated,
+              float discount, const int *row_task /* padded [rows_p] or null */, float *action, float *out) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    Layered &L = h->lay;
+    const size_t rows_p = round_up((size_t)rows, GBM);
+    const int rpe = (int)rows_p;  // one "plan" spanning the call: sel index 0, noise / action index = row
+    if (h->split) hipLaunchKernelGGL(l_init_rows_s, dim3((unsigned)rows_p), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, z, rows);
+    else hipLaunchKernelGGL(l_init_rows, dim3((unsigned)rows_p), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, z, rows);
+    LAUNCH_CHECK();
+    struct Restore {  // the helpers read these from the handle
+        Layered &L; const HostNet *q; const float *bt; const int *re;
+        ~Restore() { L.qarr = q; L.bias_tab = bt; L.row_env = re; }
+    } restore{L, L.qarr, L.bias_tab, L.row_env};
+    L.qarr = target ? h->tq : h->q;
+    if (c.multitask) { L.bias_tab = h->beff_tab; L.row_env = row_task; }
+    int rc;
+    // a = pi(z): into the action columns of X, and into `action` [rows, A] when asked for
+    if ((rc = lay_policy(h, st, (size_t)rows, rows_p, rpe, rows, c.multitask ? h->mask_tab : nullptr, pi_eps, 0, seed, call, SITE_PI, 0,
+                         action, 0))) return rc;
+    for (int j = 0; j < 2; ++j) {
+        if ((rc = lay_hidden(h, st, L.qarr[0], BE_Q0, (size_t)rows, rows_p, rpe, qidx_dev + j, true))) return rc;
+        if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, rpe, L.qarr[0].l[2], q_wstride(h, 2), q_bstride(h, 2), -1, qidx_dev + j, L.LG,
+                           L.ldl))) return rc;
+        ValueHeadParams p{};
+        p.lg = L.LG; p.ld = L.ldl; p.rows = rows; p.num_bins = c.num_bins; p.mode = j; p.reduce_min = reduce_min ? 1 : 0;
+        p.bins = h->bins; p.qtmp = L.QT; p.out = out; p.reward = reward; p.terminated = terminated; p.discount = discount;
+        p.disc_tab = (c.multitask && reward) ? h->disc_tab : nullptr; p.row_env = row_task;
+        hipLaunchKernelGGL(l_value_head, dim3((unsigned)((rows + RW_THREADS / 64 - 1) / (RW_THREADS / 64))), dim3(RW_THREADS), 0, st, p);
+        LAUNCH_CHECK();
+    }
+    return 0;
 }

@@ -58,6 +58,7 @@ struct GemmParams {
     const int *sel;     // per-plan ensemble member (Q heads) or null; requires rows_per_env % GBM == 0
     long sel_stride;
     int rows_per_env;   // env(r) = r / rows_per_env
+    const int *row_env; // or: env(r) = row_env[r] for the per-row bias (training batches: one task per row); sel keeps r / rows_per_env
     float *out;         // [Rp, ldo]
     int ldo;
 };
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm(GemmParams p) {
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = row0 + wr * 64 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                 float bv = bshared;
-                if (p.bias_env_stride != 0) bv = bsel[(size_t)(row / p.rows_per_env) * p.bias_env_stride + col];
+                if (p.bias_env_stride != 0)
+                    bv = bsel[(size_t)(p.row_env ? p.row_env[row] : row / p.rows_per_env) * p.bias_env_stride + col];
                 p.out[(size_t)row * p.ldo + col] = acc[rt][c][reg] + bv;
             }
     }
@@ -165,6 +167,8 @@ struct LnActParams {
     const int *sel;
     long sel_stride;
     int pad_to;  // operand-form rows (split arithmetic): columns [width, pad_to) are zeroed in both planes
+    const float *ascale;   // split arithmetic: operand scale of this layer's output (LayerScal::ascale), + sel * asc_sel_stride
+    long asc_sel_stride;
 };
 
 template <int ACT>
@@ -301,6 +305,7 @@ struct PiHeadParams {
     float *actions;         // [E, H, N, A] or null
     int t, H, N;
     float *trace;           // optional [rows, H+2+A]: a_H into columns H+2..
+    const int *row_env;     // optional: the mask row of each sample row (training batches); eps / actions keep e = row / rows_per_env
 };
 
 __global__ void l_pi_head(PiHeadParams p) {
@@ -317,7 +322,7 @@ __global__ void l_pi_head(PiHeadParams p) {
         eps = p.eps ? p.eps[(size_t)e * p.eps_estride + ridx] : rng_normal(p.seed, p.call, p.site, p.iter, e, ridx);
     }
     if (p.mask) {
-        const float mk = p.mask[(size_t)e * p.A + a];
+        const float mk = p.mask[(size_t)(p.row_env ? p.row_env[row] : e) * p.A + a];
         mu *= mk;
         ls *= mk;
         eps *= mk;
@@ -436,4 +441,42 @@ __global__ void l_copy_qidx(int E, const int *src, long estride, int *dst) {
     if (e >= E) return;
     dst[2 * e] = src[(size_t)e * estride];
     dst[2 * e + 1] = src[(size_t)e * estride + 1];
+}
+
+// ---------------------------------------------------------------- pi + two Q heads on a batch of latent rows (layered family)
+// X[row, 0:L) <- z[row] (rows >= nvalid: zeros); X[row, L:ldx) <- 0.  One workgroup per row.
+__global__ void l_init_rows(float *X, int ldx, int L, const float *z, int nvalid) {
+    const int row = blockIdx.x;
+    float *xr = X + (size_t)row * ldx;
+    for (int c = threadIdx.x; c < ldx; c += blockDim.x) xr[c] = (c < L && row < nvalid) ? z[(size_t)row * L + c] : 0.f;
+}
+
+// The value heads of TDMPC2._td_target / update_pi (tdmpc2/tdmpc2.py:208-254) on two-hot logits, one wavefront per row:
+// mode 0: qtmp <- two_hot_inv(first head); mode 1: out <- min | mean of (qtmp, second head), then optionally
+// reward + discount (1 - terminated) out with the row's task discount.
+struct ValueHeadParams {
+    const float *lg;
+    int ld, rows, num_bins, mode, reduce_min;
+    const float *bins;
+    float *qtmp, *out;
+    const float *reward, *terminated;  // [rows] or null
+    float discount;
+    const float *disc_tab;             // [n_tasks] or null
+    const int *row_env;                // [rows] task of each row (with disc_tab)
+};
+__global__ __launch_bounds__(RW_THREADS) void l_value_head(ValueHeadParams p) {
+    const int row = blockIdx.x * (RW_THREADS / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= p.rows) return;
+    const float q = twohot_wave(p.lg + (size_t)row * p.ld, p.bins, p.num_bins, lane);
+    if (lane != 0) return;
+    if (p.mode == 0) {
+        p.qtmp[row] = q;
+        return;
+    }
+    float v = p.reduce_min ? fminf(p.qtmp[row], q) : (p.qtmp[row] + q) / 2.f;
+    if (p.reward) {
+        const float disc = p.disc_tab ? p.disc_tab[p.row_env[row]] : p.discount;
+        v = p.reward[row] + disc * (1.f - p.terminated[row]) * v;
+    }
+    p.out[row] = v;
 }

@@ -27,6 +27,7 @@ struct GemmSParams {
     const int *sel;
     long sel_stride;
     int rows_per_env;
+    const int *row_env; // optional per-row env of the bias lookup (see GemmParams)
     float *out;         // fp32 [Rp, ldo]
     int ldo;
 };
@@ -165,14 +166,15 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = row0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
                 float bv = bshared;
-                if (p.bias_env_stride != 0) bv = bsel[(size_t)(row / p.rows_per_env) * p.bias_env_stride + col];
+                if (p.bias_env_stride != 0)
+                    bv = bsel[(size_t)(p.row_env ? p.row_env[row] : row / p.rows_per_env) * p.bias_env_stride + col];
                 p.out[(size_t)row * p.ldo + col] = fmaf(acc[n][rt][reg], osc, bv);
             }
     }
 }
 
 // ---------------------------------------------------------------- row kernels writing operand form
-__device__ __forceinline__ void put_split(_Float16 *rowp, int ld, int col, float v) {
+__device__ __forceinline__ void put_split(_Float16 *rowp, int ld, int col, float v) {  // bounded operands: latents, actions
     const float vs = v * ACT_SCALE;
     const _Float16 h = (_Float16)vs;
     rowp[col] = h;
@@ -214,6 +216,8 @@ __global__ __launch_bounds__(RW_THREADS) void l_ln_act_s(LnActParams p) {
     }
     const float var = group_sum<64>(ss) / (float)p.width;
     const float rstd = 1.0f / sqrtf(var + LN_EPS);
+    // operand scale of this layer's output: chosen at bind time for Mish layers (k_ascale), fixed for SimNorm outputs
+    const float oscl = ACT == 0 ? p.ascale[(size_t)sel * p.asc_sel_stride] : ACT_SCALE;
     _Float16 *hp = reinterpret_cast<_Float16 *>(xr);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(RW_THREADS) void l_ln_act_s(LnActParams p) {
         }
         if (ok) {
             f16x4 hi, lo;
-            split4(y, hi, lo);
+            split4(y, hi, lo, oscl);
             *reinterpret_cast<f16x4 *>(hp + 4 * c4) = hi;
             *reinterpret_cast<f16x4 *>(hp + p.ld + 4 * c4) = lo;
         }
@@ -297,7 +301,7 @@ __global__ void l_pi_head_s(PiHeadParams p) {
         eps = p.eps ? p.eps[(size_t)e * p.eps_estride + ridx] : rng_normal(p.seed, p.call, p.site, p.iter, e, ridx);
     }
     if (p.mask) {
-        const float mk = p.mask[(size_t)e * p.A + a];
+        const float mk = p.mask[(size_t)(p.row_env ? p.row_env[row] : e) * p.A + a];
         mu *= mk;
         ls *= mk;
         eps *= mk;
@@ -306,4 +310,11 @@ __global__ void l_pi_head_s(PiHeadParams p) {
     put_split(reinterpret_cast<_Float16 *>(p.X + (size_t)row * p.ldx), p.ldx, p.L + a, act);
     if (p.actions && n < p.nvalid) p.actions[(((size_t)e * p.H + p.t) * p.N + n) * p.A + a] = act;
     if (p.trace) p.trace[(size_t)row * (p.H + 2 + p.A) + p.H + 2 + a] = act;
+}
+
+// X[row] <- operand form of [z[row] | zeros] (rows >= nvalid: zeros).  One workgroup per row.
+__global__ void l_init_rows_s(float *X, int ldx, int L, const float *z, int nvalid) {
+    const int row = blockIdx.x;
+    _Float16 *xr = reinterpret_cast<_Float16 *>(X + (size_t)row * ldx);
+    for (int c = threadIdx.x; c < ldx; c += blockDim.x) put_split(xr, ldx, c, (c < L && row < nvalid) ? z[(size_t)row * L + c] : 0.f);
 }

@@ -23,6 +23,7 @@
 // between rollout launches (k_refit below).  DESIGN.md has the full account.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -48,12 +49,38 @@ constexpr int MAXH = 8;
 constexpr float LN_EPS = 1e-5f;
 
 // ---------------------------------------------------------------- kernel parameter blocks (NET = NetS, fused_kernels.cuh)
+// elite select + refit (tdmpc2/tdmpc2.py:184-206): refit_plan() below
+struct RefitParams {
+    int E, N, H, A, K, iter, last, eval_mode;
+    int stage;             // elite actions are staged in LDS ([K][H*A] floats after the other arrays): see refit_lds_bytes
+    float temperature, min_std, max_std;
+    float *value;          // [E,N] in/out (nan_to_num)
+    const float *actions;  // [E,H,N,A]
+    const float *act_mask; // [E,A] or null
+    float *mean, *std;     // [E,H,A] out
+    float *score;          // [E,K] out (may be null)
+    int *elite_idx;        // [E,K] out (may be null)
+    // last iteration only
+    const float *gumbel_exp;  // [E,K] or null -> Philox
+    const float *final_eps;   // [E,A] or null -> Philox
+    unsigned long long seed;
+    unsigned int call;
+    float *prev_mean;  // [E,H,A]
+    float *action;     // [E,A]
+    // debug copies (per iteration slices already offset by the host; env stride given)
+    float *dbg_value; long dbg_value_es;
+    int *dbg_idx; long dbg_idx_es;
+    float *dbg_score; long dbg_score_es;
+    float *dbg_mean; long dbg_mean_es;
+    float *dbg_std; long dbg_std_es;
+};
+
 template <class NET>
 struct RolloutParamsT {
     int E, N, H, A, Apad, P, stride, tiles, nq, num_bins, multitask, given_actions, iter, iters_total;
     int nnets;  // vectors per plan in `beff`
     float log_std_min, log_std_dif;
-    NET dyn, rew, pi;
+    NET dyn, rew, pi, term;
     NET q[MAXQ];
     const float *bins;
     const float *z0;        // [E,L]
@@ -77,6 +104,10 @@ struct RolloutParamsT {
     float *trace_tiles;    // optional [E*tiles, 5H+7, 64, WIDTH] activations after each phase
     float *trace_scalars;  // optional [E, N, H+2+A]: r_0..r_{H-1}, Q_a, Q_b, a_H[A]
     unsigned long long *timing;  // profiling builds (-DSPLIT_TIMING): 16 cycle counters summed over workgroups, else null
+    // elite selection + refit by the last workgroup of each plan to finish (one launch per CEM iteration)
+    int fold_refit;
+    unsigned int *ticket;   // [E] arrival counters, zero between launches
+    RefitParams rf;
 };
 
 // pi + two Q heads on a batch of latent rows (fused_kernels.cuh: ks_value)
@@ -95,6 +126,12 @@ struct ValueParamsT {
     const float *reward, *terminated;  // [rows] or null
     float *action;         // [rows, A] or null
     float *out;            // [rows]
+    // multitask batches: one task per row
+    int nnets;
+    const int *task_ids;     // [rows] or null (single task)
+    const float *beff_tab;   // [n_tasks, nnets, WIDTH] effective first-layer biases (ks_task_bias)
+    const float *mask_tab;   // [n_tasks, A]
+    const float *disc_tab;   // [n_tasks] or null (scalar `discount`)
 };
 
 // net slots inside `beff`
@@ -190,101 +227,97 @@ struct PiTrajParamsT {
     long zscratch_estride;
 };
 
-// ================================================================ kernel: elite select + refit
-// grid = E, block = N threads.  tdmpc2/tdmpc2.py:184-206.
-struct RefitParams {
-    int E, N, H, A, K, iter, last, eval_mode;
-    int stage;             // elite actions are staged in LDS ([K][H*A] floats after the other arrays): see refit_lds_bytes
-    float temperature, min_std, max_std;
-    float *value;          // [E,N] in/out (nan_to_num)
-    const float *actions;  // [E,H,N,A]
-    const float *act_mask; // [E,A] or null
-    float *mean, *std;     // [E,H,A] out
-    float *score;          // [E,K] out (may be null)
-    int *elite_idx;        // [E,K] out (may be null)
-    // last iteration only
-    const float *gumbel_exp;  // [E,K] or null -> Philox
-    const float *final_eps;   // [E,A] or null -> Philox
-    unsigned long long seed;
-    unsigned int call;
-    float *prev_mean;  // [E,H,A]
-    float *action;     // [E,A]
-    // debug copies (per iteration slices already offset by the host; env stride given)
-    float *dbg_value; long dbg_value_es;
-    int *dbg_idx; long dbg_idx_es;
-    float *dbg_score; long dbg_score_es;
-    float *dbg_mean; long dbg_mean_es;
-    float *dbg_std; long dbg_std_es;
-};
-
-// dynamic LDS of k_refit; `stage` out: whether the K x H x A elite actions fit next to the rest (they are then gathered
+// ================================================================ kernel: elite select + refit (struct RefitParams: above)
+// dynamic LDS of the refit; `stage` out: whether the K x H x A elite actions fit next to the rest (they are then gathered
 // by the whole workgroup in one round of loads instead of 2 K dependent global loads per (t, a) thread: 35 -> 12 us)
-inline size_t refit_lds_bytes(int N, int K, int H, int A, int *stage) {
-    const size_t base = ((size_t)N + 3 * K + 2 * H * A) * 4 + 64;
+inline size_t refit_lds_bytes(int N, int K, int H, int A, int *stage, size_t budget = 48 * 1024) {
+    const size_t base = ((size_t)N + 3 * K + 2 * H * A + 48) * 4 + 64;
     const size_t elite = (size_t)K * H * A * 4;
-    *stage = base + elite <= 48 * 1024;
+    *stage = base + elite <= budget;
     return *stage ? base + elite : base;
 }
 
-__global__ void k_refit(RefitParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// block-wide sum / max over `n` floats in LDS: strided thread-local partials, wavefront shuffle reduction, one LDS slot per
+// wave, every thread reads the slots back (fixed order -> deterministic, the same value in every thread)
+__device__ __forceinline__ float block_sum_lds(const float *x, int n, float *slots, int tid, int nthr) {
+    float s = 0.f;
+    for (int i = tid; i < n; i += nthr) s += x[i];
+    s = group_sum<64>(s);
+    __syncthreads();  // slots may still be read from a previous reduction
+    if ((tid & 63) == 0) slots[tid >> 6] = s;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < (nthr >> 6); ++w) t += slots[w];
+    return t;
+}
+__device__ __forceinline__ float block_max_lds(const float *x, int n, float *slots, int tid, int nthr) {
+    float s = -INFINITY;
+    for (int i = tid; i < n; i += nthr) s = fmaxf(s, x[i]);
+    s = group_max<64>(s);
+    __syncthreads();
+    if ((tid & 63) == 0) slots[tid >> 6] = s;
+    __syncthreads();
+    float t = -INFINITY;
+    for (int w = 0; w < (nthr >> 6); ++w) t = fmaxf(t, slots[w]);
+    return t;
+}
+
+// Elite selection + refit (+ final pick) of plan `e` by one workgroup of `nthr` threads (a multiple of 64; any N <= 1024).
+// tdmpc2/tdmpc2.py:184-206.  Called by k_refit (one workgroup per plan) and by the last workgroup of a plan to finish
+// its rollouts (ks_rollout, fused family): the elite statistics are wavefront-shuffle reductions.
+__device__ void refit_plan(const RefitParams &p, int e, float *smem, int tid, int nthr) {
     float *sv = smem;                           // [N]
     float *ev = sv + p.N;                       // [K]
     float *sc = ev + p.K;                       // [K]
     int *ei = reinterpret_cast<int *>(sc + p.K);  // [K]
     float *smean = reinterpret_cast<float *>(ei + p.K);  // [H*A]
     float *sstd = smean + p.H * p.A;                     // [H*A]
-    __shared__ float s_sum, s_ssum;
-    __shared__ int s_pick;
-    const int e = blockIdx.x, tid = threadIdx.x;
+    float *slots = sstd + p.H * p.A;                     // [16] per-wave partials + [16] scratch scalars
+    int *s_pick = reinterpret_cast<int *>(slots + 32);
+    float *ea = slots + 48;                              // [K][H*A] elite_actions (tdmpc2.py:186) when staged
     // value.nan_to_num(0): nan -> 0, +-inf -> +-FLT_MAX (tdmpc2.py:184)
-    float v = p.value[(size_t)e * p.N + tid];
-    if (v != v) v = 0.f;
-    else if (v == INFINITY) v = 3.402823466e+38f;
-    else if (v == -INFINITY) v = -3.402823466e+38f;
-    p.value[(size_t)e * p.N + tid] = v;
-    if (p.dbg_value) p.dbg_value[(size_t)e * p.dbg_value_es + tid] = v;
-    sv[tid] = v;
-    __syncthreads();
-    // rank = position in (value desc, index asc) order; torch.topk(..., sorted=True) (tdmpc2.py:185)
-    int rank = 0;
-    for (int j = 0; j < p.N; ++j) {
-        const float u = sv[j];
-        rank += (u > v) || (u == v && j < tid);
-    }
-    if (rank < p.K) {
-        ei[rank] = tid;
-        ev[rank] = v;
+    for (int i = tid; i < p.N; i += nthr) {
+        float v = p.value[(size_t)e * p.N + i];
+        if (v != v) v = 0.f;
+        else if (v == INFINITY) v = 3.402823466e+38f;
+        else if (v == -INFINITY) v = -3.402823466e+38f;
+        p.value[(size_t)e * p.N + i] = v;
+        if (p.dbg_value) p.dbg_value[(size_t)e * p.dbg_value_es + i] = v;
+        sv[i] = v;
     }
     __syncthreads();
-    if (tid < p.K) sc[tid] = expf(p.temperature * (ev[tid] - ev[0]));  // max(elite_value) == ev[0]
-    __syncthreads();
-    if (tid == 0) {
-        float s = 0.f;
-        for (int k = 0; k < p.K; ++k) s += sc[k];
-        s_sum = s;
+    // rank = position in (value desc, index asc) order; torch.topk(..., sorted=True) (tdmpc2.py:185).  Every thread
+    // compares its value with the whole LDS array: broadcast reads, no bank conflicts.
+    for (int i = tid; i < p.N; i += nthr) {
+        const float v = sv[i];
+        int rank = 0;
+        for (int j = 0; j < p.N; j += 4) {
+            const f32x4 u = *reinterpret_cast<const f32x4 *>(sv + j);  // N is a multiple of 64
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rank += (u[q] > v) || (u[q] == v && j + q < i);
+        }
+        if (rank < p.K) {
+            ei[rank] = i;
+            ev[rank] = v;
+        }
     }
     __syncthreads();
-    if (tid < p.K) sc[tid] = sc[tid] / s_sum;  // score / score.sum(0)  (tdmpc2.py:191)
-    __syncthreads();
-    if (tid == 0) {
-        float s = 0.f;
-        for (int k = 0; k < p.K; ++k) s += sc[k];
-        s_ssum = s + 1e-9f;  // score.sum(0) + 1e-9 (tdmpc2.py:192-193)
-    }
-    __syncthreads();
+    const float vmax = ev[0];  // max(elite_value)
+    for (int k = tid; k < p.K; k += nthr) sc[k] = expf(p.temperature * (ev[k] - vmax));
+    const float s1 = block_sum_lds(sc, p.K, slots, tid, nthr);
+    for (int k = tid; k < p.K; k += nthr) sc[k] = sc[k] / s1;  // score / score.sum(0)  (tdmpc2.py:191)
+    const float s_ssum = block_sum_lds(sc, p.K, slots, tid, nthr) + 1e-9f;  // score.sum(0) + 1e-9 (tdmpc2.py:192-193)
     const float *acts = p.actions + (size_t)e * p.H * p.N * p.A;
     const int HA = p.H * p.A;
-    float *ea = sstd + HA;  // [K][H*A] elite_actions (tdmpc2.py:186) when staged
     if (p.stage) {
-        for (int idx = tid; idx < p.K * HA; idx += blockDim.x) {
+        for (int idx = tid; idx < p.K * HA; idx += nthr) {
             const int k = idx / HA, ha = idx % HA;
             const int t = ha / p.A, a = ha % p.A;
             ea[idx] = acts[((size_t)t * p.N + ei[k]) * p.A + a];
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < HA; idx += blockDim.x) {
+    for (int idx = tid; idx < HA; idx += nthr) {
         const int t = idx / p.A, a = idx % p.A;
         const float *at = acts + (size_t)t * p.N * p.A + a;
         float m = 0.f;  // sums run over k in elite order in both forms: identical results
@@ -313,43 +346,33 @@ __global__ void k_refit(RefitParams p) {
         if (p.dbg_mean) p.dbg_mean[(size_t)e * p.dbg_mean_es + idx] = m;
         if (p.dbg_std) p.dbg_std[(size_t)e * p.dbg_std_es + idx] = sd;
     }
-    if (tid < p.K) {
-        if (p.score) p.score[(size_t)e * p.K + tid] = sc[tid];
-        if (p.elite_idx) p.elite_idx[(size_t)e * p.K + tid] = ei[tid];
-        if (p.dbg_score) p.dbg_score[(size_t)e * p.dbg_score_es + tid] = sc[tid];
-        if (p.dbg_idx) p.dbg_idx[(size_t)e * p.dbg_idx_es + tid] = ei[tid];
+    for (int k = tid; k < p.K; k += nthr) {
+        if (p.score) p.score[(size_t)e * p.K + k] = sc[k];
+        if (p.elite_idx) p.elite_idx[(size_t)e * p.K + k] = ei[k];
+        if (p.dbg_score) p.dbg_score[(size_t)e * p.dbg_score_es + k] = sc[k];
+        if (p.dbg_idx) p.dbg_idx[(size_t)e * p.dbg_idx_es + k] = ei[k];
     }
     if (!p.last) return;
     __syncthreads();
-    // gumbel_softmax_sample(score) (tdmpc2/common/math.py:86-94): argmax softmax(log p - log Exp(1))
-    if (tid == 0) {
-        float gmax = -INFINITY;
-        for (int k = 0; k < p.K; ++k) {
-            const float ex = p.gumbel_exp ? p.gumbel_exp[(size_t)e * p.K + k]
-                                          : rng_exponential(p.seed, p.call, SITE_GUMBEL, 0, e, (unsigned)k);
-            const float gk = logf(sc[k]) + (-logf(ex));
-            ev[k] = gk;
-            gmax = fmaxf(gmax, gk);
-        }
-        float s = 0.f;
-        for (int k = 0; k < p.K; ++k) {
-            ev[k] = expf(ev[k] - gmax);
-            s += ev[k];
-        }
-        int best = 0;
-        float bv = -1.f;
-        for (int k = 0; k < p.K; ++k) {
-            const float y = ev[k] / s;
-            if (y > bv) {
-                bv = y;
-                best = k;
-            }
-        }
-        s_pick = ei[best];
+    // gumbel_softmax_sample(score) (tdmpc2/common/math.py:86-94): argmax softmax(log p - log Exp(1)); first index on ties
+    for (int k = tid; k < p.K; k += nthr) {
+        const float ex = p.gumbel_exp ? p.gumbel_exp[(size_t)e * p.K + k]
+                                      : rng_exponential(p.seed, p.call, SITE_GUMBEL, 0, e, (unsigned)k);
+        ev[k] = logf(sc[k]) + (-logf(ex));
     }
+    const float gmax = block_max_lds(ev, p.K, slots, tid, nthr);
+    for (int k = tid; k < p.K; k += nthr) ev[k] = expf(ev[k] - gmax);
+    const float gs = block_sum_lds(ev, p.K, slots, tid, nthr);
+    for (int k = tid; k < p.K; k += nthr) ev[k] = ev[k] / gs;
+    const float ymax = block_max_lds(ev, p.K, slots, tid, nthr);
+    if (tid == 0) *s_pick = p.K;
     __syncthreads();
-    for (int a = tid; a < p.A; a += blockDim.x) {
-        float x = acts[(size_t)s_pick * p.A + a];  // elite_actions[0, rand_idx]
+    for (int k = tid; k < p.K; k += nthr)
+        if (ev[k] == ymax) atomicMin(s_pick, k);
+    __syncthreads();
+    const int pick = ei[*s_pick];
+    for (int a = tid; a < p.A; a += nthr) {
+        float x = acts[(size_t)pick * p.A + a];  // elite_actions[0, rand_idx]
         if (!p.eval_mode) {
             const float n = p.final_eps ? p.final_eps[(size_t)e * p.A + a]
                                         : rng_normal(p.seed, p.call, SITE_FINAL, 0, e, (unsigned)a);
@@ -357,8 +380,14 @@ __global__ void k_refit(RefitParams p) {
         }
         p.action[(size_t)e * p.A + a] = fminf(fmaxf(x, -1.f), 1.f);
     }
-    for (int idx = tid; idx < p.H * p.A; idx += blockDim.x)
+    for (int idx = tid; idx < p.H * p.A; idx += nthr)
         p.prev_mean[(size_t)e * p.H * p.A + idx] = smean[idx];  // _prev_mean.copy_(mean) (tdmpc2.py:205)
+}
+
+// one workgroup per plan (layered family; tdmpc2_plan_refit)
+__global__ void k_refit(RefitParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    refit_plan(p, blockIdx.x, smem, threadIdx.x, blockDim.x);
 }
 
 // ================================================================ weight packing kernels
@@ -418,17 +447,39 @@ int fail(int code, const char *fmt, ...) {
         if (_e != hipSuccess) return fail(TDMPC2_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
+// Every entry point that allocates or launches runs on the handle's device and restores the caller's current device
+// (a C caller with several GPUs may have another one current).
+struct DevGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DevGuard(int dev) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        if (cur != dev) {
+            ok = hipSetDevice(dev) == hipSuccess;
+            if (ok) prev = cur;
+        }
+    }
+    ~DevGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DevGuard(const DevGuard &) = delete;
+    DevGuard &operator=(const DevGuard &) = delete;
+};
+
 struct HostLayer {
     float *wp = nullptr, *bias = nullptr, *g = nullptr, *b = nullptr, *wemb = nullptr;
     // f16x2-split form (fused_kernels.cuh): hi/lo packed weights, per-matrix power-of-two scales (device scalars)
     _Float16 *wps = nullptr;
-    float *wscale = nullptr, *oscale = nullptr;
-    unsigned int *maxbits = nullptr;
+    LayerScal *scal = nullptr;   // split arithmetic: this layer's record inside the net's [heads][3] table
+    float *oscale = nullptr, *ascale = nullptr;  // -> scal->oscale / ascale (split) or the unit scalar (exact fp32)
     int KB = 0, CT = 0, out = 0;  // KB: k-blocks of 8 (fp32 MFMA) or of 16 (split)
     bool bound = false, alloc = false;
+    size_t wbytes = 0;            // bytes of this layer's packed weights (tdmpc2_plan_export_packed)
 };
 struct HostNet {
     HostLayer l[3];
+    LayerScal *scal = nullptr;   // [heads][3] (heads of an ensemble share one allocation: stride 3 records)
 };
 
 }  // namespace
@@ -442,11 +493,23 @@ struct Layered {
     int Ppad = 0;   // rows per plan in the policy-prior pass: round_up(P, 32)
     float *X = nullptr, *HA = nullptr, *HB = nullptr, *LG = nullptr, *G = nullptr, *QT = nullptr, *TERM = nullptr;
     int *qidx = nullptr;  // [E, 2] heads of the current iteration
+    // what the GEMM / row helpers of layered_host.cuh read besides their arguments (lay_value re-points them for a call)
+    const HostNet *qarr = nullptr;   // the Q ensemble in use: online (planning) or target (td_target)
+    const float *bias_tab = nullptr; // effective first-layer biases: per plan (h->beff) or per task (h->beff_tab)
+    const int *row_env = nullptr;    // per-row env of the bias / mask lookups, or null: row / rows_per_env
 };
 
 struct tdmpc2_plan {
     tdmpc2_plan_cfg cfg;
     Layered lay;
+    std::atomic<int> busy{0};  // handles are not reentrant: a second concurrent call is refused (Busy), not raced
+    int fold_refit = 1;        // fused family: the last workgroup of a plan refits it inside the rollout launch
+    unsigned int *ticket = nullptr;  // [max_envs] arrival counters of that hand-over
+    // per-task tables of policy_value / td_target on multitask batches (grown on demand)
+    float *beff_tab = nullptr, *mask_tab = nullptr, *disc_tab = nullptr;
+    int *task_rows = nullptr;  // [rows] copy of the row -> task map, padded to whole GEMM tiles (layered family)
+    int tab_tasks = 0;
+    size_t task_rows_cap = 0;
     bool split = false;  // fused kernels on the f16 matrix pipe with hi/lo operand split (fused_kernels.cuh)
     int force_rows = 0;  // TDMPC2_TUNE_ROWS_PER_WORKGROUP: 0 auto, 32, 64
     size_t row_bytes = 0;  // bytes of one sample row of the fused kernels' LDS tile
@@ -482,6 +545,27 @@ struct tdmpc2_plan {
 
 namespace {
 
+// A handle owns one workspace and one call counter: two threads inside the same handle would corrupt both.  The second
+// caller gets TDMPC2_ERR_STATE instead (use one handle per thread / stream; handles share nothing).
+struct Busy {
+    tdmpc2_plan *h;
+    bool ok;
+    explicit Busy(tdmpc2_plan *hh) : h(hh), ok(false) {
+        int expected = 0;
+        ok = h->busy.compare_exchange_strong(expected, 1, std::memory_order_acquire);
+    }
+    ~Busy() {
+        if (ok) h->busy.store(0, std::memory_order_release);
+    }
+    Busy(const Busy &) = delete;
+    Busy &operator=(const Busy &) = delete;
+};
+#define ENTER(h)                                                                                                   \
+    Busy busy_(h);                                                                                                 \
+    if (!busy_.ok) return fail(TDMPC2_ERR_STATE, "the handle is in use by another call (handles are not reentrant)"); \
+    DevGuard dev_((h)->cfg.device);                                                                                \
+    if (!dev_.ok) return fail(TDMPC2_ERR_HIP, "hipSetDevice(%d) failed", (h)->cfg.device)
+
 int dev_alloc(tdmpc2_plan *h, void **p, size_t bytes) {
     HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
     h->allocs.push_back(*p);
@@ -494,7 +578,7 @@ template <> NetS to_dev<NetS>(const HostNet &n) {  // split: hi/lo f16 packing +
     NetS w;
     for (int i = 0; i < 3; ++i)
         w.l[i] = LayerS{n.l[i].wps ? n.l[i].wps : reinterpret_cast<const _Float16 *>(n.l[i].wp), n.l[i].bias, n.l[i].g, n.l[i].b,
-                        n.l[i].oscale, n.l[i].KB, n.l[i].CT};
+                        n.l[i].oscale, n.l[i].ascale, n.l[i].KB, n.l[i].CT};
     return w;
 }
 
@@ -584,17 +668,18 @@ template <> struct Kern<NetS> {
     static void rollout(const tdmpc2_plan *h, const RolloutParamsT<NetS> &p, int grid, hipStream_t st, int nst, int nw) {
         (void)nw;
         const int ar = h->split ? 0 : 1;
-        if (nst == 2) {
-            const size_t lds = h->lds_bytes;
-#define CALL_ROLL2(AP, AR) hipLaunchKernelGGL((ks_rollout<AP, 2, 8, AR>), dim3(grid), dim3(NTHREADS), lds, st, p);
-            FUSED_DISPATCH(h->Apad, ar, CALL_ROLL2)
-#undef CALL_ROLL2
-        } else {
-            const size_t lds = h->lds_bytes - (size_t)32 * h->row_bytes;
-#define CALL_ROLL1(AP, AR) hipLaunchKernelGGL((ks_rollout<AP, 1, 8, AR>), dim3(grid), dim3(NTHREADS), lds, st, p);
-            FUSED_DISPATCH(h->Apad, ar, CALL_ROLL1)
-#undef CALL_ROLL1
-        }
+        const bool ep = h->cfg.episodic != 0;
+        const size_t lds = nst == 2 ? h->lds_bytes : h->lds_bytes - (size_t)32 * h->row_bytes;
+#define CALL_ROLL(AP, AR)                                                                                                       \
+    if (nst == 2) {                                                                                                             \
+        if (ep) hipLaunchKernelGGL((ks_rollout<AP, 2, 8, AR, 1>), dim3(grid), dim3(NTHREADS), lds, st, p);                        \
+        else hipLaunchKernelGGL((ks_rollout<AP, 2, 8, AR, 0>), dim3(grid), dim3(NTHREADS), lds, st, p);                           \
+    } else {                                                                                                                    \
+        if (ep) hipLaunchKernelGGL((ks_rollout<AP, 1, 8, AR, 1>), dim3(grid), dim3(NTHREADS), lds, st, p);                        \
+        else hipLaunchKernelGGL((ks_rollout<AP, 1, 8, AR, 0>), dim3(grid), dim3(NTHREADS), lds, st, p);                           \
+    }
+        FUSED_DISPATCH(h->Apad, ar, CALL_ROLL)
+#undef CALL_ROLL
     }
 };
 
@@ -622,9 +707,11 @@ void fill_rollout(tdmpc2_plan *h, RolloutParamsT<NET> &p, int E) {
     p.stride = h->stride; p.tiles = h->tiles; p.nq = c.num_q; p.num_bins = c.num_bins; p.multitask = c.multitask;
     p.nnets = h->nnets; p.log_std_min = c.log_std_min; p.log_std_dif = c.log_std_dif;
     p.dyn = to_dev<NET>(h->dyn); p.rew = to_dev<NET>(h->rew); p.pi = to_dev<NET>(h->pi);
+    if (c.episodic) p.term = to_dev<NET>(h->term);
     for (int i = 0; i < c.num_q; ++i) p.q[i] = to_dev<NET>(h->q[i]);
     p.bins = h->bins; p.beff = h->beff; p.cvec = h->cvec; p.mean = h->mean; p.std = h->std;
     p.actions = h->actions; p.value = h->value; p.zscratch = h->zscratch;
+    p.ticket = h->ticket; p.fold_refit = 0;
     p.iters_total = c.iterations;
     p.timing = h->timing;
 }
@@ -663,8 +750,11 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
     rp.z0 = z0; rp.act_mask = act_mask; rp.disc_pow = disc_pow; rp.seed = seed; rp.call = call; rp.given_actions = 0;
     const int nst = Kern<NET>::sample_tiles(h, E, false), nw = Kern<NET>::waves(h, E, nst);
     rp.tiles = h->tiles * (2 / nst);
+    // elite selection + refit: inside the rollout launch (last workgroup of each plan, LDS budget = the 32-row tile) or as
+    // a launch of its own (TDMPC2_TUNE_FOLD_REFIT 0)
+    const bool fold = h->fold_refit != 0;
     int refit_stage = 0;
-    const size_t refit_lds = refit_lds_bytes(N, K, H, A, &refit_stage);
+    const size_t refit_lds = refit_lds_bytes(N, K, H, A, &refit_stage, fold ? (size_t)32 * h->row_bytes : 48 * 1024);
     for (int it = 0; it < I; ++it) {
         rp.iter = it;
         if (tape) {
@@ -675,17 +765,8 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
             rp.qidx = tape->qidx + (size_t)it * 2;
             rp.qidx_estride = (long)I * 2;
         }
-        if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
-        Kern<NET>::rollout(h, rp, E * rp.tiles, st, nst, nw);
-        HIP_TRY(hipGetLastError());
-        if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) {
-            HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
-            h->ev_used += 2;
-        }
-        if (dbg && dbg->actions)
-            HIP_TRY(hipMemcpy2DAsync(dbg->actions + (size_t)it * H * N * A, (size_t)I * H * N * A * 4, h->actions,
-                                     (size_t)H * N * A * 4, (size_t)H * N * A * 4, E, hipMemcpyDeviceToDevice, st));
-        RefitParams fp{};
+        RefitParams &fp = rp.rf;
+        fp = RefitParams{};
         fp.E = E; fp.N = N; fp.H = H; fp.A = A; fp.K = K; fp.iter = it; fp.last = (it == I - 1); fp.eval_mode = eval_mode; fp.stage = refit_stage;
         fp.temperature = c.temperature; fp.min_std = c.min_std; fp.max_std = c.max_std;
         fp.value = h->value; fp.actions = h->actions; fp.act_mask = act_mask; fp.mean = h->mean; fp.std = h->std;
@@ -698,8 +779,22 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
             if (dbg->mean) { fp.dbg_mean = dbg->mean + (size_t)it * H * A; fp.dbg_mean_es = (long)I * H * A; }
             if (dbg->std) { fp.dbg_std = dbg->std + (size_t)it * H * A; fp.dbg_std_es = (long)I * H * A; }
         }
-        hipLaunchKernelGGL(k_refit, dim3(E), dim3(N), refit_lds, st, fp);
+        rp.fold_refit = fold ? 1 : 0;
+        if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
+        Kern<NET>::rollout(h, rp, E * rp.tiles, st, nst, nw);
         HIP_TRY(hipGetLastError());
+        if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) {
+            HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
+            h->ev_used += 2;
+        }
+        if (!fold) {
+            hipLaunchKernelGGL(k_refit, dim3(E), dim3(N), refit_lds, st, fp);
+            HIP_TRY(hipGetLastError());
+        }
+        // the per-iteration action dump reads h->actions after the refit (which does not write them)
+        if (dbg && dbg->actions)
+            HIP_TRY(hipMemcpy2DAsync(dbg->actions + (size_t)it * H * N * A, (size_t)I * H * N * A * 4, h->actions,
+                                     (size_t)H * N * A * 4, (size_t)H * N * A * 4, E, hipMemcpyDeviceToDevice, st));
     }
     return TDMPC2_OK;
 }
@@ -733,6 +828,12 @@ int fused_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0,
 
 }  // namespace
 
+namespace {
+int run_impl(tdmpc2_plan *h, int n_envs, const float *z0, const float *task_emb, const float *act_mask, const float *disc_pow,
+             float *prev_mean, const uint8_t *t0, int eval_mode, const tdmpc2_noise *tape, uint64_t seed, float *action,
+             const tdmpc2_debug *dbg, void *stream);
+}
+
 extern "C" {
 
 int tdmpc2_plan_abi_version(void) { return TDMPC2_PLAN_ABI_VERSION; }
@@ -760,13 +861,13 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
     if (c.latent_dim < 8 || c.mlp_dim < 8 || c.latent_dim % 8 != 0)
         return fail(TDMPC2_ERR_UNSUPPORTED, "latent_dim %d / mlp_dim %d", c.latent_dim, c.mlp_dim);
     // ---- kernel family
-    const bool fits_fused = c.latent_dim == WIDTH && c.mlp_dim == WIDTH && !c.episodic;
+    const bool fits_fused = c.latent_dim == WIDTH && c.mlp_dim == WIDTH;
     const bool fits_layered = c.latent_dim % 32 == 0 && c.mlp_dim % 32 == 0 && c.num_samples % GBM == 0;
     int path = c.path;
     if (path == TDMPC2_PATH_AUTO) path = fits_fused ? TDMPC2_PATH_FUSED : TDMPC2_PATH_LAYERED;
     if (path == TDMPC2_PATH_FUSED && !fits_fused)
-        return fail(TDMPC2_ERR_UNSUPPORTED, "fused planner kernels are built for latent_dim == mlp_dim == %d, non-episodic "
-                    "(got %d / %d, episodic %d)", WIDTH, c.latent_dim, c.mlp_dim, c.episodic);
+        return fail(TDMPC2_ERR_UNSUPPORTED, "fused planner kernels are built for latent_dim == mlp_dim == %d (got %d / %d)",
+                    WIDTH, c.latent_dim, c.mlp_dim);
     if (path == TDMPC2_PATH_LAYERED && !fits_layered)
         return fail(TDMPC2_ERR_UNSUPPORTED, "layered planner kernels need latent_dim %% 32 == 0, mlp_dim %% 32 == 0 and "
                     "num_samples %% %d == 0 (got %d / %d / %d)", GBM, c.latent_dim, c.mlp_dim, c.num_samples);
@@ -776,7 +877,8 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
     if (prec != TDMPC2_PREC_FP32 && prec != TDMPC2_PREC_SPLIT_F16) return fail(TDMPC2_ERR_INVALID, "unknown precision %d", c.precision);
     if (prec == TDMPC2_PREC_SPLIT_F16 && path == TDMPC2_PATH_LAYERED && (c.mlp_dim > 4096 || c.latent_dim > 4096))
         return fail(TDMPC2_ERR_UNSUPPORTED, "the layered f16x2-split row kernels hold a row of at most 4096 columns in registers");
-    if (hipSetDevice(c.device) != hipSuccess) return fail(TDMPC2_ERR_HIP, "hipSetDevice(%d) failed", c.device);
+    DevGuard dev_(c.device);
+    if (!dev_.ok) return fail(TDMPC2_ERR_HIP, "hipSetDevice(%d) failed", c.device);
 
     tdmpc2_plan *h = new (std::nothrow) tdmpc2_plan();
     if (!h) return fail(TDMPC2_ERR_INVALID, "out of host memory");
@@ -784,6 +886,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
     h->cfg.path = path;
     h->cfg.precision = prec;
     h->lay.on = (path == TDMPC2_PATH_LAYERED);
+    h->lay.qarr = h->q;
     h->split = (prec == TDMPC2_PREC_SPLIT_F16);
     if (hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, c.device) != hipSuccess) h->num_cus = 0;
     h->Apad = (c.action_dim + 15) / 16 * 16;  // the fused kernels are instantiated for action paddings 16 / 32 / 48 / 64
@@ -802,8 +905,10 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             h->stride = WIDTH + h->Apad + 4;  // in floats
             h->row_bytes = (size_t)h->stride * 4;
         }
-        h->lds_bytes = (size_t)ROWS * h->row_bytes + 4096 /* LayerNorm partials */ + 4096 /* LayerNorm affine, CtxT::gb */ +
-                       (size_t)2 * c.horizon * c.action_dim * 4 + 64;
+        // after the tile: LayerNorm partials, LayerNorm affine (CtxT::gb), then mean / std [2 H A] of the rollout kernel or
+        // the 64 row -> task entries of ks_value
+        const size_t tail = std::max<size_t>((size_t)2 * c.horizon * c.action_dim * 4, 256);
+        h->lds_bytes = (size_t)ROWS * h->row_bytes + 4096 /* LayerNorm partials */ + 4096 /* LayerNorm affine */ + tail + 64;
         if (h->lds_bytes > 160 * 1024) {
             const size_t need = h->lds_bytes;
             delete h;
@@ -822,9 +927,21 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
         (rc = dev_alloc(h, (void **)&h->actions, E * H * N * A * 4)) ||
         (rc = dev_alloc(h, (void **)&h->value, E * N * 4)) ||
         (rc = dev_alloc(h, (void **)&h->mean, E * H * A * 4)) ||
-        (rc = dev_alloc(h, (void **)&h->std, E * H * A * 4))) {
+        (rc = dev_alloc(h, (void **)&h->std, E * H * A * 4)) ||
+        (rc = dev_alloc(h, (void **)&h->ticket, E * 4))) {
         tdmpc2_plan_destroy(h);
         return rc;
+    }
+    if (hipMemset(h->ticket, 0, E * 4) != hipSuccess) {
+        tdmpc2_plan_destroy(h);
+        return fail(TDMPC2_ERR_HIP, "hipMemset(ticket) failed");
+    }
+    if (!h->split) {  // unit scale of the exact arithmetic (LayerS::oscale / ascale)
+        const float one = 1.f;
+        if ((rc = dev_alloc(h, (void **)&h->one, 4)) || hipMemcpy(h->one, &one, 4, hipMemcpyHostToDevice) != hipSuccess) {
+            tdmpc2_plan_destroy(h);
+            return fail(TDMPC2_ERR_HIP, "allocating the unit output scale failed");
+        }
     }
     if (!h->lay.on) {
         if ((rc = dev_alloc(h, (void **)&h->cvec, E * 2 * WIDTH * 4)) ||
@@ -849,6 +966,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             tdmpc2_plan_destroy(h);
             return rc;
         }
+        L.bias_tab = h->beff;
         // stale rows of padded tiles are computed but never read back; start them finite
         if (hipMemset(L.X, 0, Rp * L.Kin * 4) != hipSuccess || hipMemset(L.HA, 0, Rp * L.Mp * 4) != hipSuccess ||
             hipMemset(L.HB, 0, Rp * L.Mp * 4) != hipSuccess || hipMemset(h->beff, 0, (E + 4) * h->nnets * L.Mp * 4) != hipSuccess) {
@@ -864,20 +982,14 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
         const int ar = h->split ? 0 : 1;
 #define CALL_SETLDS(AP, AR)                                                                                          \
     rc = set_lds(ks_setup<AP, AR>, h->lds_bytes) || set_lds(ks_pitraj<AP, 2, AR>, h->lds_bytes) ||                   \
-         set_lds(ks_pitraj<AP, 1, AR>, h->lds_bytes) || set_lds(ks_rollout<AP, 2, 8, AR>, h->lds_bytes) ||            \
-         set_lds(ks_rollout<AP, 1, 8, AR>, h->lds_bytes) || set_lds(ks_value<AP, AR>, h->lds_bytes);
+         set_lds(ks_pitraj<AP, 1, AR>, h->lds_bytes) || set_lds(ks_value<AP, AR>, h->lds_bytes) ||                    \
+         (c.episodic ? (set_lds(ks_rollout<AP, 2, 8, AR, 1>, h->lds_bytes) || set_lds(ks_rollout<AP, 1, 8, AR, 1>, h->lds_bytes)) \
+                     : (set_lds(ks_rollout<AP, 2, 8, AR, 0>, h->lds_bytes) || set_lds(ks_rollout<AP, 1, 8, AR, 0>, h->lds_bytes)));
         FUSED_DISPATCH(h->Apad, ar, CALL_SETLDS)
 #undef CALL_SETLDS
         if (rc) {
             tdmpc2_plan_destroy(h);
             return TDMPC2_ERR_HIP;
-        }
-        if (!h->split) {  // output scale of the exact arithmetic
-            const float one = 1.f;
-            if ((rc = dev_alloc(h, (void **)&h->one, 4)) || hipMemcpy(h->one, &one, 4, hipMemcpyHostToDevice) != hipSuccess) {
-                tdmpc2_plan_destroy(h);
-                return fail(TDMPC2_ERR_HIP, "allocating the unit output scale failed");
-            }
         }
     }
     if (getenv("TDMPC2_TIMING")) {
@@ -889,6 +1001,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
 
 void tdmpc2_plan_destroy(tdmpc2_plan_t *h) {
     if (!h) return;
+    DevGuard dev_(h->cfg.device);
     if (h->timing) {  // in-kernel phase timers of a -DSPLIT_TIMING build (tools/ablate.sh)
         unsigned long long t[16];
         if (hipMemcpy(t, h->timing, sizeof t, hipMemcpyDeviceToHost) == hipSuccess && t[15] > 0) {
@@ -909,6 +1022,95 @@ uint64_t tdmpc2_plan_device_bytes(const tdmpc2_plan_t *h) { return h ? h->bytes 
 int tdmpc2_plan_path(const tdmpc2_plan_t *h) { return h ? h->cfg.path : -1; }
 int tdmpc2_plan_precision(const tdmpc2_plan_t *h) { return h ? h->cfg.precision : -1; }
 
+namespace {
+// Shape of one nn.Linear of the world model as the planner stores it (tdmpc2/common/world_model.py:26-30).
+struct LayerShape {
+    int in, out;      // nn.Linear in_features / out_features
+    int nz, nt, na;   // source columns: latent or hidden | task embedding | action
+    int KB, CT;
+    bool has_ln, mish;  // LayerNorm after the Linear; Mish (hidden layers) as opposed to SimNorm / none
+    int heads;
+    size_t wsz /* floats' worth of packed weights per head */, bsz, gsz, esz;
+};
+LayerShape layer_shape(const tdmpc2_plan *h, int net, int layer) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    LayerShape s{};
+    const bool is_q = net == TDMPC2_NET_Q || net == TDMPC2_NET_TARGET_Q;
+    const bool takes_action = (net == TDMPC2_NET_DYNAMICS || net == TDMPC2_NET_REWARD || is_q);
+    s.heads = is_q ? c.num_q : 1;
+    if (layer == 0) {
+        s.in = c.latent_dim + c.task_dim + (takes_action ? c.action_dim : 0);
+        s.out = c.mlp_dim;
+    } else if (layer == 1) {
+        s.in = c.mlp_dim;
+        s.out = c.mlp_dim;
+    } else {
+        s.in = c.mlp_dim;
+        s.out = net == TDMPC2_NET_DYNAMICS ? c.latent_dim : net == TDMPC2_NET_PI ? 2 * c.action_dim
+                : net == TDMPC2_NET_TERMINATION ? 1 : c.num_bins;
+    }
+    s.has_ln = (layer < 2) || net == TDMPC2_NET_DYNAMICS;
+    s.mish = layer < 2;
+    s.nz = (layer == 0) ? c.latent_dim : c.mlp_dim;
+    s.nt = (layer == 0) ? c.task_dim : 0;
+    s.na = (layer == 0 && takes_action) ? c.action_dim : 0;
+    // packed contraction length: the fused kernels pad the action columns to 16, the layered GEMMs the whole row to GBK
+    const int Kp = h->lay.on ? (int)round_up((size_t)s.nz + s.na, GBK) : s.nz + (s.na + 15) / 16 * 16;
+    s.KB = h->split ? Kp / 16 : Kp / 8;
+    s.CT = (s.out + 31) / 32;
+    s.wsz = h->split ? (size_t)s.CT * s.KB * 512 /* floats' worth of 1024 halfs */ : (size_t)s.CT * s.KB * 256;
+    s.bsz = (size_t)s.CT * 32;
+    s.gsz = round_up((size_t)s.out, 4);
+    s.esz = (size_t)s.out * (s.nt > 0 ? s.nt : 0);
+    return s;
+}
+
+// One slab per tensor kind holding all ensemble members at a constant stride (the layered GEMM selects a member per plan
+// by stride); allocated on the first bind (or import) of a (net, layer).
+int ensure_layer_alloc(tdmpc2_plan *h, int net, int layer, const LayerShape &sh) {
+    HostLayer &L0 = net_of(h, net, 0)->l[layer];
+    if (L0.alloc) return 0;
+    int rc;
+    if (h->split && !net_of(h, net, 0)->scal) {  // the net's [heads][3] scalar table, defaults: scales 2^5, kw 0
+        LayerScal *tab = nullptr;
+        if ((rc = dev_alloc(h, (void **)&tab, (size_t)sh.heads * 3 * sizeof(LayerScal)))) return rc;
+        std::vector<LayerScal> init((size_t)sh.heads * 3, LayerScal{1.f, 1.f / ACT_SCALE, 0u, 0, ACT_SCALE, ACT_SCALE_LOG2, 0u, 0u});
+        HIP_TRY(hipMemcpy(tab, init.data(), init.size() * sizeof(LayerScal), hipMemcpyHostToDevice));
+        for (int hd = 0; hd < sh.heads; ++hd) net_of(h, net, hd)->scal = tab + (size_t)hd * 3;
+    }
+    float *wslab = nullptr, *bslab = nullptr, *gslab = nullptr, *betaslab = nullptr, *eslab = nullptr;
+    if ((rc = dev_alloc(h, (void **)&wslab, sh.heads * sh.wsz * 4))) return rc;
+    if ((rc = dev_alloc(h, (void **)&bslab, sh.heads * sh.bsz * 4))) return rc;
+    if (sh.has_ln) {
+        if ((rc = dev_alloc(h, (void **)&gslab, sh.heads * sh.gsz * 4))) return rc;
+        if ((rc = dev_alloc(h, (void **)&betaslab, sh.heads * sh.gsz * 4))) return rc;
+    }
+    if (sh.nt > 0 && (rc = dev_alloc(h, (void **)&eslab, sh.heads * sh.esz * 4))) return rc;
+    for (int hd = 0; hd < sh.heads; ++hd) {
+        HostNet *N = net_of(h, net, hd);
+        HostLayer &L = N->l[layer];
+        L.alloc = true;
+        L.KB = sh.KB; L.CT = sh.CT; L.out = sh.out;
+        L.wbytes = sh.wsz * 4;
+        if (h->split) {
+            L.wps = reinterpret_cast<_Float16 *>(wslab + hd * sh.wsz);
+            L.scal = N->scal + layer;
+            L.oscale = &L.scal->oscale;
+            L.ascale = &L.scal->ascale;
+        } else {
+            L.wp = wslab + hd * sh.wsz;
+            L.oscale = h->one;  // the exact arithmetic has no scales
+            L.ascale = h->one;
+        }
+        L.bias = bslab + hd * sh.bsz;
+        L.g = sh.has_ln ? gslab + hd * sh.gsz : nullptr;
+        L.b = sh.has_ln ? betaslab + hd * sh.gsz : nullptr;
+        L.wemb = sh.nt > 0 ? eslab + hd * sh.esz : nullptr;
+    }
+    return 0;
+}
+}  // namespace
+
 int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *W, const float *b, const float *ln_g,
                              const float *ln_b, int out_features, int in_features, void *stream) {
     if (!h || !W || !b) return fail(TDMPC2_ERR_INVALID, "null argument");
@@ -917,112 +1119,53 @@ int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *
     const tdmpc2_plan_cfg &c = h->cfg;
     if (net == TDMPC2_NET_TERMINATION && !c.episodic)
         return fail(TDMPC2_ERR_INVALID, "termination head bound on a non-episodic planner");
+    ENTER(h);
     hipStream_t st = (hipStream_t)stream;
-    const bool is_q = net == TDMPC2_NET_Q || net == TDMPC2_NET_TARGET_Q;
-    const int heads = is_q ? c.num_q : 1;
-    const bool takes_action = (net == TDMPC2_NET_DYNAMICS || net == TDMPC2_NET_REWARD || is_q);
-    // expected shapes (tdmpc2/common/world_model.py:26-30)
-    int exp_in, exp_out;
-    if (layer == 0) {
-        exp_in = c.latent_dim + c.task_dim + (takes_action ? c.action_dim : 0);
-        exp_out = c.mlp_dim;
-    } else if (layer == 1) {
-        exp_in = c.mlp_dim;
-        exp_out = c.mlp_dim;
-    } else {
-        exp_in = c.mlp_dim;
-        exp_out = net == TDMPC2_NET_DYNAMICS ? c.latent_dim
-                  : net == TDMPC2_NET_PI ? 2 * c.action_dim
-                  : net == TDMPC2_NET_TERMINATION ? 1 : c.num_bins;
-    }
-    if (in_features != exp_in || out_features != exp_out)
+    const LayerShape sh = layer_shape(h, net, layer);
+    if (in_features != sh.in || out_features != sh.out)
         return fail(TDMPC2_ERR_INVALID, "net %d layer %d: got [%d, %d], expected [%d, %d]", net, layer, out_features,
-                    in_features, exp_out, exp_in);
-    const bool has_ln = (layer < 2) || net == TDMPC2_NET_DYNAMICS;
-    if (has_ln && (!ln_g || !ln_b)) return fail(TDMPC2_ERR_INVALID, "net %d layer %d needs LayerNorm parameters", net, layer);
-    const int nz = (layer == 0) ? c.latent_dim : c.mlp_dim;
-    const int nt = (layer == 0) ? c.task_dim : 0;
-    const int na = (layer == 0 && takes_action) ? c.action_dim : 0;
-    // packed contraction length: the fused kernels pad the action columns to 16, the layered GEMMs the whole row to GBK
-    const int Kp = h->lay.on ? (int)round_up((size_t)nz + na, GBK) : nz + (na + 15) / 16 * 16;
-    const int KB = h->split ? Kp / 16 : Kp / 8;
-    const int CT = (out_features + 31) / 32;
-    // one slab per tensor kind holding all ensemble members at a constant stride (the layered GEMM selects a member
-    // per plan by stride); allocated on first bind
-    const size_t wsz = h->split ? (size_t)CT * KB * 512 /* floats' worth of 1024 halfs */ : (size_t)CT * KB * 256,
-                 bsz = (size_t)CT * 32, gsz = round_up((size_t)out_features, 4),
-                 esz = (size_t)out_features * (nt > 0 ? nt : 0);
-    HostLayer &L0 = net_of(h, net, 0)->l[layer];
-    if (!L0.alloc) {
-        float *wslab = nullptr, *bslab = nullptr, *gslab = nullptr, *betaslab = nullptr, *eslab = nullptr, *sslab = nullptr;
-        int rc;
-        if (h->split && (rc = dev_alloc(h, (void **)&sslab, heads * 4 * 4))) return rc;
-        if ((rc = dev_alloc(h, (void **)&wslab, heads * wsz * 4))) return rc;
-        if ((rc = dev_alloc(h, (void **)&bslab, heads * bsz * 4))) return rc;
-        if (has_ln) {
-            if ((rc = dev_alloc(h, (void **)&gslab, heads * gsz * 4))) return rc;
-            if ((rc = dev_alloc(h, (void **)&betaslab, heads * gsz * 4))) return rc;
-        }
-        if (nt > 0 && (rc = dev_alloc(h, (void **)&eslab, heads * esz * 4))) return rc;
-        for (int hd = 0; hd < heads; ++hd) {
-            HostLayer &L = net_of(h, net, hd)->l[layer];
-            L.alloc = true;
-            if (h->split) {
-                L.wps = reinterpret_cast<_Float16 *>(wslab + hd * wsz);
-                L.wscale = sslab + hd * 4;
-                L.oscale = sslab + hd * 4 + 1;
-                L.maxbits = reinterpret_cast<unsigned int *>(sslab + hd * 4 + 2);
-            } else {
-                L.wp = wslab + hd * wsz;
-                L.oscale = h->one;  // null on the layered fp32 path, which has no output scale
-            }
-            L.bias = bslab + hd * bsz;
-            L.g = has_ln ? gslab + hd * gsz : nullptr;
-            L.b = has_ln ? betaslab + hd * gsz : nullptr;
-            L.wemb = nt > 0 ? eslab + hd * esz : nullptr;
-        }
-    }
-    for (int hd = 0; hd < heads; ++hd) {
-        HostLayer &L = net_of(h, net, hd)->l[layer];
-        L.KB = KB; L.CT = CT; L.out = out_features;
+                    in_features, sh.out, sh.in);
+    if (sh.has_ln && (!ln_g || !ln_b)) return fail(TDMPC2_ERR_INVALID, "net %d layer %d needs LayerNorm parameters", net, layer);
+    int rc = ensure_layer_alloc(h, net, layer, sh);
+    if (rc) return rc;
+    for (int hd = 0; hd < sh.heads; ++hd) {
+        HostNet *N = net_of(h, net, hd);
+        HostLayer &L = N->l[layer];
         const float *Wh = W + (size_t)hd * out_features * in_features;
         if (h->split) {
-            HIP_TRY(hipMemsetAsync(L.maxbits, 0, 4, st));
-            hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, st, Wh, (size_t)out_features * in_features, L.maxbits);
-            hipLaunchKernelGGL(k_wscale, dim3(1), dim3(1), 0, st, L.maxbits, L.wscale, L.oscale);
-            hipLaunchKernelGGL(k_pack_split, dim3(512), dim3(256), 0, st, Wh, out_features, in_features, nz, nt, na, CT, KB,
-                               L.wscale, L.wps);
+            HIP_TRY(hipMemsetAsync(&L.scal->maxbits, 0, 4, st));
+            hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, st, Wh, (size_t)out_features * in_features, &L.scal->maxbits);
+            hipLaunchKernelGGL(k_wscale, dim3(1), dim3(1), 0, st, L.scal);
+            hipLaunchKernelGGL(k_pack_split, dim3(512), dim3(256), 0, st, Wh, out_features, in_features, sh.nz, sh.nt, sh.na, sh.CT,
+                               sh.KB, &L.scal->wscale, L.wps);
+            if (sh.has_ln) {
+                HIP_TRY(hipMemsetAsync(&L.scal->gmax, 0, 8, st));
+                hipLaunchKernelGGL(k_absmax, dim3(4), dim3(256), 0, st, ln_g + (size_t)hd * out_features, (size_t)out_features, &L.scal->gmax);
+                hipLaunchKernelGGL(k_absmax, dim3(4), dim3(256), 0, st, ln_b + (size_t)hd * out_features, (size_t)out_features, &L.scal->bmax);
+            }
+            hipLaunchKernelGGL(k_ascale, dim3(1), dim3(1), 0, st, L.scal, out_features, sh.has_ln && sh.mish ? 1 : 0);
+            hipLaunchKernelGGL(k_net_scales, dim3(1), dim3(1), 0, st, N->scal);
         } else {
-            hipLaunchKernelGGL(k_pack_weight, dim3(512), dim3(256), 0, st, Wh, out_features, in_features, nz, nt, na, CT, KB, L.wp);
+            hipLaunchKernelGGL(k_pack_weight, dim3(512), dim3(256), 0, st, Wh, out_features, in_features, sh.nz, sh.nt, sh.na, sh.CT,
+                               sh.KB, L.wp);
         }
-        hipLaunchKernelGGL(k_copy_pad, dim3(1), dim3(256), 0, st, b + (size_t)hd * out_features, out_features, CT * 32, L.bias);
-        if (has_ln) {
+        hipLaunchKernelGGL(k_copy_pad, dim3(1), dim3(256), 0, st, b + (size_t)hd * out_features, out_features, sh.CT * 32, L.bias);
+        if (sh.has_ln) {
             const int gb = (out_features + 255) / 256;
             hipLaunchKernelGGL(k_copy_pad, dim3(gb), dim3(256), 0, st, ln_g + (size_t)hd * out_features, out_features, out_features, L.g);
             hipLaunchKernelGGL(k_copy_pad, dim3(gb), dim3(256), 0, st, ln_b + (size_t)hd * out_features, out_features, out_features, L.b);
         }
-        if (nt > 0)
-            hipLaunchKernelGGL(k_copy_cols, dim3(64), dim3(256), 0, st, Wh, out_features, in_features, nz, nt, L.wemb);
+        if (sh.nt > 0)
+            hipLaunchKernelGGL(k_copy_cols, dim3(64), dim3(256), 0, st, Wh, out_features, in_features, sh.nz, sh.nt, L.wemb);
         HIP_TRY(hipGetLastError());
         L.bound = true;
     }
     return TDMPC2_OK;
 }
 
-int tdmpc2_plan_bind_encoder(tdmpc2_plan_t *h, int layer, int n_layers, const float *W, const float *b, const float *ln_g,
-                             const float *ln_b, int out_features, int in_features, void *stream) {
-    if (!h || !W || !b || !ln_g || !ln_b) return fail(TDMPC2_ERR_INVALID, "null argument");
-    if (n_layers < 1 || n_layers > ENC_MAX_LAYERS) return fail(TDMPC2_ERR_INVALID, "encoder depth %d outside [1, %d]", n_layers, ENC_MAX_LAYERS);
-    if (layer < 0 || layer >= n_layers) return fail(TDMPC2_ERR_INVALID, "encoder layer %d outside [0, %d)", layer, n_layers);
-    if (out_features < 1 || out_features > ENC_THREADS * ENC_MAX_PER_THREAD || in_features < 1)
-        return fail(TDMPC2_ERR_UNSUPPORTED, "encoder layer %d: width %d outside [1, %d]", layer, out_features, ENC_THREADS * ENC_MAX_PER_THREAD);
+namespace {
+int ensure_enc_alloc(tdmpc2_plan *h, int layer, int in_features, int out_features) {
     const tdmpc2_plan_cfg &c = h->cfg;
-    if (layer == n_layers - 1 && out_features != c.latent_dim)
-        return fail(TDMPC2_ERR_INVALID, "the last encoder layer has %d outputs, latent_dim is %d", out_features, c.latent_dim);
-    if (layer == n_layers - 1 && (c.latent_dim % c.simnorm_dim || (c.simnorm_dim & (c.simnorm_dim - 1)) || c.simnorm_dim > 64))
-        return fail(TDMPC2_ERR_UNSUPPORTED, "SimNorm groups of %d over %d latents", c.simnorm_dim, c.latent_dim);
-    if (h->enc_layers && h->enc_layers != n_layers) return fail(TDMPC2_ERR_STATE, "encoder depth changed from %d to %d", h->enc_layers, n_layers);
-    HIP_TRY(hipSetDevice(c.device));
     tdmpc2_plan::Enc &L = h->enc[layer];
     if (L.wt && (L.in != in_features || L.out != out_features))
         return fail(TDMPC2_ERR_STATE, "encoder layer %d re-bound with a different shape", layer);
@@ -1042,6 +1185,27 @@ int tdmpc2_plan_bind_encoder(tdmpc2_plan_t *h, int layer, int n_layers, const fl
         if ((rc = dev_alloc(h, (void **)&h->enc_x, (size_t)c.max_envs * w * 4))) return rc;
         h->enc_ws_width = w;
     }
+    return 0;
+}
+}  // namespace
+
+int tdmpc2_plan_bind_encoder(tdmpc2_plan_t *h, int layer, int n_layers, const float *W, const float *b, const float *ln_g,
+                             const float *ln_b, int out_features, int in_features, void *stream) {
+    if (!h || !W || !b || !ln_g || !ln_b) return fail(TDMPC2_ERR_INVALID, "null argument");
+    if (n_layers < 1 || n_layers > ENC_MAX_LAYERS) return fail(TDMPC2_ERR_INVALID, "encoder depth %d outside [1, %d]", n_layers, ENC_MAX_LAYERS);
+    if (layer < 0 || layer >= n_layers) return fail(TDMPC2_ERR_INVALID, "encoder layer %d outside [0, %d)", layer, n_layers);
+    if (out_features < 1 || out_features > ENC_THREADS * ENC_MAX_PER_THREAD || in_features < 1)
+        return fail(TDMPC2_ERR_UNSUPPORTED, "encoder layer %d: width %d outside [1, %d]", layer, out_features, ENC_THREADS * ENC_MAX_PER_THREAD);
+    const tdmpc2_plan_cfg &c = h->cfg;
+    if (layer == n_layers - 1 && out_features != c.latent_dim)
+        return fail(TDMPC2_ERR_INVALID, "the last encoder layer has %d outputs, latent_dim is %d", out_features, c.latent_dim);
+    if (layer == n_layers - 1 && (c.latent_dim % c.simnorm_dim || (c.simnorm_dim & (c.simnorm_dim - 1)) || c.simnorm_dim > 64))
+        return fail(TDMPC2_ERR_UNSUPPORTED, "SimNorm groups of %d over %d latents", c.simnorm_dim, c.latent_dim);
+    if (h->enc_layers && h->enc_layers != n_layers) return fail(TDMPC2_ERR_STATE, "encoder depth changed from %d to %d", h->enc_layers, n_layers);
+    ENTER(h);
+    int rc = ensure_enc_alloc(h, layer, in_features, out_features);
+    if (rc) return rc;
+    tdmpc2_plan::Enc &L = h->enc[layer];
     hipStream_t st = (hipStream_t)stream;
     const size_t n = (size_t)in_features * out_features;
     hipLaunchKernelGGL(k_transpose, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, W, L.wt, out_features, in_features);
@@ -1100,7 +1264,7 @@ int tdmpc2_plan_encode(tdmpc2_plan_t *h, int n_envs, const float *obs, int obs_d
                        void *stream) {
     if (!h || !obs || !z_out) return fail(TDMPC2_ERR_INVALID, "null argument");
     if (n_envs < 1) return fail(TDMPC2_ERR_INVALID, "n_envs %d < 1", n_envs);
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    ENTER(h);
     return launch_encode(h, n_envs, obs, obs_dim, task_emb, z_out, (hipStream_t)stream);
 }
 
@@ -1109,21 +1273,55 @@ int tdmpc2_plan_run_obs(tdmpc2_plan_t *h, int n_envs, const float *obs, int obs_
                         const tdmpc2_noise *tape, uint64_t seed, float *action, void *stream) {
     if (!h || !obs) return fail(TDMPC2_ERR_INVALID, "null argument");
     if (n_envs < 1 || n_envs > h->cfg.max_envs) return fail(TDMPC2_ERR_INVALID, "n_envs %d outside [1, %d]", n_envs, h->cfg.max_envs);
-    HIP_TRY(hipSetDevice(h->cfg.device));
+    ENTER(h);
     int rc = launch_encode(h, n_envs, obs, obs_dim, task_emb, h->zenc, (hipStream_t)stream);
     if (rc) return rc;
-    return tdmpc2_plan_run(h, n_envs, h->zenc, task_emb, act_mask, discount_pow, prev_mean, t0, eval_mode, tape, seed, action,
-                           nullptr, stream);
+    return run_impl(h, n_envs, h->zenc, task_emb, act_mask, discount_pow, prev_mean, t0, eval_mode, tape, seed, action, nullptr,
+                    stream);
 }
 
 namespace {
-int launch_value(tdmpc2_plan *h, int rows, const float *z, bool target, bool reduce_min, const float *pi_eps, const int32_t *qidx,
-                 uint64_t seed, const float *reward, const float *terminated, float discount, float *action, float *out,
-                 hipStream_t st) {
+// per-task tables of a multitask value call: effective first-layer biases of pi and of the chosen Q ensemble, action
+// masks, discounts; (re)built on every call (the weights may have been re-bound), storage grown on demand
+int build_task_tables(tdmpc2_plan *h, const tdmpc2_task_tables *tk, bool target, size_t rows_p, hipStream_t st) {
     const tdmpc2_plan_cfg &c = h->cfg;
-    if (h->lay.on)
-        return fail(TDMPC2_ERR_UNSUPPORTED, "policy_value / td_target run on the fused kernel family (latent_dim = mlp_dim = 512)");
-    if (c.multitask) return fail(TDMPC2_ERR_UNSUPPORTED, "policy_value / td_target: single-task models only");
+    const int nt = tk->n_tasks;
+    const size_t width = h->lay.on ? (size_t)h->lay.Mp : (size_t)WIDTH;
+    int rc;
+    if (nt > h->tab_tasks) {
+        if ((rc = dev_alloc(h, (void **)&h->beff_tab, (size_t)nt * h->nnets * width * 4))) return rc;
+        if ((rc = dev_alloc(h, (void **)&h->mask_tab, (size_t)nt * c.action_dim * 4))) return rc;
+        if ((rc = dev_alloc(h, (void **)&h->disc_tab, (size_t)nt * 4))) return rc;
+        h->tab_tasks = nt;
+    }
+    if (rows_p > h->task_rows_cap) {
+        if ((rc = dev_alloc(h, (void **)&h->task_rows, rows_p * 4))) return rc;
+        h->task_rows_cap = rows_p;
+    }
+    HIP_TRY(hipMemcpyAsync(h->mask_tab, tk->act_mask, (size_t)nt * c.action_dim * 4, hipMemcpyDeviceToDevice, st));
+    if (tk->discount) HIP_TRY(hipMemcpyAsync(h->disc_tab, tk->discount, (size_t)nt * 4, hipMemcpyDeviceToDevice, st));
+    const HostNet *qarr = target ? h->tq : h->q;
+    if (h->lay.on) return lay_setup(h, st, nt, tk->task_emb, nullptr, nullptr, false, h->beff_tab, qarr);
+    TaskBiasParams p{};
+    p.T = c.task_dim; p.nq = c.num_q; p.nnets = h->nnets; p.task_emb = tk->task_emb; p.beff_tab = h->beff_tab;
+    p.wemb[BE_PI] = h->pi.l[0].wemb; p.bias[BE_PI] = h->pi.l[0].bias;
+    for (int i = 0; i < c.num_q; ++i) { p.wemb[BE_Q0 + i] = qarr[i].l[0].wemb; p.bias[BE_Q0 + i] = qarr[i].l[0].bias; }
+    hipLaunchKernelGGL(ks_task_bias, dim3(nt), dim3(WIDTH), 0, st, p);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_value(tdmpc2_plan *h, int rows, const float *z, bool target, bool reduce_min, const float *pi_eps, const int32_t *qidx,
+                 uint64_t seed, const float *reward, const float *terminated, float discount, const tdmpc2_task_tables *tk,
+                 float *action, float *out, hipStream_t st) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    if (c.multitask) {
+        if (!tk || !tk->task_ids || !tk->task_emb || !tk->act_mask || tk->n_tasks < 1)
+            return fail(TDMPC2_ERR_INVALID, "multitask policy_value / td_target need the row -> task map and the per-task tables");
+        if (reward && !tk->discount) return fail(TDMPC2_ERR_INVALID, "multitask td_target needs the per-task discounts");
+    } else if (tk) {
+        return fail(TDMPC2_ERR_INVALID, "task tables given to a single-task handle");
+    }
     int rc = check_ready(h);
     if (rc) return rc;
     if (target)
@@ -1131,13 +1329,36 @@ int launch_value(tdmpc2_plan *h, int rows, const float *z, bool target, bool red
             for (int qh = 0; qh < c.num_q; ++qh)
                 if (!h->tq[qh].l[i].bound)
                     return fail(TDMPC2_ERR_STATE, "layer %d of target Q head %d is not bound (net TDMPC2_NET_TARGET_Q)", i, qh);
+    const unsigned call = ++h->call;
+    if (h->lay.on) {
+        const size_t rows_p = round_up((size_t)rows, GBM), cap = round_up((size_t)c.max_envs * c.num_samples, GBM);
+        if (rows_p > cap)
+            return fail(TDMPC2_ERR_INVALID, "the layered workspace holds %zu rows (max_envs x num_samples); got %d", cap, rows);
+        if (c.multitask) {
+            if ((rc = build_task_tables(h, tk, target, rows_p, st))) return rc;
+            HIP_TRY(hipMemsetAsync(h->task_rows, 0, rows_p * 4, st));
+            HIP_TRY(hipMemcpyAsync(h->task_rows, tk->task_ids, (size_t)rows * 4, hipMemcpyDeviceToDevice, st));
+        }
+        // the two heads: given, or randperm(num_q)[:2] once per call (world_model.py:212)
+        if (qidx) hipLaunchKernelGGL(l_copy_qidx, dim3(1), dim3(64), 0, st, 1, qidx, 2L, h->lay.qidx);
+        else hipLaunchKernelGGL(l_qidx, dim3(1), dim3(64), 0, st, 1, c.num_q, 0, (unsigned long long)seed, call, h->lay.qidx);
+        HIP_TRY(hipGetLastError());
+        return lay_value(h, st, rows, z, target, reduce_min, pi_eps, h->lay.qidx, seed, call, reward, terminated, discount,
+                         c.multitask ? h->task_rows : nullptr, action, out);
+    }
+    if (c.multitask && (rc = build_task_tables(h, tk, target, 0, st))) return rc;
     ValueParamsT<NetS> p{};
     p.rows = rows; p.A = c.action_dim; p.Apad = h->Apad; p.nq = c.num_q; p.num_bins = c.num_bins; p.reduce_min = reduce_min ? 1 : 0;
     p.log_std_min = c.log_std_min; p.log_std_dif = c.log_std_dif; p.discount = discount;
     p.pi = to_dev<NetS>(h->pi);
     for (int i = 0; i < c.num_q; ++i) p.q[i] = to_dev<NetS>(target ? h->tq[i] : h->q[i]);
-    p.bins = h->bins; p.z = z; p.pi_eps = pi_eps; p.qidx = qidx; p.seed = seed; p.call = ++h->call;
+    p.bins = h->bins; p.z = z; p.pi_eps = pi_eps; p.qidx = qidx; p.seed = seed; p.call = call;
     p.reward = reward; p.terminated = terminated; p.action = action; p.out = out;
+    p.nnets = h->nnets;
+    if (c.multitask) {
+        p.task_ids = tk->task_ids; p.beff_tab = h->beff_tab; p.mask_tab = h->mask_tab;
+        p.disc_tab = reward ? h->disc_tab : nullptr;
+    }
     const int grid = (rows + ROWS - 1) / ROWS;
     const size_t lds = h->lds_bytes;
     const int ar = h->split ? 0 : 1;
@@ -1149,22 +1370,197 @@ int launch_value(tdmpc2_plan *h, int rows, const float *z, bool target, bool red
 }
 }  // namespace
 
-int tdmpc2_plan_policy_value(tdmpc2_plan_t *h, int n_rows, const float *z, int use_target, int reduce_min, const float *pi_eps,
-                             const int32_t *qidx, uint64_t seed, float *action, float *q, void *stream) {
+int tdmpc2_plan_policy_value_mt(tdmpc2_plan_t *h, int n_rows, const float *z, const tdmpc2_task_tables *tasks, int use_target,
+                                int reduce_min, const float *pi_eps, const int32_t *qidx, uint64_t seed, float *action, float *q,
+                                void *stream) {
     if (!h || !z || !q) return fail(TDMPC2_ERR_INVALID, "null argument");
     if (n_rows < 1) return fail(TDMPC2_ERR_INVALID, "n_rows %d < 1", n_rows);
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    return launch_value(h, n_rows, z, use_target != 0, reduce_min != 0, pi_eps, qidx, seed, nullptr, nullptr, 0.f, action, q,
+    ENTER(h);
+    return launch_value(h, n_rows, z, use_target != 0, reduce_min != 0, pi_eps, qidx, seed, nullptr, nullptr, 0.f, tasks, action, q,
+                        (hipStream_t)stream);
+}
+
+int tdmpc2_plan_policy_value(tdmpc2_plan_t *h, int n_rows, const float *z, int use_target, int reduce_min, const float *pi_eps,
+                             const int32_t *qidx, uint64_t seed, float *action, float *q, void *stream) {
+    return tdmpc2_plan_policy_value_mt(h, n_rows, z, nullptr, use_target, reduce_min, pi_eps, qidx, seed, action, q, stream);
+}
+
+int tdmpc2_plan_td_target_mt(tdmpc2_plan_t *h, int n_rows, const float *next_z, const float *reward, const float *terminated,
+                             float discount, const tdmpc2_task_tables *tasks, const float *pi_eps, const int32_t *qidx,
+                             uint64_t seed, float *td, void *stream) {
+    if (!h || !next_z || !reward || !terminated || !td) return fail(TDMPC2_ERR_INVALID, "null argument");
+    if (n_rows < 1) return fail(TDMPC2_ERR_INVALID, "n_rows %d < 1", n_rows);
+    ENTER(h);
+    return launch_value(h, n_rows, next_z, true, true, pi_eps, qidx, seed, reward, terminated, discount, tasks, nullptr, td,
                         (hipStream_t)stream);
 }
 
 int tdmpc2_plan_td_target(tdmpc2_plan_t *h, int n_rows, const float *next_z, const float *reward, const float *terminated,
                           float discount, const float *pi_eps, const int32_t *qidx, uint64_t seed, float *td, void *stream) {
-    if (!h || !next_z || !reward || !terminated || !td) return fail(TDMPC2_ERR_INVALID, "null argument");
-    if (n_rows < 1) return fail(TDMPC2_ERR_INVALID, "n_rows %d < 1", n_rows);
-    HIP_TRY(hipSetDevice(h->cfg.device));
-    return launch_value(h, n_rows, next_z, true, true, pi_eps, qidx, seed, reward, terminated, discount, nullptr, td,
-                        (hipStream_t)stream);
+    return tdmpc2_plan_td_target_mt(h, n_rows, next_z, reward, terminated, discount, nullptr, pi_eps, qidx, seed, td, stream);
+}
+
+// ---------------------------------------------------------------- packed weight file
+// Everything a bind produces -- fragment-ordered (and, for the split arithmetic, hi/lo-split and scaled) weights, padded
+// biases, LayerNorm parameters, task-embedding columns, the per-layer scale records, the transposed encoder -- as one
+// host blob: [PackHdr][segment sizes][segment data].  Importing it is a sequence of plain host-to-device copies: no
+// packing kernels, no fp32 checkpoint on the device (reference load path: tdmpc2/tdmpc2.py:81-95).
+namespace {
+struct PackHdr {
+    char magic[8];
+    uint32_t version, abi;
+    tdmpc2_plan_cfg cfg;  // as resolved by create (path and precision are concrete); max_envs / device are not compared
+    uint32_t has_target, enc_layers;
+    int32_t enc_in[ENC_MAX_LAYERS], enc_out[ENC_MAX_LAYERS];
+    uint64_t nseg, data_bytes;
+};
+struct Seg {
+    void *p;
+    size_t bytes;
+};
+const int kPackNets[] = {TDMPC2_NET_DYNAMICS, TDMPC2_NET_REWARD, TDMPC2_NET_PI, TDMPC2_NET_TERMINATION, TDMPC2_NET_Q, TDMPC2_NET_TARGET_Q};
+
+bool net_in_pack(const tdmpc2_plan *h, int net, bool has_target) {
+    if (net == TDMPC2_NET_TERMINATION) return h->cfg.episodic != 0;
+    if (net == TDMPC2_NET_TARGET_Q) return has_target;
+    return true;
+}
+// canonical walk; every visited layer must be allocated
+void collect_segments(tdmpc2_plan *h, bool has_target, int enc_layers, std::vector<Seg> &out) {
+    for (int net : kPackNets) {
+        if (!net_in_pack(h, net, has_target)) continue;
+        const int heads = layer_shape(h, net, 0).heads;
+        for (int hd = 0; hd < heads; ++hd) {
+            HostNet *N = net_of(h, net, hd);
+            for (int l = 0; l < 3; ++l) {
+                const LayerShape sh = layer_shape(h, net, l);
+                HostLayer &L = N->l[l];
+                out.push_back({h->split ? (void *)L.wps : (void *)L.wp, sh.wsz * 4});
+                out.push_back({L.bias, sh.bsz * 4});
+                if (sh.has_ln) {
+                    out.push_back({L.g, sh.gsz * 4});
+                    out.push_back({L.b, sh.gsz * 4});
+                }
+                if (sh.nt > 0) out.push_back({L.wemb, sh.esz * 4});
+            }
+            if (h->split) out.push_back({N->scal, 3 * sizeof(LayerScal)});
+        }
+    }
+    for (int l = 0; l < enc_layers; ++l) {
+        tdmpc2_plan::Enc &E = h->enc[l];
+        out.push_back({E.wt, (size_t)E.in * E.out * 4});
+        out.push_back({E.bias, (size_t)E.out * 4});
+        out.push_back({E.g, (size_t)E.out * 4});
+        out.push_back({E.b, (size_t)E.out * 4});
+    }
+}
+bool target_bound(const tdmpc2_plan *h) {
+    for (int i = 0; i < 3; ++i)
+        for (int q = 0; q < h->cfg.num_q; ++q)
+            if (!h->tq[q].l[i].bound) return false;
+    return true;
+}
+bool same_model(const tdmpc2_plan_cfg &a, const tdmpc2_plan_cfg &b) {
+    return a.horizon == b.horizon && a.num_samples == b.num_samples && a.action_dim == b.action_dim && a.latent_dim == b.latent_dim &&
+           a.mlp_dim == b.mlp_dim && a.task_dim == b.task_dim && a.num_bins == b.num_bins && a.num_q == b.num_q &&
+           a.simnorm_dim == b.simnorm_dim && a.multitask == b.multitask && a.episodic == b.episodic && a.path == b.path &&
+           a.precision == b.precision;
+}
+}  // namespace
+
+int tdmpc2_plan_packed_size(tdmpc2_plan_t *h, uint64_t *bytes) {
+    if (!h || !bytes) return fail(TDMPC2_ERR_INVALID, "null argument");
+    ENTER(h);
+    int rc = check_ready(h);
+    if (rc) return rc;
+    std::vector<Seg> segs;
+    collect_segments(h, target_bound(h), h->enc_layers, segs);
+    uint64_t total = sizeof(PackHdr) + segs.size() * sizeof(uint64_t);
+    for (const Seg &sg : segs) total += sg.bytes;
+    *bytes = total;
+    return TDMPC2_OK;
+}
+
+int tdmpc2_plan_export_packed(tdmpc2_plan_t *h, void *host_buf, uint64_t bytes, void *stream) {
+    if (!h || !host_buf) return fail(TDMPC2_ERR_INVALID, "null argument");
+    ENTER(h);
+    int rc = check_ready(h);
+    if (rc) return rc;
+    for (int l = 0; l < h->enc_layers; ++l)
+        if (!h->enc[l].bound) return fail(TDMPC2_ERR_STATE, "encoder layer %d of %d is not bound", l, h->enc_layers);
+    const bool has_target = target_bound(h);
+    std::vector<Seg> segs;
+    collect_segments(h, has_target, h->enc_layers, segs);
+    PackHdr hdr{};
+    memcpy(hdr.magic, "TDMPC2PK", 8);
+    hdr.version = 1; hdr.abi = TDMPC2_PLAN_ABI_VERSION; hdr.cfg = h->cfg; hdr.has_target = has_target ? 1 : 0;
+    hdr.enc_layers = (uint32_t)h->enc_layers;
+    for (int l = 0; l < h->enc_layers; ++l) { hdr.enc_in[l] = h->enc[l].in; hdr.enc_out[l] = h->enc[l].out; }
+    hdr.nseg = segs.size();
+    for (const Seg &sg : segs) hdr.data_bytes += sg.bytes;
+    const uint64_t need = sizeof(PackHdr) + segs.size() * sizeof(uint64_t) + hdr.data_bytes;
+    if (bytes < need) return fail(TDMPC2_ERR_INVALID, "buffer of %llu bytes, the packed weights need %llu", (unsigned long long)bytes, (unsigned long long)need);
+    char *dst = static_cast<char *>(host_buf);
+    memcpy(dst, &hdr, sizeof hdr);
+    uint64_t *sizes = reinterpret_cast<uint64_t *>(dst + sizeof hdr);
+    char *data = dst + sizeof hdr + segs.size() * sizeof(uint64_t);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));  // binds on this stream have landed
+    for (size_t i = 0; i < segs.size(); ++i) {
+        sizes[i] = segs[i].bytes;
+        HIP_TRY(hipMemcpy(data, segs[i].p, segs[i].bytes, hipMemcpyDeviceToHost));
+        data += segs[i].bytes;
+    }
+    return TDMPC2_OK;
+}
+
+int tdmpc2_plan_import_packed(tdmpc2_plan_t *h, const void *host_buf, uint64_t bytes, void *stream) {
+    if (!h || !host_buf) return fail(TDMPC2_ERR_INVALID, "null argument");
+    ENTER(h);
+    if (bytes < sizeof(PackHdr)) return fail(TDMPC2_ERR_INVALID, "packed weights: truncated header");
+    PackHdr hdr;
+    memcpy(&hdr, host_buf, sizeof hdr);
+    if (memcmp(hdr.magic, "TDMPC2PK", 8) != 0 || hdr.version != 1) return fail(TDMPC2_ERR_INVALID, "not a packed weight blob (magic / version)");
+    if (!same_model(hdr.cfg, h->cfg))
+        return fail(TDMPC2_ERR_INVALID, "packed weights were exported for another model / kernel family / arithmetic "
+                    "(latent %d mlp %d A %d path %d precision %d; this handle: %d %d %d %d %d)", hdr.cfg.latent_dim, hdr.cfg.mlp_dim,
+                    hdr.cfg.action_dim, hdr.cfg.path, hdr.cfg.precision, h->cfg.latent_dim, h->cfg.mlp_dim, h->cfg.action_dim,
+                    h->cfg.path, h->cfg.precision);
+    if (hdr.enc_layers > (uint32_t)ENC_MAX_LAYERS) return fail(TDMPC2_ERR_INVALID, "packed weights: bad encoder depth");
+    if (h->enc_layers && hdr.enc_layers && h->enc_layers != (int)hdr.enc_layers)
+        return fail(TDMPC2_ERR_STATE, "encoder depth changed from %d to %u", h->enc_layers, hdr.enc_layers);
+    int rc;
+    for (int net : kPackNets) {
+        if (!net_in_pack(h, net, hdr.has_target != 0)) continue;
+        for (int l = 0; l < 3; ++l)
+            if ((rc = ensure_layer_alloc(h, net, l, layer_shape(h, net, l)))) return rc;
+    }
+    for (uint32_t l = 0; l < hdr.enc_layers; ++l)
+        if ((rc = ensure_enc_alloc(h, (int)l, hdr.enc_in[l], hdr.enc_out[l]))) return rc;
+    std::vector<Seg> segs;
+    collect_segments(h, hdr.has_target != 0, (int)hdr.enc_layers, segs);
+    if (segs.size() != hdr.nseg || bytes < sizeof(PackHdr) + hdr.nseg * sizeof(uint64_t) + hdr.data_bytes)
+        return fail(TDMPC2_ERR_INVALID, "packed weights: %llu segments / %llu bytes, expected %zu segments", (unsigned long long)hdr.nseg,
+                    (unsigned long long)bytes, segs.size());
+    const char *src = static_cast<const char *>(host_buf);
+    const uint64_t *sizes = reinterpret_cast<const uint64_t *>(src + sizeof hdr);
+    for (size_t i = 0; i < segs.size(); ++i)
+        if (sizes[i] != segs[i].bytes) return fail(TDMPC2_ERR_INVALID, "packed weights: segment %zu has %llu bytes, expected %zu", i, (unsigned long long)sizes[i], segs[i].bytes);
+    const char *data = src + sizeof hdr + segs.size() * sizeof(uint64_t);
+    hipStream_t st = (hipStream_t)stream;
+    for (size_t i = 0; i < segs.size(); ++i) {
+        HIP_TRY(hipMemcpyAsync(segs[i].p, data, segs[i].bytes, hipMemcpyHostToDevice, st));
+        data += segs[i].bytes;
+    }
+    HIP_TRY(hipStreamSynchronize(st));  // the host blob may be released on return
+    for (int net : kPackNets) {
+        if (!net_in_pack(h, net, hdr.has_target != 0)) continue;
+        const int heads = layer_shape(h, net, 0).heads;
+        for (int hd = 0; hd < heads; ++hd)
+            for (int l = 0; l < 3; ++l) net_of(h, net, hd)->l[l].bound = true;
+    }
+    for (uint32_t l = 0; l < hdr.enc_layers; ++l) h->enc[l].bound = true;
+    if (hdr.enc_layers) h->enc_layers = (int)hdr.enc_layers;
+    return TDMPC2_OK;
 }
 
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value) {
@@ -1174,11 +1570,17 @@ int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value) {
         h->force_rows = value;
         return TDMPC2_OK;
     }
+    if (key == TDMPC2_TUNE_FOLD_REFIT) {
+        if (value != 0 && value != 1) return fail(TDMPC2_ERR_INVALID, "fold_refit must be 0 or 1");
+        h->fold_refit = value;
+        return TDMPC2_OK;
+    }
     return fail(TDMPC2_ERR_INVALID, "unknown tuning key %d", key);
 }
 
 int tdmpc2_plan_set_profiling(tdmpc2_plan_t *h, int max_launches) {
     if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
+    ENTER(h);
     h->profiling = max_launches > 0;
     if ((int)h->ev.size() < 2 * max_launches) {
         const size_t old = h->ev.size();
@@ -1191,6 +1593,7 @@ int tdmpc2_plan_set_profiling(tdmpc2_plan_t *h, int max_launches) {
 
 int tdmpc2_plan_profile_read(tdmpc2_plan_t *h, float *rollout_ms_total, int *rollout_launches) {
     if (!h || !rollout_ms_total || !rollout_launches) return fail(TDMPC2_ERR_INVALID, "null argument");
+    ENTER(h);
     float total = 0.f;
     for (int i = 0; i + 1 < h->ev_used; i += 2) {
         HIP_TRY(hipEventSynchronize(h->ev[i + 1]));
@@ -1207,6 +1610,16 @@ int tdmpc2_plan_profile_read(tdmpc2_plan_t *h, float *rollout_ms_total, int *rol
 int tdmpc2_plan_run(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *task_emb, const float *act_mask,
                     const float *disc_pow, float *prev_mean, const uint8_t *t0, int eval_mode, const tdmpc2_noise *tape,
                     uint64_t seed, float *action, const tdmpc2_debug *dbg, void *stream) {
+    if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
+    ENTER(h);
+    return run_impl(h, n_envs, z0, task_emb, act_mask, disc_pow, prev_mean, t0, eval_mode, tape, seed, action, dbg, stream);
+}
+
+}  // extern "C"
+namespace {
+int run_impl(tdmpc2_plan *h, int n_envs, const float *z0, const float *task_emb, const float *act_mask, const float *disc_pow,
+             float *prev_mean, const uint8_t *t0, int eval_mode, const tdmpc2_noise *tape, uint64_t seed, float *action,
+             const tdmpc2_debug *dbg, void *stream) {
     int rc = validate_envs(h, n_envs);
     if (rc) return rc;
     if (!z0 || !disc_pow || !prev_mean || !t0 || !action) return fail(TDMPC2_ERR_INVALID, "null argument");
@@ -1221,6 +1634,8 @@ int tdmpc2_plan_run(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *
         return lay_run(h, st, n_envs, z0, task_emb, act_mask, disc_pow, prev_mean, t0, eval_mode, tape, seed, action, dbg);
     return fused_run<NetS>(h, st, n_envs, z0, task_emb, act_mask, disc_pow, prev_mean, t0, eval_mode, tape, seed, action, dbg);
 }
+}  // namespace
+extern "C" {
 
 int tdmpc2_plan_estimate_value(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *task_emb,
                                const float *act_mask, const float *disc_pow, const float *actions, const float *pi_eps,
@@ -1233,6 +1648,8 @@ int tdmpc2_plan_estimate_value_trace(tdmpc2_plan_t *h, int n_envs, const float *
                                      const float *act_mask, const float *disc_pow, const float *actions,
                                      const float *pi_eps, const int32_t *qidx, float *value, float *trace_tiles,
                                      float *trace_scalars, void *stream) {
+    if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
+    ENTER(h);
     int rc = validate_envs(h, n_envs);
     if (rc) return rc;
     if (!z0 || !disc_pow || !actions || !pi_eps || !qidx || !value) return fail(TDMPC2_ERR_INVALID, "null argument");
@@ -1258,6 +1675,7 @@ int tdmpc2_plan_refit(tdmpc2_plan_t *h, int n_envs, float *value, const float *a
     if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
     if (n_envs < 1 || n_envs > h->cfg.max_envs) return fail(TDMPC2_ERR_INVALID, "n_envs=%d outside [1, %d]", n_envs, h->cfg.max_envs);
     if (!value || !actions) return fail(TDMPC2_ERR_INVALID, "null argument");
+    ENTER(h);
     const tdmpc2_plan_cfg &c = h->cfg;
     hipStream_t st = (hipStream_t)stream;
     int refit_stage = 0;

@@ -1,7 +1,8 @@
 """Host-side (PyTorch) building blocks of the world model.
 
-These exist for what stays on the host side of the boundary: the observation
-encoder, checkpoint I/O in the reference's key layout, and the non-planning
+These exist for what stays on the host side of the boundary: the pixel
+observation encoder (state observations are also encoded inside the library),
+checkpoint I/O in the reference's key layout, and the non-planning
 `act()` path.  The planner itself never runs through them — it runs in the HIP
 library (tdmpc2_amd/csrc).  Behaviour follows tdmpc2/common/layers.py:74-164 of
 the reference.
@@ -55,15 +56,72 @@ def mlp(in_dim, mlp_dims, out_dim, act=None, dropout=0.0):
     return nn.Sequential(*mods)
 
 
-def state_encoder(cfg):
-    """Reference layers.py:153-164, 'state' branch only (pixel encoders are outside the hot-path scope)."""
+class ShiftAug(nn.Module):
+    """Random +-`pad` pixel shift (reference layers.py:36-59: replicate-pad, then bilinear resampling on a grid shifted
+    by an integer number of pixels per image).  The integer shift comes from `torch.randint` exactly as in the reference,
+    so a seeded run draws the same shifts."""
+
+    def __init__(self, pad: int = 3):
+        super().__init__()
+        self.pad = pad
+
+    def forward(self, x):
+        x = x.float()
+        n, _, h, w = x.shape
+        if h != w:
+            raise ValueError(f"ShiftAug expects square images, got {h}x{w}")
+        p = self.pad
+        x = F.pad(x, (p, p, p, p), mode="replicate")
+        full = h + 2 * p
+        eps = 1.0 / full
+        lin = torch.linspace(-1.0 + eps, 1.0 - eps, full, device=x.device, dtype=x.dtype)[:h]
+        gx = lin.view(1, h, 1).expand(h, h, 1)          # x coordinate varies along the width
+        grid = torch.cat([gx, gx.transpose(0, 1)], dim=2).unsqueeze(0).expand(n, h, h, 2)
+        shift = torch.randint(0, 2 * p + 1, size=(n, 1, 1, 2), device=x.device, dtype=x.dtype) * (2.0 / full)
+        return F.grid_sample(x, grid + shift, padding_mode="zeros", align_corners=False)
+
+
+class PixelPreprocess(nn.Module):
+    """uint8-range pixels -> [-0.5, 0.5] (reference layers.py:62-71)."""
+
+    def forward(self, x):
+        return x.div(255.0).sub(0.5)
+
+
+def conv(in_shape, num_channels: int, act=None):
+    """Pixel encoder with the reference's module indices, hence its checkpoint keys `_encoder.rgb.{2,4,6,8}.*`
+    (reference layers.py:136-150): ShiftAug, PixelPreprocess, four Conv2d (7/2, 5/2, 3/2, 3/1) with ReLU between,
+    Flatten, then the optional activation (SimNorm).  64 x 64 inputs shrink 64 -> 29 -> 13 -> 6 -> 4, so Flatten yields
+    16 * num_channels features (512 for the default 32 channels = the 5M model's latent_dim).  Host-side PyTorch-ROCm
+    (MIOpen convolutions): the planner is handed the latent (`tdmpc2_plan_run`)."""
+    if in_shape[-1] != 64:
+        raise ValueError(f"the pixel encoder is laid out for 64x64 observations (got {tuple(in_shape)})")
+    mods = [ShiftAug(), PixelPreprocess(),
+            nn.Conv2d(in_shape[0], num_channels, 7, stride=2), nn.ReLU(inplace=False),
+            nn.Conv2d(num_channels, num_channels, 5, stride=2), nn.ReLU(inplace=False),
+            nn.Conv2d(num_channels, num_channels, 3, stride=2), nn.ReLU(inplace=False),
+            nn.Conv2d(num_channels, num_channels, 3, stride=1), nn.Flatten()]
+    if act is not None:
+        mods.append(act)
+    return nn.Sequential(*mods)
+
+
+def encoders(cfg):
+    """One encoder per observation key (reference layers.py:153-164): 'state' -> NormedLinear stack with a SimNorm output,
+    'rgb' -> `conv`.  A fresh dict per call (the reference's mutable default argument shares encoders between models)."""
     out = {}
     for k, shape in cfg.obs_shape.items():
-        if k != "state":
-            raise NotImplementedError(f"encoder for observation type {k!r} is outside this package's scope")
-        out[k] = mlp(shape[0] + cfg.task_dim, max(cfg.num_enc_layers - 1, 1) * [cfg.enc_dim], cfg.latent_dim,
-                     act=SimNorm(cfg.simnorm_dim))
+        if k == "state":
+            out[k] = mlp(shape[0] + cfg.task_dim, max(cfg.num_enc_layers - 1, 1) * [cfg.enc_dim], cfg.latent_dim,
+                         act=SimNorm(cfg.simnorm_dim))
+        elif k == "rgb":
+            out[k] = conv(shape, cfg.num_channels, act=SimNorm(cfg.simnorm_dim))
+        else:
+            raise NotImplementedError(f"Encoder for observation type {k} not implemented.")
     return nn.ModuleDict(out)
+
+
+state_encoder = encoders  # name used by round-1 callers
 
 
 class _StackedLayer(nn.Module):

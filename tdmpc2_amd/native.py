@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("TDMPC2_PLAN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtdmpc2_plan.so")
 _lib = None
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/tdmpc2_plan.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
@@ -25,7 +25,8 @@ ABI_SYMBOLS = [
     "tdmpc2_plan_device_bytes", "tdmpc2_plan_path", "tdmpc2_plan_precision", "tdmpc2_plan_bind_weights", "tdmpc2_plan_run", "tdmpc2_plan_estimate_value",
     "tdmpc2_plan_estimate_value_trace", "tdmpc2_plan_refit", "tdmpc2_plan_set_tuning", "tdmpc2_plan_set_profiling",
     "tdmpc2_plan_profile_read", "tdmpc2_plan_bind_encoder", "tdmpc2_plan_encode", "tdmpc2_plan_run_obs",
-    "tdmpc2_plan_policy_value", "tdmpc2_plan_td_target",
+    "tdmpc2_plan_policy_value", "tdmpc2_plan_td_target", "tdmpc2_plan_policy_value_mt", "tdmpc2_plan_td_target_mt",
+    "tdmpc2_plan_packed_size", "tdmpc2_plan_export_packed", "tdmpc2_plan_import_packed",
 ]
 
 NET_DYNAMICS, NET_REWARD, NET_PI, NET_Q, NET_TERMINATION, NET_TARGET_Q = range(6)
@@ -45,6 +46,12 @@ class PlanCfg(C.Structure):
 class Noise(C.Structure):
     _fields_ = [("pi_traj_eps", C.c_void_p), ("sample_eps", C.c_void_p), ("pi_eps", C.c_void_p),
                 ("qidx", C.c_void_p), ("gumbel_exp", C.c_void_p), ("final_eps", C.c_void_p)]
+
+
+class TaskTables(C.Structure):
+    """struct tdmpc2_task_tables: one task per row of a training batch + the per-task tables."""
+    _fields_ = [("task_ids", C.c_void_p), ("task_emb", C.c_void_p), ("act_mask", C.c_void_p), ("discount", C.c_void_p),
+                ("n_tasks", C.c_int32)]
 
 
 class Debug(C.Structure):
@@ -97,6 +104,16 @@ def load_library():
     lib.tdmpc2_plan_policy_value.restype = i32
     lib.tdmpc2_plan_td_target.argtypes = [vp, i32, vp, vp, vp, C.c_float, vp, vp, u64, vp, vp]
     lib.tdmpc2_plan_td_target.restype = i32
+    lib.tdmpc2_plan_policy_value_mt.argtypes = [vp, i32, vp, C.POINTER(TaskTables), i32, i32, vp, vp, u64, vp, vp, vp]
+    lib.tdmpc2_plan_policy_value_mt.restype = i32
+    lib.tdmpc2_plan_td_target_mt.argtypes = [vp, i32, vp, vp, vp, C.c_float, C.POINTER(TaskTables), vp, vp, u64, vp, vp]
+    lib.tdmpc2_plan_td_target_mt.restype = i32
+    lib.tdmpc2_plan_packed_size.argtypes = [vp, C.POINTER(u64)]
+    lib.tdmpc2_plan_packed_size.restype = i32
+    lib.tdmpc2_plan_export_packed.argtypes = [vp, vp, u64, vp]
+    lib.tdmpc2_plan_export_packed.restype = i32
+    lib.tdmpc2_plan_import_packed.argtypes = [vp, vp, u64, vp]
+    lib.tdmpc2_plan_import_packed.restype = i32
     lib.tdmpc2_plan_estimate_value.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tdmpc2_plan_estimate_value.restype = i32
     lib.tdmpc2_plan_estimate_value_trace.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -162,7 +179,8 @@ class NativePlanner:
                     multitask=int(bool(cfg.multitask)), episodic=int(bool(cfg.episodic)), max_envs=self.max_envs,
                     device=device.index, path=int(path), precision=int(precision))
         h = C.c_void_p()
-        self._check(self.lib.tdmpc2_plan_create(C.byref(c), C.byref(h)))
+        with torch.cuda.device(device):  # the library restores the caller's device itself; this keeps torch's view in step
+            self._check(self.lib.tdmpc2_plan_create(C.byref(c), C.byref(h)))
         self._h = h
         self.path = int(self.lib.tdmpc2_plan_path(h))  # PATH_FUSED or PATH_LAYERED
         self.precision = int(self.lib.tdmpc2_plan_precision(h))  # PREC_FP32 or PREC_SPLIT_F16
@@ -201,7 +219,7 @@ class NativePlanner:
         nets = [(NET_DYNAMICS, "_dynamics"), (NET_REWARD, "_reward"), (NET_PI, "_pi"), (NET_Q, "_Qs.params")]
         if self.cfg.episodic:
             nets.append((NET_TERMINATION, "_termination"))
-        if "_target_Qs_params.0.weight" in sd and self.path == PATH_FUSED and not self.cfg.multitask:
+        if "_target_Qs_params.0.weight" in sd:
             nets.append((NET_TARGET_Q, "_target_Qs_params"))  # optional: td_target (tdmpc2.py:239-254)
         keep = []
         with torch.cuda.device(self.device):
@@ -301,9 +319,31 @@ class NativePlanner:
         return Noise(**{k: tape[k].data_ptr() for k in shapes})
 
     # ------------------------------------------------------------------ training-side forward pieces
-    def policy_value(self, z, use_target=False, reduce="avg", pi_eps=None, qidx=None, seed: int = 0, return_action=True):
+    def _task_tables(self, R, task_ids, task_emb_table, act_mask_table, discount_table=None):
+        """struct tdmpc2_task_tables for a multitask batch (None for single-task handles).  Returns (ctypes pointer | None,
+        keep-alive tuple)."""
+        cfg, dev = self.cfg, self.device
+        if not cfg.multitask:
+            if task_ids is not None:
+                raise ValueError("task_ids given to a single-task planner")
+            return None, ()
+        if task_ids is None or task_emb_table is None or act_mask_table is None:
+            raise ValueError("multitask policy_value / td_target need task_ids, task_emb_table and act_mask_table")
+        n_tasks = int(task_emb_table.shape[0])
+        _chk_tensor("task_ids", task_ids, torch.int32, (R,), dev)
+        _chk_tensor("task_emb_table", task_emb_table, torch.float32, (n_tasks, cfg.task_dim), dev)
+        _chk_tensor("act_mask_table", act_mask_table, torch.float32, (n_tasks, cfg.action_dim), dev)
+        if discount_table is not None:
+            _chk_tensor("discount_table", discount_table, torch.float32, (n_tasks,), dev)
+        tt = TaskTables(task_ids=task_ids.data_ptr(), task_emb=task_emb_table.data_ptr(), act_mask=act_mask_table.data_ptr(),
+                        discount=None if discount_table is None else discount_table.data_ptr(), n_tasks=n_tasks)
+        return C.byref(tt), (tt, task_ids, task_emb_table, act_mask_table, discount_table)
+
+    def policy_value(self, z, use_target=False, reduce="avg", pi_eps=None, qidx=None, seed: int = 0, return_action=True,
+                     task_ids=None, task_emb_table=None, act_mask_table=None):
         """a = pi(z), then two Q heads of the online / target ensemble, 'avg' or 'min' (the forward half of
-        TDMPC2.update_pi, tdmpc2.py:208-225).  z [R, L] -> (action [R, A] or None, q [R])."""
+        TDMPC2.update_pi, tdmpc2.py:208-225).  z [R, L] -> (action [R, A] or None, q [R]).  Multitask models: one task
+        per row (`task_ids` int32 [R]) + the model's embedding / action-mask tables (world_model.py:88-101)."""
         cfg, dev = self.cfg, self.device
         R = int(z.shape[0])
         _chk_tensor("z", z, torch.float32, (R, cfg.latent_dim), dev)
@@ -311,16 +351,19 @@ class NativePlanner:
             _chk_tensor("pi_eps", pi_eps, torch.float32, (R, cfg.action_dim), dev)
         if qidx is not None:
             _chk_tensor("qidx", qidx, torch.int32, (2,), dev)
+        tt, keep = self._task_tables(R, task_ids, task_emb_table, act_mask_table)
         action = torch.empty(R, cfg.action_dim, device=dev) if return_action else None
         q = torch.empty(R, device=dev)
         with torch.cuda.device(dev):
-            self._check(self.lib.tdmpc2_plan_policy_value(self._h, R, _ptr(z), int(bool(use_target)), int(reduce == "min"),
-                                                          _ptr(pi_eps), _ptr(qidx), C.c_uint64(int(seed) & (2**64 - 1)),
-                                                          _ptr(action), _ptr(q), self._stream()))
+            self._check(self.lib.tdmpc2_plan_policy_value_mt(self._h, R, _ptr(z), tt, int(bool(use_target)), int(reduce == "min"),
+                                                             _ptr(pi_eps), _ptr(qidx), C.c_uint64(int(seed) & (2**64 - 1)),
+                                                             _ptr(action), _ptr(q), self._stream()))
         return action, q
 
-    def td_target(self, next_z, reward, terminated, discount: float, pi_eps=None, qidx=None, seed: int = 0):
-        """TDMPC2._td_target (tdmpc2.py:239-254) on flattened rows: next_z [R, L], reward / terminated [R] -> td [R]."""
+    def td_target(self, next_z, reward, terminated, discount, pi_eps=None, qidx=None, seed: int = 0,
+                  task_ids=None, task_emb_table=None, act_mask_table=None):
+        """TDMPC2._td_target (tdmpc2.py:239-254) on flattened rows: next_z [R, L], reward / terminated [R] -> td [R].
+        `discount`: python float (single task) or the per-task fp32 tensor TDMPC2.discount (multitask, tdmpc2.py:35-37)."""
         cfg, dev = self.cfg, self.device
         R = int(next_z.shape[0])
         _chk_tensor("next_z", next_z, torch.float32, (R, cfg.latent_dim), dev)
@@ -330,12 +373,42 @@ class NativePlanner:
             _chk_tensor("pi_eps", pi_eps, torch.float32, (R, cfg.action_dim), dev)
         if qidx is not None:
             _chk_tensor("qidx", qidx, torch.int32, (2,), dev)
+        disc_tab = discount if cfg.multitask else None
+        tt, keep = self._task_tables(R, task_ids, task_emb_table, act_mask_table, disc_tab)
         td = torch.empty(R, device=dev)
         with torch.cuda.device(dev):
-            self._check(self.lib.tdmpc2_plan_td_target(self._h, R, _ptr(next_z), _ptr(reward), _ptr(terminated),
-                                                       C.c_float(float(discount)), _ptr(pi_eps), _ptr(qidx),
-                                                       C.c_uint64(int(seed) & (2**64 - 1)), _ptr(td), self._stream()))
+            self._check(self.lib.tdmpc2_plan_td_target_mt(self._h, R, _ptr(next_z), _ptr(reward), _ptr(terminated),
+                                                          C.c_float(0.0 if cfg.multitask else float(discount)), tt,
+                                                          _ptr(pi_eps), _ptr(qidx), C.c_uint64(int(seed) & (2**64 - 1)),
+                                                          _ptr(td), self._stream()))
         return td
+
+    # ------------------------------------------------------------------ packed weight file
+    def export_packed(self) -> bytes:
+        """Everything the binds produced (fragment-ordered weights, scales, LayerNorm parameters, encoder, target ensemble when
+        bound) as one blob; specific to this handle's kernel family and arithmetic (tdmpc2_plan_export_packed)."""
+        n = C.c_uint64()
+        with torch.cuda.device(self.device):
+            self._check(self.lib.tdmpc2_plan_packed_size(self._h, C.byref(n)))
+            buf = (C.c_char * n.value)()
+            self._check(self.lib.tdmpc2_plan_export_packed(self._h, C.cast(buf, C.c_void_p), n, self._stream()))
+        return bytes(buf)
+
+    def import_packed(self, blob: bytes, obs_dim: Optional[int] = None):
+        """Restore the weights from `export_packed` output: host-to-device copies only (no packing kernels)."""
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.tdmpc2_plan_import_packed(self._h, C.cast(buf, C.c_void_p), C.c_uint64(len(blob)), self._stream()))
+        if obs_dim is not None:
+            self.obs_dim = int(obs_dim)
+
+    def save_packed(self, path: str):
+        with open(path, "wb") as f:
+            f.write(self.export_packed())
+
+    def load_packed(self, path: str, obs_dim: Optional[int] = None):
+        with open(path, "rb") as f:
+            self.import_packed(f.read(), obs_dim)
 
     # ------------------------------------------------------------------ planning
     def _common_inputs(self, E, z0, task_emb, act_mask, disc_pow):
@@ -420,6 +493,10 @@ class NativePlanner:
     def set_rows_per_workgroup(self, rows: int):
         """0 = automatic (32-row workgroups for calls with few plans: latency), or force 32 / 64 sample rows."""
         self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 0, int(rows)))
+
+    def set_fold_refit(self, on: bool):
+        """Fused family: elite selection + refit inside the rollout launch (default) or as a launch of its own."""
+        self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 1, int(bool(on))))
 
     def set_profiling(self, max_launches: int):
         """Bracket up to `max_launches` rollout-kernel launches with HIP events (0 = off)."""

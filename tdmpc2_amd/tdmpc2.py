@@ -24,6 +24,12 @@ from .native import NativePlanner
 from .world_model import WorldModel
 
 
+def _rank() -> int:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return int(torch.distributed.get_rank())
+    return int(os.environ.get("RANK", 0))
+
+
 class TDMPC2(torch.nn.Module):
     def __init__(self, cfg, device: Optional[torch.device] = None, max_envs: int = 1):
         super().__init__()
@@ -43,8 +49,12 @@ class TDMPC2(torch.nn.Module):
         self.max_envs = int(max_envs)
         self.native_encoder = True  # False: encode with the PyTorch-ROCm module (the parity tests compare both)
         self._planner: Optional[NativePlanner] = None
+        self._planner_log_std = None
         self._prev_mean_batch = None
-        self._seed = int(getattr(cfg, "seed", 0))
+        # Philox stream of the in-library noise: cfg.seed in the low word, the rank in the high word, so that env-sharded
+        # ranks built from one cfg (tdmpc2_amd/dist.py) do not draw identical exploration noise; a per-call counter is
+        # added on top.  (torch.manual_seed does not reach the planner: its RNG lives in the kernels.)
+        self._seed = (_rank() << 32) ^ (int(getattr(cfg, "seed", 0)) & 0xFFFFFFFF)
         self.noise_tape = None  # optional dict of device tensors (tdmpc2_noise) for reproducible plans
         self._one = torch.ones(1, dtype=torch.uint8, device=self.device) if self.device.type == "cuda" else None
         self._zero = torch.zeros(1, dtype=torch.uint8, device=self.device) if self.device.type == "cuda" else None
@@ -61,13 +71,18 @@ class TDMPC2(torch.nn.Module):
         else:
             state_dict = torch.load(fp, map_location=self.device, weights_only=False)
         state_dict = state_dict["model"] if "model" in state_dict else state_dict
-        state_dict = checkpoint.convert_state_dict(dict(state_dict))
-        self.model.load_state_dict(state_dict)
+        # key conversion (old API -> new, tensordict meta entries dropped, buffers an old file lacks filled from this
+        # model as reference layers.py:167-221 does) happens in WorldModel's load_state_dict pre-hook
+        self.model.load_state_dict(dict(state_dict))
         self.sync_planner_weights()
 
     # ------------------------------------------------------------------ native planner
     def planner(self) -> NativePlanner:
+        if self._planner is not None and self._planner_log_std != self._log_std():
+            self._planner.close()  # log_std_min / log_std_dif are constants of the handle: a load() changed them
+            self._planner = None
         if self._planner is None:
+            self._planner_log_std = self._log_std()
             self._planner = NativePlanner(self.cfg, self.cfg.iterations, self.device, max_envs=self.max_envs,
                                           log_std_min=float(self.model.log_std_min),
                                           log_std_dif=float(self.model.log_std_dif))
@@ -75,15 +90,22 @@ class TDMPC2(torch.nn.Module):
             self._bind_encoder()
         return self._planner
 
+    def _log_std(self):
+        return float(self.model.log_std_min), float(self.model.log_std_dif)
+
     def _bind_encoder(self):
         # state observations: WorldModel.encode runs inside the library as well (include/tdmpc2_plan.h,
-        # tdmpc2_plan_run_obs); pixel observations keep the PyTorch-ROCm encoder
+        # tdmpc2_plan_run_obs); pixel observations are encoded by the PyTorch-ROCm conv module (layers.conv) and enter
+        # the library as latents (tdmpc2_plan_run)
         if self.native_encoder and self.cfg.obs == "state":
             sd = {k: v for k, v in self.model.state_dict().items() if torch.is_tensor(v) and k.startswith("_encoder.state.")}
             self._planner.bind_encoder(sd)
 
     def sync_planner_weights(self):
         """Re-pack the model's current weights into the planner (after load / a training step)."""
+        if self._planner is not None and self._planner_log_std != self._log_std():
+            self._planner.close()
+            self._planner = None  # rebuilt (with the new constants and weights) by the next planner() call
         if self._planner is not None:
             self._planner.bind_state_dict(self.model.planner_state_dict())
             self._bind_encoder()

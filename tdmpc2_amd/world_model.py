@@ -40,7 +40,7 @@ class WorldModel(nn.Module):
             self.register_buffer("_action_masks", torch.zeros(len(cfg.tasks), A))
             for i in range(len(cfg.tasks)):
                 self._action_masks[i, : cfg.action_dims[i]] = 1.0
-        self._encoder = layers.state_encoder(cfg)
+        self._encoder = layers.encoders(cfg)
         self._dynamics = layers.mlp(L + A + T, 2 * [M], L, act=layers.SimNorm(cfg.simnorm_dim))
         self._reward = layers.mlp(L + A + T, 2 * [M], max(cfg.num_bins, 1))
         self._termination = layers.mlp(L + T, 2 * [M], 1) if cfg.episodic else None
@@ -79,7 +79,15 @@ class WorldModel(nn.Module):
 
     @staticmethod
     def _convert_incoming(module, state_dict, prefix, *args):
-        conv = checkpoint.convert_state_dict({k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)})
+        incoming = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+        conv = checkpoint.convert_state_dict(incoming)
+        if checkpoint.is_old_format(incoming):
+            # released (old-API) checkpoints predate these buffers; the reference's loader takes them from the freshly
+            # constructed model (layers.py:211-215) -- and overwrites any value the file might carry, as done here
+            conv["log_std_min"] = module.log_std_min.detach().clone()
+            conv["log_std_dif"] = module.log_std_dif.detach().clone()
+            if hasattr(module, "_action_masks"):
+                conv["_action_masks"] = module._action_masks.detach().clone()
         for k in [k for k in state_dict if k.startswith(prefix)]:
             del state_dict[k]
         for k, v in conv.items():
@@ -103,8 +111,11 @@ class WorldModel(nn.Module):
         return torch.cat([x, emb], dim=-1)
 
     def encode(self, obs, task):
+        """reference world_model.py:103-112, including the [T, B, C, H, W] pixel-sequence branch."""
         if self.cfg.multitask:
             obs = self.task_emb(obs, task)
+        if self.cfg.obs == "rgb" and obs.ndim == 5:
+            return torch.stack([self._encoder[self.cfg.obs](o) for o in obs])
         return self._encoder[self.cfg.obs](obs)
 
     def next(self, z, a, task):

@@ -28,3 +28,23 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Write the parity report of a GPU session (tests/helpers.py: record_parity)."""
+    try:
+        from tests import helpers
+    except Exception:
+        return
+    if not helpers.PARITY:
+        return
+    import json
+
+    out = os.environ.get("TDMPC2_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "parity_r02.json"))
+    try:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        with open(out, "w") as f:
+            json.dump({"tolerances": {"value_rel": helpers.VALUE_RTOL, "action_abs": helpers.ACT_ATOL},
+                       "exit_status": int(exitstatus), "cases": helpers.PARITY}, f, indent=1, sort_keys=True)
+    except OSError:
+        pass

@@ -31,3 +31,21 @@ def boundary_gap(value, k):
     elite swap between two fp32 implementations is legitimate."""
     v = np.sort(np.asarray(value, np.float64))[::-1]
     return float((v[k - 1] - v[k]) / max(1.0, abs(v[k - 1])))
+
+
+# ---- parity report: every -m gpu comparison records its worst errors here; tests/conftest.py writes the collection to
+# gpurun_out/parity_<round>.json at the end of the session (committed under profiles/ as the round's parity evidence)
+PARITY = {}
+
+
+def record_parity(key, **metrics):
+    """Keep the worst (largest) value seen for every metric of `key`."""
+    cur = PARITY.setdefault(key, {})
+    for k, v in metrics.items():
+        v = float(v) if not isinstance(v, (str, bool, int)) else v
+        if isinstance(v, float):
+            cur[k] = max(cur.get(k, 0.0), v)
+        elif isinstance(v, int) and not isinstance(v, bool):
+            cur[k] = cur.get(k, 0) + v
+        else:
+            cur[k] = v

@@ -33,10 +33,12 @@ def test_header_and_binding_agree():
 
 
 def test_library_exports_every_declared_symbol(lib):
+    from tdmpc2_amd import native
+
     for sym in _declared_symbols():
         assert hasattr(lib, sym), sym
     lib.tdmpc2_plan_abi_version.restype = ctypes.c_int
-    assert lib.tdmpc2_plan_abi_version() == 4
+    assert lib.tdmpc2_plan_abi_version() == native.ABI_VERSION
 
 
 def test_cfg_struct_matches_header_layout():

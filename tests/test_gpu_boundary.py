@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import ACT_ATOL
+from tests.helpers import ACT_ATOL, boundary_gap, record_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -43,8 +43,13 @@ def test_act_matches_oracle_with_encode(name):
         da = (a - wa).abs().max().item()
         dm = (agent._prev_mean.cpu() - wpm).abs().max().item()
         print(f"[{name}] step {step}: action diff {da:.2e}, prev_mean diff {dm:.2e}")
-        if da >= ACT_ATOL:  # only legitimate through an elite-boundary swap; report and stop
-            pytest.skip(f"elite-boundary swap suspected (action diff {da:.2e}); stage tests are the gate")
+        record_parity(f"{name}/act()/step{step}", action_abs=da, prev_mean_abs=dm)
+        if da >= ACT_ATOL:
+            # legitimate only through an elite-boundary swap: the oracle's own k-th / (k+1)-th values must be closer than
+            # 1e-4 at some iteration (top-k is discontinuous there); anything else is a wiring regression and fails
+            gaps = [boundary_gap(st["value"][it].numpy(), cfg.num_elites) for it in range(c["iterations"])]
+            assert min(gaps) < 1e-4, f"act() differs from the oracle by {da:.2e} with no elite boundary within 1e-4 (gaps {gaps})"
+            return
         assert dm < ACT_ATOL
         prev = wpm
 

@@ -26,6 +26,8 @@ def _edge_cases():
         "layered_min": (named_config("small", horizon=1, num_elites=128, num_pi_trajs=0), 2, False, None, 2, 1),
         "layered_episodic_h1": (named_config("small", horizon=1, episodic=True), 2, True, [True, False], 2, 1),
         "layered_1m_model": (named_config("c1", model_size=1, task="mt30", action_dim=4, iterations=2), 2, False, None, 0, 0),
+        "fused_episodic_h1_eval": (named_config("c1", horizon=1, episodic=True, iterations=2), 2, True, [True, False], 1, 2),
+        "fused_episodic_h5_rows32": (named_config("c1", horizon=5, episodic=True, iterations=2, num_samples=128, num_elites=16), 1, False, None, 1, 1),
     }
 
 
@@ -45,5 +47,5 @@ def test_edge_configuration_matches_oracle(name):
                               c["iterations"])
     got = _run_native(c, model, planner)
     assert np.isfinite(got["action"]).all() and np.abs(got["action"]).max() <= 1.0
-    _compare_stages(name, c, got, {k: v.numpy() for k, v in st.items()}, a.numpy(), pm.numpy())
+    _compare_stages(name, c, got, {k: v.numpy() for k, v in st.items()}, a.numpy(), pm.numpy(), tag="/edge/oracle")
     planner.close()

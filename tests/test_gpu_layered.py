@@ -14,7 +14,8 @@ from tests.test_gpu_planner import _compare_stages, _oracle_stage_inputs, _run_n
 pytestmark = pytest.mark.gpu
 
 PATH_FUSED, PATH_LAYERED = 1, 2
-LAYERED_CASES = ["small", "small_ep", "small_mt", "c1_ep", "c3", "c4"]
+LAYERED_CASES = ["small", "small_ep", "small_mt", "c1_ep", "c3", "c4", "c4_l1024"]
+_PN = {1: "fp32", 2: "split"}
 # both arithmetic modes of the layered family: exact-fp32 MFMA GEMMs (1) and the f16x2 split (2)
 PRECS = pytest.mark.parametrize("prec", [1, 2], ids=["fp32", "split"])
 
@@ -30,7 +31,7 @@ def test_layered_plan_matches_reference_golden(name, prec):
     g = load_golden(name)
     got = _run_native(c, model, planner)
     assert np.isfinite(got["action"]).all() and np.abs(got["action"]).max() <= 1.0
-    _compare_stages(name, c, got, g, g["action"], g["prev_mean_out"])
+    _compare_stages(name, c, got, g, g["action"], g["prev_mean_out"], tag=f"/layered/{_PN[prec]}/golden")
 
 
 @PRECS
@@ -45,7 +46,7 @@ def test_layered_family_on_fused_size_class(name, prec):
     assert lay.path == PATH_LAYERED and fus.path == PATH_FUSED
     g = load_golden(name)
     got = _run_native(c, model, lay)
-    _compare_stages(name, c, got, g, g["action"], g["prev_mean_out"])
+    _compare_stages(name, c, got, g, g["action"], g["prev_mean_out"], tag=f"/layered/{_PN[prec]}/golden")
     ref = _run_native(c, model, fus)
     err = value_err(got["value"][:, 0], ref["value"][:, 0])
     print(f"[{name}] layered vs fused first-iteration value rel err {err:.3e}")

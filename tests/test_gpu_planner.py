@@ -8,11 +8,12 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import ACT_ATOL, VALUE_RTOL, boundary_gap, elite_sets_equal, load_golden, value_err
+from tests.helpers import ACT_ATOL, VALUE_RTOL, boundary_gap, elite_sets_equal, load_golden, record_parity, value_err
 
 pytestmark = pytest.mark.gpu
 
-FUSED_CASES = ["c1", "c1_wide", "c2", "mt5"]
+FUSED_CASES = ["c1", "c1_wide", "c2", "c2_i6", "mt5"]
+MID_ATOL = 2.5e-4  # cap of the conditioning slack on the per-iteration mean / std (the final action is held to ACT_ATOL)
 # the fused family in both arithmetic modes: exact-fp32 MFMA (1) and the f16x2 split on the f16 matrix pipe (2)
 PRECS = pytest.mark.parametrize("prec", [1, 2], ids=["fp32", "split"])
 
@@ -52,6 +53,7 @@ def test_estimate_value_matches_oracle(name, prec):
                                      task_emb=inp["task_emb"], act_mask=inp["act_mask"]).cpu().numpy()
         err = value_err(got, torch.stack(want).numpy())
         print(f"[{name}] iteration {it}: value rel err {err:.3e}")
+        record_parity(f"{name}/fused/{_PN[prec]}/estimate_value", value_rel=err)
         assert np.isfinite(got).all()
         assert err < VALUE_RTOL, (name, it, err)
 
@@ -87,11 +89,15 @@ def test_refit_matches_oracle(name):
             np.testing.assert_allclose(value[e].cpu().numpy(), wv.squeeze(1).numpy(), rtol=0, atol=0)
 
 
-def _compare_stages(name, c, got, ref_stages, ref_action, ref_prev):
-    """Stage-wise comparison until (if ever) a legitimate elite-boundary swap."""
+def _compare_stages(name, c, got, ref_stages, ref_action, ref_prev, tag=""):
+    """Stage-wise comparison until (if ever) a legitimate elite-boundary swap.  Gates: every trajectory value within
+    VALUE_RTOL (relative to max(1, |v|)); elite SETS identical unless the reference's own k-th / (k+1)-th values are closer
+    than 1e-4 (top-k is discontinuous); per-iteration mean / std within ACT_ATOL plus the first-order conditioning of the
+    softmax refit, capped at MID_ATOL; the final action and the new _prev_mean within ACT_ATOL, no slack (north_star:
+    "within 1e-4").  The worst numbers go to the parity report (tests/helpers.py)."""
     cfg = c["cfg"]
     K = cfg.num_elites
-    worst = dict(value=0.0, mean=0.0, std=0.0, action=0.0)
+    worst = dict(value=0.0, mean=0.0, std=0.0, action=0.0, prev_mean=0.0)
     swaps = 0
     for e in range(c["n_envs"]):
         diverged = False
@@ -111,16 +117,20 @@ def _compare_stages(name, c, got, ref_stages, ref_action, ref_prev):
             worst["mean"], worst["std"] = max(worst["mean"], dm), max(worst["std"], ds)
             # first-order conditioning of the refit: score_k = exp(temperature * (v_k - v_max)), so an absolute
             # value error eps_v moves mean/std (actions are in [-1, 1]) by up to ~4 * temperature * eps_v.
-            # For value ranges of a few units this is far below 1e-4; synthetic heads with |v| ~ 200 need it.
             eps_v = np.abs(got["value"][e, it].astype(np.float64) - ref_stages["value"][e, it]).max()
-            tol = ACT_ATOL + 4.0 * cfg.temperature * eps_v
+            tol = min(ACT_ATOL + 4.0 * cfg.temperature * eps_v, MID_ATOL)
             assert dm < tol and ds < tol, (name, e, it, dm, ds, tol)
         if not diverged:
             da = np.abs(got["action"][e] - ref_action[e]).max()
-            worst["action"] = max(worst["action"], da)
-            assert da < tol, (name, e, da)
-            assert np.abs(got["prev_mean"][e] - ref_prev[e]).max() < tol
-    print(f"[{name}] worst errors {worst}, elite-boundary swaps {swaps}")
+            dp = np.abs(got["prev_mean"][e] - ref_prev[e]).max()
+            worst["action"], worst["prev_mean"] = max(worst["action"], da), max(worst["prev_mean"], dp)
+            assert da < ACT_ATOL, (name, e, da)
+            assert dp < ACT_ATOL, (name, e, dp)
+    print(f"[{name}{tag}] worst errors {worst}, elite-boundary swaps {swaps}")
+    record_parity(f"{name}{tag}", value_rel=worst["value"], mean_abs=worst["mean"], std_abs=worst["std"],
+                  action_abs=worst["action"], prev_mean_abs=worst["prev_mean"], elite_swaps=int(swaps), plans=int(c["n_envs"]),
+                  iterations=int(c["iterations"]))
+    return worst
 
 
 def _run_native(c, model, planner):
@@ -146,7 +156,58 @@ def test_plan_matches_reference_golden(name, prec):
     g = load_golden(name)
     got = _run_native(c, model, planner)
     assert np.isfinite(got["action"]).all() and np.abs(got["action"]).max() <= 1.0
-    _compare_stages(name, c, got, g, g["action"], g["prev_mean_out"])
+    _compare_stages(name, c, got, g, g["action"], g["prev_mean_out"], tag=f"/fused/{_PN[prec]}/golden")
+
+
+_PN = {0: "auto", 1: "fp32", 2: "split"}
+
+
+@PRECS
+@pytest.mark.parametrize("name", ["c1_ep", "c2_ep"])
+def test_fused_episodic_plan_matches_reference_golden(name, prec):
+    """Episodic 5M models (termination head, world_model.py:132-141; tdmpc2.py:133-134) on the FUSED family."""
+    from tests.gpu_common import case_on_gpu
+
+    c, model, planner = case_on_gpu(name, 1, prec)
+    assert planner.path == 1
+    g = load_golden(name)
+    got = _run_native(c, model, planner)
+    _compare_stages(name, c, got, g, g["action"], g["prev_mean_out"], tag=f"/fused/{_PN[prec]}/golden")
+
+
+@PRECS
+def test_fused_episodic_estimate_value_matches_oracle(prec):
+    """The termination mask must actually bite: the synthetic head terminates a share of the rows, and the values agree."""
+    from tests.gpu_common import case_on_gpu, dev, plan_inputs
+
+    c, model, planner = case_on_gpu("c1_ep", 1, prec)
+    inp = plan_inputs(c, model)
+    _, _, st = _oracle_stage_inputs(c, model, 0)
+    it = c["iterations"] - 1
+    acts = st["actions"][it].unsqueeze(0).to(dev()).contiguous()
+    eps = torch.as_tensor(c["tape"]["pi_eps"][0:1, it]).to(dev()).contiguous()
+    qidx = torch.as_tensor(c["tape"]["qidx"][0:1, it]).to(dev()).to(torch.int32).contiguous()
+    got = planner.estimate_value(inp["z0"][:1].contiguous(), inp["disc_pow"][:1].contiguous(), acts, eps, qidx).cpu().numpy()
+    err = value_err(got[0], st["value"][it].numpy())
+    record_parity(f"c1_ep/fused/{_PN[prec]}/estimate_value", value_rel=err)
+    assert err < VALUE_RTOL, err
+
+
+def test_refit_inside_rollout_equals_separate_launch():
+    """TDMPC2_TUNE_FOLD_REFIT: the last-arriver refit inside the rollout launch and the k_refit launch run the same device
+    function on the same data: bit-identical plans."""
+    from tests.gpu_common import case_on_gpu
+
+    for name in ("c1", "mt5"):
+        c, model, planner = case_on_gpu(name, 1, 2)
+        a = _run_native(c, model, planner)
+        planner.set_fold_refit(False)
+        try:
+            b = _run_native(c, model, planner)
+        finally:
+            planner.set_fold_refit(True)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (name, k)
 
 
 @PRECS
@@ -159,7 +220,7 @@ def test_plan_matches_oracle(name, prec):
     a, pm, st = po.plan_batch(model, c["z0"], c["tape"], c["prev_mean"], c["t0"], c["eval_mode"], c["tasks"],
                               c["discounts"], c["iterations"])
     got = _run_native(c, model, planner)
-    _compare_stages(name, c, got, {k: v.numpy() for k, v in st.items()}, a.numpy(), pm.numpy())
+    _compare_stages(name, c, got, {k: v.numpy() for k, v in st.items()}, a.numpy(), pm.numpy(), tag=f"/fused/{_PN[prec]}/oracle")
 
 
 @PRECS
@@ -192,6 +253,7 @@ def test_error_attribution_against_fp64(prec):
             err_hip = ((got[e] - v64).abs() / scale).max().item()
             err_ref = ((v32 - v64).abs() / scale).max().item()
             print(f"[{name}] env {e}: |HIP {mode} - fp64| {err_hip:.3e}   |torch fp32 - fp64| {err_ref:.3e}")
+            record_parity(f"{name}/fused/{_PN[prec]}/vs_fp64", hip_vs_fp64=err_hip, torch_fp32_vs_fp64=err_ref)
             assert err_hip < 3 * err_ref + 1e-6, (name, e, err_hip, err_ref)
 
 
@@ -279,7 +341,7 @@ def test_split_workgroup_geometries_match_golden(name, rows):
         got = _run_native(c, model, planner)
     finally:
         planner.set_rows_per_workgroup(0)
-    _compare_stages(f"{name}/rows{rows}", c, got, g, g["action"], g["prev_mean_out"])
+    _compare_stages(name, c, got, g, g["action"], g["prev_mean_out"], tag=f"/fused/split/rows{rows}/golden")
 
 
 @PRECS
@@ -317,5 +379,6 @@ def test_action_statistics_over_32_seeds(prec):
     mse, worst = float((d ** 2).mean()), float(np.abs(d).max())
     print(f"[c1 x {E} seeds, precision {prec}] action MSE {mse:.3e}, max |diff| {worst:.3e}, "
           f"{boundary} plans at an elite boundary")
+    record_parity(f"c1x32seeds/fused/{_PN[prec]}/oracle", action_abs=worst, action_mse=mse, elite_swaps=int(boundary), plans=E)
     assert len(clean) >= E - 4
     assert worst < 1e-4 and mse < 1e-9

@@ -117,3 +117,89 @@ def test_synthetic_inputs_are_deterministic():
     t = synth.make_noise_tape(cfg, 2, 6, 2)
     assert t["sample_eps"].shape == (2, 6, 3, 488, 6) and t["qidx"].shape == (2, 6, 2)
     assert (t["qidx"][..., 0] != t["qidx"][..., 1]).all()
+
+
+def test_old_checkpoint_without_log_std_and_masks_loads():
+    """Released old-API checkpoints carry neither log_std_min / log_std_dif nor _action_masks; the reference's loader
+    takes them from the freshly built model (layers.py:211-215).  ADVICE r1: a strict load used to fail here."""
+    cfg = named_config("tiny", task="mt30")
+    wm = WorldModel(cfg)
+    syn = {k: torch.as_tensor(v) for k, v in synth.make_state_dict(cfg, 0).items()}
+    wm.load_state_dict(dict(syn))
+    old = checkpoint.to_old_format(wm.state_dict())
+    for k in ("log_std_min", "log_std_dif", "_action_masks"):
+        old.pop(k)
+    assert checkpoint.is_old_format(old) and not checkpoint.is_old_format(wm.state_dict())
+    wm2 = WorldModel(cfg)
+    wm2.load_state_dict(old)  # strict
+    assert torch.equal(wm2._Qs.params.layer(2).bias, wm._Qs.params.layer(2).bias)
+    assert float(wm2.log_std_min) == float(cfg.log_std_min)
+    assert float(wm2.log_std_dif) == pytest.approx(cfg.log_std_max - cfg.log_std_min)
+    assert torch.equal(wm2._action_masks, wm._action_masks)
+    # a stale value inside an old file is overridden by the model's own, like the reference does
+    old["log_std_min"] = torch.tensor(-3.0)
+    wm3 = WorldModel(cfg)
+    wm3.load_state_dict(old)
+    assert float(wm3.log_std_min) == float(cfg.log_std_min)
+
+
+def _rgb_cfg():
+    cfg = named_config("c1")
+    cfg.obs = "rgb"
+    cfg.obs_shape = {"rgb": (9, 64, 64)}  # 3 stacked frames, reference envs/wrappers/pixels.py
+    return cfg
+
+
+def test_pixel_world_model_has_reference_keys_and_shapes():
+    """(f)4: the conv encoder (reference layers.py:136-150) as a host-side module with the reference's state-dict keys."""
+    cfg = _rgb_cfg()
+    wm = WorldModel(cfg).eval()
+    keys = set(wm.state_dict())
+    for i, shp in ((2, (32, 9, 7, 7)), (4, (32, 32, 5, 5)), (6, (32, 32, 3, 3)), (8, (32, 32, 3, 3))):
+        assert f"_encoder.rgb.{i}.weight" in keys and f"_encoder.rgb.{i}.bias" in keys
+        assert tuple(wm.state_dict()[f"_encoder.rgb.{i}.weight"].shape) == shp
+    obs = torch.randint(0, 256, (2, 9, 64, 64)).float()
+    with torch.no_grad():
+        z = wm.encode(obs, None)
+        assert z.shape == (2, cfg.latent_dim)
+        assert torch.allclose(z.view(2, -1, 8).sum(-1), torch.ones(2, 64), atol=1e-5)  # SimNorm output
+        seq = wm.encode(obs.unsqueeze(0).repeat(3, 1, 1, 1, 1), None)  # [T, B, C, H, W] branch (world_model.py:110-111)
+        assert seq.shape == (3, 2, cfg.latent_dim)
+
+
+def test_pixel_modules_match_the_reference_modules():
+    """ShiftAug / PixelPreprocess / conv against the reference's own modules on the same seed (build container only)."""
+    from oracle import ref_runner
+
+    if not ref_runner.available():
+        pytest.skip("reference tree not present")
+    from tdmpc2_amd import layers
+
+    ref = ref_runner._import_reference().layers
+    x = torch.randint(0, 256, (4, 9, 64, 64)).float()
+    torch.manual_seed(11)
+    want = ref.ShiftAug()(x)
+    torch.manual_seed(11)
+    got = layers.ShiftAug()(x)
+    assert torch.equal(got, want)
+    assert torch.equal(layers.PixelPreprocess()(x), ref.PixelPreprocess()(x))
+    torch.manual_seed(0)
+    mine = layers.conv((9, 64, 64), 32, act=layers.SimNorm(8))
+    theirs = ref.conv((9, 64, 64), 32)
+    theirs.load_state_dict(mine.state_dict())  # same module indices -> same keys
+    torch.manual_seed(5)
+    a = mine(x)
+    torch.manual_seed(5)
+    b = layers.SimNorm(8)(theirs(x))
+    assert torch.allclose(a, b, atol=1e-6)
+
+
+def test_planner_seed_differs_across_ranks(monkeypatch):
+    """env-sharded ranks built from one cfg must not share the exploration-noise stream."""
+    from tdmpc2_amd import tdmpc2 as t
+
+    monkeypatch.setenv("RANK", "0")
+    s0 = (t._rank() << 32) ^ 7
+    monkeypatch.setenv("RANK", "3")
+    s3 = (t._rank() << 32) ^ 7
+    assert s0 != s3 and (s3 >> 32) == 3 and (s3 & 0xFFFFFFFF) == 7
