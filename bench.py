@@ -231,6 +231,8 @@ def main():
     path = {"auto": 0, "fused": 1, "layered": 2}[args.path]
     prec = {"auto": 0, "fp32": 1, "split": 2}[args.precision]
     planner = NativePlanner(cfg, I, device, max_envs=E, path=path, precision=prec)
+    if os.environ.get("TDMPC2_FOLD_REFIT") and planner.path == 1:  # A/B knob: 0 never, 1 always, 2 auto (default)
+        planner.set_fold_refit(int(os.environ["TDMPC2_FOLD_REFIT"]))
     family = {1: "fused", 2: "layered"}[planner.path]
     arith = {1: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 2: "f16x2 split (3x v_mfma_f32_32x32x16_f16, fp32 accumulate)"}[planner.precision]
     planner.bind_state_dict(sd)

@@ -255,11 +255,30 @@ int tdmpc2_plan_refit(tdmpc2_plan_t *h, int n_envs, float *value, const float *a
                       const float *act_mask, float *mean, float *std, float *score,
                       int32_t *elite_idx, void *stream);
 
+/* ONE plan sharded over G GPUs (last row: worth it for 317M-class models at E = 1).  The N sample rows of
+ * every plan are split over the ranks; weights, set-up, action sampling (same tape or same Philox seed on every rank) and
+ * the elite selection + refit are replicated.  Per plan: shard_begin once (= the prologue of tdmpc2_plan_run: warm start,
+ * policy-prior trajectories, tdmpc2.py:154-170); per CEM iteration shard_values for this rank's rows
+ * [row_begin, row_end) (a multiple of 64 rows, FUSED, or 128, LAYERED) writing value[E, N] at those rows only, then the
+ * HOST all-gathers the value slices (RCCL, N * 4 bytes per plan), then shard_refit on the complete value[E, N]
+ * (tdmpc2.py:184-197; at iter == iterations - 1 also the final pick, tdmpc2.py:199-206).  With one rank and the full row
+ * range the three calls compute what tdmpc2_plan_run computes.  tdmpc2_amd/dist.py: sharded_plan. */
+int tdmpc2_plan_shard_begin(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *task_emb, const float *act_mask,
+                            const float *prev_mean, const uint8_t *t0, const tdmpc2_noise *tape, uint64_t seed, void *stream);
+int tdmpc2_plan_shard_values(tdmpc2_plan_t *h, int n_envs, int iter, int row_begin, int row_end, const float *z0,
+                             const float *act_mask, const float *disc_pow, const tdmpc2_noise *tape, uint64_t seed,
+                             float *value, void *stream);
+int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value, const float *act_mask, float *prev_mean,
+                            int eval_mode, const tdmpc2_noise *tape, uint64_t seed, float *action, const tdmpc2_debug *dbg,
+                            void *stream);
+
 /* Tuning knobs that never change results beyond fp32 round-off.  key TDMPC2_TUNE_ROWS_PER_WORKGROUP: sample rows a
  * fused split-arithmetic rollout workgroup owns -- 0 = automatic (32 when a call brings too few plans to occupy the
  * chip, i.e. single-environment latency; 64 otherwise), or 32 / 64 to force one.  key TDMPC2_TUNE_FOLD_REFIT (fused
- * family): 1 (default) = the last workgroup of a plan to finish its rollouts does the elite selection + refit
- * (tdmpc2.py:184-206) inside the rollout launch, one launch per CEM iteration; 0 = a launch of its own (k_refit). */
+ * family): 1 = the last workgroup of a plan to finish its rollouts does the elite selection + refit (tdmpc2.py:184-206)
+ * inside the rollout launch, one launch per CEM iteration; 0 = always a launch of its own (k_refit); 2 (default) = inside
+ * the rollout launch when the call's workgroups fit the chip in one round (few plans: single-environment latency), a
+ * launch of its own otherwise (many plans: the in-launch refits would delay the next round of workgroups). */
 enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0, TDMPC2_TUNE_FOLD_REFIT = 1 };
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
 

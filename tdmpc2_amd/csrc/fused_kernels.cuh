@@ -1087,7 +1087,7 @@ template <int APAD, int ST, int NW, int AR, int EP>
 __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int s_is_last;
-    const int e = blockIdx.x / p.tiles, tile = blockIdx.x % p.tiles;
+    const int e = blockIdx.x / p.tiles, tile = p.tile_off + blockIdx.x % p.tiles;  // tile_off: a row range of the plan (shard_values)
     const int tid = threadIdx.x;
     typedef CtxT<APAD, ST, NW, AR> CT;
     constexpr int TROWS = CT::TROWS, NTHR = CT::NTHR, FT = CT::FT;
@@ -1157,8 +1157,7 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
                             if (p.sample_eps)
                                 r = p.sample_eps[(size_t)e * p.sample_eps_estride +
                                                  (unsigned)(((size_t)t * (p.N - p.P) + (n - p.P)) * p.A + a)];
-                            v[u] = sm_mean[t * p.A + a] + sm_std[t * p.A + a] * r;
-                            v[u] = fminf(fmaxf(v[u], -1.f), 1.f);
+                            v[u] = sample_action(sm_mean[t * p.A + a], sm_std[t * p.A + a], r);
                         }
                         if (mask && !p.given_actions) v[u] *= mask[a];
                         if (!p.given_actions) ag[(size_t)n * p.A + a] = v[u];
@@ -1283,22 +1282,37 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
         tsc[p.H] = qa;
         tsc[p.H + 1] = qb;
     }
-    if ((tid & 7) == 0 && live) p.value[(size_t)e * p.N + row0 + (tid >> 3)] = G + disc[p.H] * (1.f - termv) * ((qa + qb) / 2.f);
-    if (!p.fold_refit) return;
+    const float val = G + disc[p.H] * (1.f - termv) * ((qa + qb) / 2.f);
+#ifdef TDMPC2_NO_FOLD  // experiment builds: the hand-over compiled out
+    if ((tid & 7) == 0 && live) p.value[(size_t)e * p.N + row0 + (tid >> 3)] = val;
+    return;
+#endif
+    if (!p.fold_refit) {
+        if ((tid & 7) == 0 && live) p.value[(size_t)e * p.N + row0 + (tid >> 3)] = val;
+        return;
+    }
     // ---- elite selection + refit by the LAST workgroup of this plan to get here (tdmpc2.py:184-206): one launch per CEM
-    // iteration.  Release: every thread's value[] / actions[] stores are made visible device-wide before the ticket is
-    // taken; acquire: the last arriver invalidates its CU's L1 before reading the other workgroups' values and actions.
-    __threadfence();
+    // iteration.  Hand-over protocol (MI355X_MICROARCH.md, inter-workgroup visibility; a plan's workgroups sit on different
+    // XCDs, whose L2s are not coherent): the only data another workgroup reads -- this workgroup's 32 / 64 values --
+    // leaves as agent-scope write-through (sc1) stores; every wave drains its stores (workgroup-scope release =
+    // s_waitcnt vmcnt(0)) before the barrier; one lane takes the plan's ticket with an agent-scope atomic; the last
+    // arriver reads the values with agent-scope (sc1) loads, which bypass its L1 and find lines its XCD's L2 has not held
+    // in this launch (refit_plan).  No cache maintenance instruction on either side.  The elite ACTIONS are not handed
+    // over at all: the refit re-derives them (RefitParams::regen).  Measured and rejected: agent-scope release / acquire
+    // fences (buffer_wbl2 / buffer_inv sc1 act on the XCD's whole L2 -- the acquire alone evicts the L2-resident weights of
+    // 32 neighbouring workgroups: +13 % on the launch, profiles/README.md r02b-r02d).
+    if ((tid & 7) == 0 && live)
+        __hip_atomic_store(p.value + (size_t)e * p.N + row0 + (tid >> 3), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(p.ticket + e, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = __hip_atomic_fetch_add(p.ticket + e, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int last = old == (unsigned)(p.tiles - 1);
         if (last) __hip_atomic_store(p.ticket + e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch starts at 0
         s_is_last = last;
     }
     __syncthreads();
     if (!s_is_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     refit_plan(p.rf, e, smem, tid, NTHR);
 }
 

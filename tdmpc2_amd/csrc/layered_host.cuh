@@ -112,7 +112,7 @@ int lay_dynamics(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int
 // a <- pi(z) into X[:, L:L+A) (+ actions[e, t, n < P] for the policy-prior trajectories)  (world_model.py:144-184)
 int lay_policy(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rpe, int nvalid, const float *mask,
                const float *eps, long eps_estride, unsigned long long seed, unsigned call, int site, int iter,
-               float *actions, int t, float *trace = nullptr) {
+               float *actions, int t, float *trace = nullptr, int n_off = 0) {
     const Layered &L = h->lay;
     const tdmpc2_plan_cfg &c = h->cfg;
     int rc;
@@ -123,7 +123,7 @@ int lay_policy(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int r
     p.L = c.latent_dim; p.ldx = L.Kin; p.lsmin = c.log_std_min; p.lsdif = c.log_std_dif; p.mask = mask;
     p.eps = eps; p.eps_estride = eps_estride; p.seed = seed; p.call = call; p.site = site; p.iter = iter;
     p.X = L.X; p.actions = actions; p.t = t; p.H = c.horizon; p.N = c.num_samples; p.trace = trace;
-    p.row_env = L.row_env;
+    p.row_env = L.row_env; p.n_off = n_off;
     if (L.row_env) { p.H = 1; p.N = (int)rows; }  // value mode: actions is a flat [rows, A] output
     const int total = (int)rows * c.action_dim;
     if (h->split) hipLaunchKernelGGL(l_pi_head_s, dim3((total + 255) / 256), dim3(256), 0, st, p);
@@ -133,12 +133,13 @@ int lay_policy(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int r
 }
 
 int lay_twohot(tdmpc2_plan *h, hipStream_t st, size_t rows, int rpe, int mode, int t, const float *disc_pow, float *value,
-               float *trace) {
+               float *trace, int n_full = 0, int n_off = 0) {
     const Layered &L = h->lay;
     TwoHotParams p{};
     p.lg = L.LG; p.ld = L.ldl; p.rows = (int)rows; p.rows_per_env = rpe; p.num_bins = h->cfg.num_bins; p.mode = mode;
     p.t = t; p.H = h->cfg.horizon; p.bins = h->bins; p.disc_pow = disc_pow; p.G = L.G; p.qtmp = L.QT; p.value = value;
     p.term = h->cfg.episodic ? L.TERM : nullptr; p.trace = trace; p.trace_ld = h->cfg.horizon + 2 + h->cfg.action_dim;
+    p.n_full = n_full; p.n_off = n_off;
     const int grid = (int)((rows + RW_THREADS / 64 - 1) / (RW_THREADS / 64));
     hipLaunchKernelGGL(l_twohot, dim3(grid), dim3(RW_THREADS), 0, st, p);
     LAUNCH_CHECK();
@@ -167,10 +168,15 @@ int lay_setup(tdmpc2_plan *h, hipStream_t st, int E, const float *task_emb, cons
 // TDMPC2._estimate_value (tdmpc2/tdmpc2.py:122-136) for E plans with the step actions in `actions` [E,H,N,A].
 int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float *act_mask, const float *disc_pow,
                        const float *actions, const float *pi_eps, long pi_eps_estride, const int *qidx /* dense [E,2] */,
-                       unsigned long long seed, unsigned call, int iter, float *value, float *trace) {
+                       unsigned long long seed, unsigned call, int iter, float *value, float *trace, int n_off = 0,
+                       int n_sub = 0) {
+    // rows n_off .. n_off + n_sub of every plan (default: all num_samples rows): the sample-row range of one rank when a
+    // plan is sharded over GPUs (tdmpc2_plan_shard_values); n_sub is a multiple of the GEMM row tile
     const tdmpc2_plan_cfg &c = h->cfg;
     const Layered &L = h->lay;
-    const int N = c.num_samples, H = c.horizon, A = c.action_dim;
+    const int NF = c.num_samples, H = c.horizon, A = c.action_dim;
+    const int N = n_sub > 0 ? n_sub : NF;
+    const bool ranged = N != NF;
     const size_t rows = (size_t)E * N, rows_p = round_up(rows, GBM);
     int rc;
     if (h->split) hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM);
@@ -179,11 +185,11 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
     for (int t = 0; t < H; ++t) {
         const int total = (int)rows * A;
         if (h->split)
-            hipLaunchKernelGGL(l_set_action_s, dim3((total + 255) / 256), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, A, N, H, t,
-                               (int)rows, actions);
+            hipLaunchKernelGGL(l_set_action_s, dim3((total + 255) / 256), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, A, NF, H, t,
+                               (int)rows, actions, N, n_off);
         else
-            hipLaunchKernelGGL(l_set_action, dim3((total + 255) / 256), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, A, N, H, t,
-                               (int)rows, actions);
+            hipLaunchKernelGGL(l_set_action, dim3((total + 255) / 256), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, A, NF, H, t,
+                               (int)rows, actions, N, n_off);
         LAUNCH_CHECK();
         // reward(z, a_t) -> two_hot_inv -> G += disc * (1 - term) * r
         if ((rc = lay_hidden(h, st, h->rew, BE_REW, rows, rows_p, N, nullptr, false))) return rc;
@@ -200,12 +206,12 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
     }
     // a_H = pi(z_H); value = G + disc^H (1 - term) avg of the two selected Q heads
     if ((rc = lay_policy(h, st, rows, rows_p, N, N, act_mask, pi_eps, pi_eps_estride, seed, call, SITE_PI, iter, nullptr, 0,
-                         trace))) return rc;
+                         trace, n_off))) return rc;
     for (int j = 0; j < 2; ++j) {
         if ((rc = lay_hidden(h, st, h->q[0], BE_Q0, rows, rows_p, N, qidx + j, true))) return rc;
         if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, N, h->q[0].l[2], q_wstride(h, 2), q_bstride(h, 2), -1, qidx + j, L.LG,
                            L.ldl))) return rc;
-        if ((rc = lay_twohot(h, st, rows, N, 1 + j, 0, disc_pow, value, trace))) return rc;
+        if ((rc = lay_twohot(h, st, rows, N, 1 + j, 0, disc_pow, value, trace, ranged ? NF : 0, n_off))) return rc;
     }
     return 0;
 }

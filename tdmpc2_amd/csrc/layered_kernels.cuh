@@ -257,6 +257,7 @@ struct TwoHotParams {
     const float *term;             // [rows] or null (non-episodic)
     float *trace;                  // optional [rows, trace_ld]: r_0..r_{H-1}, Q_a, Q_b, (a_H[A] written by l_pi_head)
     int trace_ld;
+    int n_full, n_off;             // value[env * n_full + n_off + row % rows_per_env]: a row range of every plan (n_full = 0: value[row])
 };
 
 __global__ __launch_bounds__(RW_THREADS) void l_twohot(TwoHotParams p) {
@@ -274,7 +275,8 @@ __global__ __launch_bounds__(RW_THREADS) void l_twohot(TwoHotParams p) {
         p.qtmp[row] = r;
         if (p.trace) p.trace[(size_t)row * p.trace_ld + p.H] = r;
     } else {
-        p.value[row] = p.G[row] + disc[p.H] * live * ((p.qtmp[row] + r) / 2.f);
+        const size_t vi = p.n_full ? (size_t)(row / p.rows_per_env) * p.n_full + p.n_off + row % p.rows_per_env : (size_t)row;
+        p.value[vi] = p.G[row] + disc[p.H] * live * ((p.qtmp[row] + r) / 2.f);
         if (p.trace) p.trace[(size_t)row * p.trace_ld + p.H + 1] = r;
     }
 }
@@ -306,6 +308,7 @@ struct PiHeadParams {
     int t, H, N;
     float *trace;           // optional [rows, H+2+A]: a_H into columns H+2..
     const int *row_env;     // optional: the mask row of each sample row (training batches); eps / actions keep e = row / rows_per_env
+    int n_off;              // sample index of the first row of every plan (row ranges: shard_values)
 };
 
 __global__ void l_pi_head(PiHeadParams p) {
@@ -318,7 +321,7 @@ __global__ void l_pi_head(PiHeadParams p) {
     float ls = p.lsmin + 0.5f * p.lsdif * (tanhf(lr[p.A + a]) + 1.f);
     float eps = 0.f;
     if (n < p.nvalid) {
-        const unsigned ridx = (unsigned)((size_t)n * p.A + a);
+        const unsigned ridx = (unsigned)((size_t)(n + p.n_off) * p.A + a);
         eps = p.eps ? p.eps[(size_t)e * p.eps_estride + ridx] : rng_normal(p.seed, p.call, p.site, p.iter, e, ridx);
     }
     if (p.mask) {
@@ -367,19 +370,18 @@ __global__ void l_sample(SampleParams p) {
         const int t = r % p.H, e = r / p.H;
         const unsigned ridx = (unsigned)(((size_t)t * (p.N - p.P) + n) * p.A + a);
         const float z = p.eps ? p.eps[(size_t)e * p.eps_estride + ridx] : rng_normal(p.seed, p.call, SITE_SAMPLE, p.iter, e, ridx);
-        float v = p.mean[((size_t)e * p.H + t) * p.A + a] + p.std[((size_t)e * p.H + t) * p.A + a] * z;
-        v = fminf(fmaxf(v, -1.f), 1.f);
+        float v = sample_action(p.mean[((size_t)e * p.H + t) * p.A + a], p.std[((size_t)e * p.H + t) * p.A + a], z);
         if (p.mask) v *= p.mask[(size_t)e * p.A + a];
         p.actions[(((size_t)e * p.H + t) * p.N + p.P + n) * p.A + a] = v;
     }
 }
 
-// X[row, L + a] <- actions[e, t, n, a]
-__global__ void l_set_action(float *X, int ldx, int L, int A, int N, int H, int t, int rows, const float *actions) {
+// X[row, L + a] <- actions[e, t, n_off + n, a]; rows are (e, n) with n < nsub
+__global__ void l_set_action(float *X, int ldx, int L, int A, int N, int H, int t, int rows, const float *actions, int nsub, int n_off) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * A) return;
     const int row = idx / A, a = idx % A;
-    const int e = row / N, n = row % N;
+    const int e = row / nsub, n = n_off + row % nsub;
     X[(size_t)row * ldx + L + a] = actions[(((size_t)e * H + t) * N + n) * A + a];
 }
 

@@ -279,11 +279,11 @@ __global__ void l_init_x_s(float *X, int ldx, int L, int rows_per_env, const flo
     }
 }
 
-__global__ void l_set_action_s(float *X, int ldx, int L, int A, int N, int H, int t, int rows, const float *actions) {
+__global__ void l_set_action_s(float *X, int ldx, int L, int A, int N, int H, int t, int rows, const float *actions, int nsub, int n_off) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= rows * A) return;
     const int row = idx / A, a = idx % A;
-    const int e = row / N, n = row % N;
+    const int e = row / nsub, n = n_off + row % nsub;
     put_split(reinterpret_cast<_Float16 *>(X + (size_t)row * ldx), ldx, L + a, actions[(((size_t)e * H + t) * N + n) * A + a]);
 }
 
@@ -297,7 +297,7 @@ __global__ void l_pi_head_s(PiHeadParams p) {
     float ls = p.lsmin + 0.5f * p.lsdif * (tanhf(lr[p.A + a]) + 1.f);
     float eps = 0.f;
     if (n < p.nvalid) {
-        const unsigned ridx = (unsigned)((size_t)n * p.A + a);
+        const unsigned ridx = (unsigned)((size_t)(n + p.n_off) * p.A + a);
         eps = p.eps ? p.eps[(size_t)e * p.eps_estride + ridx] : rng_normal(p.seed, p.call, p.site, p.iter, e, ridx);
     }
     if (p.mask) {

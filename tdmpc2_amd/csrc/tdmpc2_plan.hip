@@ -67,6 +67,15 @@ struct RefitParams {
     unsigned int call;
     float *prev_mean;  // [E,H,A]
     float *action;     // [E,A]
+    // In-launch refit (fused family, ks_rollout's last-arriver epilogue): the elite actions are RE-DERIVED from the
+    // iteration's sampling distribution and noise instead of being read back from `actions` -- the workgroups that sampled
+    // them sit on other XCDs, and shipping 64 x H x A floats per workgroup through write-through stores cost 13 % of the
+    // launch (profiles/README.md r02c).  regen = 1: rows n >= P: clamp(old_mean + old_std * eps) * mask with eps from the tape
+    // slice or Philox (the rollout kernel's own formula and indices); rows n < P: the policy-prior actions written by an
+    // earlier launch.
+    int regen, P, Apad;
+    const float *sample_eps;   // tape slice of this iteration (or null: Philox)
+    long sample_eps_estride;
     // debug copies (per iteration slices already offset by the host; env stride given)
     float *dbg_value; long dbg_value_es;
     int *dbg_idx; long dbg_idx_es;
@@ -78,6 +87,7 @@ struct RefitParams {
 template <class NET>
 struct RolloutParamsT {
     int E, N, H, A, Apad, P, stride, tiles, nq, num_bins, multitask, given_actions, iter, iters_total;
+    int tile_off;  // first row tile of the range this launch covers (tiles = tiles in the range)
     int nnets;  // vectors per plan in `beff`
     float log_std_min, log_std_dif;
     NET dyn, rew, pi, term;
@@ -151,6 +161,12 @@ __device__ __forceinline__ float symexp_f(float x) {
     // tdmpc2/common/math.py:50-55: sign(x) * (exp(|x|) - 1)
     const float m = expf(fabsf(x)) - 1.f;
     return x > 0.f ? m : (x < 0.f ? -m : 0.f);
+}
+
+// One sampled action (tdmpc2/tdmpc2.py:176-178): (mean + std * r).clamp(-1, 1) with the reference's two roundings (torch
+// does not fuse the multiply-add); used by every kernel that draws or re-derives a sample, so that they agree bit for bit.
+__device__ __forceinline__ float sample_action(float mean, float std, float r) {
+    return fminf(fmaxf(__fadd_rn(mean, __fmul_rn(std, r)), -1.f), 1.f);
 }
 
 template <int W>
@@ -231,11 +247,14 @@ struct PiTrajParamsT {
 // dynamic LDS of the refit; `stage` out: whether the K x H x A elite actions fit next to the rest (they are then gathered
 // by the whole workgroup in one round of loads instead of 2 K dependent global loads per (t, a) thread: 35 -> 12 us)
 inline size_t refit_lds_bytes(int N, int K, int H, int A, int *stage, size_t budget = 48 * 1024) {
-    const size_t base = ((size_t)N + 3 * K + 2 * H * A + 48) * 4 + 64;
+    const size_t base = ((size_t)N + 3 * K + 4 * H * A + 48) * 4 + 64;
     const size_t elite = (size_t)K * H * A * 4;
     *stage = base + elite <= budget;
     return *stage ? base + elite : base;
 }
+
+__device__ __forceinline__ void rng_normal2(unsigned long long seed, unsigned call, int site, int iter, int env, unsigned pair,
+                                            float &n0, float &n1);  // fused_kernels.cuh
 
 // block-wide sum / max over `n` floats in LDS: strided thread-local partials, wavefront shuffle reduction, one LDS slot per
 // wave, every thread reads the slots back (fixed order -> deterministic, the same value in every thread)
@@ -274,10 +293,16 @@ __device__ void refit_plan(const RefitParams &p, int e, float *smem, int tid, in
     float *sstd = smean + p.H * p.A;                     // [H*A]
     float *slots = sstd + p.H * p.A;                     // [16] per-wave partials + [16] scratch scalars
     int *s_pick = reinterpret_cast<int *>(slots + 32);
-    float *ea = slots + 48;                              // [K][H*A] elite_actions (tdmpc2.py:186) when staged
+    float *omean = slots + 48;                           // [H*A] the distribution this iteration sampled from (regen)
+    float *ostd = omean + p.H * p.A;                     // [H*A]
+    float *ea = ostd + p.H * p.A;                        // [K][H*A] elite_actions (tdmpc2.py:186) when staged
     // value.nan_to_num(0): nan -> 0, +-inf -> +-FLT_MAX (tdmpc2.py:184)
     for (int i = tid; i < p.N; i += nthr) {
-        float v = p.value[(size_t)e * p.N + i];
+        // in-launch refit: the values of the plan's other workgroups arrive as write-through stores from other XCDs; read
+        // them with agent-scope (sc1) loads -- past the L1, from lines this XCD's L2 cannot hold yet -- and do NOT
+        // invalidate caches (an agent-scope acquire here, buffer_inv sc1, drops the XCD's L2-resident weights: +13 %)
+        float v = p.regen ? __hip_atomic_load(p.value + (size_t)e * p.N + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                          : p.value[(size_t)e * p.N + i];
         if (v != v) v = 0.f;
         else if (v == INFINITY) v = 3.402823466e+38f;
         else if (v == -INFINITY) v = -3.402823466e+38f;
@@ -309,7 +334,45 @@ __device__ void refit_plan(const RefitParams &p, int e, float *smem, int tid, in
     const float s_ssum = block_sum_lds(sc, p.K, slots, tid, nthr) + 1e-9f;  // score.sum(0) + 1e-9 (tdmpc2.py:192-193)
     const float *acts = p.actions + (size_t)e * p.H * p.N * p.A;
     const int HA = p.H * p.A;
-    if (p.stage) {
+    if (p.regen) {  // (always staged) elite actions re-derived from (old mean, old std, noise): see RefitParams
+        for (int idx = tid; idx < HA; idx += nthr) {
+            omean[idx] = p.mean[(size_t)e * HA + idx];
+            ostd[idx] = p.std[(size_t)e * HA + idx];
+        }
+        __syncthreads();
+        // one work item per PAIR of action columns (a, a + 1): one Philox call yields both normals, as in the rollout
+        const int hp = p.Apad / 2, hpa = (p.A + 1) / 2, per_k = p.H * hpa;
+        for (int idx = tid; idx < p.K * per_k; idx += nthr) {
+            const int k = idx / per_k, rem = idx - k * per_k;
+            const int t = rem / hpa, a0 = 2 * (rem - t * hpa);
+            const int n = ei[k];
+            float v[2] = {0.f, 0.f};
+            if (n < p.P) {  // policy-prior rows: written by ks_pitraj, an earlier launch
+                v[0] = acts[((size_t)t * p.N + n) * p.A + a0];
+                if (a0 + 1 < p.A) v[1] = acts[((size_t)t * p.N + n) * p.A + a0 + 1];
+            } else {
+                float r[2] = {0.f, 0.f};
+                if (p.sample_eps) {
+                    const float *ep = p.sample_eps + (size_t)e * p.sample_eps_estride + (unsigned)(((size_t)t * (p.N - p.P) + (n - p.P)) * p.A + a0);
+                    r[0] = ep[0];
+                    if (a0 + 1 < p.A) r[1] = ep[1];
+                } else {
+                    const unsigned pair = (unsigned)(((size_t)t * (p.N - p.P) + (n - p.P)) * hp + a0 / 2);
+                    rng_normal2(p.seed, p.call, SITE_SAMPLE, p.iter, e, pair, r[0], r[1]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (a0 + u < p.A) {
+                        v[u] = sample_action(omean[t * p.A + a0 + u], ostd[t * p.A + a0 + u], r[u]);
+                        if (p.act_mask) v[u] *= p.act_mask[(size_t)e * p.A + a0 + u];
+                    }
+                }
+            }
+            ea[k * HA + t * p.A + a0] = v[0];
+            if (a0 + 1 < p.A) ea[k * HA + t * p.A + a0 + 1] = v[1];
+        }
+        __syncthreads();
+    } else if (p.stage) {
         for (int idx = tid; idx < p.K * HA; idx += nthr) {
             const int k = idx / HA, ha = idx % HA;
             const int t = ha / p.A, a = ha % p.A;
@@ -372,7 +435,7 @@ __device__ void refit_plan(const RefitParams &p, int e, float *smem, int tid, in
     __syncthreads();
     const int pick = ei[*s_pick];
     for (int a = tid; a < p.A; a += nthr) {
-        float x = acts[(size_t)pick * p.A + a];  // elite_actions[0, rand_idx]
+        float x = p.stage ? ea[(size_t)*s_pick * HA + a] : acts[(size_t)pick * p.A + a];  // elite_actions[0, rand_idx]
         if (!p.eval_mode) {
             const float n = p.final_eps ? p.final_eps[(size_t)e * p.A + a]
                                         : rng_normal(p.seed, p.call, SITE_FINAL, 0, e, (unsigned)a);
@@ -503,8 +566,10 @@ struct tdmpc2_plan {
     tdmpc2_plan_cfg cfg;
     Layered lay;
     std::atomic<int> busy{0};  // handles are not reentrant: a second concurrent call is refused (Busy), not raced
-    int fold_refit = 1;        // fused family: the last workgroup of a plan refits it inside the rollout launch
+    int fold_refit = 2;        // fused family: the last workgroup of a plan refits it inside the rollout launch (2 = auto)
     unsigned int *ticket = nullptr;  // [max_envs] arrival counters of that hand-over
+    int *qidx_buf = nullptr;         // [max_envs, 2] the two Q heads of the current iteration (shard_values)
+    unsigned int shard_call = 0;     // call counter captured by shard_begin (Philox stream of the sharded plan)
     // per-task tables of policy_value / td_target on multitask batches (grown on demand)
     float *beff_tab = nullptr, *mask_tab = nullptr, *disc_tab = nullptr;
     int *task_rows = nullptr;  // [rows] copy of the row -> task map, padded to whole GEMM tiles (layered family)
@@ -618,6 +683,10 @@ int set_lds(K kernel, size_t bytes) {
 #ifndef TDMPC2_DEFAULT_THROUGHPUT_ST
 #define TDMPC2_DEFAULT_THROUGHPUT_ST 2  // sample tiles per workgroup when a call has enough plans to fill the chip
 #endif
+#ifdef TDMPC2_ONLY_APAD  // experiment builds (tools/ablate.sh): one action padding only, a quarter of the compile time
+#define FUSED_DISPATCH(APAD_VALUE, AR_VALUE, CALL) \
+    if (AR_VALUE) { CALL(TDMPC2_ONLY_APAD, 1) } else { CALL(TDMPC2_ONLY_APAD, 0) }
+#else
 #define FUSED_DISPATCH(APAD_VALUE, AR_VALUE, CALL) \
     switch (APAD_VALUE) {                          \
         case 16: if (AR_VALUE) { CALL(16, 1) } else { CALL(16, 0) } break; \
@@ -625,6 +694,7 @@ int set_lds(K kernel, size_t bytes) {
         case 48: if (AR_VALUE) { CALL(48, 1) } else { CALL(48, 0) } break; \
         default: if (AR_VALUE) { CALL(64, 1) } else { CALL(64, 0) } break; \
     }
+#endif
 template <class NET> struct Kern;
 template <> struct Kern<NetS> {
     // 32- or 64-row workgroups.  A 64-row workgroup reuses every weight fragment for two row tiles and is the
@@ -752,9 +822,16 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
     rp.tiles = h->tiles * (2 / nst);
     // elite selection + refit: inside the rollout launch (last workgroup of each plan, LDS budget = the 32-row tile) or as
     // a launch of its own (TDMPC2_TUNE_FOLD_REFIT 0)
-    const bool fold = h->fold_refit != 0;
     int refit_stage = 0;
-    const size_t refit_lds = refit_lds_bytes(N, K, H, A, &refit_stage, fold ? (size_t)32 * h->row_bytes : 48 * 1024);
+    size_t refit_lds = refit_lds_bytes(N, K, H, A, &refit_stage, (size_t)32 * h->row_bytes);
+    // the in-launch refit stages the re-derived elite actions in the (then idle) tile memory; if they do not fit, or the
+    // caller wants the per-iteration action dump, the refit runs as a launch of its own
+    // auto: only when the whole launch is one round of workgroups (few plans: latency).  With several rounds every round
+    // ends with the refits of the plans that completed in it, on CUs whose next workgroup then starts late: measured
+    // +0.5 ms on the 4.4 ms launch of 256 plans, against 30 us for the separate k_refit launch.
+    const bool one_round = (long)E * rp.tiles <= (h->num_cus > 0 ? h->num_cus : 256);
+    const bool fold = refit_stage && (h->fold_refit == 1 || (h->fold_refit == 2 && one_round));
+    if (!fold) refit_lds = refit_lds_bytes(N, K, H, A, &refit_stage);
     for (int it = 0; it < I; ++it) {
         rp.iter = it;
         if (tape) {
@@ -780,6 +857,10 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
             if (dbg->std) { fp.dbg_std = dbg->std + (size_t)it * H * A; fp.dbg_std_es = (long)I * H * A; }
         }
         rp.fold_refit = fold ? 1 : 0;
+        if (fold) {
+            fp.regen = 1; fp.P = P; fp.Apad = h->Apad;
+            fp.sample_eps = rp.sample_eps; fp.sample_eps_estride = rp.sample_eps_estride;
+        }
         if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
         Kern<NET>::rollout(h, rp, E * rp.tiles, st, nst, nw);
         HIP_TRY(hipGetLastError());
@@ -928,7 +1009,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
         (rc = dev_alloc(h, (void **)&h->value, E * N * 4)) ||
         (rc = dev_alloc(h, (void **)&h->mean, E * H * A * 4)) ||
         (rc = dev_alloc(h, (void **)&h->std, E * H * A * 4)) ||
-        (rc = dev_alloc(h, (void **)&h->ticket, E * 4))) {
+        (rc = dev_alloc(h, (void **)&h->ticket, E * 4)) || (rc = dev_alloc(h, (void **)&h->qidx_buf, E * 2 * 4))) {
         tdmpc2_plan_destroy(h);
         return rc;
     }
@@ -1400,6 +1481,140 @@ int tdmpc2_plan_td_target(tdmpc2_plan_t *h, int n_rows, const float *next_z, con
     return tdmpc2_plan_td_target_mt(h, n_rows, next_z, reward, terminated, discount, nullptr, pi_eps, qidx, seed, td, stream);
 }
 
+// ---------------------------------------------------------------- one plan sharded over several GPUs (last row)
+// The sample rows of every plan are split over the ranks; everything else is replicated: every rank holds the weights, runs
+// the identical set-up, draws the identical actions (same tape / same Philox seed) and performs the identical elite
+// selection + refit on the all-gathered values.  Per CEM iteration a rank calls shard_values for ITS row range, the host
+// all-gathers value[E, N / G] over RCCL (4 KB per plan), and every rank calls shard_refit.  tdmpc2_amd/dist.py drives it.
+namespace {
+void fill_refit(tdmpc2_plan *h, RefitParams &fp, int E, int it, int eval_mode, float *value, const float *act_mask,
+                const tdmpc2_noise *tape, uint64_t seed, unsigned call, float *prev_mean, float *action, const tdmpc2_debug *dbg,
+                int stage) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    const int H = c.horizon, N = c.num_samples, A = c.action_dim, K = c.num_elites, I = c.iterations;
+    fp = RefitParams{};
+    fp.E = E; fp.N = N; fp.H = H; fp.A = A; fp.K = K; fp.iter = it; fp.last = (it == I - 1); fp.eval_mode = eval_mode; fp.stage = stage;
+    fp.temperature = c.temperature; fp.min_std = c.min_std; fp.max_std = c.max_std;
+    fp.value = value; fp.actions = h->actions; fp.act_mask = act_mask; fp.mean = h->mean; fp.std = h->std;
+    fp.gumbel_exp = tape ? tape->gumbel_exp : nullptr; fp.final_eps = tape ? tape->final_eps : nullptr;
+    fp.seed = seed; fp.call = call; fp.prev_mean = prev_mean; fp.action = action;
+    if (dbg) {
+        if (dbg->value) { fp.dbg_value = dbg->value + (size_t)it * N; fp.dbg_value_es = (long)I * N; }
+        if (dbg->elite_idx) { fp.dbg_idx = dbg->elite_idx + (size_t)it * K; fp.dbg_idx_es = (long)I * K; }
+        if (dbg->score) { fp.dbg_score = dbg->score + (size_t)it * K; fp.dbg_score_es = (long)I * K; }
+        if (dbg->mean) { fp.dbg_mean = dbg->mean + (size_t)it * H * A; fp.dbg_mean_es = (long)I * H * A; }
+        if (dbg->std) { fp.dbg_std = dbg->std + (size_t)it * H * A; fp.dbg_std_es = (long)I * H * A; }
+    }
+}
+}  // namespace
+
+int tdmpc2_plan_shard_begin(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *task_emb, const float *act_mask,
+                            const float *prev_mean, const uint8_t *t0, const tdmpc2_noise *tape, uint64_t seed, void *stream) {
+    if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
+    ENTER(h);
+    int rc = validate_envs(h, n_envs);
+    if (rc) return rc;
+    if (!z0 || !prev_mean || !t0) return fail(TDMPC2_ERR_INVALID, "null argument");
+    const tdmpc2_plan_cfg &c = h->cfg;
+    if (c.multitask && (!task_emb || !act_mask)) return fail(TDMPC2_ERR_INVALID, "multitask plan needs task_emb and act_mask");
+    if (!c.multitask) { task_emb = nullptr; act_mask = nullptr; }
+    if (tape && c.num_pi_trajs > 0 && !tape->pi_traj_eps) return fail(TDMPC2_ERR_INVALID, "noise tape has null fields");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned call = h->call++;
+    h->shard_call = call;
+    const int E = n_envs, P = c.num_pi_trajs;
+    if (h->lay.on) {
+        if ((rc = lay_setup(h, st, E, task_emb, prev_mean, t0, true))) return rc;
+        if (P > 0 && (rc = lay_pitraj(h, st, E, z0, act_mask, tape ? tape->pi_traj_eps : nullptr, seed, call))) return rc;
+        return TDMPC2_OK;
+    }
+    if ((rc = launch_setup<NetS>(h, E, z0, task_emb, prev_mean, t0, st))) return rc;
+    if (P > 0) {
+        PiTrajParamsT<NetS> p{};
+        p.E = E; p.N = c.num_samples; p.H = c.horizon; p.A = c.action_dim; p.Apad = h->Apad; p.P = P; p.stride = h->stride;
+        p.multitask = c.multitask; p.nnets = h->nnets; p.log_std_min = c.log_std_min; p.log_std_dif = c.log_std_dif;
+        p.dyn = to_dev<NetS>(h->dyn); p.pi = to_dev<NetS>(h->pi);
+        p.z0 = z0; p.beff = h->beff; p.act_mask = act_mask; p.pi_traj_eps = tape ? tape->pi_traj_eps : nullptr;
+        p.seed = seed; p.call = call; p.actions = h->actions; p.zscratch = h->zscratch;
+        p.zscratch_estride = (long)h->tiles * ROWS * WIDTH;
+        Kern<NetS>::pitraj(h, p, E, st);
+        HIP_TRY(hipGetLastError());
+    }
+    return TDMPC2_OK;
+}
+
+int tdmpc2_plan_shard_values(tdmpc2_plan_t *h, int n_envs, int iter, int row_begin, int row_end, const float *z0,
+                             const float *act_mask, const float *disc_pow, const tdmpc2_noise *tape, uint64_t seed,
+                             float *value, void *stream) {
+    if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
+    ENTER(h);
+    int rc = validate_envs(h, n_envs);
+    if (rc) return rc;
+    if (!z0 || !disc_pow || !value) return fail(TDMPC2_ERR_INVALID, "null argument");
+    const tdmpc2_plan_cfg &c = h->cfg;
+    const int E = n_envs, H = c.horizon, N = c.num_samples, A = c.action_dim, P = c.num_pi_trajs, I = c.iterations;
+    if (iter < 0 || iter >= I) return fail(TDMPC2_ERR_INVALID, "iteration %d outside [0, %d)", iter, I);
+    const int gran = h->lay.on ? GBM : ROWS;
+    if (row_begin < 0 || row_end > N || row_begin >= row_end || row_begin % gran || row_end % gran)
+        return fail(TDMPC2_ERR_INVALID, "row range [%d, %d) must be non-empty, inside [0, %d) and aligned to %d rows", row_begin, row_end, N, gran);
+    if (c.multitask && !act_mask) return fail(TDMPC2_ERR_INVALID, "multitask plan needs act_mask");
+    if (!c.multitask) act_mask = nullptr;
+    if (tape && (!tape->sample_eps || !tape->pi_eps || !tape->qidx)) return fail(TDMPC2_ERR_INVALID, "noise tape has null fields");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned call = h->shard_call;
+    // (1) the actions of ALL rows of this iteration (replicated: the refit needs every elite's actions)
+    SampleParams sp{};
+    sp.E = E; sp.H = H; sp.N = N; sp.A = A; sp.P = P; sp.iter = iter; sp.mean = h->mean; sp.std = h->std; sp.mask = act_mask;
+    sp.eps = tape ? tape->sample_eps + (size_t)iter * H * (N - P) * A : nullptr;
+    sp.eps_estride = (long)I * H * (N - P) * A;
+    sp.seed = seed; sp.call = call; sp.actions = h->actions;
+    hipLaunchKernelGGL(l_sample, dim3(1024), dim3(256), 0, st, sp);
+    int *qbuf = h->lay.on ? h->lay.qidx : h->qidx_buf;
+    if (tape) hipLaunchKernelGGL(l_copy_qidx, dim3((E + 255) / 256), dim3(256), 0, st, E, tape->qidx + (size_t)iter * 2, (long)I * 2, qbuf);
+    else hipLaunchKernelGGL(l_qidx, dim3((E + 255) / 256), dim3(256), 0, st, E, c.num_q, iter, (unsigned long long)seed, call, qbuf);
+    HIP_TRY(hipGetLastError());
+    const float *pi_eps = tape ? tape->pi_eps + (size_t)iter * N * A : nullptr;
+    // (2) this rank's rows
+    if (h->lay.on)
+        return lay_estimate_value(h, st, E, z0, act_mask, disc_pow, h->actions, pi_eps, (long)I * N * A, qbuf, seed, call, iter, value,
+                                  nullptr, row_begin, row_end - row_begin);
+    RolloutParamsT<NetS> rp{};
+    fill_rollout<NetS>(h, rp, E);
+    rp.z0 = z0; rp.act_mask = act_mask; rp.disc_pow = disc_pow; rp.seed = seed; rp.call = call; rp.given_actions = 1; rp.iter = iter;
+    rp.value = value; rp.pi_eps = pi_eps; rp.pi_eps_estride = (long)I * N * A; rp.qidx = qbuf; rp.qidx_estride = 2;
+    const int nst = h->force_rows == 32 ? 1 : 2;
+    const int trows = 32 * nst;
+    rp.tiles = (row_end - row_begin) / trows; rp.tile_off = row_begin / trows;
+    Kern<NetS>::rollout(h, rp, E * rp.tiles, st, nst, 8);
+    HIP_TRY(hipGetLastError());
+    return TDMPC2_OK;
+}
+
+int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value, const float *act_mask, float *prev_mean,
+                            int eval_mode, const tdmpc2_noise *tape, uint64_t seed, float *action, const tdmpc2_debug *dbg,
+                            void *stream) {
+    if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
+    ENTER(h);
+    if (n_envs < 1 || n_envs > h->cfg.max_envs) return fail(TDMPC2_ERR_INVALID, "n_envs=%d outside [1, %d]", n_envs, h->cfg.max_envs);
+    if (!value || !prev_mean || !action) return fail(TDMPC2_ERR_INVALID, "null argument");
+    const tdmpc2_plan_cfg &c = h->cfg;
+    if (iter < 0 || iter >= c.iterations) return fail(TDMPC2_ERR_INVALID, "iteration %d outside [0, %d)", iter, c.iterations);
+    if (tape && (!tape->gumbel_exp || (!eval_mode && !tape->final_eps))) return fail(TDMPC2_ERR_INVALID, "noise tape has null fields");
+    hipStream_t st = (hipStream_t)stream;
+    int stage = 0;
+    const size_t lds = refit_lds_bytes(c.num_samples, c.num_elites, c.horizon, c.action_dim, &stage);
+    RefitParams fp;
+    fill_refit(h, fp, n_envs, iter, eval_mode, value, c.multitask ? act_mask : nullptr, tape, seed, h->shard_call, prev_mean, action, dbg, stage);
+    hipLaunchKernelGGL(k_refit, dim3(n_envs), dim3(c.num_samples), lds, st, fp);
+    HIP_TRY(hipGetLastError());
+    if (dbg && dbg->actions)
+        HIP_TRY(hipMemcpy2DAsync(dbg->actions + (size_t)iter * c.horizon * c.num_samples * c.action_dim,
+                                 (size_t)c.iterations * c.horizon * c.num_samples * c.action_dim * 4, h->actions,
+                                 (size_t)c.horizon * c.num_samples * c.action_dim * 4, (size_t)c.horizon * c.num_samples * c.action_dim * 4,
+                                 n_envs, hipMemcpyDeviceToDevice, st));
+    return TDMPC2_OK;
+}
+
 // ---------------------------------------------------------------- packed weight file
 // Everything a bind produces -- fragment-ordered (and, for the split arithmetic, hi/lo-split and scaled) weights, padded
 // biases, LayerNorm parameters, task-embedding columns, the per-layer scale records, the transposed encoder -- as one
@@ -1571,7 +1786,7 @@ int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value) {
         return TDMPC2_OK;
     }
     if (key == TDMPC2_TUNE_FOLD_REFIT) {
-        if (value != 0 && value != 1) return fail(TDMPC2_ERR_INVALID, "fold_refit must be 0 or 1");
+        if (value < 0 || value > 2) return fail(TDMPC2_ERR_INVALID, "fold_refit must be 0 (never), 1 (always) or 2 (auto)");
         h->fold_refit = value;
         return TDMPC2_OK;
     }

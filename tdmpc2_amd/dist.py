@@ -9,7 +9,7 @@ The same code runs on gloo for the CPU tests.
 """
 from __future__ import annotations
 
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -22,23 +22,44 @@ def shard_range(n_envs: int, world_size: int, rank: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def broadcast_state_dict(sd: Dict[str, torch.Tensor], src: int = 0) -> Dict[str, torch.Tensor]:
-    """In-place broadcast of every tensor of a (structurally identical) state dict from `src`.
-    Tensors are flattened into one bucket per dtype so the 5M model moves in one collective."""
+BUCKET_BYTES = 256 << 20  # weight broadcast bucket: large enough for xGMI's per-link rate, small next to 288 GB of HBM
+
+
+def broadcast_state_dict(sd: Dict[str, torch.Tensor], src: int = 0, bucket_bytes: int = BUCKET_BYTES) -> Dict[str, torch.Tensor]:
+    """In-place broadcast of every tensor of a (structurally identical) state dict from `src`, streamed in flat buckets of
+    at most `bucket_bytes` per dtype: the 5M model moves in one collective, the 317M model (1.27 GB) in five, and the
+    temporary never exceeds one bucket (a tensor larger than a bucket is broadcast in place, without a copy)."""
     if not (dist.is_available() and dist.is_initialized()):
         return sd
     keys = sorted(k for k, v in sd.items() if torch.is_tensor(v))
     by_dtype: Dict[torch.dtype, list] = {}
     for k in keys:
         by_dtype.setdefault(sd[k].dtype, []).append(k)
-    for dt, ks in by_dtype.items():
-        flat = torch.cat([sd[k].reshape(-1) for k in ks])
+
+    def flush(bucket):
+        if not bucket:
+            return
+        flat = torch.cat([sd[k].reshape(-1) for k in bucket])
         dist.broadcast(flat, src=src)
         off = 0
-        for k in ks:
+        for k in bucket:
             n = sd[k].numel()
             sd[k].copy_(flat[off:off + n].view_as(sd[k]))
             off += n
+
+    for dt, ks in by_dtype.items():
+        bucket, size = [], 0
+        for k in ks:
+            nbytes = sd[k].numel() * sd[k].element_size()
+            if nbytes >= bucket_bytes and sd[k].is_contiguous():
+                dist.broadcast(sd[k], src=src)  # big tensors go as they are
+                continue
+            if size + nbytes > bucket_bytes:
+                flush(bucket)
+                bucket, size = [], 0
+            bucket.append(k)
+            size += nbytes
+        flush(bucket)
     return sd
 
 
@@ -55,3 +76,37 @@ def gather_actions(local_actions: torch.Tensor, n_envs: int) -> torch.Tensor:
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
     return torch.cat([o[: b - a] for o, (a, b) in zip(out, sizes)], dim=0)
+
+
+def sharded_plan(backend, z0, disc_pow, prev_mean, t0, eval_mode: bool = False, task_emb=None, act_mask=None, tape=None,
+                 seed: int = 0, group=None, stages: Optional[dict] = None) -> torch.Tensor:
+    """ONE plan per environment with its sample rows split over the ranks of `group` (last row:
+    317M-class models at E = 1).  Every rank calls this with IDENTICAL arguments (same z0, same noise tape or Philox seed):
+    the prologue, the action sampling and the elite selection + refit are replicated; a rank evaluates only rows
+    [rank * N / G, (rank + 1) * N / G) of every plan and the value slices are all-gathered once per CEM iteration
+    (N / G * 4 bytes per plan per rank over RCCL / xGMI).  Returns action [E, A] -- the same on every rank; `prev_mean` is
+    updated in place.
+
+    `backend` is a `NativePlanner` (or anything with its shard_begin / shard_values / shard_refit / shard_granularity /
+    cfg / iterations: the CPU tests drive this function over gloo with an oracle-backed stand-in)."""
+    cfg = backend.cfg
+    N, E = cfg.num_samples, int(z0.shape[0])
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    gran = backend.shard_granularity
+    if N % (world * gran) != 0:
+        raise ValueError(f"num_samples {N} does not split into {world} ranges of a multiple of {gran} rows")
+    per = N // world
+    r0, r1 = rank * per, (rank + 1) * per
+    value = torch.zeros(E, N, dtype=torch.float32, device=z0.device)
+    action = torch.empty(E, cfg.action_dim, dtype=torch.float32, device=z0.device)
+    backend.shard_begin(z0, prev_mean, t0, task_emb=task_emb, act_mask=act_mask, tape=tape, seed=seed)
+    for it in range(backend.iterations):
+        backend.shard_values(it, r0, r1, z0, disc_pow, value, act_mask=act_mask, seed=seed)
+        if world > 1:
+            local = value[:, r0:r1].contiguous()
+            gathered = torch.empty(world, E, per, dtype=value.dtype, device=value.device)
+            dist.all_gather_into_tensor(gathered.view(-1), local.view(-1), group=group)
+            value.copy_(gathered.permute(1, 0, 2).reshape(E, N))
+        backend.shard_refit(it, value, prev_mean, action, act_mask=act_mask, eval_mode=eval_mode, seed=seed, stages=stages)
+    return action

@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "tdmpc2_plan_profile_read", "tdmpc2_plan_bind_encoder", "tdmpc2_plan_encode", "tdmpc2_plan_run_obs",
     "tdmpc2_plan_policy_value", "tdmpc2_plan_td_target", "tdmpc2_plan_policy_value_mt", "tdmpc2_plan_td_target_mt",
     "tdmpc2_plan_packed_size", "tdmpc2_plan_export_packed", "tdmpc2_plan_import_packed",
+    "tdmpc2_plan_shard_begin", "tdmpc2_plan_shard_values", "tdmpc2_plan_shard_refit",
 ]
 
 NET_DYNAMICS, NET_REWARD, NET_PI, NET_Q, NET_TERMINATION, NET_TARGET_Q = range(6)
@@ -114,6 +115,12 @@ def load_library():
     lib.tdmpc2_plan_export_packed.restype = i32
     lib.tdmpc2_plan_import_packed.argtypes = [vp, vp, u64, vp]
     lib.tdmpc2_plan_import_packed.restype = i32
+    lib.tdmpc2_plan_shard_begin.argtypes = [vp, i32, vp, vp, vp, vp, vp, C.POINTER(Noise), u64, vp]
+    lib.tdmpc2_plan_shard_begin.restype = i32
+    lib.tdmpc2_plan_shard_values.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, C.POINTER(Noise), u64, vp, vp]
+    lib.tdmpc2_plan_shard_values.restype = i32
+    lib.tdmpc2_plan_shard_refit.argtypes = [vp, i32, i32, vp, vp, vp, i32, C.POINTER(Noise), u64, vp, C.POINTER(Debug), vp]
+    lib.tdmpc2_plan_shard_refit.restype = i32
     lib.tdmpc2_plan_estimate_value.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tdmpc2_plan_estimate_value.restype = i32
     lib.tdmpc2_plan_estimate_value_trace.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -489,14 +496,72 @@ class NativePlanner:
                                                    _ptr(std), _ptr(score), _ptr(idx), self._stream()))
         return mean, std, score, idx
 
+    # ------------------------------------------------------------------ one plan sharded over ranks (tdmpc2_amd/dist.py)
+    @property
+    def shard_granularity(self) -> int:
+        """Row ranges of shard_values are multiples of this many sample rows."""
+        return 64 if self.path == PATH_FUSED else 128
+
+    def shard_begin(self, z0, prev_mean, t0, task_emb=None, act_mask=None, tape=None, seed: int = 0):
+        """Prologue of a plan whose sample rows are split over ranks: warm start + policy-prior trajectories
+        (tdmpc2.py:154-170), replicated on every rank."""
+        cfg, dev = self.cfg, self.device
+        E = int(z0.shape[0])
+        _chk_tensor("z0", z0, torch.float32, (E, cfg.latent_dim), dev)
+        _chk_tensor("prev_mean", prev_mean, torch.float32, (E, cfg.horizon, cfg.action_dim), dev)
+        _chk_tensor("t0", t0, torch.uint8, (E,), dev)
+        self._shard_noise = self._noise(tape, E) if tape is not None else None
+        noise_p = C.byref(self._shard_noise) if self._shard_noise is not None else None
+        with torch.cuda.device(dev):
+            self._check(self.lib.tdmpc2_plan_shard_begin(self._h, E, _ptr(z0), _ptr(task_emb), _ptr(act_mask), _ptr(prev_mean),
+                                                         _ptr(t0), noise_p, C.c_uint64(int(seed) & (2**64 - 1)), self._stream()))
+
+    def shard_values(self, it: int, row_begin: int, row_end: int, z0, disc_pow, value, act_mask=None, seed: int = 0):
+        """Sample the iteration's actions (all rows, replicated) and evaluate rows [row_begin, row_end) of every plan into
+        value[E, N] (other columns untouched)."""
+        cfg, dev = self.cfg, self.device
+        E = int(z0.shape[0])
+        _chk_tensor("value", value, torch.float32, (E, cfg.num_samples), dev)
+        _chk_tensor("disc_pow", disc_pow, torch.float32, (E, cfg.horizon + 1), dev)
+        noise_p = C.byref(self._shard_noise) if self._shard_noise is not None else None
+        with torch.cuda.device(dev):
+            self._check(self.lib.tdmpc2_plan_shard_values(self._h, E, int(it), int(row_begin), int(row_end), _ptr(z0), _ptr(act_mask),
+                                                          _ptr(disc_pow), noise_p, C.c_uint64(int(seed) & (2**64 - 1)), _ptr(value),
+                                                          self._stream()))
+
+    def shard_refit(self, it: int, value, prev_mean, action, act_mask=None, eval_mode=False, seed: int = 0, stages=None):
+        """Elite selection + refit on the complete value[E, N] (identical on every rank); the last iteration also picks the
+        action and writes the new prev_mean."""
+        cfg, dev = self.cfg, self.device
+        E = int(value.shape[0])
+        _chk_tensor("value", value, torch.float32, (E, cfg.num_samples), dev)
+        _chk_tensor("action", action, torch.float32, (E, cfg.action_dim), dev)
+        noise_p = C.byref(self._shard_noise) if self._shard_noise is not None else None
+        dbg_p = None
+        if stages is not None:
+            dbg = Debug(**{k: v.data_ptr() for k, v in stages.items()})
+            dbg_p = C.byref(dbg)
+        with torch.cuda.device(dev):
+            self._check(self.lib.tdmpc2_plan_shard_refit(self._h, E, int(it), _ptr(value), _ptr(act_mask), _ptr(prev_mean),
+                                                         int(bool(eval_mode)), noise_p, C.c_uint64(int(seed) & (2**64 - 1)),
+                                                         _ptr(action), dbg_p, self._stream()))
+
+    def debug_buffers(self, E: int):
+        cfg, dev, I = self.cfg, self.device, self.iterations
+        H, N, K, A = cfg.horizon, cfg.num_samples, cfg.num_elites, cfg.action_dim
+        return {"value": torch.empty(E, I, N, device=dev), "elite_idx": torch.empty(E, I, K, device=dev, dtype=torch.int32),
+                "score": torch.empty(E, I, K, device=dev), "mean": torch.empty(E, I, H, A, device=dev),
+                "std": torch.empty(E, I, H, A, device=dev), "actions": torch.empty(E, I, H, N, A, device=dev)}
+
     # ------------------------------------------------------------------ tuning / profiling
     def set_rows_per_workgroup(self, rows: int):
         """0 = automatic (32-row workgroups for calls with few plans: latency), or force 32 / 64 sample rows."""
         self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 0, int(rows)))
 
-    def set_fold_refit(self, on: bool):
-        """Fused family: elite selection + refit inside the rollout launch (default) or as a launch of its own."""
-        self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 1, int(bool(on))))
+    def set_fold_refit(self, mode):
+        """Fused family: elite selection + refit inside the rollout launch (True / 1), as a launch of its own (False / 0),
+        or chosen per call (2, the default: inside when the call fits the chip in one round of workgroups)."""
+        self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 1, int(mode)))
 
     def set_profiling(self, max_launches: int):
         """Bracket up to `max_launches` rollout-kernel launches with HIP events (0 = off)."""

@@ -82,3 +82,148 @@ def test_two_rank_sharded_planning_equals_single_process(tmp_path):
     want, _, _ = po.plan_batch(model, z0, tape, np.zeros((n_envs, cfg.horizon, cfg.action_dim), np.float32),
                                [True] * n_envs, False, None, [0.99] * n_envs, c["iterations"])
     assert torch.allclose(r0, want, atol=1e-6)
+
+
+# ---------------------------------------------------------------- one plan sharded over ranks (tdmpc2_amd/dist.py: sharded_plan)
+class OracleShardBackend:
+    """Stand-in for NativePlanner's shard_* entry points built from the oracle's pieces (CPU tests only): the same
+    replicated prologue / sampling / refit and row-range evaluation, so that `dist.sharded_plan` -- the host logic under
+    test -- can run over gloo.  Rows are evaluated in fixed chunks of `chunk` rows whatever the range, so results do not
+    depend on how the rows are split over ranks (identical matmul shapes -> bit-identical values)."""
+
+    def __init__(self, case, chunk=32):
+        from oracle import planner_oracle as po
+
+        self.po = po
+        self.cfg = case["cfg"]
+        self.iterations = case["iterations"]
+        self.shard_granularity = chunk
+        self.chunk = chunk
+        self.model = po.OracleModel(self.cfg, {k: torch.as_tensor(v) for k, v in case["sd"].items()})
+        self.discount = case["discounts"][0]
+
+    def shard_begin(self, z0, prev_mean, t0, task_emb=None, act_mask=None, tape=None, seed=0):
+        cfg, po = self.cfg, self.po
+        H, N, P, A = cfg.horizon, cfg.num_samples, cfg.num_pi_trajs, cfg.action_dim
+        assert z0.shape[0] == 1
+        self.tape = {k: torch.as_tensor(v[0]) for k, v in tape.items()}
+        z = z0[:1]
+        self.actions = torch.empty(H, N, A)
+        _z = z.repeat(P, 1)
+        for t in range(H - 1):
+            self.actions[t, :P] = self.model.pi(_z, None, self.tape["pi_traj_eps"][t])
+            _z = self.model.next(_z, self.actions[t, :P], None)
+        self.actions[-1, :P] = self.model.pi(_z, None, self.tape["pi_traj_eps"][H - 1])
+        self.mean = torch.zeros(H, A)
+        self.std = torch.full((H, A), cfg.max_std)
+        if not bool(t0[0]):
+            self.mean[:-1] = prev_mean[0, 1:]
+
+    def shard_values(self, it, r0, r1, z0, disc_pow, value, act_mask=None, seed=0):
+        cfg, po = self.cfg, self.po
+        P = cfg.num_pi_trajs
+        self.actions[:, P:] = (self.mean.unsqueeze(1) + self.std.unsqueeze(1) * self.tape["sample_eps"][it]).clamp(-1, 1)
+        for c0 in range(r0, r1, self.chunk):
+            sl = slice(c0, c0 + self.chunk)
+            sub = type("C", (), {})()
+            sub.__dict__.update(vars(cfg))
+            sub.num_samples = self.chunk
+            m = po.OracleModel(sub, self.model.sd)
+            v = po.estimate_value(m, z0[:1].repeat(self.chunk, 1), self.actions[:, sl], None, self.discount,
+                                  self.tape["pi_eps"][it][sl], self.tape["qidx"][it])
+            value[0, sl] = v.squeeze(1)
+
+    def shard_refit(self, it, value, prev_mean, action, act_mask=None, eval_mode=False, seed=0, stages=None):
+        cfg, po = self.cfg, self.po
+        v, idx, score, elite_actions, self.mean, self.std = po.refit(cfg, value[0].unsqueeze(1).clone(), self.actions, None)
+        if stages is not None:
+            stages.setdefault("elite_idx", []).append(idx.clone())
+            stages.setdefault("value", []).append(value[0].clone())
+        if it == self.iterations - 1:
+            pick = po.gumbel_select(score.squeeze(1), self.tape["gumbel_exp"])
+            a = elite_actions[0, pick]
+            if not eval_mode:
+                a = a + self.std[0] * self.tape["final_eps"]
+            action[0] = a.clamp(-1, 1)
+            prev_mean[0] = self.mean
+
+
+def _shard_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import cases
+        from tdmpc2_amd.dist import sharded_plan
+
+        c = cases.build_case("tiny")
+        be = OracleShardBackend(c)
+        z0 = torch.as_tensor(c["z0"][:1])
+        prev = torch.as_tensor(c["prev_mean"][:1]).clone()
+        t0 = torch.tensor([0], dtype=torch.uint8)  # warm start
+        tape = {k: v[:1] for k, v in c["tape"].items()}
+        stages = {}
+        a = sharded_plan(be, z0, None, prev, t0, tape=tape, stages=stages)
+        torch.save({"action": a, "prev_mean": prev, "idx": torch.stack(stages["elite_idx"]), "value": torch.stack(stages["value"])},
+                   os.path.join(out_dir, f"shard{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_plan_sharded_over_two_ranks_is_bit_identical_to_one_rank(tmp_path):
+    """N split over 2 ranks, value slices all-gathered per iteration, replicated refit: both ranks end with the
+    same action, bit-identical to the unsharded run of the same backend, and equal to the oracle's plan()."""
+    from oracle import cases
+    from oracle import planner_oracle as po
+    from tdmpc2_amd.dist import sharded_plan
+
+    mp.spawn(_shard_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "shard0.pt")
+    r1 = torch.load(tmp_path / "shard1.pt")
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k
+    c = cases.build_case("tiny")
+    be = OracleShardBackend(c)
+    prev = torch.as_tensor(c["prev_mean"][:1]).clone()
+    tape = {k: v[:1] for k, v in c["tape"].items()}
+    stages = {}
+    a = sharded_plan(be, torch.as_tensor(c["z0"][:1]), None, prev, torch.tensor([0], dtype=torch.uint8), tape=tape, stages=stages)
+    assert torch.equal(a, r0["action"]) and torch.equal(prev, r0["prev_mean"])
+    assert torch.equal(torch.stack(stages["elite_idx"]), r0["idx"])
+    wa, wpm, st = po.plan(be.model, z0=torch.as_tensor(c["z0"][:1]), tape=po.env_tape(c["tape"], 0),
+                          prev_mean=torch.as_tensor(c["prev_mean"][0]), t0=False, eval_mode=False, task=None,
+                          discount=c["discounts"][0], iterations=c["iterations"])
+    assert torch.allclose(a[0], wa, atol=1e-5) and torch.allclose(prev[0], wpm, atol=1e-5)
+
+
+def test_sharded_plan_rejects_ragged_splits():
+    from oracle import cases
+    from tdmpc2_amd.dist import sharded_plan
+
+    c = cases.build_case("tiny")
+    be = OracleShardBackend(c, chunk=48)  # 64 rows do not split into multiples of 48
+    with pytest.raises(ValueError, match="does not split"):
+        sharded_plan(be, torch.as_tensor(c["z0"][:1]), None, torch.zeros(1, 2, 4), torch.tensor([1], dtype=torch.uint8),
+                     tape={k: v[:1] for k, v in c["tape"].items()})
+
+
+def _bcast_worker(rank, world, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tdmpc2_amd.dist import broadcast_state_dict
+
+        g = torch.Generator().manual_seed(0)
+        ref = {"a": torch.randn(1000, generator=g), "b": torch.randn(37, 5, generator=g), "big": torch.randn(5000, generator=g),
+               "i": torch.arange(11), "c": torch.randn(3, generator=g)}
+        sd = {k: (v.clone() if rank == 0 else torch.zeros_like(v)) for k, v in ref.items()}
+        # a 4 KB bucket: "a" fills one, "big" (20 KB) exceeds it and is broadcast in place, the rest share buckets
+        broadcast_state_dict(sd, src=0, bucket_bytes=4096)
+        assert all(torch.equal(sd[k], ref[k]) for k in ref)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_streams_in_buckets():
+    mp.spawn(_bcast_worker, args=(2, _free_port()), nprocs=2, join=True)

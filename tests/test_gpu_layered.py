@@ -26,7 +26,7 @@ def test_layered_plan_matches_reference_golden(name, prec):
     """Whole plan() with the recorded noise tape against the outputs of the reference's own code."""
     from tests.gpu_common import case_on_gpu
 
-    c, model, planner = case_on_gpu(name, 0, prec)
+    c, model, planner = case_on_gpu(name, PATH_LAYERED, prec)  # (c1_ep also fits the fused family: test_gpu_planner.py)
     assert planner.path == PATH_LAYERED and planner.precision == prec
     g = load_golden(name)
     got = _run_native(c, model, planner)
@@ -59,7 +59,7 @@ def test_layered_estimate_value_matches_oracle(name, prec):
     """_estimate_value (tdmpc2.py:122-136, incl. the termination head when episodic) on identical actions."""
     from tests.gpu_common import case_on_gpu, dev, plan_inputs
 
-    c, model, planner = case_on_gpu(name, 0, prec)
+    c, model, planner = case_on_gpu(name, PATH_LAYERED, prec)
     inp = plan_inputs(c, model)
     E = c["n_envs"]
     for it in (0, c["iterations"] - 1):
@@ -85,7 +85,7 @@ def test_layered_trace_scalars_match_oracle():
     from oracle import planner_oracle as po
     from tests.gpu_common import case_on_gpu, dev, plan_inputs
 
-    c, model, planner = case_on_gpu("small", 0, 1)
+    c, model, planner = case_on_gpu("small", PATH_LAYERED, 1)
     cfg = c["cfg"]
     inp = plan_inputs(c, model)
     E, H, N, A = c["n_envs"], cfg.horizon, cfg.num_samples, cfg.action_dim

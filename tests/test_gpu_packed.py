@@ -35,8 +35,10 @@ def test_packed_round_trip_is_bit_identical(name, path, prec, tmp_path):
     if not c["cfg"].multitask:
         z = torch.as_tensor(c["z0"]).to(dev())
         r = torch.zeros(z.shape[0], device=dev())
-        t0 = dst.td_target(z, r, r, 0.99, seed=1)
-        t1 = src.td_target(z, r, r, 0.99, seed=1)
+        eps = torch.randn(z.shape[0], c["cfg"].action_dim, device=dev())
+        qidx = torch.tensor([1, 0], dtype=torch.int32, device=dev())
+        t0 = dst.td_target(z, r, r, 0.99, pi_eps=eps, qidx=qidx)
+        t1 = src.td_target(z, r, r, 0.99, pi_eps=eps, qidx=qidx)
         assert torch.equal(t0, t1)
     dst.close()
 
