@@ -180,6 +180,69 @@ def cpu_baseline(cfg, iterations, sd_np, budget_s=12.0):
             "ms_per_plan": round(1e3 * el / n, 2)}
 
 
+def config_leg(name, E, steps, device, rank=0):
+    """A short measurement of another BASELINE.json configuration (c3: mt30 48M, one plan per task id; c4: mt80 317M, H5
+    N1024) in the same process, reported under extra.configs with its own roofline -- so that the driver's default run
+    carries numbers for configs[2] and configs[3] too (missing #7).  Same rules as the main line: inputs
+    resident in HBM, random-init weights of the named architecture, in-kernel Philox noise, HIP-event timing of the
+    rollout stage on the launch stream, nothing skipped."""
+    from tdmpc2_amd.native import NativePlanner
+
+    cfg = named_config(name)
+    I = cfg.iterations + 2 * int(cfg.action_dim >= 20)
+    t_leg = time.perf_counter()
+    sd_np = synth.make_state_dict(cfg, seed=0)
+    sd = {k: torch.as_tensor(v).to(device) for k, v in sd_np.items() if not k.startswith("_encoder.")}
+    planner = NativePlanner(cfg, I, device, max_envs=E)
+    planner.bind_state_dict(sd)
+    family = {1: "fused", 2: "layered"}[planner.path]
+    split = planner.precision == 2
+    z0 = torch.as_tensor(synth.make_latents(cfg, E, seed=2000 + rank)).to(device)
+    disc = disc_pow_rows(cfg, E, device)
+    emb = mask = None
+    if cfg.multitask:
+        tasks = torch.arange(E) % len(cfg.tasks)
+        w = torch.as_tensor(sd_np["_task_emb.weight"])[tasks]
+        n = w.norm(dim=1, keepdim=True)
+        emb = torch.where(n > 1.0, w / (n + 1e-7), w).to(device).contiguous()
+        mask = torch.as_tensor(sd_np["_action_masks"])[tasks].to(device).contiguous()
+    del sd_np
+    prev = torch.zeros(E, cfg.horizon, cfg.action_dim, device=device)
+    warm = torch.zeros(E, dtype=torch.uint8, device=device)
+    cold = torch.ones(E, dtype=torch.uint8, device=device)
+    out = torch.empty(E, cfg.action_dim, device=device)
+    planner.plan(z0, disc, prev, cold, task_emb=emb, act_mask=mask, seed=1, out=out)
+    planner.plan(z0, disc, prev, warm, task_emb=emb, act_mask=mask, seed=2, out=out)
+    planner.set_profiling(steps * I)
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    for i in range(steps):
+        planner.plan(z0, disc, prev, warm, task_emb=emb, act_mask=mask, seed=10 + i, out=out)
+    torch.cuda.synchronize(device)
+    el = time.perf_counter() - t1
+    ms, n = planner.profile_read()
+    finite = bool(torch.isfinite(out).all())
+    dev_mib = planner.device_bytes / 2**20
+    planner.close()
+    launch_s = (ms / 1e3) / max(n, 1)
+    peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
+    ach = flops_rollout_launch(cfg, E) / launch_s / 1e12
+    ach_x = flops_rollout_executed(cfg, E, family == "fused") / launch_s / 1e12
+    return {
+        "value": round(steps * E / el, 2), "unit": "plans/s", "steps": steps, "ms_per_step": round(1e3 * el / steps, 3), "finite": finite,
+        "config": {"workload": f"{name}: {cfg.task} world model (L{cfg.latent_dim} M{cfg.mlp_dim} A{cfg.action_dim} nq{cfg.num_q} "
+                               f"T{cfg.task_dim}), plan() H={cfg.horizon} N={cfg.num_samples} K={cfg.num_elites} P={cfg.num_pi_trajs} "
+                               f"I={I}, {E} concurrent plans (one per task id, round-robin), random-init weights",
+                   "envs": E, "iterations": I, "kernel_family": family, "device_MiB": round(dev_mib),
+                   "gflop_per_plan_as_written": round(flops_plan(cfg, I) / 1e9, 1)},
+        "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                     "achieved_executed": round(ach_x, 2), "traffic": None,
+                     "kernel": ("g_gemm_s" if split else "g_gemm") + " + row kernels of one _estimate_value" if family == "layered" else "ks_rollout",
+                     "launches_timed": n, "avg_stage_ms": round(1e3 * launch_s, 3)},
+        "leg_wall_s": round(time.perf_counter() - t_leg, 1),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +258,8 @@ def main():
                          "accuracy); auto = split")
     ap.add_argument("--rows-per-workgroup", type=int, default=0, help="fused split kernels: 0 auto, 32 or 64 sample rows")
     ap.add_argument("--skip-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-extra-configs", action="store_true",
+                    help="do not append the short c3 / c4 legs (extra.configs) to the default c2 line")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -378,6 +443,16 @@ def main():
                              "frac_executed": round(ach_x / FP32_MFMA_PEAK_TFLOPS, 4),
                              "avg_launch_ms": round(ms / max(n, 1), 4)}}
             ex.close()
+
+        if args.config == "c2" and world == 1 and not args.skip_extra_configs:
+            planner.close()  # free the c2 workspace before the 317M model arrives
+            extra["configs"] = {}
+            for name, e_leg, k_leg in (("c3", 30, 3), ("c4", 8, 2)):
+                try:
+                    extra["configs"][name] = config_leg(name, e_leg, k_leg, device, rank)
+                    log(f"extra config {name}: {extra['configs'][name]['value']} plans/s")
+                except Exception as ex:
+                    extra["configs"][name] = {"error": repr(ex)}
 
     if rank != 0:
         if use_dist:

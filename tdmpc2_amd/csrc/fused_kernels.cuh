@@ -1004,7 +1004,12 @@ __device__ __forceinline__ float head_term_s(const CT &c, const LayerS &ly) {
 
 // Two first layers over the same [z | a] operand tile in ONE pass (dynamics + reward, or the two selected Q heads): the
 // activation fragments are read from LDS once per k-block and feed both nets' feature tiles (24 MFMAs per k-block per
-// wave instead of 2 x 12 with two reads of the same fragments).  -DSPLIT_PAIR; weight ring one k-block deep per net.
+// wave instead of 2 x 12 with two reads of the same fragments): identical sums in identical order, so results do not change
+// by a bit; +1.5 ... 2.6 % on the launch (A/B in one gpurun call, profiles/README.md r02c).  Weight ring one k-block deep
+// per net.  -DSPLIT_NO_PAIR restores the two separate loops.
+#ifndef SPLIT_NO_PAIR
+#define SPLIT_PAIR 1
+#endif
 #ifdef SPLIT_PAIR
 template <class CT>
 __device__ __forceinline__ void kloop_pair_s(const CT &c, const LayerS &la, const LayerS &lb, int kb0, int kb1,

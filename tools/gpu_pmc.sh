@@ -9,7 +9,7 @@ OUT="$R/gpurun_out/pmc_${TAG}"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="${*:---steps 2 --warmup 1 --skip-cpu-baseline}"
+ARGS="${*:---steps 2 --warmup 1 --skip-cpu-baseline --skip-extra-configs}"
 pass() {
   local name="$1"; shift
   timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o "$name" -- \
