@@ -289,7 +289,7 @@ int lay_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float 
             if (dbg->mean) { fp.dbg_mean = dbg->mean + (size_t)it * H * A; fp.dbg_mean_es = (long)I * H * A; }
             if (dbg->std) { fp.dbg_std = dbg->std + (size_t)it * H * A; fp.dbg_std_es = (long)I * H * A; }
         }
-        hipLaunchKernelGGL(k_refit, dim3(E), dim3(N), refit_lds, st, fp);
+        hipLaunchKernelGGL(k_refit, dim3(E), dim3(refit_threads(N)), refit_lds, st, fp);
         LAUNCH_CHECK();
     }
     return TDMPC2_OK;

@@ -247,7 +247,9 @@ struct PiTrajParamsT {
 // dynamic LDS of the refit; `stage` out: whether the K x H x A elite actions fit next to the rest (they are then gathered
 // by the whole workgroup in one round of loads instead of 2 K dependent global loads per (t, a) thread: 35 -> 12 us)
 inline size_t refit_lds_bytes(int N, int K, int H, int A, int *stage, size_t budget = 48 * 1024) {
-    const size_t base = ((size_t)N + 3 * K + 4 * H * A + 48) * 4 + 64;
+    size_t M = 64;
+    while (M < (size_t)N) M <<= 1;  // sort keys: 8 bytes per padded sample
+    const size_t base = (2 * M + 3 * (size_t)K + 4 * H * A + 48) * 4 + 64;
     const size_t elite = (size_t)K * H * A * 4;
     *stage = base + elite <= budget;
     return *stage ? base + elite : base;
@@ -284,9 +286,28 @@ __device__ __forceinline__ float block_max_lds(const float *x, int n, float *slo
 // Elite selection + refit (+ final pick) of plan `e` by one workgroup of `nthr` threads (a multiple of 64; any N <= 1024).
 // tdmpc2/tdmpc2.py:184-206.  Called by k_refit (one workgroup per plan) and by the last workgroup of a plan to finish
 // its rollouts (ks_rollout, fused family): the elite statistics are wavefront-shuffle reductions.
+// monotone map float -> uint (larger float <-> larger uint) and back; -0.0 has been folded into +0.0 by the caller
+__device__ __forceinline__ unsigned ordered_of(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_of_ordered(unsigned o) {
+    return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
+}
+#ifdef REFIT_TIMING  // probe builds: thread 0 leaves the cycle count of every phase in score[e][phase] (tools/probes)
+#define RT_MARK(i) { if (tid == 0 && p.score) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); p.score[(size_t)e * p.K + (i)] = (float)(t_ - rt_last); rt_last = t_; } }
+#define RT_INIT unsigned long long rt_last = __builtin_amdgcn_s_memtime();
+#else
+#define RT_MARK(i)
+#define RT_INIT
+#endif
+
 __device__ void refit_plan(const RefitParams &p, int e, float *smem, int tid, int nthr) {
-    float *sv = smem;                           // [N]
-    float *ev = sv + p.N;                       // [K]
+    int M = 64;  // sort width: the power of two >= N
+    while (M < p.N) M <<= 1;
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);  // [M] sort keys (or: [N] floats, counting path)
+    float *sv = smem;
+    float *ev = smem + 2 * M;                   // [K]
     float *sc = ev + p.K;                       // [K]
     int *ei = reinterpret_cast<int *>(sc + p.K);  // [K]
     float *smean = reinterpret_cast<float *>(ei + p.K);  // [H*A]
@@ -296,7 +317,10 @@ __device__ void refit_plan(const RefitParams &p, int e, float *smem, int tid, in
     float *omean = slots + 48;                           // [H*A] the distribution this iteration sampled from (regen)
     float *ostd = omean + p.H * p.A;                     // [H*A]
     float *ea = ostd + p.H * p.A;                        // [K][H*A] elite_actions (tdmpc2.py:186) when staged
+    RT_INIT
+    const bool sorted_path = M <= nthr;  // one key per thread
     // value.nan_to_num(0): nan -> 0, +-inf -> +-FLT_MAX (tdmpc2.py:184)
+    unsigned long long key = 0ull;  // padding keys sort last
     for (int i = tid; i < p.N; i += nthr) {
         // in-launch refit: the values of the plan's other workgroups arrive as write-through stores from other XCDs; read
         // them with agent-scope (sc1) loads -- past the L1, from lines this XCD's L2 cannot hold yet -- and do NOT
@@ -308,30 +332,64 @@ __device__ void refit_plan(const RefitParams &p, int e, float *smem, int tid, in
         else if (v == -INFINITY) v = -3.402823466e+38f;
         p.value[(size_t)e * p.N + i] = v;
         if (p.dbg_value) p.dbg_value[(size_t)e * p.dbg_value_es + i] = v;
-        sv[i] = v;
+        if (sorted_path) key = ((unsigned long long)ordered_of(v + 0.f) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        else sv[i] = v;
     }
-    __syncthreads();
-    // rank = position in (value desc, index asc) order; torch.topk(..., sorted=True) (tdmpc2.py:185).  Every thread
-    // compares its value with the whole LDS array: broadcast reads, no bank conflicts.
-    for (int i = tid; i < p.N; i += nthr) {
-        const float v = sv[i];
-        int rank = 0;
-        for (int j = 0; j < p.N; j += 4) {
-            const f32x4 u = *reinterpret_cast<const f32x4 *>(sv + j);  // N is a multiple of 64
+    RT_MARK(0)
+    if (sorted_path) {
+        // torch.topk(..., sorted=True) order (value desc, index asc on ties; tdmpc2.py:185) = descending order of the 64-bit
+        // keys (ordered value | ~index): a bitonic sort with one key per thread -- the 39 of 45 stages (N = 512) whose
+        // partner sits in the same wavefront are register shuffles, the rest go through LDS.
+        for (int k = 2; k <= M; k <<= 1) {
+            const bool desc = (tid & k) == 0;  // this k-block ends up descending (the last level: everyone)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                unsigned long long other;
+                if (j >= 64) {
+                    if (tid < M) keys[tid] = key;
+                    __syncthreads();
+                    other = tid < M ? keys[tid ^ j] : 0ull;
+                    __syncthreads();
+                } else {
+                    const unsigned lo = __shfl_xor((unsigned)key, j), hi = __shfl_xor((unsigned)(key >> 32), j);
+                    other = ((unsigned long long)hi << 32) | lo;
+                }
+                const bool lower = (tid & j) == 0;
+                const bool keep_max = lower == desc;
+                key = keep_max ? (key > other ? key : other) : (key < other ? key : other);
+            }
+        }
+        if (tid < p.K) {
+            ei[tid] = (int)(0xFFFFFFFFu - (unsigned)key);
+            ev[tid] = float_of_ordered((unsigned)(key >> 32));
+        }
+        __syncthreads();
+    } else {
+        __syncthreads();
+        // rank = position in (value desc, index asc) order by counting: every thread compares its value with the whole LDS
+        // array (broadcast reads, no bank conflicts).  Only when N exceeds the workgroup (N = 1024 inside the 512-thread
+        // rollout kernel).
+        for (int i = tid; i < p.N; i += nthr) {
+            const float v = sv[i];
+            int rank = 0;
+            for (int j = 0; j < p.N; j += 4) {
+                const f32x4 u = *reinterpret_cast<const f32x4 *>(sv + j);  // N is a multiple of 64
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rank += (u[q] > v) || (u[q] == v && j + q < i);
+                for (int q = 0; q < 4; ++q) rank += (u[q] > v) || (u[q] == v && j + q < i);
+            }
+            if (rank < p.K) {
+                ei[rank] = i;
+                ev[rank] = v;
+            }
         }
-        if (rank < p.K) {
-            ei[rank] = i;
-            ev[rank] = v;
-        }
+        __syncthreads();
     }
-    __syncthreads();
+    RT_MARK(1)
     const float vmax = ev[0];  // max(elite_value)
     for (int k = tid; k < p.K; k += nthr) sc[k] = expf(p.temperature * (ev[k] - vmax));
     const float s1 = block_sum_lds(sc, p.K, slots, tid, nthr);
     for (int k = tid; k < p.K; k += nthr) sc[k] = sc[k] / s1;  // score / score.sum(0)  (tdmpc2.py:191)
     const float s_ssum = block_sum_lds(sc, p.K, slots, tid, nthr) + 1e-9f;  // score.sum(0) + 1e-9 (tdmpc2.py:192-193)
+    RT_MARK(2)
     const float *acts = p.actions + (size_t)e * p.H * p.N * p.A;
     const int HA = p.H * p.A;
     if (p.regen) {  // (always staged) elite actions re-derived from (old mean, old std, noise): see RefitParams
@@ -373,26 +431,61 @@ __device__ void refit_plan(const RefitParams &p, int e, float *smem, int tid, in
         }
         __syncthreads();
     } else if (p.stage) {
-        for (int idx = tid; idx < p.K * HA; idx += nthr) {
-            const int k = idx / HA, ha = idx % HA;
-            const int t = ha / p.A, a = ha % p.A;
-            ea[idx] = acts[((size_t)t * p.N + ei[k]) * p.A + a];
+        // gather K x H x A elite actions: a wave takes every (nthr / 64)-th elite, its lanes the (t, a) columns -- one
+        // integer division per column instead of two per element, and the loads of a wave's elites are independent
+        const int wv = tid >> 6, ln = tid & 63, nwv = nthr >> 6;
+        for (int ha = ln; ha < HA; ha += 64) {
+            const int t = ha / p.A, a = ha - t * p.A;
+            const float *col = acts + (size_t)t * p.N * p.A + a;
+#pragma unroll 8
+            for (int k = wv; k < p.K; k += nwv) ea[k * HA + ha] = col[(size_t)ei[k] * p.A];
         }
         __syncthreads();
     }
+    RT_MARK(3)
+    if (p.stage) {
+        // four lanes per (t, a) output, each over a quarter of the elites, combined with two quad shuffles
+        const int sub = tid & 3;
+        for (int idx = tid >> 2; idx < HA; idx += nthr >> 2) {  // the four lanes of a quad share idx: uniform trip count
+            float m = 0.f;
+#pragma unroll 4
+            for (int k = sub; k < p.K; k += 4) m += sc[k] * ea[k * HA + idx];
+            m += __shfl_xor(m, 1);
+            m += __shfl_xor(m, 2);
+            m = m / s_ssum;
+            float s2 = 0.f;
+#pragma unroll 4
+            for (int k = sub; k < p.K; k += 4) {
+                const float d = ea[k * HA + idx] - m;
+                s2 += sc[k] * (d * d);
+            }
+            s2 += __shfl_xor(s2, 1);
+            s2 += __shfl_xor(s2, 2);
+            if (sub != 0) continue;
+            float sd = sqrtf(s2 / s_ssum);
+            sd = fminf(fmaxf(sd, p.min_std), p.max_std);
+            if (p.act_mask) {
+                const float mk = p.act_mask[(size_t)e * p.A + idx % p.A];
+                m *= mk;
+                sd *= mk;
+            }
+            smean[idx] = m;
+            sstd[idx] = sd;
+            p.mean[(size_t)e * p.H * p.A + idx] = m;
+            p.std[(size_t)e * p.H * p.A + idx] = sd;
+            if (p.dbg_mean) p.dbg_mean[(size_t)e * p.dbg_mean_es + idx] = m;
+            if (p.dbg_std) p.dbg_std[(size_t)e * p.dbg_std_es + idx] = sd;
+        }
+    } else
     for (int idx = tid; idx < HA; idx += nthr) {
         const int t = idx / p.A, a = idx % p.A;
         const float *at = acts + (size_t)t * p.N * p.A + a;
-        float m = 0.f;  // sums run over k in elite order in both forms: identical results
-        if (p.stage) {
-            for (int k = 0; k < p.K; ++k) m += sc[k] * ea[k * HA + idx];
-        } else {
-            for (int k = 0; k < p.K; ++k) m += sc[k] * at[(size_t)ei[k] * p.A];
-        }
+        float m = 0.f;
+        for (int k = 0; k < p.K; ++k) m += sc[k] * at[(size_t)ei[k] * p.A];
         m = m / s_ssum;
         float s2 = 0.f;
         for (int k = 0; k < p.K; ++k) {
-            const float d = (p.stage ? ea[k * HA + idx] : at[(size_t)ei[k] * p.A]) - m;
+            const float d = at[(size_t)ei[k] * p.A] - m;
             s2 += sc[k] * (d * d);
         }
         float sd = sqrtf(s2 / s_ssum);
@@ -409,12 +502,16 @@ __device__ void refit_plan(const RefitParams &p, int e, float *smem, int tid, in
         if (p.dbg_mean) p.dbg_mean[(size_t)e * p.dbg_mean_es + idx] = m;
         if (p.dbg_std) p.dbg_std[(size_t)e * p.dbg_std_es + idx] = sd;
     }
+    RT_MARK(4)
+#ifndef REFIT_TIMING
     for (int k = tid; k < p.K; k += nthr) {
         if (p.score) p.score[(size_t)e * p.K + k] = sc[k];
         if (p.elite_idx) p.elite_idx[(size_t)e * p.K + k] = ei[k];
         if (p.dbg_score) p.dbg_score[(size_t)e * p.dbg_score_es + k] = sc[k];
         if (p.dbg_idx) p.dbg_idx[(size_t)e * p.dbg_idx_es + k] = ei[k];
     }
+#endif
+    RT_MARK(5)
     if (!p.last) return;
     __syncthreads();
     // gumbel_softmax_sample(score) (tdmpc2/common/math.py:86-94): argmax softmax(log p - log Exp(1)); first index on ties
@@ -445,6 +542,14 @@ __device__ void refit_plan(const RefitParams &p, int e, float *smem, int tid, in
     }
     for (int idx = tid; idx < p.H * p.A; idx += nthr)
         p.prev_mean[(size_t)e * p.H * p.A + idx] = smean[idx];  // _prev_mean.copy_(mean) (tdmpc2.py:205)
+    RT_MARK(6)
+}
+
+// threads of a k_refit workgroup: the sort width (one key per thread)
+inline int refit_threads(int N) {
+    int M = 64;
+    while (M < N) M <<= 1;
+    return M;
 }
 
 // one workgroup per plan (layered family; tdmpc2_plan_refit)
@@ -869,7 +974,7 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
             h->ev_used += 2;
         }
         if (!fold) {
-            hipLaunchKernelGGL(k_refit, dim3(E), dim3(N), refit_lds, st, fp);
+            hipLaunchKernelGGL(k_refit, dim3(E), dim3(refit_threads(N)), refit_lds, st, fp);
             HIP_TRY(hipGetLastError());
         }
         // the per-iteration action dump reads h->actions after the refit (which does not write them)
@@ -1605,7 +1710,7 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
     const size_t lds = refit_lds_bytes(c.num_samples, c.num_elites, c.horizon, c.action_dim, &stage);
     RefitParams fp;
     fill_refit(h, fp, n_envs, iter, eval_mode, value, c.multitask ? act_mask : nullptr, tape, seed, h->shard_call, prev_mean, action, dbg, stage);
-    hipLaunchKernelGGL(k_refit, dim3(n_envs), dim3(c.num_samples), lds, st, fp);
+    hipLaunchKernelGGL(k_refit, dim3(n_envs), dim3(refit_threads(c.num_samples)), lds, st, fp);
     HIP_TRY(hipGetLastError());
     if (dbg && dbg->actions)
         HIP_TRY(hipMemcpy2DAsync(dbg->actions + (size_t)iter * c.horizon * c.num_samples * c.action_dim,
@@ -1900,7 +2005,7 @@ int tdmpc2_plan_refit(tdmpc2_plan_t *h, int n_envs, float *value, const float *a
     fp.temperature = c.temperature; fp.min_std = c.min_std; fp.max_std = c.max_std;
     fp.value = value; fp.actions = actions; fp.act_mask = c.multitask ? act_mask : nullptr;
     fp.mean = mean ? mean : h->mean; fp.std = std ? std : h->std; fp.score = score; fp.elite_idx = elite_idx;
-    hipLaunchKernelGGL(k_refit, dim3(n_envs), dim3(c.num_samples), refit_lds, st, fp);
+    hipLaunchKernelGGL(k_refit, dim3(n_envs), dim3(refit_threads(c.num_samples)), refit_lds, st, fp);
     HIP_TRY(hipGetLastError());
     return TDMPC2_OK;
 }
