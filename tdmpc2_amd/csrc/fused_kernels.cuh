@@ -270,12 +270,174 @@ __device__ __forceinline__ void kloop_f32(const CT &c, const LayerS &ly, int kb0
     }
 }
 
+// ---------------------------------------------------------------- hand-ordered contraction loop (split arithmetic)
+// hipcc schedules the C++ loop above as [12 MFMA] [4 weight loads] [4 LDS reads of the NEXT block] -> the LDS reads sit
+// right in front of their first use (the register coalescer merges "next" into "current" fragments; sched_group_barrier
+// does not move them).  tools/probes/order_probe.hip: with the same traffic, issuing the LDS reads FIRST is 3 % faster, and
+// the probe's loop -- no per-step VALU address arithmetic, no partial waits -- runs at 0.89 of the matrix pipe (at the
+// power-managed clock) against 0.71 for the compiler's loop inside the kernel.  So the loop is written out: every LDS
+// read, weight load and MFMA of a step is an `asm volatile` (source order = issue order), weights through SGPR base +
+// one VGPR lane offset (no 64-bit VALU adds), activations from two fragment sets used alternately, explicit s_waitcnt:
+//     top of step kk:  lgkmcnt(0)            this block's activation fragments (issued a whole step earlier)
+//                      4 ds_read_b128        block kk + 1 -> the other fragment set
+//                      vmcnt(4 | 0)          this block's weight fragments (all but the 4 newer loads of block kk + 1)
+//                      12 MFMA
+//                      4 global_load_dwordx4 block kk + 2 -> this block's ring slot
+// Counter hygiene: only "all but the newest N of MY OWN loads" waits are used for vmcnt (loads return in order, anything
+// the compiler still has in flight is older: the wait is merely conservative), lgkmcnt is only ever waited to 0 (scalar
+// loads share that counter and return out of order), no load is in flight when the loop ends (the compiler reuses the
+// destination registers), and 16 wait states separate the last MFMA from the compiler's first read of an accumulator.
+#ifndef SPLIT_NO_ASM_KLOOP
+#define SPLIT_ASM_KLOOP 1
+#endif
+#ifdef SPLIT_ASM_KLOOP
+#define A_MFMA(ACC, WF, AF) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(WF), "v"(AF))
+template <int OFF>
+__device__ __forceinline__ void a_dsrd(f16x8 &dst, unsigned addr) {
+#ifdef ASMK_NO_DS
+    dst = *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>((size_t)(addr + OFF));
+#else
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+#endif
+}
+template <int OFF>
+__device__ __forceinline__ void a_gld(f16x8 &dst, unsigned voff, const char *sbase) {
+#ifdef ASMK_NO_GLD
+    dst = *reinterpret_cast<const f16x8 *>(sbase + voff + OFF);
+#elif defined(ASMK_VADDR)
+    const char *vp = sbase + voff;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(vp), "n"(OFF));
+#elif defined(ASMK_RFL)
+    // force the base through v_readfirstlane: an "s" operand whose value the compiler only knows as per-lane
+    const unsigned long long b = (unsigned long long)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const char *ub = (const char *)(((unsigned long long)hi << 32) | lo);
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(ub), "n"(OFF));
+#else
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF));
+#endif
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void *p) {  // byte address inside the workgroup's LDS allocation
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(p);
+}
+// one block's activation fragments (hi / lo planes of the NST row tiles) from LDS byte address `la` (+ 72 KB for tile 1)
+template <class CT>
+__device__ __forceinline__ void a_load_act(AFragT<CT::NST> &a, unsigned la0, unsigned la1) {
+    a_dsrd<0>(a.h[0], la0);
+    a_dsrd<2 * CT::SH>(a.l[0], la0);
+    if constexpr (CT::NST == 2) {
+        a_dsrd<0>(a.h[1], la1);
+        a_dsrd<2 * CT::SH>(a.l[1], la1);
+    }
+}
+// one k-block of two column tiles: hi plane, lo plane (+1024 B) of tile 0 at `s0`, of tile 1 at `s1`.  ONE asm statement,
+// opened by s_nop 4: the base pointers are often restored from spill lanes (v_readlane / v_readfirstlane: VALU writes of
+// an SGPR) right in front of the loads, and a VMEM instruction that reads such an SGPR needs 5 wait states -- the
+// compiler's hazard recognizer does not look inside inline asm (found the hard way: memory faults, tools/probes/saddr_test.hip).
+__device__ __forceinline__ void a_load_w(BFragT<2> &b, unsigned voff, const char *s0, const char *s1) {
+#if defined(ASMK_NO_GLD)
+    a_gld<0>(b.h[0], voff, s0);
+    a_gld<1024>(b.l[0], voff, s0);
+    a_gld<0>(b.h[1], voff, s1);
+    a_gld<1024>(b.l[1], voff, s1);
+#else
+    asm volatile("s_nop 4\n\t"
+                 "global_load_dwordx4 %0, %4, %5\n\t"
+                 "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                 "global_load_dwordx4 %2, %4, %6\n\t"
+                 "global_load_dwordx4 %3, %4, %6 offset:1024"
+                 : "=&v"(b.h[0]), "=&v"(b.l[0]), "=&v"(b.h[1]), "=&v"(b.l[1])
+                 : "v"(voff), "s"(s0), "s"(s1));
+#endif
+}
+template <class CT>
+__device__ __forceinline__ void a_mfma12(f32x16 (&acc)[CT::NST][2], const BFragT<2> &w, const AFragT<CT::NST> &a) {
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int st = 0; st < CT::NST; ++st) A_MFMA(acc[st][cc], w.h[cc], a.h[st]);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int st = 0; st < CT::NST; ++st) A_MFMA(acc[st][cc], w.l[cc], a.h[st]);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int st = 0; st < CT::NST; ++st) A_MFMA(acc[st][cc], w.h[cc], a.l[st]);
+}
+
+template <class CT>
+__device__ __forceinline__ void kloop_asm(const CT &c, const LayerS &ly, int kb0, int kb1, f32x16 (&acc)[CT::NST][2]) {
+    static_assert(CT::FT == 2 && CT::ARITH == 0, "hand-ordered loop: 8-wave split-arithmetic geometry");
+    const int i = c.lane & 31, hh = c.lane >> 5;
+    unsigned la0 = lds_addr_of(c.act) + (unsigned)((i * CT::RSH + 8 * hh + kb0 * 16) * 2);
+    unsigned la1 = la0 + 32 * CT::RSH * 2;
+    const char *u0 = reinterpret_cast<const char *>(ly.wp) + ((size_t)(2 * c.wave) * ly.KB + kb0) * 2048;  // wave-uniform
+    const size_t cts = (size_t)ly.KB * 2048;
+    const unsigned voff = (unsigned)c.lane * 16u;
+    const int nk = kb1 - kb0;
+    BFragT<2> ring[2];
+    AFragT<CT::NST> a2[2];
+    a_load_w(ring[0], voff, u0, u0 + cts);
+    if (nk > 1) a_load_w(ring[1], voff, u0 + 2048, u0 + cts + 2048);
+    a_load_act<CT>(a2[0], la0, la1);
+    int k = 0;
+    const char *pn = u0 + 2 * 2048;  // block k + 2
+    // steady state, two steps per trip (ring slot / fragment set = step parity), no conditionals: while k + 3 < nk
+#pragma unroll 1
+    for (; k + 3 < nk; k += 2) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            la0 += 32;
+            la1 += 32;
+            a_load_act<CT>(a2[d ^ 1], la0, la1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            a_mfma12<CT>(acc, ring[d], a2[d]);
+            a_load_w(ring[d], voff, pn, pn + cts);
+            pn += 2048;
+        }
+    }
+    // the last two or three steps
+#pragma unroll 1
+    for (; k < nk; k += 2) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int kk = k + d;
+            if (kk < nk) {  // wave-uniform
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (kk + 1 < nk) {
+                    la0 += 32;
+                    la1 += 32;
+                    a_load_act<CT>(a2[d ^ 1], la0, la1);
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                a_mfma12<CT>(acc, ring[d], a2[d]);
+                if (kk + 2 < nk) {
+                    a_load_w(ring[d], voff, pn, pn + cts);
+                    pn += 2048;
+                }
+            }
+        }
+    }
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // XDL write -> VALU read of the accumulators
+}
+#endif
+
 template <class CT>
 __device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, int kb1, f32x16 (&acc)[CT::NST][CT::FT]) {
     if constexpr (CT::ARITH == 1) {
         kloop_f32(c, ly, kb0, kb1, acc);
         return;
     }
+#ifdef SPLIT_ASM_KLOOP
+    if constexpr (CT::ARITH == 0 && CT::FT == 2) {
+        kloop_asm(c, ly, kb0, kb1, acc);
+        return;
+    }
+#endif
     constexpr int FT = CT::FT;
     constexpr int PFD = FT == 2 ? PF : (PF > 1 ? PF / 2 : 1);  // ring depth in k-blocks: FT x 8 VGPRs per block
     const int i = c.lane & 31, hh = c.lane >> 5;
@@ -1007,7 +1169,7 @@ __device__ __forceinline__ float head_term_s(const CT &c, const LayerS &ly) {
 // wave instead of 2 x 12 with two reads of the same fragments): identical sums in identical order, so results do not change
 // by a bit; +1.5 ... 2.6 % on the launch (A/B in one gpurun call, profiles/README.md r02c).  Weight ring one k-block deep
 // per net.  -DSPLIT_NO_PAIR restores the two separate loops.
-#ifndef SPLIT_NO_PAIR
+#if !defined(SPLIT_NO_PAIR) && !defined(SPLIT_ASM_KLOOP)  // the hand-ordered loop (kloop_asm) beats the paired compiler loop
 #define SPLIT_PAIR 1
 #endif
 #ifdef SPLIT_PAIR

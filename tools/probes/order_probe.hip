@@ -1,0 +1,132 @@
+// Probe (MI355X): does the ISSUE ORDER inside a k-loop step matter?  Same geometry and traffic as ks_rollout's split k-loop
+// (8 waves / workgroup, 1 workgroup / CU; per wave and step: 12 v_mfma_f32_32x32x16_f16, 4 ds_read_b128 of activation
+// fragments, 4 global_load_dwordx4 of weight fragments two steps ahead), every memory instruction and MFMA as
+// `asm volatile` so that the source order IS the issue order:
+//   ORDER 0  [12 MFMA] [4 VMEM] [4 DS for the next step]            <- what hipcc schedules for the C++ loop
+//   ORDER 1  [4 DS for the next step] [12 MFMA] [4 VMEM]
+//   ORDER 2  [4 DS] then VMEM interleaved: M M M V M M M V M M M V M M M V
+//   ORDER 3  [2 DS] M M M [2 DS] V M M M V M M M V M M M V
+// build: hipcc --offload-arch=gfx950 -O3 -o order_probe order_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MFMA(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define DSRD(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:" #off : "=v"(dst) : "v"(addr))
+#define GLD(dst, ptr, off) asm volatile("global_load_dwordx4 %0, %1, off offset:" #off : "=v"(dst) : "v"(ptr))
+#define WAIT(s) asm volatile("s_waitcnt " s ::: "memory")
+
+template <int ORDER>
+__global__ __launch_bounds__(512) void probe(const f32x4 *__restrict__ w, float *out, int steps, int wg_stride_vec) {
+    extern __shared__ char lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 *l4 = reinterpret_cast<f32x4 *>(lds);
+    for (int i = threadIdx.x; i < 140 * 1024 / 16; i += 512) l4[i] = f32x4{1e-3f * i, 0.f, 1.f, 2.f};
+    __syncthreads();
+    const f32x4 *wp = w + (size_t)(blockIdx.x % 8) * wg_stride_vec + wave * 64 * 4 + lane;
+    f32x16 acc[4];
+    for (int t = 0; t < 4; ++t) for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    f32x4 g[2][4], a[2][4];
+    for (int d = 0; d < 2; ++d) for (int q = 0; q < 4; ++q) { g[d][q] = f32x4{0.f, 0.f, 0.f, 0.f}; a[d][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int nwrap = wg_stride_vec / (8 * 64 * 4);
+    unsigned laddr = (unsigned)(lane * 16);
+    int sidx = 0;
+    // prologue: both ring slots in flight (keeps vmcnt bookkeeping uniform: 8 loads outstanding at the top of a step)
+    for (int d = 0; d < 2; ++d) {
+        const f32x4 *p = wp + (size_t)sidx * 2048;
+        GLD(g[d][0], p, 0); GLD(g[d][1], p, 1024); GLD(g[d][2], p, 2048); GLD(g[d][3], p, 3072);
+        sidx = sidx + 1 == nwrap ? 0 : sidx + 1;
+    }
+#pragma unroll 1
+    for (int s = 0; s < steps; s += 2) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const f32x4 *p = wp + (size_t)sidx * 2048;
+            sidx = sidx + 1 == nwrap ? 0 : sidx + 1;
+            const unsigned la = laddr + (unsigned)(((s + d) * 592) & 0xFFFF);
+#define A_(q) __builtin_bit_cast(f16x8, a[d][q])
+#define AN_(q) a[d ^ 1][q]
+#define G_(q) __builtin_bit_cast(f16x8, g[d][q])
+            if (ORDER == 0) {
+                WAIT("vmcnt(4) lgkmcnt(0)");
+                MFMA(acc[0], G_(0), A_(0)); MFMA(acc[1], G_(0), A_(1)); MFMA(acc[2], G_(1), A_(0)); MFMA(acc[3], G_(1), A_(1));
+                MFMA(acc[0], G_(2), A_(0)); MFMA(acc[1], G_(2), A_(1)); MFMA(acc[2], G_(3), A_(0)); MFMA(acc[3], G_(3), A_(1));
+                MFMA(acc[0], G_(0), A_(2)); MFMA(acc[1], G_(0), A_(3)); MFMA(acc[2], G_(1), A_(2)); MFMA(acc[3], G_(1), A_(3));
+                GLD(g[d][0], p, 0); GLD(g[d][1], p, 1024); GLD(g[d][2], p, 2048); GLD(g[d][3], p, 3072);
+                DSRD(AN_(0), la, 0); DSRD(AN_(1), la, 2304); DSRD(AN_(2), la, 4608); DSRD(AN_(3), la, 6912);
+            } else if (ORDER == 1) {
+                DSRD(AN_(0), la, 0); DSRD(AN_(1), la, 2304); DSRD(AN_(2), la, 4608); DSRD(AN_(3), la, 6912);
+                WAIT("vmcnt(4) lgkmcnt(4)");
+                MFMA(acc[0], G_(0), A_(0)); MFMA(acc[1], G_(0), A_(1)); MFMA(acc[2], G_(1), A_(0)); MFMA(acc[3], G_(1), A_(1));
+                MFMA(acc[0], G_(2), A_(0)); MFMA(acc[1], G_(2), A_(1)); MFMA(acc[2], G_(3), A_(0)); MFMA(acc[3], G_(3), A_(1));
+                MFMA(acc[0], G_(0), A_(2)); MFMA(acc[1], G_(0), A_(3)); MFMA(acc[2], G_(1), A_(2)); MFMA(acc[3], G_(1), A_(3));
+                GLD(g[d][0], p, 0); GLD(g[d][1], p, 1024); GLD(g[d][2], p, 2048); GLD(g[d][3], p, 3072);
+            } else if (ORDER == 2) {
+                DSRD(AN_(0), la, 0); DSRD(AN_(1), la, 2304); DSRD(AN_(2), la, 4608); DSRD(AN_(3), la, 6912);
+                WAIT("vmcnt(4) lgkmcnt(4)");
+                // fragments 2, 3 (the "lo" planes) are consumed first so that their reloads can go out early
+                MFMA(acc[0], G_(2), A_(0)); MFMA(acc[1], G_(2), A_(1)); MFMA(acc[2], G_(3), A_(0)); MFMA(acc[3], G_(3), A_(1));
+                GLD(g[d][2], p, 2048);
+                MFMA(acc[0], G_(0), A_(0)); MFMA(acc[1], G_(0), A_(1)); MFMA(acc[2], G_(1), A_(0));
+                GLD(g[d][3], p, 3072);
+                MFMA(acc[3], G_(1), A_(1)); MFMA(acc[0], G_(0), A_(2)); MFMA(acc[1], G_(0), A_(3));
+                GLD(g[d][0], p, 0);
+                MFMA(acc[2], G_(1), A_(2)); MFMA(acc[3], G_(1), A_(3));
+                GLD(g[d][1], p, 1024);
+            } else {
+                DSRD(AN_(0), la, 0); DSRD(AN_(1), la, 2304);
+                WAIT("vmcnt(4) lgkmcnt(2)");
+                MFMA(acc[0], G_(2), A_(0)); MFMA(acc[1], G_(2), A_(1)); MFMA(acc[2], G_(3), A_(0)); MFMA(acc[3], G_(3), A_(1));
+                DSRD(AN_(2), la, 4608); DSRD(AN_(3), la, 6912);
+                GLD(g[d][2], p, 2048);
+                MFMA(acc[0], G_(0), A_(0)); MFMA(acc[1], G_(0), A_(1)); MFMA(acc[2], G_(1), A_(0));
+                GLD(g[d][3], p, 3072);
+                MFMA(acc[3], G_(1), A_(1)); MFMA(acc[0], G_(0), A_(2)); MFMA(acc[1], G_(0), A_(3));
+                GLD(g[d][0], p, 0);
+                MFMA(acc[2], G_(1), A_(2)); MFMA(acc[3], G_(1), A_(3));
+                GLD(g[d][1], p, 1024);
+            }
+        }
+    }
+    WAIT("vmcnt(0) lgkmcnt(0)");
+    float r = 0.f;
+    for (int t = 0; t < 4; ++t) for (int i = 0; i < 16; ++i) r += acc[t][i];
+    for (int d = 0; d < 2; ++d) for (int q = 0; q < 4; ++q) r += g[d][q][0] + a[d][q][0];
+    if (r == 12345.678f) out[threadIdx.x] = r;
+}
+
+template <int ORDER>
+float run(const f32x4 *w, float *out, int steps, int stride) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipFuncSetAttribute((const void *)probe<ORDER>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    probe<ORDER><<<256, 512, 150 * 1024>>>(w, out, 64, stride);
+    (void)hipEventRecord(e0);
+    probe<ORDER><<<256, 512, 150 * 1024>>>(w, out, steps, stride);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
+int main() {
+    const int stride = 2560 * 1024 / 16;
+    f32x4 *w; float *out;
+    (void)hipMalloc(&w, (size_t)8 * stride * 16); (void)hipMalloc(&out, 4096);
+    // random f16 bit patterns: the matrix pipe's power draw (hence the clock) depends on the operand data
+    {
+        unsigned *h = (unsigned *)malloc((size_t)8 * stride * 16);
+        unsigned x = 12345u;
+        for (size_t i = 0; i < (size_t)8 * stride * 4; ++i) { x = x * 1664525u + 1013904223u; h[i] = (x & 0x3FFF3FFFu) | 0x20002000u; }
+        (void)hipMemcpy(w, h, (size_t)8 * stride * 16, hipMemcpyHostToDevice);
+        free(h);
+    }
+    const int steps = 20000;
+    for (int rep = 0; rep < 3; ++rep)
+        printf("order0 (MFMA, VMEM, DS-late) %.3f   order1 (DS-first) %.3f   order2 (DS-first, VMEM interleaved) %.3f   order3 (DS split, interleaved) %.3f ms\n",
+               run<0>(w, out, steps, stride), run<1>(w, out, steps, stride), run<2>(w, out, steps, stride), run<3>(w, out, steps, stride));
+    printf("ideal: %d steps x 24 MFMA x 32 cycles per SIMD = %.3f ms at 1.9 GHz, %.3f ms at 2.4 GHz\n", steps, steps * 768.0 / 1.9e6, steps * 768.0 / 2.4e6);
+    return 0;
+}
