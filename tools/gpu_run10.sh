@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x 2>&1 | grep -E "passed|failed|Abort|fault|FAILED" | head -5
+TDMPC2_PLAN_LIB=$PWD/build/ablate/lib_asmh48.so timeout 600 python -m pytest tests/test_gpu_planner.py tests/test_gpu_layers.py tests/test_gpu_td_target.py -m gpu -q --tb=short -p no:cacheprovider -k "c2" 2>&1 | grep -E "passed|failed|Abort|fault|FAILED" | head -5
 run() { # name, lib
   TDMPC2_PLAN_LIB=$2 timeout 300 python bench.py --steps 10 --warmup 3 --skip-cpu-baseline --skip-extra-configs > gpurun_out/r02h_bench_$1.json 2> gpurun_out/r02h_bench_$1.err
   python - <<PY
@@ -13,6 +13,7 @@ except Exception as e:
     print("$1 FAILED", e); print(open("gpurun_out/r02h_bench_$1.err").read()[-800:])
 PY
 }
-run noasm $PWD/build/ablate/lib_noasm48.so
 run asm $PWD/build/ablate/lib_asm48.so
-run full $PWD/tdmpc2_amd/libtdmpc2_plan.so
+run asmh $PWD/build/ablate/lib_asmh48.so
+run asm2 $PWD/build/ablate/lib_asm48.so
+run asmh2 $PWD/build/ablate/lib_asmh48.so
