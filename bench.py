@@ -224,12 +224,29 @@ def config_leg(name, E, steps, device, rank=0):
     finite = bool(torch.isfinite(out).all())
     dev_mib = planner.device_bytes / 2**20
     planner.close()
+    # the reference's own semantics: one environment, one plan at a time (evaluate.py:80)
+    one = NativePlanner(cfg, I, device, max_envs=1)
+    one.bind_state_dict(sd)
+    z1, d1, p1 = z0[:1].contiguous(), disc[:1].contiguous(), torch.zeros(1, cfg.horizon, cfg.action_dim, device=device)
+    e1 = emb[:1].contiguous() if emb is not None else None
+    m1 = mask[:1].contiguous() if mask is not None else None
+    o1 = torch.empty(1, cfg.action_dim, device=device)
+    for i in range(2):
+        one.plan(z1, d1, p1, warm[:1], seed=i, out=o1, task_emb=e1, act_mask=m1)
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    for i in range(3):
+        one.plan(z1, d1, p1, warm[:1], seed=10 + i, out=o1, task_emb=e1, act_mask=m1)
+    torch.cuda.synchronize(device)
+    lat1 = (time.perf_counter() - t1) / 3 * 1e3
+    one.close()
     launch_s = (ms / 1e3) / max(n, 1)
     peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
     ach = flops_rollout_launch(cfg, E) / launch_s / 1e12
     ach_x = flops_rollout_executed(cfg, E, family == "fused") / launch_s / 1e12
     return {
         "value": round(steps * E / el, 2), "unit": "plans/s", "steps": steps, "ms_per_step": round(1e3 * el / steps, 3), "finite": finite,
+        "latency_ms_single_env": round(lat1, 3),
         "config": {"workload": f"{name}: {cfg.task} world model (L{cfg.latent_dim} M{cfg.mlp_dim} A{cfg.action_dim} nq{cfg.num_q} "
                                f"T{cfg.task_dim}), plan() H={cfg.horizon} N={cfg.num_samples} K={cfg.num_elites} P={cfg.num_pi_trajs} "
                                f"I={I}, {E} concurrent plans (one per task id, round-robin), random-init weights",

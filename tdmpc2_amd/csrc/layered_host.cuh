@@ -32,9 +32,18 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             q.bias_sel_stride = sel ? bias_sel_stride : 0;
         }
         q.sel = sel; q.sel_stride = 2; q.rows_per_env = rows_per_env; q.out = out; q.ldo = ldo;
-        const int nblk = (int)(rows_p / GBM) * q.ncolblk;
-        if (wide) hipLaunchKernelGGL(g_gemm_s<2>, dim3(nblk), dim3(GTHREADS), 0, st, q);
-        else hipLaunchKernelGGL(g_gemm_s<1>, dim3(nblk), dim3(GTHREADS), 0, st, q);
+        // rows per workgroup tile: 128 when that fills the chip (two workgroups per CU), else 64 or 32 -- few rows mean
+        // single-plan latency, where occupancy beats operand reuse (TDMPC2_GEMM_RT=4 forces the 128-row tile)
+        const long slots = 2L * (h->num_cus > 0 ? h->num_cus : 256);
+        int rt = 4;
+        if (!wide && !getenv("TDMPC2_GEMM_RT4")) {
+            while (rt > 1 && (long)(rows_p / (32 * rt)) * q.ncolblk < slots * 3 / 4) rt >>= 1;
+        }
+        const int nblk = (int)(rows_p / (32 * rt)) * q.ncolblk;
+        if (wide) hipLaunchKernelGGL((g_gemm_s<2, 4>), dim3(nblk), dim3(GTHREADS), 0, st, q);
+        else if (rt == 4) hipLaunchKernelGGL((g_gemm_s<1, 4>), dim3(nblk), dim3(GTHREADS), 0, st, q);
+        else if (rt == 2) hipLaunchKernelGGL((g_gemm_s<1, 2>), dim3(nblk), dim3(GTHREADS), 0, st, q);
+        else hipLaunchKernelGGL((g_gemm_s<1, 1>), dim3(nblk), dim3(GTHREADS), 0, st, q);
         LAUNCH_CHECK();
         return 0;
     }

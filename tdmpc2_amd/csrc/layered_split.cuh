@@ -36,14 +36,18 @@ struct GemmSParams {
 // 2 -> 128 x 256 (a wave owns 64 columns x 128 rows = 8 accumulators: per k16-block 4 KB of weight fragments and 8 KB of
 // row fragments feed 24 MFMAs, 512 operand bytes per MFMA against 853 with NCT = 1 -- operand delivery, not MFMA issue,
 // is what bounds these loops, profiles/README.md).
-template <int NCT>
+// RT = 32-row tiles per workgroup: 4 (128 rows, throughput) or 2 / 1 (64 / 32 rows: calls with few rows -- single-plan
+// latency of the 48M / 317M models, where 128-row tiles leave most of the chip idle: c3 at E = 1 is 4 x 14 = 56
+// workgroups on 512 slots; every weight fragment then feeds fewer MFMAs, which does not matter while the chip is not full).
+template <int NCT, int RT = 4>
 __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
-    __shared__ __attribute__((aligned(16))) _Float16 As[2][2][GBM * GS_LDH];  // [buffer][plane][row][k]
+    constexpr int TM = 32 * RT;  // rows of this workgroup's tile
+    __shared__ __attribute__((aligned(16))) _Float16 As[2][2][TM * GS_LDH];  // [buffer][plane][row][k]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rb, cb;
     gemm_tile_of_block(blockIdx.x, gridDim.x, p.ncolblk, rb, cb);
-    const int row0 = rb * GBM;
+    const int row0 = rb * TM;
     const int sel = p.sel ? p.sel[(size_t)(row0 / p.rows_per_env) * p.sel_stride] : 0;
     const int KB = p.K / 16;
     const int ct0 = (cb * 4 + wave) * NCT;
@@ -58,30 +62,30 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     unsigned voff = (unsigned)lane * 16u;
     asm volatile("" : "+v"(voff));
 
-    // A staging: 128 rows x 2 planes x 4 sixteen-byte pieces per 32-wide chunk = 1024 pieces, 4 per thread
+    // A staging: TM rows x 2 planes x 4 sixteen-byte pieces per 32-wide chunk = 8 TM pieces, RT per thread
     const char *ab = reinterpret_cast<const char *>(p.A) + (size_t)row0 * p.lda * 4;
-    int g_off[4], l_off[4];
+    int g_off[RT], l_off[RT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT; ++i) {
         const int idx = tid + 256 * i;
-        const int plane = idx >> 9, r = (idx >> 2) & 127, c16 = idx & 3;
+        const int plane = idx / (4 * TM), r = (idx >> 2) % TM, c16 = idx & 3;
         g_off[i] = r * p.lda * 4 + plane * p.lda * 2 + c16 * 16;
-        l_off[i] = (plane * GBM * GS_LDH + r * GS_LDH) * 2 + c16 * 16;
+        l_off[i] = (plane * TM * GS_LDH + r * GS_LDH) * 2 + c16 * 16;
     }
-    f32x4 stage[4];
+    f32x4 stage[RT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) stage[i] = *reinterpret_cast<const f32x4 *>(ab + g_off[i]);
+    for (int i = 0; i < RT; ++i) stage[i] = *reinterpret_cast<const f32x4 *>(ab + g_off[i]);
     char *lds = reinterpret_cast<char *>(&As[0][0][0]);
-    constexpr int BUF_BYTES = 2 * GBM * GS_LDH * 2;
+    constexpr int BUF_BYTES = 2 * TM * GS_LDH * 2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(lds + l_off[i]) = stage[i];
+    for (int i = 0; i < RT; ++i) *reinterpret_cast<f32x4 *>(lds + l_off[i]) = stage[i];
     __syncthreads();
 
-    f32x16 acc[NCT][4];
+    f32x16 acc[NCT][RT];
 #pragma unroll
     for (int n = 0; n < NCT; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < RT; ++r)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[n][r][e] = 0.f;
 
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
                 const bool more = ch + 1 < nchunks;
                 if (more) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < RT; ++i)
                         stage[i] = *reinterpret_cast<const f32x4 *>(ab + g_off[i] + (size_t)(ch + 1) * GBK * 2);
                 }
                 const _Float16 *ah = &As[ch & 1][0][0] + i32 * GS_LDH + 8 * hh;
@@ -115,24 +119,24 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     const int d = (cc * 2 + kb) % PFB;
-                    f16x8 fh[4], fl[4];
+                    f16x8 fh[RT], fl[RT];
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) {
+                    for (int rt = 0; rt < RT; ++rt) {
                         fh[rt] = *reinterpret_cast<const f16x8 *>(ah + rt * 32 * GS_LDH + kb * 16);
                         fl[rt] = *reinterpret_cast<const f16x8 *>(al + rt * 32 * GS_LDH + kb * 16);
                     }
 #pragma unroll
                     for (int n = 0; n < NCT; ++n)
 #pragma unroll
-                        for (int rt = 0; rt < 4; ++rt) acc[n][rt] = SPLIT_MFMA(fh[rt], rh[d][n], acc[n][rt]);
+                        for (int rt = 0; rt < RT; ++rt) acc[n][rt] = SPLIT_MFMA(fh[rt], rh[d][n], acc[n][rt]);
 #pragma unroll
                     for (int n = 0; n < NCT; ++n)
 #pragma unroll
-                        for (int rt = 0; rt < 4; ++rt) acc[n][rt] = SPLIT_MFMA(fh[rt], rl[d][n], acc[n][rt]);
+                        for (int rt = 0; rt < RT; ++rt) acc[n][rt] = SPLIT_MFMA(fh[rt], rl[d][n], acc[n][rt]);
 #pragma unroll
                     for (int n = 0; n < NCT; ++n)
 #pragma unroll
-                        for (int rt = 0; rt < 4; ++rt) acc[n][rt] = SPLIT_MFMA(fl[rt], rh[d][n], acc[n][rt]);
+                        for (int rt = 0; rt < RT; ++rt) acc[n][rt] = SPLIT_MFMA(fl[rt], rh[d][n], acc[n][rt]);
                     const int kn = ch * 2 + kb + PFB;
                     const int knc = kn < KB ? kn : KB - 1;
 #pragma unroll
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
                 if (more) {
                     char *dst = lds + ((ch + 1) & 1) * BUF_BYTES;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(dst + l_off[i]) = stage[i];
+                    for (int i = 0; i < RT; ++i) *reinterpret_cast<f32x4 *>(dst + l_off[i]) = stage[i];
                 }
                 __syncthreads();
             }
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
         const int col = (ct0 + n) * 32 + i32;
         const float bshared = p.bias_env_stride == 0 ? bsel[col] : 0.f;
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = row0 + rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
