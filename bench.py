@@ -180,6 +180,55 @@ def cpu_baseline(cfg, iterations, sd_np, budget_s=12.0):
             "ms_per_plan": round(1e3 * el / n, 2)}
 
 
+def c5_leg(device, rank, world, fence, steps=2, envs_per_gpu=64):
+    """BASELINE.json configs[4]: mt80 317M (c4's model, H5 N1024), 64 vectorised synthetic envs per GPU, env-sharded over the
+    ranks of this job (512 envs at 8 GPUs) -- run by EVERY rank after the main measurement when the job has more than one
+    GPU; same timing protocol (barrier + synchronize on both sides, max over ranks)."""
+    import torch.distributed as dist
+    from tdmpc2_amd.native import NativePlanner
+
+    cfg = named_config("c4")
+    I = cfg.iterations + 2 * int(cfg.action_dim >= 20)
+    E = envs_per_gpu
+    sd_np = synth.make_state_dict(cfg, seed=0)  # identical on every rank (seeded): no broadcast needed for the leg
+    sd = {k: torch.as_tensor(v).to(device) for k, v in sd_np.items() if not k.startswith("_encoder.")}
+    planner = NativePlanner(cfg, I, device, max_envs=E)
+    planner.bind_state_dict(sd)
+    tasks = (torch.arange(E) + rank * E) % len(cfg.tasks)
+    w = torch.as_tensor(sd_np["_task_emb.weight"])[tasks]
+    n = w.norm(dim=1, keepdim=True)
+    emb = torch.where(n > 1.0, w / (n + 1e-7), w).to(device).contiguous()
+    mask = torch.as_tensor(sd_np["_action_masks"])[tasks].to(device).contiguous()
+    del sd_np
+    z0 = torch.as_tensor(synth.make_latents(cfg, E, seed=3000 + rank)).to(device)
+    disc = disc_pow_rows(cfg, E, device)
+    prev = torch.zeros(E, cfg.horizon, cfg.action_dim, device=device)
+    warm = torch.zeros(E, dtype=torch.uint8, device=device)
+    out = torch.empty(E, cfg.action_dim, device=device)
+    planner.plan(z0, disc, prev, torch.ones_like(warm), task_emb=emb, act_mask=mask, seed=(rank << 32) + 1, out=out)
+    planner.set_profiling(steps * I)
+    fence()
+    t1 = time.perf_counter()
+    for i in range(steps):
+        planner.plan(z0, disc, prev, warm, task_emb=emb, act_mask=mask, seed=(rank << 32) + 10 + i, out=out)
+    fence()
+    el = time.perf_counter() - t1
+    ms, nl = planner.profile_read()
+    planner.close()
+    t = torch.tensor([el], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    launch_s = (ms / 1e3) / max(nl, 1)
+    ach = flops_rollout_launch(cfg, E) / launch_s / 1e12
+    return {"value": round(world * E * steps / el, 2), "unit": "plans/s (whole job)", "n_gpus": world, "steps": steps,
+            "ms_per_step": round(1e3 * el / steps, 2), "scaling": "weak",
+            "config": {"workload": f"c5: mt80 317M (L{cfg.latent_dim} M{cfg.mlp_dim} nq{cfg.num_q}), plan() H={cfg.horizon} "
+                                   f"N={cfg.num_samples} I={I}, {E} envs per GPU x {world} GPUs = {world * E} envs, env-sharded, "
+                                   "no collective in the timed region", "envs_per_gpu": E},
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (this rank)",
+                         "frac": round(ach / F16_MFMA_PEAK_TFLOPS, 4), "avg_stage_ms": round(1e3 * launch_s, 3), "traffic": None}}
+
+
 def config_leg(name, E, steps, device, rank=0):
     """A short measurement of another BASELINE.json configuration (c3: mt30 48M, one plan per task id; c4: mt80 317M, H5
     N1024) in the same process, reported under extra.configs with its own roofline -- so that the driver's default run
@@ -471,11 +520,21 @@ def main():
                 except Exception as ex:
                     extra["configs"][name] = {"error": repr(ex)}
 
+    c5 = None
+    # (TDMPC2_BENCH_FORCE_C5=1 under torch.distributed.run exercises the leg with one rank: the builder's pool has one GPU)
+    if (world > 1 or (use_dist and os.environ.get("TDMPC2_BENCH_FORCE_C5"))) and args.config == "c2" and not args.skip_extra_configs:
+        try:
+            planner.close()
+            c5 = c5_leg(device, rank, world, fence)
+        except Exception as ex:
+            c5 = {"error": repr(ex)}
     if rank != 0:
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
+    if c5 is not None:
+        extra.setdefault("configs", {})["c5"] = c5
 
     plans = world * E * K
     value = plans / elapsed
