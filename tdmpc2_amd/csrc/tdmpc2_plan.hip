@@ -743,6 +743,16 @@ int dev_alloc(tdmpc2_plan *h, void **p, size_t bytes) {
     return 0;
 }
 
+void dev_release(tdmpc2_plan *h, void *p) {  // free one allocation made with dev_alloc (tables that are re-grown)
+    if (!p) return;
+    for (size_t i = 0; i < h->allocs.size(); ++i)
+        if (h->allocs[i] == p) {
+            h->allocs.erase(h->allocs.begin() + (long)i);
+            break;
+        }
+    (void)hipFree(p);
+}
+
 template <class NET> NET to_dev(const HostNet &n);
 template <> NetS to_dev<NetS>(const HostNet &n) {  // split: hi/lo f16 packing + per-matrix scale; exact fp32: fp32 packing, scale 1
     NetS w;
@@ -1474,13 +1484,21 @@ int build_task_tables(tdmpc2_plan *h, const tdmpc2_task_tables *tk, bool target,
     const int nt = tk->n_tasks;
     const size_t width = h->lay.on ? (size_t)h->lay.Mp : (size_t)WIDTH;
     int rc;
-    if (nt > h->tab_tasks) {
+    if (nt > h->tab_tasks) {  // grow: the old tables are released (stream-ordered: earlier calls on `st` are done with them)
+        HIP_TRY(hipStreamSynchronize(st));
+        dev_release(h, h->beff_tab); dev_release(h, h->mask_tab); dev_release(h, h->disc_tab);
+        h->beff_tab = h->mask_tab = h->disc_tab = nullptr;
+        h->tab_tasks = 0;
         if ((rc = dev_alloc(h, (void **)&h->beff_tab, (size_t)nt * h->nnets * width * 4))) return rc;
         if ((rc = dev_alloc(h, (void **)&h->mask_tab, (size_t)nt * c.action_dim * 4))) return rc;
         if ((rc = dev_alloc(h, (void **)&h->disc_tab, (size_t)nt * 4))) return rc;
         h->tab_tasks = nt;
     }
     if (rows_p > h->task_rows_cap) {
+        HIP_TRY(hipStreamSynchronize(st));
+        dev_release(h, h->task_rows);
+        h->task_rows = nullptr;
+        h->task_rows_cap = 0;
         if ((rc = dev_alloc(h, (void **)&h->task_rows, rows_p * 4))) return rc;
         h->task_rows_cap = rows_p;
     }

@@ -192,6 +192,7 @@ class NativePlanner:
         self.path = int(self.lib.tdmpc2_plan_path(h))  # PATH_FUSED or PATH_LAYERED
         self.precision = int(self.lib.tdmpc2_plan_precision(h))  # PREC_FP32 or PREC_SPLIT_F16
         self._seed_calls = 0
+        self._shard_noise = None  # struct tdmpc2_noise of the sharded plan in progress (shard_begin .. shard_refit)
         self.encoder_layers = 0
         self.obs_dim = None
 
