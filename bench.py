@@ -355,6 +355,8 @@ def main():
     cfg = named_config(args.config)
     I, E, K, W = args.iterations, args.envs, args.steps, args.warmup
     sd_np = synth.make_state_dict(cfg, seed=0)
+    if os.environ.get("TDMPC2_BENCH_ZERO_WEIGHTS"):  # power probe only (profiles/README.md): all-zero operands, same instruction stream
+        sd_np = {k: (np.zeros_like(v) if k.endswith(".weight") and v.ndim >= 2 else v) for k, v in sd_np.items()}
     # weights: rank 0's copy is broadcast over RCCL (one bucketed collective), outside the timed region
     sd = {k: (torch.as_tensor(v).to(device) if rank == 0 else torch.zeros(v.shape, dtype=torch.float32, device=device))
           for k, v in sd_np.items()}

@@ -206,3 +206,56 @@ class TDMPC2(torch.nn.Module):
         planner, emb, mask, disc = self._plan_inputs(z.shape[0], tasks)
         return planner.plan(z.to(torch.float32), disc, prev_mean, t0, eval_mode=eval_mode, task_emb=emb,
                             act_mask=mask, tape=self.noise_tape, seed=self._seed)
+
+    # ------------------------------------------------------------------ training-side forward
+    def _task_tables(self):
+        """The per-task tables a training batch indexes with `task` (world_model.py:88-101; tdmpc2.py:35-37)."""
+        w = self.model._task_emb.weight.detach().to(torch.float32)
+        n = w.norm(2, dim=-1, keepdim=True)
+        emb = torch.where(n > 1.0, w * (1.0 / (n + 1e-7)), w).contiguous()  # nn.Embedding(max_norm=1) at lookup
+        return emb, self.model._action_masks.to(torch.float32).contiguous(), self.discount.to(torch.float32).contiguous()
+
+    @torch.no_grad()
+    def _td_target(self, next_z, reward, terminated, task=None, pi_eps=None, qidx=None):
+        """reference tdmpc2.py:239-254 (already `@torch.no_grad()` there): the TD target of a training batch on the planner's
+        kernels.  next_z [H, B, L] (or [R, L]), reward / terminated [H, B, 1]; task int64 [B] for multitask models (the
+        reference broadcasts it over the H leading rows).  `pi_eps` / `qidx` pin the policy noise and the two target heads
+        (parity tests); by default they are drawn inside the library."""
+        lead = next_z.shape[:-1]
+        z2 = next_z.reshape(-1, next_z.shape[-1]).to(self.device, torch.float32).contiguous()
+        r2 = reward.reshape(-1).to(self.device, torch.float32).contiguous()
+        t2 = terminated.reshape(-1).to(self.device, torch.float32).contiguous()
+        kw = {}
+        if self.cfg.multitask:
+            task = torch.as_tensor(task, device=self.device)
+            if next_z.dim() == 3 and task.numel() == next_z.shape[1]:
+                task = task.repeat(next_z.shape[0])
+            emb, mask, disc = self._task_tables()
+            kw = dict(task_ids=task.to(torch.int32).contiguous(), task_emb_table=emb, act_mask_table=mask)
+            discount = disc
+        else:
+            discount = self.discount
+        if pi_eps is not None:
+            pi_eps = pi_eps.reshape(-1, pi_eps.shape[-1]).to(self.device, torch.float32).contiguous()
+        self._seed += 1
+        td = self.planner().td_target(z2, r2, t2, discount, pi_eps=pi_eps, qidx=qidx, seed=self._seed, **kw)
+        return td.reshape(*lead, 1)
+
+    @torch.no_grad()
+    def policy_value(self, zs, task=None, reduce="avg", target=False, pi_eps=None, qidx=None):
+        """The forward half of `update_pi` (reference tdmpc2.py:208-225): action = pi(zs), q = Q(zs, action, 'avg') on the
+        online ensemble -- returned as (action [..., A], q [..., 1]); gradients are outside this package's scope."""
+        lead = zs.shape[:-1]
+        z2 = zs.reshape(-1, zs.shape[-1]).to(self.device, torch.float32).contiguous()
+        kw = {}
+        if self.cfg.multitask:
+            task = torch.as_tensor(task, device=self.device)
+            if zs.dim() == 3 and task.numel() == zs.shape[1]:
+                task = task.repeat(zs.shape[0])
+            emb, mask, _ = self._task_tables()
+            kw = dict(task_ids=task.to(torch.int32).contiguous(), task_emb_table=emb, act_mask_table=mask)
+        if pi_eps is not None:
+            pi_eps = pi_eps.reshape(-1, pi_eps.shape[-1]).to(self.device, torch.float32).contiguous()
+        self._seed += 1
+        a, q = self.planner().policy_value(z2, use_target=target, reduce=reduce, pi_eps=pi_eps, qidx=qidx, seed=self._seed, **kw)
+        return a.reshape(*lead, -1), q.reshape(*lead, 1)

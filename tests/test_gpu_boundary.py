@@ -155,3 +155,54 @@ def test_rebinding_weights_and_concurrent_handles():
     torch.cuda.synchronize()
     for oa, ob in outs:
         assert torch.equal(oa, ra) and torch.equal(ob, rb)
+
+
+@pytest.mark.parametrize("name", ["c1", "mt5"])
+def test_agent_td_target_matches_reference_golden(name):
+    """TDMPC2._td_target with the reference's signature (next_z [H, B, L], reward / terminated [H, B, 1], task [B]) against the
+    reference-minted fixture."""
+    from oracle import cases
+    from tests.helpers import load_golden
+
+    c, agent = _agent(name)
+    tb = cases.td_batch(c["cfg"])
+    task = None if tb["tasks"] is None else torch.as_tensor(tb["tasks"])
+    td = agent._td_target(torch.as_tensor(tb["next_z"]), torch.as_tensor(tb["reward"]), torch.as_tensor(tb["terminated"]), task,
+                          pi_eps=torch.as_tensor(tb["pi_eps"]), qidx=torch.as_tensor(tb["qidx"]).to(agent.device))
+    want = torch.as_tensor(load_golden(name)["td_target"])
+    assert td.shape == want.shape
+    err = ((td.cpu() - want).abs() / want.abs().clamp(min=1)).max().item()
+    record_parity(f"{name}/agent._td_target", value_rel=err)
+    assert err < 1e-4
+    a, q = agent.policy_value(torch.as_tensor(tb["next_z"]), task)
+    assert a.shape == (*tb["next_z"].shape[:2], c["cfg"].action_dim) and q.shape == (*tb["next_z"].shape[:2], 1)
+    assert torch.isfinite(a).all() and torch.isfinite(q).all()
+
+
+def test_pixel_observation_agent_plans():
+    """obs = 'rgb': the conv encoder (host-side module with the reference's keys) feeds the planner its latent; act() works
+    end to end and equals planning from the same latent through the library directly (same seed, fresh handle)."""
+    from tdmpc2_amd.config import named_config
+    from tdmpc2_amd.native import NativePlanner
+    from tdmpc2_amd.tdmpc2 import TDMPC2
+
+    cfg = named_config("c1")
+    cfg.obs = "rgb"
+    cfg.obs_shape = {"rgb": (9, 64, 64)}
+    torch.manual_seed(0)
+    agent = TDMPC2(cfg, device=torch.device("cuda", 0))
+    for p in agent.model._reward[2].parameters():  # fresh models zero these heads (all values equal): make them informative
+        torch.nn.init.normal_(p, std=0.05)
+    agent.sync_planner_weights()
+    obs = torch.randint(0, 256, (9, 64, 64)).float()
+    torch.manual_seed(3)  # ShiftAug's shift
+    a = agent.act(obs, t0=True)
+    assert a.shape == (cfg.action_dim,) and torch.isfinite(a).all() and a.abs().max() <= 1
+    torch.manual_seed(3)
+    z = agent.model.encode(obs.to(agent.device).unsqueeze(0), None).float().contiguous()
+    ref = NativePlanner(cfg, agent.cfg.iterations, agent.device, max_envs=1)
+    ref.bind_state_dict(agent.model.planner_state_dict())
+    disc = agent._disc_pow(None).unsqueeze(0).contiguous()
+    b = ref.plan(z, disc, torch.zeros(1, cfg.horizon, cfg.action_dim, device=agent.device),
+                 torch.ones(1, dtype=torch.uint8, device=agent.device), seed=agent._seed)
+    assert torch.equal(a, b[0].cpu())
