@@ -278,8 +278,12 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
  * family): 1 = the last workgroup of a plan to finish its rollouts does the elite selection + refit (tdmpc2.py:184-206)
  * inside the rollout launch, one launch per CEM iteration; 0 = always a launch of its own (k_refit); 2 (default) = inside
  * the rollout launch when the call's workgroups fit the chip in one round (few plans: single-environment latency), a
- * launch of its own otherwise (many plans: the in-launch refits would delay the next round of workgroups). */
-enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0, TDMPC2_TUNE_FOLD_REFIT = 1 };
+ * launch of its own otherwise (many plans: the in-launch refits would delay the next round of workgroups).
+ * key TDMPC2_TUNE_CLUSTER (fused family, f16x2-split arithmetic, non-episodic): single-plan latency path -- every 512-wide
+ * layer of a 32-row sample tile is split over a cluster of 8 workgroups on 8 CUs that exchange the layer's raw sums through
+ * L2 (tdmpc2_amd/csrc/cluster_kernels.cuh); used when all of a call's clusters fit the chip at once (one or two plans of
+ * 512 samples on 256 CUs).  0 = never, 1 / 2 (default) = whenever the call fits. */
+enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0, TDMPC2_TUNE_FOLD_REFIT = 1, TDMPC2_TUNE_CLUSTER = 2 };
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
 
 /* Live timing of the dominant (rollout) stage: after set_profiling(h, n > 0) every rollout launch

@@ -1,0 +1,364 @@
+// Single-plan latency: one CEM iteration's rollouts (TDMPC2._estimate_value, tdmpc2/tdmpc2.py:122-136, under the sampling
+// of tdmpc2.py:176-181) with every 512-wide layer split over a CLUSTER of 8 workgroups per 32-row sample tile.
+//
+// Why: a single environment's plan (evaluate.py:80 -> tdmpc2.py:111) has 512 sample rows = 16 row tiles.  ks_rollout gives
+// each tile to one workgroup, which then streams every layer's whole weight matrix (1 MB in hi / lo f16 form) through ONE
+// CU's L1 at 64 B/clk: 23 MB per CEM iteration, 172 us of the 314 us the iteration takes, on 16 of 256 CUs
+// (profiles/README.md).  Here 8 workgroups on 8 CUs of one XCD share a row tile: member r computes output features
+// [64 r, 64 r + 64) of a layer (its 8 waves: 2 feature tiles x 4 quarters of the contraction, summed through LDS), writes
+// the 32 x 64 raw sums to the cluster's exchange tile in L2, waits for the other seven and reads all 32 x 512 back -- in
+// the register order of ks_rollout's epilogue, so LayerNorm / Mish / SimNorm / hi-lo split are epi_t itself, run
+// redundantly by every member on the full row (LayerNorm needs it) into the member's own LDS operand tile.  The narrow
+// heads (two-hot reward / Q, policy) are computed by every member from its own tile.  A member streams 1/8 of the weights.
+//
+// Hand-over protocol (measured stand-alone first: tools/probes/cluster_probe.hip, profiles/README.md r02k): data leave as
+// agent-scope write-through stores and are read with agent-scope loads (correct wherever the members run; 2.1 us per
+// exchange when they share an XCD, 2.8 us across XCDs); arrival = one word per member holding the phase number, written
+// after every wave drained its stores and the workgroup barrier, polled by 8 lanes.  Phase numbers grow monotonically
+// through the I rollout launches of a plan (ks_setup zeroes the words), so a launch needs no reset and a captured
+// hipGraph replays.  Every wait is BOUNDED: a member that gives up raises the handle's error word (host-mapped; the next
+// API call fails loudly and turns the cluster path off) instead of hanging the GPU.
+// Members are placed on one XCD by construction of the block index (workgroups go to XCDs round-robin): blocks
+// {64 g + x + 8 r : r = 0..7} form cluster 8 g + x.  Only speed depends on that.
+// Co-residency: a cluster launch has at most one workgroup per CU (<= num_cus workgroups, 147 KB LDS each); the host
+// serialises cluster launches of different streams (an event per device) so that two partially resident launches cannot
+// wait for each other.
+//
+// Exchange tiles S0..S3 per cluster ([32 x 512] fp32 each); a tile exchanged at barrier j and read before the reader's arrival
+// at barrier j + 1 may be rewritten from phase j + 2 on (the writer has passed barrier j + 1, so every member arrived there):
+//   step t:   phase 4t+1  dyn.l0 -> S0, rew.l0 -> S1 (one barrier for both; S0 stays parked)      epilogue rew.l0 <- S1
+//             phase 4t+2  rew.l1 -> S2                                                            epilogue, reward head
+//                         epilogue dyn.l0 <- S0 (parked)
+//             phase 4t+3  dyn.l1 -> S1                                                            epilogue
+//             phase 4t+4  dyn.l2 -> S2                                                            SimNorm epilogue
+//   value:    phase 4H+1  pi.l0 -> S0;  4H+2  pi.l1 -> S1;  policy head;  z_H back into the tile
+//             phase 4H+3  q1.l0 -> S2 (parked), q0.l0 -> S3;  4H+4  q0.l1 -> S0;  head;  epilogue q1.l0 <- S2
+//             phase 4H+5  q1.l1 -> S1;  head.
+#pragma once
+
+constexpr int CL = 8;                  // workgroups per cluster
+constexpr int CL_SLOTS = 4;            // exchange tiles per cluster
+constexpr int CL_TILE = 32 * WIDTH;    // floats per exchange tile
+constexpr int CL_FLAG_STRIDE = 16;     // arrival words reserved per cluster (64 B)
+constexpr int CL_MAXSPIN = 1 << 17;    // polls before a member gives up (~0.2 s; a healthy wait is microseconds)
+constexpr int CL_MAXKQ = 9;            // k-blocks of 16 per contraction quarter: ceil((512 + 64) / 16 / 4)
+__host__ __device__ constexpr int cl_phases(int H) { return 4 * H + 5; }
+
+struct ClState {
+    float *xbuf;       // this cluster's CL_SLOTS exchange tiles
+    unsigned *flags;   // this cluster's arrival words [CL]
+    unsigned *err;     // the handle's error word
+    float *red;        // LDS [2 layers][8 waves][4][64 lanes][4]: contraction-quarter partial sums
+    int *dead;         // LDS flag: a wait of this member timed out -- it stops waiting (and the plan is reported invalid)
+    int rank;
+    unsigned phase;    // last phase this member arrived at
+};
+
+__device__ __forceinline__ void cl_st16(float *p, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void cl_ld16(f32x4 &v, const float *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+}
+
+// One wave's share of a layer: column tile `ct`, k-blocks [k0, k0 + n), n <= CL_MAXKQ -> raw partial sums in the C layout
+// of kloop_s (weight fragment = A operand: lane (j, hh) holds features 8 m + 4 hh + r of sample row j in register 4 m + r).
+// All weight fragments of the share are requested up front (<= 72 VGPRs): the contraction is short, latency-bound.
+template <class CT>
+__device__ __forceinline__ void cl_kloop(const CT &c, const LayerS &ly, int ct, int k0, int n, f32x16 &out) {
+    static_assert(CT::ARITH == 0 && CT::NST == 1, "cluster path: split arithmetic, 32-row tiles");
+    const int i = c.lane & 31, hh = c.lane >> 5;
+    const _Float16 *a0p = c.act + i * c.RSH + 8 * hh + k0 * 16;
+    const char *u = reinterpret_cast<const char *>(ly.wp) + ((size_t)ct * ly.KB + k0) * 2048;  // wave-uniform
+    unsigned voff = (unsigned)c.lane * 16u;
+    asm volatile("" : "+v"(voff));
+    f16x8 wh[CL_MAXKQ], wl[CL_MAXKQ];
+#pragma unroll
+    for (int j = 0; j < CL_MAXKQ; ++j)
+        if (j < n) {  // wave-uniform
+            wh[j] = ldw(u + (size_t)j * 2048, voff, 0);
+            wl[j] = ldw(u + (size_t)j * 2048, voff, 1024);
+        }
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CL_MAXKQ; ++j)
+        if (j < n) {
+            const f16x8 ah = *reinterpret_cast<const f16x8 *>(a0p + j * 16);
+            const f16x8 al = *reinterpret_cast<const f16x8 *>(a0p + CT::SH + j * 16);
+            acc[0] = SPLIT_MFMA(wh[j], ah, acc[0]);
+            acc[1] = SPLIT_MFMA(wl[j], ah, acc[1]);
+            acc[2] = SPLIT_MFMA(wh[j], al, acc[2]);
+        }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e] = acc[0][e] + (acc[1][e] + acc[2][e]);
+}
+
+// partial sums of this wave -> LDS, [layer][wave][m][lane] float4
+template <class CT>
+__device__ __forceinline__ void cl_to_red(const CT &c, const ClState &x, int layer, const f32x16 &v) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f32x4 q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q[r] = v[4 * m + r];
+        *reinterpret_cast<f32x4 *>(x.red + ((size_t)((layer * 8 + c.wave) * 4 + m) * 64 + c.lane) * 4) = q;
+    }
+}
+
+// arrive at the next phase (all data stores of this workgroup are issued), wait for the other members
+template <class CT>
+__device__ __forceinline__ void cl_barrier(const CT &c, ClState &x) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through stores are acknowledged
+    __syncthreads();
+    x.phase += 1;
+    if (c.tid == 0) __hip_atomic_store(x.flags + x.rank, x.phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c.tid < CL && !*x.dead) {
+        int spin = 0;
+        while (__hip_atomic_load(x.flags + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < x.phase) {
+            if (++spin > CL_MAXSPIN) {  // host-mapped word: a plain system-scope store
+                __hip_atomic_store(x.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                *x.dead = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+}
+
+// The contraction of one or two layers over the member's operand tile -> the cluster's exchange tile(s), one barrier.
+// Wave w: feature tile ft = w >> 2 of the member's two, quarter kq = w & 3 of the k-blocks [kb0, kb1).
+template <class CT>
+__device__ __forceinline__ void cl_gemm(const CT &c, ClState &x, const LayerS &la, int slot_a, const LayerS *lb, int slot_b, int kb0,
+                                        int kb1) {
+    const int ft = c.wave >> 2, kq = c.wave & 3;
+    const int nk = kb1 - kb0;
+    const int k0 = kb0 + (nk * kq) / 4, k1 = kb0 + (nk * (kq + 1)) / 4;
+    const int ct = 2 * x.rank + ft;
+    {
+        f32x16 v;
+        cl_kloop(c, la, ct, k0, k1 - k0, v);
+        cl_to_red(c, x, 0, v);
+    }
+    if (lb) {
+        f32x16 v;
+        cl_kloop(c, *lb, ct, k0, k1 - k0, v);
+        cl_to_red(c, x, 1, v);
+    }
+    __syncthreads();
+    // thread (ft', m, lane') sums the four quarters of one float4 and stores it where wave `rank` of ks_rollout's register
+    // order would park it: idx4 = (rank * 2 + ft') * 4 + m
+    const int rft = c.tid >> 8, rm = (c.tid >> 6) & 3, rl = c.tid & 63;
+    const int nl = lb ? 2 : 1;
+    for (int layer = 0; layer < nl; ++layer) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 pq = *reinterpret_cast<const f32x4 *>(x.red + ((size_t)((layer * 8 + rft * 4 + q) * 4 + rm) * 64 + rl) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] += pq[r];
+        }
+        float *dst = x.xbuf + (size_t)(layer == 0 ? slot_a : slot_b) * CL_TILE + ((size_t)((x.rank * 2 + rft) * 4 + rm) * 64 + rl) * 4;
+        cl_st16(dst, s);
+    }
+    cl_barrier(c, x);
+}
+
+// exchange tile -> raw sums in ks_rollout's accumulator layout (wave w: features [64 w, 64 w + 64) = member w's slice)
+template <class CT>
+__device__ __forceinline__ void cl_unpark(const CT &c, const ClState &x, int slot, f32x16 (&acc)[1][2]) {
+    const float *src = x.xbuf + (size_t)slot * CL_TILE + ((size_t)(c.wave * 2) * 4 * 64 + c.lane) * 4;
+    f32x4 v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cl_ld16(v[q], src + (size_t)q * 256);
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[0][ft][4 * m + r] = v[ft * 4 + m][r];
+}
+
+// epilogue of a layer whose raw sums wait in exchange tile `slot`: ACT(LayerNorm(sums * oscale + bias)) -> operand tile
+template <int ACT, class CT>
+__device__ __forceinline__ void cl_epi(const CT &c, const ClState &x, int slot, const LayerS &ly, const float *bias, GB next,
+                                       float *zcopy = nullptr) {
+    if (next.g) gb_prefetch(c, next.g, next.b);
+    f32x16 acc[1][2];
+    cl_unpark(c, x, slot, acc);
+    epi_t<ACT>(c, acc, *ly.oscale, *ly.ascale, bias, next, zcopy);
+    epi_barrier(c);
+}
+
+// a whole hidden layer: contraction over the member's tile, exchange, epilogue
+template <int ACT, class CT>
+__device__ __forceinline__ void cl_layer(const CT &c, ClState &x, const LayerS &ly, const float *bias, int kb0, int kb1, int slot, GB next,
+                                         float *zcopy = nullptr) {
+    if (next.g) gb_prefetch(c, next.g, next.b);
+    cl_gemm(c, x, ly, slot, nullptr, 0, kb0, kb1);
+    f32x16 acc[1][2];
+    cl_unpark(c, x, slot, acc);
+    epi_t<ACT>(c, acc, *ly.oscale, *ly.ascale, bias, GB{}, zcopy);
+    epi_barrier(c);
+}
+
+template <int APAD>
+__global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS> p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int s_is_last, s_dead;
+    typedef CtxT<APAD, 1, 8, 0> CT;
+    constexpr int TROWS = CT::TROWS, NTHR = CT::NTHR;
+    constexpr int ZKB16 = CT::ZKB;
+    const int tid = threadIdx.x;
+    // blocks {64 g + xc + 8 r : r = 0..7} = cluster 8 g + xc (one XCD under round-robin dispatch)
+    const int xc = blockIdx.x & 7, bq = blockIdx.x >> 3;
+    const int rank = bq & 7, cl = (bq >> 3) * 8 + xc;
+    if (cl >= p.E * p.tiles) return;  // the whole cluster leaves
+    const int e = cl / p.tiles, tile = cl % p.tiles;
+    CT c{reinterpret_cast<_Float16 *>(smem), smem + TROWS * CT::RSF(), smem + TROWS * CT::RSF() + 1024, tid,
+         __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    float *sm_mean = smem + TROWS * CT::RSF() + 2048;
+    float *sm_std = sm_mean + p.H * p.A;
+    ClState x{p.cl_xbuf + (size_t)cl * CL_SLOTS * CL_TILE, p.cl_flags + (size_t)cl * CL_FLAG_STRIDE, p.cl_err,
+              smem + TROWS * CT::RSF() + 2048 + ((2 * p.H * p.A + 3) & ~3), &s_dead, rank, (unsigned)(p.iter * cl_phases(p.H))};
+    if (tid == 0) s_dead = 0;
+    const int row0 = tile * TROWS;
+    const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
+    const float *disc = p.disc_pow + (size_t)e * (p.H + 1);
+    const int KBA = ZKB16 + p.Apad / CT::KBLK;
+    float *zs = p.cl_zs + (size_t)(cl * CL + rank) * TROWS * WIDTH;
+    const bool live = (tid >> 3) < TROWS;
+
+    for (int idx = tid; idx < p.H * p.A; idx += NTHR) {
+        sm_mean[idx] = p.mean[(size_t)e * p.H * p.A + idx];
+        sm_std[idx] = p.std[(size_t)e * p.H * p.A + idx];
+    }
+    int q0, q1;
+    if (p.qidx) {
+        q0 = p.qidx[(size_t)e * p.qidx_estride + 0];
+        q1 = p.qidx[(size_t)e * p.qidx_estride + 1];
+    } else {
+        const uint4 r = rng_raw(p.seed, p.call, SITE_QIDX, p.iter, e, 0);
+        q0 = (int)(r.x % (unsigned)p.nq);
+        q1 = (int)(r.y % (unsigned)(p.nq - 1));
+        if (q1 >= q0) ++q1;
+    }
+    const float *b_rew = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_REW) * WIDTH : p.rew.l[0].bias;
+    const float *b_dyn = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_DYN) * WIDTH : p.dyn.l[0].bias;
+    const float *b_pi = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_PI) * WIDTH : p.pi.l[0].bias;
+    const float *b_q0 = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_Q0 + q0) * WIDTH : p.q[q0].l[0].bias;
+    const float *b_q1 = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_Q0 + q1) * WIDTH : p.q[q1].l[0].bias;
+    gb_prefetch(c, p.rew.l[0].g, p.rew.l[0].b);
+    epi_barrier(c);
+
+    float G = 0.f;
+    for (int t = 0; t < p.H; ++t) {
+        // ---- actions of step t (tdmpc2.py:176-181): every member fills its own tile; member 0 also writes them out
+        {
+            float *ag = p.actions + ((size_t)e * p.H + t) * p.N * p.A;
+            const int hp = p.Apad / 2;
+            for (int idx = tid; idx < TROWS * hp; idx += NTHR) {
+                const int row = idx / hp, a0 = 2 * (idx % hp);
+                const int n = row0 + row;
+                float v[2] = {0.f, 0.f};
+                const bool sampled = !(p.given_actions || n < p.P);
+                float z[2] = {0.f, 0.f};
+                if (sampled && a0 < p.A && !p.sample_eps) {
+                    const unsigned pair = (unsigned)(((size_t)t * (p.N - p.P) + (n - p.P)) * hp + a0 / 2);
+                    rng_normal2(p.seed, p.call, SITE_SAMPLE, p.iter, e, pair, z[0], z[1]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int a = a0 + u;
+                    if (a < p.A) {
+                        if (!sampled) {
+                            v[u] = ag[(size_t)n * p.A + a];
+                        } else {
+                            float r = z[u];
+                            if (p.sample_eps)
+                                r = p.sample_eps[(size_t)e * p.sample_eps_estride +
+                                                 (unsigned)(((size_t)t * (p.N - p.P) + (n - p.P)) * p.A + a)];
+                            v[u] = sample_action(sm_mean[t * p.A + a], sm_std[t * p.A + a], r);
+                        }
+                        if (mask && !p.given_actions) v[u] *= mask[a];
+                        if (!p.given_actions && rank == 0 && sampled) ag[(size_t)n * p.A + a] = v[u];
+                    }
+                    put_action(c, row, a, v[u]);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- first layers of dynamics (parked in S0) and reward (S1) over the same [z_t | a_t] tile
+        gb_prefetch(c, p.rew.l[1].g, p.rew.l[1].b);
+        cl_gemm(c, x, p.dyn.l[0], 0, &p.rew.l[0], 1, t == 0 ? ZKB16 : 0, KBA);
+        {
+            f32x16 acc[1][2];
+            cl_unpark(c, x, 1, acc);
+            epi_t<0>(c, acc, *p.rew.l[0].oscale, *p.rew.l[0].ascale, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew, GB{},
+                     nullptr);
+            epi_barrier(c);
+        }
+        // ---- reward: layer 2, two-hot head
+        cl_layer<0>(c, x, p.rew.l[1], p.rew.l[1].bias, 0, ZKB16, 2, gb_of(p.dyn.l[0]));
+        const float r = head_twohot_s(c, p.rew.l[2], p.bins, p.num_bins);
+        G += disc[t] * r;
+        // ---- dynamics: the parked first layer, layers 2 and 3 (SimNorm)
+        cl_epi<0>(c, x, 0, p.dyn.l[0], t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn, gb_of(p.dyn.l[1]));
+        cl_layer<0>(c, x, p.dyn.l[1], p.dyn.l[1].bias, 0, ZKB16, 1, gb_of(p.dyn.l[2]));
+        cl_layer<1>(c, x, p.dyn.l[2], p.dyn.l[2].bias, 0, ZKB16, 2, t == p.H - 1 ? gb_of(p.pi.l[0]) : gb_of(p.rew.l[0]),
+                    t == p.H - 1 ? zs : nullptr);
+    }
+    // ---- a_H = pi(z_H) (tdmpc2.py:135); z_H was also saved to zs
+    cl_layer<0>(c, x, p.pi.l[0], b_pi, 0, ZKB16, 0, gb_of(p.pi.l[1]));
+    cl_layer<0>(c, x, p.pi.l[1], p.pi.l[1].bias, 0, ZKB16, 1, gb_of(p.q[q0].l[0]));
+    {
+        auto eps = [&](int row, int a) -> float {
+            const unsigned ridx = (unsigned)((size_t)(row0 + row) * p.A + a);
+            if (p.pi_eps) return p.pi_eps[(size_t)e * p.pi_eps_estride + ridx];
+            return rng_normal(p.seed, p.call, SITE_PI, p.iter, e, ridx);
+        };
+        head_pi_s(c, p.pi.l[2], p.A, p.Apad, p.log_std_min, p.log_std_dif, mask, eps, nullptr, 0, nullptr);
+    }
+    tile_from_global_s(c, zs);
+    __syncthreads();
+    // ---- Q(z_H, a_H): the two selected heads (world_model.py:186-216); the second one's first layer is parked in S2
+    gb_prefetch(c, p.q[q0].l[1].g, p.q[q0].l[1].b);
+    cl_gemm(c, x, p.q[q1].l[0], 2, &p.q[q0].l[0], 3, 0, KBA);
+    {
+        f32x16 acc[1][2];
+        cl_unpark(c, x, 3, acc);
+        epi_t<0>(c, acc, *p.q[q0].l[0].oscale, *p.q[q0].l[0].ascale, b_q0, GB{}, nullptr);
+        epi_barrier(c);
+    }
+    cl_layer<0>(c, x, p.q[q0].l[1], p.q[q0].l[1].bias, 0, ZKB16, 0, gb_of(p.q[q1].l[0]));
+    const float qa = head_twohot_s(c, p.q[q0].l[2], p.bins, p.num_bins);
+    cl_epi<0>(c, x, 2, p.q[q1].l[0], b_q1, gb_of(p.q[q1].l[1]));
+    cl_layer<0>(c, x, p.q[q1].l[1], p.q[q1].l[1].bias, 0, ZKB16, 1, GB{});
+    if (rank != 0) return;  // nothing left to contribute: member 0 owns the values
+    const float qb = head_twohot_s(c, p.q[q1].l[2], p.bins, p.num_bins);
+    const float val = G + disc[p.H] * ((qa + qb) / 2.f);
+    if (!p.fold_refit) {
+        if ((tid & 7) == 0 && live) p.value[(size_t)e * p.N + row0 + (tid >> 3)] = val;
+        return;
+    }
+    // ---- elite selection + refit by the last member-0 workgroup of the plan (the hand-over of ks_rollout)
+    if ((tid & 7) == 0 && live)
+        __hip_atomic_store(p.value + (size_t)e * p.N + row0 + (tid >> 3), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(p.ticket + e, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == (unsigned)(p.tiles - 1);
+        if (last) __hip_atomic_store(p.ticket + e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_is_last = last;
+    }
+    __syncthreads();
+    if (!s_is_last) return;
+    refit_plan(p.rf, e, smem, tid, NTHR);
+}

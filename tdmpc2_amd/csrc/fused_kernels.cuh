@@ -1050,6 +1050,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
     typedef CtxT<APAD, 2, 8, AR> CT;  // 64 rows, 8 waves
     CT c{reinterpret_cast<_Float16 *>(smem), smem + ROWS * CT::RSF(), smem + ROWS * CT::RSF() + 1024, tid,
          __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
+    if (p.cl_flags)  // cluster path (cluster_kernels.cuh): this plan's arrival words start at phase 0
+        for (int idx = tid; idx < p.cl_flag_words; idx += NTHREADS) p.cl_flags[(size_t)e * p.cl_flag_words + idx] = 0u;
     if (p.multitask) {
         const float *emb = p.task_emb + (size_t)e * p.T;
         for (int net = 0; net < p.nnets; ++net) {

@@ -30,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -118,6 +119,11 @@ struct RolloutParamsT {
     int fold_refit;
     unsigned int *ticket;   // [E] arrival counters, zero between launches
     RefitParams rf;
+    // cluster path (cluster_kernels.cuh): exchange tiles, arrival words, the handle's error word, per-member z_H scratch
+    float *cl_xbuf;
+    unsigned int *cl_flags;
+    unsigned int *cl_err;
+    float *cl_zs;
 };
 
 // pi + two Q heads on a batch of latent rows (fused_kernels.cuh: ks_value)
@@ -226,6 +232,8 @@ struct SetupParamsT {
     const float *z0, *task_emb, *prev_mean;
     const unsigned char *t0;
     float *beff, *cvec, *mean, *std;
+    unsigned int *cl_flags;  // cluster path: arrival words, zeroed at the start of every plan ([E][cl_flag_words]) or null
+    int cl_flag_words;
 };
 
 // policy-prior trajectories (tdmpc2/tdmpc2.py:154-160): rows < P of one tile per plan
@@ -594,6 +602,7 @@ __global__ void k_copy_pad(const float *src, int n, int npad, float *dst) {
 }
 
 #include "fused_kernels.cuh"
+#include "cluster_kernels.cuh"
 #include "layered_kernels.cuh"
 #include "layered_split.cuh"
 #include "encoder_kernels.cuh"
@@ -680,6 +689,13 @@ struct tdmpc2_plan {
     int *task_rows = nullptr;  // [rows] copy of the row -> task map, padded to whole GEMM tiles (layered family)
     int tab_tasks = 0;
     size_t task_rows_cap = 0;
+    // cluster path of the fused family (cluster_kernels.cuh): single-plan latency
+    int cluster_mode = 2;            // TDMPC2_TUNE_CLUSTER: 0 never, 1 whenever the call fits, 2 auto (= 1 today)
+    int cl_max_clusters = 0;         // clusters the buffers below were sized for (0: path not available on this handle)
+    float *cl_xbuf = nullptr, *cl_zs = nullptr;
+    unsigned int *cl_flags = nullptr;
+    unsigned int *cl_err_host = nullptr, *cl_err_dev = nullptr;  // host-mapped error word of the bounded waits
+    size_t cl_lds = 0;
     bool split = false;  // fused kernels on the f16 matrix pipe with hi/lo operand split (fused_kernels.cuh)
     int force_rows = 0;  // TDMPC2_TUNE_ROWS_PER_WORKGROUP: 0 auto, 32, 64
     size_t row_bytes = 0;  // bytes of one sample row of the fused kernels' LDS tile
@@ -866,7 +882,26 @@ template <> struct Kern<NetS> {
         FUSED_DISPATCH(h->Apad, ar, CALL_ROLL)
 #undef CALL_ROLL
     }
+    // cluster path: `clusters` row tiles of 32 samples, 8 workgroups each, in groups of 8 clusters (one per XCD)
+    static void rollout_cluster(const tdmpc2_plan *h, const RolloutParamsT<NetS> &p, int clusters, hipStream_t st) {
+        const int grid = (clusters + 7) / 8 * 64;
+#define CALL_ROLL_CL(AP, AR) hipLaunchKernelGGL((ks_rollout_cl<AP>), dim3(grid), dim3(NTHREADS), h->cl_lds, st, p);
+        FUSED_DISPATCH(h->Apad, 0, CALL_ROLL_CL)
+#undef CALL_ROLL_CL
+    }
 };
+
+// Cluster launches of different streams are serialised per device: a launch whose workgroups are only partly resident
+// spins on members that wait for a CU, and two such launches could wait for each other.  (Other kernels may share the
+// device: they finish without the cluster's help.)  The lock covers [wait for the previous plan's event, this plan's
+// launches, record]; nothing here blocks the host on the GPU.
+struct ClusterGate {
+    std::mutex mu;
+    hipEvent_t ev[64] = {};
+    bool have[64] = {};
+    hipStream_t last[64] = {};
+};
+ClusterGate g_cluster_gate;
 
 template <class NET>
 int launch_setup(tdmpc2_plan *h, int E, const float *z0, const float *task_emb, const float *prev_mean,
@@ -880,6 +915,9 @@ int launch_setup(tdmpc2_plan *h, int E, const float *z0, const float *task_emb, 
     for (int i = 0; i < h->cfg.num_q; ++i) p.wemb[BE_Q0 + i] = h->q[i].l[0].wemb;
     p.z0 = z0; p.task_emb = task_emb; p.prev_mean = prev_mean; p.t0 = t0;
     p.beff = h->beff; p.cvec = h->cvec; p.mean = h->mean; p.std = h->std;
+    // cluster path: the arrival words of this call's clusters start every plan at zero (phase numbers grow through its launches)
+    p.cl_flags = (h->cl_max_clusters && (long)E * h->tiles * 2 <= h->cl_max_clusters) ? h->cl_flags : nullptr;
+    p.cl_flag_words = h->tiles * 2 * CL_FLAG_STRIDE;
     Kern<NET>::setup(h, p, E, st);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -904,6 +942,12 @@ void fill_rollout(tdmpc2_plan *h, RolloutParamsT<NET> &p, int E) {
 int validate_envs(tdmpc2_plan *h, int E) {
     if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
     if (E < 1 || E > h->cfg.max_envs) return fail(TDMPC2_ERR_INVALID, "n_envs=%d outside [1, max_envs=%d]", E, h->cfg.max_envs);
+    if (h->cl_err_host && *(volatile unsigned int *)h->cl_err_host) {  // raised by a member of an EARLIER cluster launch
+        *(volatile unsigned int *)h->cl_err_host = 0;
+        h->cluster_mode = 0;
+        return fail(TDMPC2_ERR_HIP, "a cluster hand-over of an earlier plan timed out (its result was invalid); the cluster path "
+                                    "is now off for this handle");
+    }
     return check_ready(h);
 }
 
@@ -933,8 +977,31 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
     RolloutParamsT<NET> rp{};
     fill_rollout<NET>(h, rp, E);
     rp.z0 = z0; rp.act_mask = act_mask; rp.disc_pow = disc_pow; rp.seed = seed; rp.call = call; rp.given_actions = 0;
-    const int nst = Kern<NET>::sample_tiles(h, E, false), nw = Kern<NET>::waves(h, E, nst);
+    // single-plan latency: 8 workgroups per 32-row tile when the whole call then still fits the chip in one round
+    const long clusters = (long)E * h->tiles * 2;
+    const bool cluster = h->cluster_mode != 0 && h->cl_max_clusters > 0 && clusters <= h->cl_max_clusters &&
+                         (clusters + 7) / 8 * 64 <= (h->num_cus > 0 ? h->num_cus : 256);
+    const int nst = cluster ? 1 : Kern<NET>::sample_tiles(h, E, false), nw = Kern<NET>::waves(h, E, nst);
     rp.tiles = h->tiles * (2 / nst);
+    rp.cl_xbuf = h->cl_xbuf; rp.cl_flags = h->cl_flags; rp.cl_err = h->cl_err_dev; rp.cl_zs = h->cl_zs;
+    std::unique_lock<std::mutex> gate;
+    bool gate_record = false;
+    const int gdev = c.device >= 0 && c.device < 64 ? c.device : 0;
+    if (cluster) {
+        gate = std::unique_lock<std::mutex>(g_cluster_gate.mu);
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap == hipStreamCaptureStatusNone) {  // (a captured plan replays on one stream: ordered by the graph itself)
+            if (!g_cluster_gate.have[gdev]) {
+                HIP_TRY(hipEventCreateWithFlags(&g_cluster_gate.ev[gdev], hipEventDisableTiming));
+                g_cluster_gate.have[gdev] = true;
+                g_cluster_gate.last[gdev] = st;
+            } else if (g_cluster_gate.last[gdev] != st) {
+                HIP_TRY(hipStreamWaitEvent(st, g_cluster_gate.ev[gdev], 0));
+            }
+            gate_record = true;
+        }
+    }
     // elite selection + refit: inside the rollout launch (last workgroup of each plan, LDS budget = the 32-row tile) or as
     // a launch of its own (TDMPC2_TUNE_FOLD_REFIT 0)
     int refit_stage = 0;
@@ -944,7 +1011,7 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
     // auto: only when the whole launch is one round of workgroups (few plans: latency).  With several rounds every round
     // ends with the refits of the plans that completed in it, on CUs whose next workgroup then starts late: measured
     // +0.5 ms on the 4.4 ms launch of 256 plans, against 30 us for the separate k_refit launch.
-    const bool one_round = (long)E * rp.tiles <= (h->num_cus > 0 ? h->num_cus : 256);
+    const bool one_round = cluster || (long)E * rp.tiles <= (h->num_cus > 0 ? h->num_cus : 256);
     const bool fold = refit_stage && (h->fold_refit == 1 || (h->fold_refit == 2 && one_round));
     if (!fold) refit_lds = refit_lds_bytes(N, K, H, A, &refit_stage);
     for (int it = 0; it < I; ++it) {
@@ -977,7 +1044,8 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
             fp.sample_eps = rp.sample_eps; fp.sample_eps_estride = rp.sample_eps_estride;
         }
         if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
-        Kern<NET>::rollout(h, rp, E * rp.tiles, st, nst, nw);
+        if (cluster) Kern<NET>::rollout_cluster(h, rp, (int)clusters, st);
+        else Kern<NET>::rollout(h, rp, E * rp.tiles, st, nst, nw);
         HIP_TRY(hipGetLastError());
         if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) {
             HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
@@ -991,6 +1059,10 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
         if (dbg && dbg->actions)
             HIP_TRY(hipMemcpy2DAsync(dbg->actions + (size_t)it * H * N * A, (size_t)I * H * N * A * 4, h->actions,
                                      (size_t)H * N * A * 4, (size_t)H * N * A * 4, E, hipMemcpyDeviceToDevice, st));
+    }
+    if (gate_record) {
+        HIP_TRY(hipEventRecord(g_cluster_gate.ev[gdev], st));
+        g_cluster_gate.last[gdev] = st;
     }
     return TDMPC2_OK;
 }
@@ -1188,6 +1260,43 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             return TDMPC2_ERR_HIP;
         }
     }
+    // cluster path (single-plan latency): split arithmetic, non-episodic, sized for the calls that fit the chip in one round
+    if (!h->lay.on && h->split && !c.episodic) {
+        const long cus = h->num_cus > 0 ? h->num_cus : 256;
+        const long per_env = (long)h->tiles * 2;                       // 32-row tiles = clusters per plan
+        long envs = std::min<long>((long)c.max_envs, cus / (per_env * CL));
+        const size_t tail = ((size_t)2 * c.horizon * c.action_dim * 4 + 15) / 16 * 16;
+        h->cl_lds = (size_t)32 * h->row_bytes + 8192 + tail + (size_t)2 * 8 * 4 * 64 * 16 + 64;
+        if (envs >= 1 && h->cl_lds <= 160 * 1024) {
+            const size_t ncl = (size_t)(envs * per_env);
+            if ((rc = dev_alloc(h, (void **)&h->cl_xbuf, ncl * CL_SLOTS * CL_TILE * 4)) ||
+                (rc = dev_alloc(h, (void **)&h->cl_zs, ncl * CL * 32 * WIDTH * 4)) ||
+                (rc = dev_alloc(h, (void **)&h->cl_flags, ncl * CL_FLAG_STRIDE * 4))) {
+                tdmpc2_plan_destroy(h);
+                return rc;
+            }
+            if (hipMemset(h->cl_flags, 0, ncl * CL_FLAG_STRIDE * 4) != hipSuccess ||
+                hipHostMalloc((void **)&h->cl_err_host, 64, hipHostMallocMapped) != hipSuccess) {
+                tdmpc2_plan_destroy(h);
+                return fail(TDMPC2_ERR_HIP, "allocating the cluster path's arrival / error words failed");
+            }
+            *h->cl_err_host = 0;
+            if (hipHostGetDevicePointer((void **)&h->cl_err_dev, h->cl_err_host, 0) != hipSuccess) {
+                tdmpc2_plan_destroy(h);
+                return fail(TDMPC2_ERR_HIP, "hipHostGetDevicePointer failed");
+            }
+            int rcl = 0;
+#define CALL_SETLDS_CL(AP, AR) rcl = set_lds(ks_rollout_cl<AP>, h->cl_lds);
+            FUSED_DISPATCH(h->Apad, 0, CALL_SETLDS_CL)
+#undef CALL_SETLDS_CL
+            if (rcl) {
+                tdmpc2_plan_destroy(h);
+                return TDMPC2_ERR_HIP;
+            }
+            h->cl_max_clusters = (int)ncl;
+        }
+    }
+    if (const char *cm = getenv("TDMPC2_CLUSTER")) h->cluster_mode = atoi(cm);
     if (getenv("TDMPC2_TIMING")) {
         if (dev_alloc(h, (void **)&h->timing, 16 * 8) == 0) (void)hipMemset(h->timing, 0, 16 * 8);
     }
@@ -1210,6 +1319,7 @@ void tdmpc2_plan_destroy(tdmpc2_plan_t *h) {
         }
     }
     for (void *p : h->allocs) (void)hipFree(p);
+    if (h->cl_err_host) (void)hipHostFree(h->cl_err_host);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
 }
@@ -1906,6 +2016,11 @@ int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value) {
     if (key == TDMPC2_TUNE_ROWS_PER_WORKGROUP) {
         if (value != 0 && value != 32 && value != 64) return fail(TDMPC2_ERR_INVALID, "rows per workgroup must be 0, 32 or 64");
         h->force_rows = value;
+        return TDMPC2_OK;
+    }
+    if (key == TDMPC2_TUNE_CLUSTER) {
+        if (value < 0 || value > 2) return fail(TDMPC2_ERR_INVALID, "cluster must be 0 (never), 1 (whenever the call fits) or 2 (auto)");
+        h->cluster_mode = value;
         return TDMPC2_OK;
     }
     if (key == TDMPC2_TUNE_FOLD_REFIT) {

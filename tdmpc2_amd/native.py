@@ -564,6 +564,11 @@ class NativePlanner:
         or chosen per call (2, the default: inside when the call fits the chip in one round of workgroups)."""
         self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 1, int(mode)))
 
+    def set_cluster(self, mode):
+        """Fused family, split arithmetic: the single-plan latency path (8 workgroups per 32-row tile, cluster_kernels.cuh):
+        0 never, 1 / 2 (default) whenever all of a call's clusters fit the chip at once."""
+        self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 2, int(mode)))
+
     def set_profiling(self, max_launches: int):
         """Bracket up to `max_launches` rollout-kernel launches with HIP events (0 = off)."""
         self._check(self.lib.tdmpc2_plan_set_profiling(self._h, int(max_launches)))

@@ -168,6 +168,49 @@ def test_plan_matches_reference_golden(name, prec):
 _PN = {0: "auto", 1: "fp32", 2: "split"}
 
 
+@pytest.mark.parametrize("name", FUSED_CASES)
+def test_plan_without_cluster_path_matches_reference_golden(name):
+    """The goldens above run one or two plans per call: the split arithmetic then takes the cluster path (8 workgroups per
+    32-row tile, cluster_kernels.cuh).  The same cases with TDMPC2_TUNE_CLUSTER = 0: one workgroup per tile (ks_rollout)."""
+    from tests.gpu_common import case_on_gpu
+
+    c, model, planner = case_on_gpu(name, 1, 2)
+    g = load_golden(name)
+    planner.set_cluster(0)
+    try:
+        got = _run_native(c, model, planner)
+    finally:
+        planner.set_cluster(2)
+    _compare_stages(name, c, got, g, g["action"], g["prev_mean_out"], tag="/fused/split/golden/no_cluster")
+
+
+@pytest.mark.parametrize("name", ["c1", "c2_i6", "mt5"])
+def test_cluster_path_runs_and_agrees_with_one_workgroup_per_tile(name):
+    """Both kernels compute the same sums in a different order (the cluster splits every contraction in four quarters): the
+    iteration-0 values -- identical actions -- agree to fp32 round-off but not bit for bit (which also proves that the
+    tuning knob switches kernels), every stage stays within the parity gates, and repeated cluster plans are bit-identical."""
+    from tests.gpu_common import case_on_gpu
+
+    c, model, planner = case_on_gpu(name, 1, 2)
+    planner.set_cluster(1)
+    a = _run_native(c, model, planner)
+    a2 = _run_native(c, model, planner)
+    planner.set_cluster(0)
+    try:
+        b = _run_native(c, model, planner)
+    finally:
+        planner.set_cluster(2)
+    for k in a:
+        assert np.array_equal(a[k], a2[k]), (name, k)
+    v_on, v_off = a["value"][:, 0], b["value"][:, 0]
+    assert not np.array_equal(v_on, v_off), "the cluster knob did not change the kernel"
+    err = value_err(v_on, v_off)
+    print(f"[{name}] cluster vs one workgroup per tile, iteration 0 values: rel err {err:.2e}")
+    record_parity(f"{name}/fused/split/cluster_vs_single", value_rel=err)
+    assert err < 2e-5
+    assert np.array_equal(a["actions"][:, 0], b["actions"][:, 0])  # the sampled actions do not depend on the kernel
+
+
 @PRECS
 @pytest.mark.parametrize("name", ["c1_ep", "c2_ep"])
 def test_fused_episodic_plan_matches_reference_golden(name, prec):
