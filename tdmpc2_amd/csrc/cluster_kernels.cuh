@@ -37,12 +37,12 @@
 #pragma once
 
 constexpr int CL = 8;                  // workgroups per cluster
-constexpr int CL_SLOTS = 4;            // exchange tiles per cluster
+constexpr int CL_SLOTS = 5;            // exchange tiles per cluster (the fifth holds a head's logits, [32][128] fp32)
 constexpr int CL_TILE = 32 * WIDTH;    // floats per exchange tile
 constexpr int CL_FLAG_STRIDE = 16;     // arrival words reserved per cluster (64 B)
 constexpr int CL_MAXSPIN = 1 << 17;    // polls before a member gives up (~0.2 s; a healthy wait is microseconds)
-constexpr int CL_MAXKQ = 9;            // k-blocks of 16 per contraction quarter: ceil((512 + 64) / 16 / 4)
 __host__ __device__ constexpr int cl_phases(int H) { return 4 * H + 5; }
+__host__ __device__ constexpr int cl_heads(int H) { return H + 3; }  // narrow heads per launch: H reward, policy, two Q
 
 struct ClState {
     float *xbuf;       // this cluster's CL_SLOTS exchange tiles
@@ -50,51 +50,102 @@ struct ClState {
     unsigned *err;     // the handle's error word
     float *red;        // LDS [2 layers][8 waves][4][64 lanes][4]: contraction-quarter partial sums
     int *dead;         // LDS flag: a wait of this member timed out -- it stops waiting (and the plan is reported invalid)
+    int *fast;         // LDS flag: all members of the cluster run on one XCD (set at the launch's first barrier)
     int rank;
+    unsigned xcc;      // this workgroup's XCC_ID
     unsigned phase;    // last phase this member arrived at
+    unsigned hphase;   // narrow heads so far (arrival words 8..15 of the cluster)
 };
 
-__device__ __forceinline__ void cl_st16(float *p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+__device__ __forceinline__ void cl_st16(float *p, f32x4 v, int fast) {
+    // members on one XCD share its L2: a plain (write-through-to-L2) store is visible to the others' agent-scope loads;
+    // otherwise the line has to leave the XCD: agent-scope write-through
+    if (fast) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void cl_ld16(f32x4 &v, const float *p) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
 }
 
-// One wave's share of a layer: column tile `ct`, k-blocks [k0, k0 + n), n <= CL_MAXKQ -> raw partial sums in the C layout
-// of kloop_s (weight fragment = A operand: lane (j, hh) holds features 8 m + 4 hh + r of sample row j in register 4 m + r).
-// All weight fragments of the share are requested up front (<= 72 VGPRs): the contraction is short, latency-bound.
-template <class CT>
-__device__ __forceinline__ void cl_kloop(const CT &c, const LayerS &ly, int ct, int k0, int n, f32x16 &out) {
-    static_assert(CT::ARITH == 0 && CT::NST == 1, "cluster path: split arithmetic, 32-row tiles");
-    const int i = c.lane & 31, hh = c.lane >> 5;
-    const _Float16 *a0p = c.act + i * c.RSH + 8 * hh + k0 * 16;
-    const char *u = reinterpret_cast<const char *>(ly.wp) + ((size_t)ct * ly.KB + k0) * 2048;  // wave-uniform
+// What a weight request needs to know of a layer, BY VALUE: a pointer to (an element of) the kernel-argument struct --
+// let alone one selected at run time, p.q[q1] -- makes the compiler copy the 2.5 KB struct to scratch and chase the
+// layer's fields through it (measured: 1.47 -> 2.1 ms per plan)
+struct WRef {
+    const _Float16 *wp = nullptr;  // null: no layer
+    int KB = 0;
+};
+__device__ __forceinline__ WRef wref(const LayerS &ly) { return WRef{ly.wp, ly.KB}; }
+
+// One wave's share of a layer: wave w takes feature tile ft = w >> 2 of the member's two and quarter kq = w & 3 of the
+// k-blocks [kb0, kb1): column tile ct, k-blocks [k0, k0 + n).  N k-blocks as STRAIGHT-LINE code: every weight fragment is
+// requested up front and block j's MFMAs wait for exactly its own two loads, so the matrix pipe runs under the rest of the
+// weight stream (with a run-time trip count the compiler's wait before the first MFMA covers all loads: 5.2 k cycles per
+// layer, profiles/README.md r02s).  Raw partial sums in the C layout of kloop_s (weight fragment = A operand: lane (j, hh)
+// holds features 8 m + 4 hh + r of sample row j in register 4 m + r); three independent accumulator chains.
+template <class CT, int N>
+__device__ __forceinline__ void cl_kshare_n(const CT &c, const char *u, const _Float16 *a0p, f32x16 &out) {
     unsigned voff = (unsigned)c.lane * 16u;
     asm volatile("" : "+v"(voff));
-    f16x8 wh[CL_MAXKQ], wl[CL_MAXKQ];
+    f16x8 wh[N > 0 ? N : 1], wl[N > 0 ? N : 1];
 #pragma unroll
-    for (int j = 0; j < CL_MAXKQ; ++j)
-        if (j < n) {  // wave-uniform
-            wh[j] = ldw(u + (size_t)j * 2048, voff, 0);
-            wl[j] = ldw(u + (size_t)j * 2048, voff, 1024);
-        }
+    for (int j = 0; j < N; ++j) {
+        wh[j] = ldw(u + (size_t)j * 2048, voff, 0);
+        wl[j] = ldw(u + (size_t)j * 2048, voff, 1024);
+    }
+    // pins the requests here: the machine scheduler otherwise sinks every load to its first use (load, wait, MFMA, load ...)
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 acc[3];
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    f16x8 ah, al;
+    if (N > 0) {
+        ah = *reinterpret_cast<const f16x8 *>(a0p);
+        al = *reinterpret_cast<const f16x8 *>(a0p + CT::SH);
+    }
 #pragma unroll
-    for (int j = 0; j < CL_MAXKQ; ++j)
-        if (j < n) {
-            const f16x8 ah = *reinterpret_cast<const f16x8 *>(a0p + j * 16);
-            const f16x8 al = *reinterpret_cast<const f16x8 *>(a0p + CT::SH + j * 16);
-            acc[0] = SPLIT_MFMA(wh[j], ah, acc[0]);
-            acc[1] = SPLIT_MFMA(wl[j], ah, acc[1]);
-            acc[2] = SPLIT_MFMA(wh[j], al, acc[2]);
+    for (int j = 0; j < N; ++j) {  // the NEXT block's activation fragments are read in front of this block's MFMAs
+        f16x8 nh = ah, nl = al;
+        if (j + 1 < N) {
+            nh = *reinterpret_cast<const f16x8 *>(a0p + (j + 1) * 16);
+            nl = *reinterpret_cast<const f16x8 *>(a0p + CT::SH + (j + 1) * 16);
         }
+        acc[0] = SPLIT_MFMA(wh[j], ah, acc[0]);
+        acc[1] = SPLIT_MFMA(wl[j], ah, acc[1]);
+        acc[2] = SPLIT_MFMA(wh[j], al, acc[2]);
+        __builtin_amdgcn_sched_barrier(0);
+        ah = nh;
+        al = nl;
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) out[e] = acc[0][e] + (acc[1][e] + acc[2][e]);
+}
+template <class CT>
+__device__ __forceinline__ void cl_kshare(const CT &c, const ClState &x, const WRef ly, int kb0, int kb1, f32x16 &out) {
+    static_assert(CT::ARITH == 0 && CT::NST == 1, "cluster path: split arithmetic, 32-row tiles");
+    const int ft = c.wave >> 2, kq = c.wave & 3;
+    const int nk = kb1 - kb0;
+    const int k0 = kb0 + (nk * kq) / 4;
+    const int n = kb0 + (nk * (kq + 1)) / 4 - k0;  // wave-uniform: 8 or 9 (whole layers), 0 .. 1 (action columns at t = 0)
+    const int ct = 2 * x.rank + ft;
+    const char *u = reinterpret_cast<const char *>(ly.wp) + ((size_t)ct * ly.KB + k0) * 2048;
+    const int i = c.lane & 31, hh = c.lane >> 5;
+    const _Float16 *a0p = c.act + i * c.RSH + 8 * hh + k0 * 16;
+    if (n == 8) cl_kshare_n<CT, 8>(c, u, a0p, out);
+    else if (n == 9) cl_kshare_n<CT, 9>(c, u, a0p, out);
+    else if (n == 1) cl_kshare_n<CT, 1>(c, u, a0p, out);
+    else if (n == 0) cl_kshare_n<CT, 0>(c, u, a0p, out);
+    else {  // any other split (not reached with latent 512 and action paddings 16 .. 64): block by block
+#pragma unroll
+        for (int e = 0; e < 16; ++e) out[e] = 0.f;
+        for (int j = 0; j < n; ++j) {
+            f32x16 part;
+            cl_kshare_n<CT, 1>(c, u + (size_t)j * 2048, a0p + j * 16, part);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) out[e] += part[e];
+        }
+    }
 }
 
 // partial sums of this wave -> LDS, [layer][wave][m][lane] float4
@@ -109,51 +160,63 @@ __device__ __forceinline__ void cl_to_red(const CT &c, const ClState &x, int lay
     }
 }
 
-// arrive at the next phase (all data stores of this workgroup are issued), wait for the other members
+// arrive at the next phase (all data stores of this workgroup are issued), wait for the other members.  The arrival word
+// carries the member's XCC_ID in its top byte: at the first barrier of a launch the pollers learn whether the cluster
+// shares an XCD (x.fast), which later exchanges use to pick the store flavour.
 template <class CT>
-__device__ __forceinline__ void cl_barrier(const CT &c, ClState &x) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through stores are acknowledged
+__device__ __forceinline__ void cl_barrier(const CT &c, ClState &x, bool learn) {
+#ifdef CL_ABL_NO_WAIT  // timing experiment: no hand-over (results are wrong)
+    x.phase += 1;
+    __syncthreads();
+    return;
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores are acknowledged (by the L2 / the fabric)
     __syncthreads();
     x.phase += 1;
-    if (c.tid == 0) __hip_atomic_store(x.flags + x.rank, x.phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c.tid == 0) __hip_atomic_store(x.flags + x.rank, x.phase | (x.xcc << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (c.tid < CL && !*x.dead) {
         int spin = 0;
-        while (__hip_atomic_load(x.flags + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < x.phase) {
+        unsigned v;
+        while (((v = __hip_atomic_load(x.flags + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffffu) < x.phase) {
             if (++spin > CL_MAXSPIN) {  // host-mapped word: a plain system-scope store
                 __hip_atomic_store(x.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 *x.dead = 1;
+                v = 0xff000000u;
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
+        }
+        if (learn) {
+            const unsigned long long same = __ballot((v >> 24) == x.xcc);
+            if (c.tid == 0) *x.fast = (same & 0xffull) == 0xffull;
         }
     }
     __syncthreads();
 }
 
 // The contraction of one or two layers over the member's operand tile -> the cluster's exchange tile(s), one barrier.
-// Wave w: feature tile ft = w >> 2 of the member's two, quarter kq = w & 3 of the k-blocks [kb0, kb1).
 template <class CT>
-__device__ __forceinline__ void cl_gemm(const CT &c, ClState &x, const LayerS &la, int slot_a, const LayerS *lb, int slot_b, int kb0,
-                                        int kb1) {
-    const int ft = c.wave >> 2, kq = c.wave & 3;
-    const int nk = kb1 - kb0;
-    const int k0 = kb0 + (nk * kq) / 4, k1 = kb0 + (nk * (kq + 1)) / 4;
-    const int ct = 2 * x.rank + ft;
+__device__ __forceinline__ void cl_gemm(const CT &c, ClState &x, const WRef la, int slot_a, const WRef lb, int slot_b,
+                                        int kb0, int kb1, bool learn = false) {
+#ifdef CL_ABL_NO_GEMM  // timing experiment
+    kb1 = kb0;
+#endif
     {
         f32x16 v;
-        cl_kloop(c, la, ct, k0, k1 - k0, v);
+        cl_kshare(c, x, la, kb0, kb1, v);
         cl_to_red(c, x, 0, v);
+        if (lb.wp) {  // (both layers' shares in flight at once: 144 VGPRs, spills; measured)
+            cl_kshare(c, x, lb, kb0, kb1, v);
+            cl_to_red(c, x, 1, v);
+        }
     }
-    if (lb) {
-        f32x16 v;
-        cl_kloop(c, *lb, ct, k0, k1 - k0, v);
-        cl_to_red(c, x, 1, v);
-    }
+    TIMER_MARK(c, T_KLOOP)
     __syncthreads();
     // thread (ft', m, lane') sums the four quarters of one float4 and stores it where wave `rank` of ks_rollout's register
     // order would park it: idx4 = (rank * 2 + ft') * 4 + m
     const int rft = c.tid >> 8, rm = (c.tid >> 6) & 3, rl = c.tid & 63;
-    const int nl = lb ? 2 : 1;
+    const int nl = lb.wp ? 2 : 1;
+    const int fast = learn ? 0 : *x.fast;
     for (int layer = 0; layer < nl; ++layer) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -163,9 +226,25 @@ __device__ __forceinline__ void cl_gemm(const CT &c, ClState &x, const LayerS &l
             for (int r = 0; r < 4; ++r) s[r] += pq[r];
         }
         float *dst = x.xbuf + (size_t)(layer == 0 ? slot_a : slot_b) * CL_TILE + ((size_t)((x.rank * 2 + rft) * 4 + rm) * 64 + rl) * 4;
-        cl_st16(dst, s);
+        cl_st16(dst, s, fast);
     }
-    cl_barrier(c, x);
+    TIMER_MARK(c, T_PARK)
+    cl_barrier(c, x, learn);
+    TIMER_MARK(c, T_CL_WAIT)
+}
+
+// this lane's bias values in accumulator order (what epi_t's HASBIAS path reads): requested in front of the exchange-tile
+// loads, so that their latency overlaps
+struct ClBias {
+    f32x4 b[2][4];
+};
+template <class CT>
+__device__ __forceinline__ void cl_bias_load(const CT &c, const float *bias, ClBias &bb) {
+    const int poff = 64 * c.wave + 4 * (c.lane >> 5);
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) bb.b[ft][m] = *reinterpret_cast<const f32x4 *>(bias + poff + 32 * ft + 8 * m);
 }
 
 // exchange tile -> raw sums in ks_rollout's accumulator layout (wave w: features [64 w, 64 w + 64) = member w's slice)
@@ -183,35 +262,143 @@ __device__ __forceinline__ void cl_unpark(const CT &c, const ClState &x, int slo
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[0][ft][4 * m + r] = v[ft * 4 + m][r];
+    TIMER_MARK(c, T_TILE)
 }
 
-// epilogue of a layer whose raw sums wait in exchange tile `slot`: ACT(LayerNorm(sums * oscale + bias)) -> operand tile
+// Epilogue of a layer whose raw sums are in exchange tile `slot`: ACT(LayerNorm(sums * oscale + bias)) -> operand tile.
+// `next`: the LayerNorm parameters of the epilogue after this one (gb protocol of fused_kernels.cuh).  The layer's scales
+// and bias pointer come BY VALUE: a pointer to (an element of) the kernel-argument struct that the compiler cannot fold
+// makes it copy the 2.5 KB struct to scratch and read every parameter from there.
 template <int ACT, class CT>
-__device__ __forceinline__ void cl_epi(const CT &c, const ClState &x, int slot, const LayerS &ly, const float *bias, GB next,
-                                       float *zcopy = nullptr) {
+__device__ __forceinline__ void cl_epi(const CT &c, const ClState &x, int slot, const float *oscale, const float *ascale,
+                                       const float *bias, GB next, float *zcopy = nullptr) {
     if (next.g) gb_prefetch(c, next.g, next.b);
+    const float osc = *oscale, asc = *ascale;
+    ClBias bb;
+    cl_bias_load(c, bias, bb);
     f32x16 acc[1][2];
     cl_unpark(c, x, slot, acc);
-    epi_t<ACT>(c, acc, *ly.oscale, *ly.ascale, bias, next, zcopy);
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[0][ft][4 * m + r] = fmaf(acc[0][ft][4 * m + r], osc, bb.b[ft][m][r]);
+#ifdef CL_ABL_NO_EPI  // timing experiment: raw sums straight into the tile
+    regs_to_tile(c, acc, 1.f);
+    if (zcopy) park(c, acc, zcopy);
+    __syncthreads();
+#else
+    epi_t<ACT, CT, false>(c, acc, osc, asc, bias, GB{}, zcopy);
+#endif
     epi_barrier(c);
+    TIMER_MARK(c, T_EPI)
 }
 
 // a whole hidden layer: contraction over the member's tile, exchange, epilogue
 template <int ACT, class CT>
-__device__ __forceinline__ void cl_layer(const CT &c, ClState &x, const LayerS &ly, const float *bias, int kb0, int kb1, int slot, GB next,
-                                         float *zcopy = nullptr) {
+__device__ __forceinline__ void cl_layer(const CT &c, ClState &x, const WRef ly, const float *oscale, const float *ascale,
+                                         const float *bias, int kb0, int kb1, int slot, GB next, float *zcopy = nullptr) {
     if (next.g) gb_prefetch(c, next.g, next.b);
-    cl_gemm(c, x, ly, slot, nullptr, 0, kb0, kb1);
-    f32x16 acc[1][2];
-    cl_unpark(c, x, slot, acc);
-    epi_t<ACT>(c, acc, *ly.oscale, *ly.ascale, bias, GB{}, zcopy);
-    epi_barrier(c);
+    cl_gemm(c, x, ly, slot, WRef{}, 0, kb0, kb1);
+    cl_epi<ACT>(c, x, slot, oscale, ascale, bias, GB{}, zcopy);
+}
+// shorthand for the call sites: the fields of layer L that cl_layer / cl_epi take by value
+#define CL_L(L) wref(L), (L).oscale, (L).ascale
+#define CL_E(L) (L).oscale, (L).ascale
+
+
+// A narrow head (two-hot reward / Q: 4 column tiles of 32 logits; policy: <= 4) across the cluster: member m < CT computes
+// column tile m -- its 8 waves take 4 k-blocks each, summed through LDS -- and writes the 32 x 32 logits to the cluster's
+// head tile; the consumers (member 0 for a two-hot head: only it needs the values; every member for the policy head) wait
+// for the CT arrival words and copy the logits into their staging view, where the row math of fused_kernels.cuh takes
+// over.  One member running the whole head -- 4 waves x 32 k-blocks, 4 blocks in flight -- took 13.4 k cycles, as much as
+// two hidden layers' contractions (profiles/README.md r02m); the member alone on all 8 waves with every fragment in flight
+// was slower still (r02v).  Members that are neither producer nor consumer walk through.
+// Reuse of the head tile: two heads are always separated by a cluster barrier, which a consumer reaches after its reads.
+template <class CT>
+__device__ __forceinline__ void cl_head_logits(const CT &c, ClState &x, const LayerS &ly, bool consume) {
+    static_assert(CT::ZKB == 32, "8 waves x 4 k-blocks");
+#ifdef CL_ABL_NO_HEAD  // timing experiment: results are wrong
+    return;
+#endif
+    x.hphase += 1;
+    float *hbuf = x.xbuf + (size_t)4 * CL_TILE;
+    unsigned *hflags = x.flags + 8;
+    const bool produce = x.rank < ly.CT;
+    if (produce) {
+        f32x16 acc[1];
+        kloop_tile_s(c, ly, x.rank, 4 * c.wave, 4 * c.wave + 4, acc);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) x.red[(size_t)(c.wave * 16 + reg) * 64 + c.lane] = acc[0][reg];
+    }
+    __syncthreads();  // partials in LDS; every wave is past its reads of the operand tile
+    if (produce) {
+        const float osc = *ly.oscale;
+        const int lane = c.tid & 63, col = lane & 31;
+        const float bv = ly.bias[x.rank * 32 + col];
+        const int fast = *x.fast;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int reg = (c.tid >> 6) + 8 * u;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += x.red[(size_t)(w * 16 + reg) * 64 + lane];
+            const int row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+            float *dst = hbuf + row * 128 + x.rank * 32 + col;
+            const float v = fmaf(s, osc, bv);
+            if (fast) asm volatile("global_store_dword %0, %1, off" ::"v"(dst), "v"(v) : "memory");
+            else asm volatile("global_store_dword %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (c.tid == 0) __hip_atomic_store(hflags + x.rank, x.hphase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!consume) return;
+    if (c.tid < ly.CT && !*x.dead) {
+        int spin = 0;
+        while (__hip_atomic_load(hflags + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < x.hphase) {
+            if (++spin > CL_MAXSPIN) {
+                __hip_atomic_store(x.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                *x.dead = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    {  // head tile -> staging view: thread t takes row t >> 4, columns 4 (t & 15) .. +3 and 64 + 4 (t & 15) .. +3
+        const int row = c.tid >> 4, c4 = (c.tid & 15) * 4;
+        f32x4 v0, v1;
+        cl_ld16(v0, hbuf + row * 128 + c4);
+        cl_ld16(v1, hbuf + row * 128 + 64 + c4);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
+        float *f = c.f32() + row * CT::RSF();
+        *reinterpret_cast<f32x4 *>(f + c4) = v0;
+        *reinterpret_cast<f32x4 *>(f + 64 + c4) = v1;
+    }
+    __syncthreads();
+}
+
+
+// two-hot head: the value is returned on member 0 only (the others get 0 and never use it)
+template <class CT>
+__device__ __forceinline__ float cl_head_twohot(const CT &c, ClState &x, const LayerS &ly, const float *bins, int num_bins) {
+    const bool consume = x.rank == 0;
+    cl_head_logits(c, x, ly, consume);
+    if (!consume) return 0.f;
+#ifdef CL_ABL_NO_HEAD
+    return 1.f;
+#endif
+    const float r = twohot_rows_s(c, bins, num_bins);
+    __syncthreads();
+    return r;
 }
 
 template <int APAD>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ int s_is_last, s_dead;
+    __shared__ int s_is_last, s_dead, s_fast;
     typedef CtxT<APAD, 1, 8, 0> CT;
     constexpr int TROWS = CT::TROWS, NTHR = CT::NTHR;
     constexpr int ZKB16 = CT::ZKB;
@@ -226,8 +413,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS
     float *sm_mean = smem + TROWS * CT::RSF() + 2048;
     float *sm_std = sm_mean + p.H * p.A;
     ClState x{p.cl_xbuf + (size_t)cl * CL_SLOTS * CL_TILE, p.cl_flags + (size_t)cl * CL_FLAG_STRIDE, p.cl_err,
-              smem + TROWS * CT::RSF() + 2048 + ((2 * p.H * p.A + 3) & ~3), &s_dead, rank, (unsigned)(p.iter * cl_phases(p.H))};
-    if (tid == 0) s_dead = 0;
+              smem + TROWS * CT::RSF() + 2048 + ((2 * p.H * p.A + 3) & ~3), &s_dead, &s_fast, rank, 0u,
+              (unsigned)(p.iter * cl_phases(p.H)), (unsigned)(p.iter * cl_heads(p.H))};
+    {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        x.xcc = xcc & 0xfu;
+    }
+    if (tid == 0) {
+        s_dead = 0;
+        s_fast = 0;
+    }
     const int row0 = tile * TROWS;
     const float *mask = p.act_mask ? p.act_mask + (size_t)e * p.A : nullptr;
     const float *disc = p.disc_pow + (size_t)e * (p.H + 1);
@@ -258,6 +454,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS
     epi_barrier(c);
 
     float G = 0.f;
+    TIMER_START(c)
     for (int t = 0; t < p.H; ++t) {
         // ---- actions of step t (tdmpc2.py:176-181): every member fills its own tile; member 0 also writes them out
         {
@@ -294,54 +491,51 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS
             }
         }
         __syncthreads();
+        TIMER_MARK(c, T_ACT)
         // ---- first layers of dynamics (parked in S0) and reward (S1) over the same [z_t | a_t] tile
         gb_prefetch(c, p.rew.l[1].g, p.rew.l[1].b);
-        cl_gemm(c, x, p.dyn.l[0], 0, &p.rew.l[0], 1, t == 0 ? ZKB16 : 0, KBA);
-        {
-            f32x16 acc[1][2];
-            cl_unpark(c, x, 1, acc);
-            epi_t<0>(c, acc, *p.rew.l[0].oscale, *p.rew.l[0].ascale, t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew, GB{},
-                     nullptr);
-            epi_barrier(c);
-        }
+        cl_gemm(c, x, wref(p.dyn.l[0]), 0, wref(p.rew.l[0]), 1, t == 0 ? ZKB16 : 0, KBA, t == 0);
+        cl_epi<0>(c, x, 1, CL_E(p.rew.l[0]), t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew, GB{});
         // ---- reward: layer 2, two-hot head
-        cl_layer<0>(c, x, p.rew.l[1], p.rew.l[1].bias, 0, ZKB16, 2, gb_of(p.dyn.l[0]));
-        const float r = head_twohot_s(c, p.rew.l[2], p.bins, p.num_bins);
+        cl_layer<0>(c, x, CL_L(p.rew.l[1]), p.rew.l[1].bias, 0, ZKB16, 2, gb_of(p.dyn.l[0]));
+        const float r = cl_head_twohot(c, x, p.rew.l[2], p.bins, p.num_bins);
+        TIMER_MARK(c, T_HEAD)
         G += disc[t] * r;
         // ---- dynamics: the parked first layer, layers 2 and 3 (SimNorm)
-        cl_epi<0>(c, x, 0, p.dyn.l[0], t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn, gb_of(p.dyn.l[1]));
-        cl_layer<0>(c, x, p.dyn.l[1], p.dyn.l[1].bias, 0, ZKB16, 1, gb_of(p.dyn.l[2]));
-        cl_layer<1>(c, x, p.dyn.l[2], p.dyn.l[2].bias, 0, ZKB16, 2, t == p.H - 1 ? gb_of(p.pi.l[0]) : gb_of(p.rew.l[0]),
+        cl_epi<0>(c, x, 0, CL_E(p.dyn.l[0]), t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn, gb_of(p.dyn.l[1]));
+        cl_layer<0>(c, x, CL_L(p.dyn.l[1]), p.dyn.l[1].bias, 0, ZKB16, 1, gb_of(p.dyn.l[2]));
+        cl_layer<1>(c, x, CL_L(p.dyn.l[2]), p.dyn.l[2].bias, 0, ZKB16, 2, t == p.H - 1 ? gb_of(p.pi.l[0]) : gb_of(p.rew.l[0]),
                     t == p.H - 1 ? zs : nullptr);
     }
     // ---- a_H = pi(z_H) (tdmpc2.py:135); z_H was also saved to zs
-    cl_layer<0>(c, x, p.pi.l[0], b_pi, 0, ZKB16, 0, gb_of(p.pi.l[1]));
-    cl_layer<0>(c, x, p.pi.l[1], p.pi.l[1].bias, 0, ZKB16, 1, gb_of(p.q[q0].l[0]));
+    cl_layer<0>(c, x, CL_L(p.pi.l[0]), b_pi, 0, ZKB16, 0, gb_of(p.pi.l[1]));
+    cl_layer<0>(c, x, CL_L(p.pi.l[1]), p.pi.l[1].bias, 0, ZKB16, 1, gb_of(p.q[q0].l[0]));
     {
         auto eps = [&](int row, int a) -> float {
             const unsigned ridx = (unsigned)((size_t)(row0 + row) * p.A + a);
             if (p.pi_eps) return p.pi_eps[(size_t)e * p.pi_eps_estride + ridx];
             return rng_normal(p.seed, p.call, SITE_PI, p.iter, e, ridx);
         };
-        head_pi_s(c, p.pi.l[2], p.A, p.Apad, p.log_std_min, p.log_std_dif, mask, eps, nullptr, 0, nullptr);
+        cl_head_logits(c, x, p.pi.l[2], true);
+        head_pi_rows_s(c, p.A, p.Apad, p.log_std_min, p.log_std_dif, mask, eps, nullptr, 0, nullptr);
     }
+    TIMER_MARK(c, T_HEAD)
     tile_from_global_s(c, zs);
     __syncthreads();
+    TIMER_MARK(c, T_ACT)
     // ---- Q(z_H, a_H): the two selected heads (world_model.py:186-216); the second one's first layer is parked in S2
     gb_prefetch(c, p.q[q0].l[1].g, p.q[q0].l[1].b);
-    cl_gemm(c, x, p.q[q1].l[0], 2, &p.q[q0].l[0], 3, 0, KBA);
-    {
-        f32x16 acc[1][2];
-        cl_unpark(c, x, 3, acc);
-        epi_t<0>(c, acc, *p.q[q0].l[0].oscale, *p.q[q0].l[0].ascale, b_q0, GB{}, nullptr);
-        epi_barrier(c);
-    }
-    cl_layer<0>(c, x, p.q[q0].l[1], p.q[q0].l[1].bias, 0, ZKB16, 0, gb_of(p.q[q1].l[0]));
-    const float qa = head_twohot_s(c, p.q[q0].l[2], p.bins, p.num_bins);
-    cl_epi<0>(c, x, 2, p.q[q1].l[0], b_q1, gb_of(p.q[q1].l[1]));
-    cl_layer<0>(c, x, p.q[q1].l[1], p.q[q1].l[1].bias, 0, ZKB16, 1, GB{});
-    if (rank != 0) return;  // nothing left to contribute: member 0 owns the values
-    const float qb = head_twohot_s(c, p.q[q1].l[2], p.bins, p.num_bins);
+    cl_gemm(c, x, wref(p.q[q1].l[0]), 2, wref(p.q[q0].l[0]), 3, 0, KBA);
+    cl_epi<0>(c, x, 3, CL_E(p.q[q0].l[0]), b_q0, GB{});
+    cl_layer<0>(c, x, CL_L(p.q[q0].l[1]), p.q[q0].l[1].bias, 0, ZKB16, 0, gb_of(p.q[q1].l[0]));
+    const float qa = cl_head_twohot(c, x, p.q[q0].l[2], p.bins, p.num_bins);
+    TIMER_MARK(c, T_HEAD)
+    cl_epi<0>(c, x, 2, CL_E(p.q[q1].l[0]), b_q1, gb_of(p.q[q1].l[1]));
+    cl_layer<0>(c, x, CL_L(p.q[q1].l[1]), p.q[q1].l[1].bias, 0, ZKB16, 1, GB{});
+    const float qb = cl_head_twohot(c, x, p.q[q1].l[2], p.bins, p.num_bins);
+    if (rank != 0) return;  // member 0 owns the values
+    TIMER_MARK(c, T_HEAD)
+    TIMER_FLUSH(c, p.timing)
     const float val = G + disc[p.H] * ((qa + qb) / 2.f);
     if (!p.fold_refit) {
         if ((tid & 7) == 0 && live) p.value[(size_t)e * p.N + row0 + (tid >> 3)] = val;

@@ -41,7 +41,7 @@
 #define TIMER_FLUSH(c, ptr)
 #endif
 enum { T_KLOOP = 0, T_EPI = 1, T_HEAD = 2, T_ACT = 3, T_PARK = 4, T_TILE = 5, T_EPI_PRE = 6, T_EPI_SYNC = 7, T_EPI_BIAS = 8,
-       T_EPI_COMB = 9, T_EPI_MATH = 10 };
+       T_EPI_COMB = 9, T_EPI_MATH = 10, T_CL_WAIT = 11 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -940,6 +940,11 @@ __device__ __forceinline__ void put_action(const CT &c, int row, int a, float v)
     rp[c.SH] = (_Float16)(vs - (float)h);
 }
 
+template <class CT, typename EpsFn>
+__device__ __forceinline__ void head_pi_rows_s(const CT &c, int A, int Apad, float lsmin, float lsdif, const float *mask_wg, EpsFn eps,
+                                               float *gdst, int nvalid, float *tsc, const float *mask_tab = nullptr,
+                                               const int *row_task = nullptr);
+
 // Policy prior output layer + squashed Gaussian sample (world_model.py:152-173); action -> operand-form action columns
 // (zero for padded columns) and optionally gdst[row * A + a] for rows < nvalid.
 template <class CT, typename EpsFn>
@@ -956,6 +961,13 @@ __device__ __forceinline__ void head_pi_s(const CT &c, const LayerS &ly, int A, 
         for (int rt = 0; rt < CT::NST; ++rt) store_tile_s(c, acc[rt], osc, ly.bias, ct, rt);
     }
     __syncthreads();
+    head_pi_rows_s(c, A, Apad, lsmin, lsdif, mask_wg, eps, gdst, nvalid, tsc, mask_tab, row_task);
+}
+
+// the policy head's logits (mean | log_std, staging view) -> squashed Gaussian sample -> operand-form action columns
+template <class CT, typename EpsFn>
+__device__ __forceinline__ void head_pi_rows_s(const CT &c, int A, int Apad, float lsmin, float lsdif, const float *mask_wg, EpsFn eps,
+                                               float *gdst, int nvalid, float *tsc, const float *mask_tab, const int *row_task) {
     const int row = c.tid >> 3, part = c.tid & 7;
     const float *rp = c.f32() + row * c.RSF();
     // action mask: one per workgroup (planning: the plan's task) or one per row (training batches: mask_tab[task of row])

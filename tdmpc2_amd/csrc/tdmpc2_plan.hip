@@ -310,7 +310,10 @@ __device__ __forceinline__ float float_of_ordered(unsigned o) {
 #define RT_INIT
 #endif
 
-__device__ void refit_plan(const RefitParams &p, int e, float *smem, int tid, int nthr) {
+// forceinline: as a real call it takes the ADDRESS of the caller's kernel-argument member (`p.rf`), which makes the compiler
+// copy the caller's whole 2.5 KB argument struct to scratch and read every parameter from there (seen when the inliner's
+// budget ran out in ks_rollout_cl: 1.47 -> 2.1 ms per plan).
+__device__ __forceinline__ void refit_plan(const RefitParams &p, int e, float *smem, int tid, int nthr) {
     int M = 64;  // sort width: the power of two >= N
     while (M < p.N) M <<= 1;
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);  // [M] sort keys (or: [N] floats, counting path)
@@ -1311,7 +1314,7 @@ void tdmpc2_plan_destroy(tdmpc2_plan_t *h) {
         unsigned long long t[16];
         if (hipMemcpy(t, h->timing, sizeof t, hipMemcpyDeviceToHost) == hipSuccess && t[15] > 0) {
             static const char *names[16] = {"kloop", "epi_post", "head", "actions", "park/unpark", "tile_from_global", "epi_stats", "epi_sync",
-                                            "epi_bias", "epi_combine", "epi_math_store", "", "", "", "total", "workgroups"};
+                                            "epi_bias", "epi_combine", "epi_math_store", "cluster_wait", "", "", "total", "workgroups"};
             fprintf(stderr, "[tdmpc2_plan timing max_envs=%d] mean cycles per workgroup (one wave, SPLIT_TIMING_WAVE):", h->cfg.max_envs);
             for (int i = 0; i < 15; ++i)
                 if (names[i][0]) fprintf(stderr, " %s=%.0f", names[i], (double)t[i] / (double)t[15]);

@@ -15,7 +15,7 @@ dev = torch.device("cuda", 0)
 for name in sys.argv[1:] or ["c2", "c1"]:
     cfg = named_config(name)
     sd = {k: torch.as_tensor(v).to(dev) for k, v in synth.make_state_dict(cfg, seed=0).items()}
-    for E in (1, 2):
+    for E in [int(m) for m in os.environ.get("CLUSTER_ENVS", "1,2").split(",")]:
         pl = NativePlanner(cfg, 6, dev, max_envs=E)
         pl.bind_state_dict(sd)
         z = torch.as_tensor(synth.make_latents(cfg, E, seed=1)).to(dev)
@@ -23,7 +23,7 @@ for name in sys.argv[1:] or ["c2", "c1"]:
         pm = torch.zeros(E, cfg.horizon, cfg.action_dim, device=dev)
         t0 = torch.zeros(E, dtype=torch.uint8, device=dev)
         out = torch.empty(E, cfg.action_dim, device=dev)
-        for mode in (1, 0, 1, 0):
+        for mode in [int(m) for m in os.environ.get("CLUSTER_MODES", "1,0,1,0").split(",")]:
             pl.set_cluster(mode)
             for i in range(3):
                 pl.plan(z, disc, pm, t0, seed=i, out=out)
