@@ -31,6 +31,9 @@
 //                         epilogue dyn.l0 <- S0 (parked)
 //             phase 4t+3  dyn.l1 -> S1                                                            epilogue
 //             phase 4t+4  dyn.l2 -> S2                                                            SimNorm epilogue
+//   (cluster 0 of a plan, first launch: the policy-prior trajectories, tdmpc2.py:154-160, are the rollout of the tile's first
+//    P rows under a_t = pi(z_t): at the top of step t  pi.l0 -> S0, pi.l1 -> S3, policy head -> the P rows' action columns and
+//    `actions`, z_t back into the tile; two more hand-overs per step -- phases are only required to grow)
 //   value:    phase 4H+1  pi.l0 -> S0;  4H+2  pi.l1 -> S1;  policy head;  z_H back into the tile
 //             phase 4H+3  q1.l0 -> S2 (parked), q0.l0 -> S3;  4H+4  q0.l1 -> S0;  head;  epilogue q1.l0 <- S2
 //             phase 4H+5  q1.l1 -> S1;  head.
@@ -41,8 +44,8 @@ constexpr int CL_SLOTS = 5;            // exchange tiles per cluster (the fifth 
 constexpr int CL_TILE = 32 * WIDTH;    // floats per exchange tile
 constexpr int CL_FLAG_STRIDE = 16;     // arrival words reserved per cluster (64 B)
 constexpr int CL_MAXSPIN = 1 << 17;    // polls before a member gives up (~0.2 s; a healthy wait is microseconds)
-__host__ __device__ constexpr int cl_phases(int H) { return 4 * H + 5; }
-__host__ __device__ constexpr int cl_heads(int H) { return H + 3; }  // narrow heads per launch: H reward, policy, two Q
+__host__ __device__ constexpr int cl_phases(int H) { return 6 * H + 5; }  // hand-overs per launch (upper bound: with the policy prior)
+__host__ __device__ constexpr int cl_heads(int H) { return 2 * H + 3; }  // narrow heads per launch: H reward (+ H policy prior), policy, two Q
 
 struct ClState {
     float *xbuf;       // this cluster's CL_SLOTS exchange tiles
@@ -55,6 +58,7 @@ struct ClState {
     unsigned xcc;      // this workgroup's XCC_ID
     unsigned phase;    // last phase this member arrived at
     unsigned hphase;   // narrow heads so far (arrival words 8..15 of the cluster)
+    bool learned;      // the launch's first hand-over is behind us (x.fast is valid)
 };
 
 __device__ __forceinline__ void cl_st16(float *p, f32x4 v, int fast) {
@@ -197,7 +201,9 @@ __device__ __forceinline__ void cl_barrier(const CT &c, ClState &x, bool learn) 
 // The contraction of one or two layers over the member's operand tile -> the cluster's exchange tile(s), one barrier.
 template <class CT>
 __device__ __forceinline__ void cl_gemm(const CT &c, ClState &x, const WRef la, int slot_a, const WRef lb, int slot_b,
-                                        int kb0, int kb1, bool learn = false) {
+                                        int kb0, int kb1) {
+    const bool learn = !x.learned;  // the first hand-over of a launch: safe stores, and the pollers compare XCC ids
+    x.learned = true;
 #ifdef CL_ABL_NO_GEMM  // timing experiment
     kb1 = kb0;
 #endif
@@ -414,7 +420,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS
     float *sm_std = sm_mean + p.H * p.A;
     ClState x{p.cl_xbuf + (size_t)cl * CL_SLOTS * CL_TILE, p.cl_flags + (size_t)cl * CL_FLAG_STRIDE, p.cl_err,
               smem + TROWS * CT::RSF() + 2048 + ((2 * p.H * p.A + 3) & ~3), &s_dead, &s_fast, rank, 0u,
-              (unsigned)(p.iter * cl_phases(p.H)), (unsigned)(p.iter * cl_heads(p.H))};
+              (unsigned)(p.iter * cl_phases(p.H)), (unsigned)(p.iter * cl_heads(p.H)), false};
     {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -450,7 +456,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS
     const float *b_pi = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_PI) * WIDTH : p.pi.l[0].bias;
     const float *b_q0 = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_Q0 + q0) * WIDTH : p.q[q0].l[0].bias;
     const float *b_q1 = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_Q0 + q1) * WIDTH : p.q[q1].l[0].bias;
-    gb_prefetch(c, p.rew.l[0].g, p.rew.l[0].b);
+    // the policy-prior trajectories of this plan: tile 0's first P rows, first launch (host: P <= 32)
+    const bool pifold = p.pi_fold && p.iter == 0 && tile == 0;
+    if (pifold) gb_prefetch(c, p.pi.l[0].g, p.pi.l[0].b);
+    else gb_prefetch(c, p.rew.l[0].g, p.rew.l[0].b);
+    tile_broadcast_row_s(c, p.z0 + (size_t)e * WIDTH);  // z_0 in every row (tdmpc2.py:163); step 0 contracts the full [z | a] range
     epi_barrier(c);
 
     float G = 0.f;
@@ -475,7 +485,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS
                     const int a = a0 + u;
                     if (a < p.A) {
                         if (!sampled) {
-                            v[u] = ag[(size_t)n * p.A + a];
+                            v[u] = pifold ? 0.f : ag[(size_t)n * p.A + a];  // pifold: filled in by the policy head below
                         } else {
                             float r = z[u];
                             if (p.sample_eps)
@@ -492,20 +502,48 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS
         }
         __syncthreads();
         TIMER_MARK(c, T_ACT)
+        if (pifold) {  // a_t = pi(z_t) for the rows < P (tdmpc2.py:156-160), then z_t back into the tile
+            if (t == 0) {  // zs <- z_0 in register order (later steps: the SimNorm epilogue's copy)
+                f32x16 y[1][2];
+                const int hh = c.lane >> 5;
+#pragma unroll
+                for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const f32x4 z = *reinterpret_cast<const f32x4 *>(p.z0 + (size_t)e * WIDTH + 64 * c.wave + 32 * ft + 8 * m + 4 * hh);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[0][ft][4 * m + r] = z[r];
+                    }
+                park(c, y, zs);
+            }
+            cl_layer<0>(c, x, CL_L(p.pi.l[0]), b_pi, 0, ZKB16, 0, gb_of(p.pi.l[1]));
+            cl_layer<0>(c, x, CL_L(p.pi.l[1]), p.pi.l[1].bias, 0, ZKB16, 3, gb_of(p.rew.l[0]));
+            const float *tape = p.pi_traj_eps ? p.pi_traj_eps + ((size_t)e * p.H + t) * p.P * p.A : nullptr;
+            auto eps = [&](int row, int a) -> float {
+                if (row >= p.P) return 0.f;
+                if (tape) return tape[row * p.A + a];
+                return rng_normal(p.seed, p.call, SITE_PITRAJ, t, e, (unsigned)(row * p.A + a));
+            };
+            cl_head_logits(c, x, p.pi.l[2], true);
+            head_pi_rows_s(c, p.A, p.Apad, p.log_std_min, p.log_std_dif, mask, eps,
+                           rank == 0 ? p.actions + ((size_t)e * p.H + t) * p.N * p.A : nullptr, p.P, nullptr, nullptr, nullptr, p.P, true);
+            tile_from_global_s(c, zs);
+            __syncthreads();
+        }
         // ---- first layers of dynamics (parked in S0) and reward (S1) over the same [z_t | a_t] tile
         gb_prefetch(c, p.rew.l[1].g, p.rew.l[1].b);
-        cl_gemm(c, x, wref(p.dyn.l[0]), 0, wref(p.rew.l[0]), 1, t == 0 ? ZKB16 : 0, KBA, t == 0);
-        cl_epi<0>(c, x, 1, CL_E(p.rew.l[0]), t == 0 ? p.cvec + ((size_t)e * 2 + 0) * WIDTH : b_rew, GB{});
+        cl_gemm(c, x, wref(p.dyn.l[0]), 0, wref(p.rew.l[0]), 1, 0, KBA);
+        cl_epi<0>(c, x, 1, CL_E(p.rew.l[0]), b_rew, GB{});
         // ---- reward: layer 2, two-hot head
         cl_layer<0>(c, x, CL_L(p.rew.l[1]), p.rew.l[1].bias, 0, ZKB16, 2, gb_of(p.dyn.l[0]));
         const float r = cl_head_twohot(c, x, p.rew.l[2], p.bins, p.num_bins);
         TIMER_MARK(c, T_HEAD)
         G += disc[t] * r;
         // ---- dynamics: the parked first layer, layers 2 and 3 (SimNorm)
-        cl_epi<0>(c, x, 0, CL_E(p.dyn.l[0]), t == 0 ? p.cvec + ((size_t)e * 2 + 1) * WIDTH : b_dyn, gb_of(p.dyn.l[1]));
+        cl_epi<0>(c, x, 0, CL_E(p.dyn.l[0]), b_dyn, gb_of(p.dyn.l[1]));
         cl_layer<0>(c, x, CL_L(p.dyn.l[1]), p.dyn.l[1].bias, 0, ZKB16, 1, gb_of(p.dyn.l[2]));
-        cl_layer<1>(c, x, CL_L(p.dyn.l[2]), p.dyn.l[2].bias, 0, ZKB16, 2, t == p.H - 1 ? gb_of(p.pi.l[0]) : gb_of(p.rew.l[0]),
-                    t == p.H - 1 ? zs : nullptr);
+        cl_layer<1>(c, x, CL_L(p.dyn.l[2]), p.dyn.l[2].bias, 0, ZKB16, 2, (t == p.H - 1 || pifold) ? gb_of(p.pi.l[0]) : gb_of(p.rew.l[0]),
+                    (t == p.H - 1 || pifold) ? zs : nullptr);
     }
     // ---- a_H = pi(z_H) (tdmpc2.py:135); z_H was also saved to zs
     cl_layer<0>(c, x, CL_L(p.pi.l[0]), b_pi, 0, ZKB16, 0, gb_of(p.pi.l[1]));

@@ -943,7 +943,7 @@ __device__ __forceinline__ void put_action(const CT &c, int row, int a, float v)
 template <class CT, typename EpsFn>
 __device__ __forceinline__ void head_pi_rows_s(const CT &c, int A, int Apad, float lsmin, float lsdif, const float *mask_wg, EpsFn eps,
                                                float *gdst, int nvalid, float *tsc, const float *mask_tab = nullptr,
-                                               const int *row_task = nullptr);
+                                               const int *row_task = nullptr, int put_rows = CT::TROWS, bool agent_store = false);
 
 // Policy prior output layer + squashed Gaussian sample (world_model.py:152-173); action -> operand-form action columns
 // (zero for padded columns) and optionally gdst[row * A + a] for rows < nvalid.
@@ -967,7 +967,10 @@ __device__ __forceinline__ void head_pi_s(const CT &c, const LayerS &ly, int A, 
 // the policy head's logits (mean | log_std, staging view) -> squashed Gaussian sample -> operand-form action columns
 template <class CT, typename EpsFn>
 __device__ __forceinline__ void head_pi_rows_s(const CT &c, int A, int Apad, float lsmin, float lsdif, const float *mask_wg, EpsFn eps,
-                                               float *gdst, int nvalid, float *tsc, const float *mask_tab, const int *row_task) {
+                                               float *gdst, int nvalid, float *tsc, const float *mask_tab, const int *row_task,
+                                               int put_rows, bool agent_store) {
+    // put_rows: only rows < put_rows take the action into their operand columns (the cluster path's in-launch policy prior:
+    // the other rows of the tile keep their sampled actions); agent_store: gdst is read by another workgroup of this launch
     const int row = c.tid >> 3, part = c.tid & 7;
     const float *rp = c.f32() + row * c.RSF();
     // action mask: one per workgroup (planning: the plan's task) or one per row (training batches: mask_tab[task of row])
@@ -988,10 +991,13 @@ __device__ __forceinline__ void head_pi_rows_s(const CT &c, int A, int Apad, flo
                 e *= mk;
             }
             out = tanhf(mu + e * expf(ls));
-            if (gdst && row < nvalid) gdst[row * A + a] = out;
+            if (gdst && row < nvalid) {
+                if (agent_store) __hip_atomic_store(gdst + row * A + a, out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else gdst[row * A + a] = out;
+            }
             if (tsc) tsc[a] = out;
         }
-        put_action(c, row, a, out);
+        if (row < put_rows) put_action(c, row, a, out);
     }
     __syncthreads();
 }
@@ -1082,6 +1088,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
         p.mean[(size_t)e * p.H * p.A + idx] = m;
         p.std[(size_t)e * p.H * p.A + idx] = p.max_std;
     }
+    if (p.skip_cvec) return;  // cluster path: step 0 contracts the full [z | a] range itself
     tile_broadcast_row_s(c, p.z0 + (size_t)e * WIDTH);
     __syncthreads();
     f32x16 acc[2][2][2];

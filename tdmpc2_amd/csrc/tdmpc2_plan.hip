@@ -124,6 +124,8 @@ struct RolloutParamsT {
     unsigned int *cl_flags;
     unsigned int *cl_err;
     float *cl_zs;
+    int pi_fold;               // the policy-prior trajectories (tdmpc2.py:154-160) are computed by cluster 0 of each plan in launch 0
+    const float *pi_traj_eps;  // [E,H,P,A] or null (Philox)
 };
 
 // pi + two Q heads on a batch of latent rows (fused_kernels.cuh: ks_value)
@@ -234,6 +236,7 @@ struct SetupParamsT {
     float *beff, *cvec, *mean, *std;
     unsigned int *cl_flags;  // cluster path: arrival words, zeroed at the start of every plan ([E][cl_flag_words]) or null
     int cl_flag_words;
+    int skip_cvec;           // cluster path: no z0 products (cvec unused)
 };
 
 // policy-prior trajectories (tdmpc2/tdmpc2.py:154-160): rows < P of one tile per plan
@@ -416,9 +419,11 @@ __device__ __forceinline__ void refit_plan(const RefitParams &p, int e, float *s
             const int t = rem / hpa, a0 = 2 * (rem - t * hpa);
             const int n = ei[k];
             float v[2] = {0.f, 0.f};
-            if (n < p.P) {  // policy-prior rows: written by ks_pitraj, an earlier launch
-                v[0] = acts[((size_t)t * p.N + n) * p.A + a0];
-                if (a0 + 1 < p.A) v[1] = acts[((size_t)t * p.N + n) * p.A + a0 + 1];
+            if (n < p.P) {  // policy-prior rows: written by ks_pitraj (an earlier launch) or, on the cluster path, by another
+                            // workgroup of THIS launch (agent-scope stores there, agent-scope loads here)
+                v[0] = __hip_atomic_load(acts + ((size_t)t * p.N + n) * p.A + a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a0 + 1 < p.A)
+                    v[1] = __hip_atomic_load(acts + ((size_t)t * p.N + n) * p.A + a0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 float r[2] = {0.f, 0.f};
                 if (p.sample_eps) {
@@ -908,7 +913,7 @@ ClusterGate g_cluster_gate;
 
 template <class NET>
 int launch_setup(tdmpc2_plan *h, int E, const float *z0, const float *task_emb, const float *prev_mean,
-                 const unsigned char *t0, hipStream_t st) {
+                 const unsigned char *t0, hipStream_t st, bool skip_cvec = false) {
     SetupParamsT<NET> p{};
     p.E = E; p.H = h->cfg.horizon; p.A = h->cfg.action_dim; p.T = h->cfg.task_dim; p.multitask = h->cfg.multitask;
     p.nq = h->cfg.num_q; p.nnets = h->nnets; p.stride = h->stride; p.max_std = h->cfg.max_std;
@@ -921,6 +926,7 @@ int launch_setup(tdmpc2_plan *h, int E, const float *z0, const float *task_emb, 
     // cluster path: the arrival words of this call's clusters start every plan at zero (phase numbers grow through its launches)
     p.cl_flags = (h->cl_max_clusters && (long)E * h->tiles * 2 <= h->cl_max_clusters) ? h->cl_flags : nullptr;
     p.cl_flag_words = h->tiles * 2 * CL_FLAG_STRIDE;
+    p.skip_cvec = skip_cvec ? 1 : 0;
     Kern<NET>::setup(h, p, E, st);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -965,8 +971,14 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
     const int H = c.horizon, N = c.num_samples, A = c.action_dim, K = c.num_elites, P = c.num_pi_trajs, I = c.iterations;
     const unsigned call = h->call++;
     int rc;
-    if ((rc = launch_setup<NET>(h, E, z0, task_emb, prev_mean, t0, st))) return rc;
-    if (P > 0) {
+    // single-plan latency: 8 workgroups per 32-row tile when the whole call then still fits the chip in one round
+    const long clusters = (long)E * h->tiles * 2;
+    const bool cluster = h->cluster_mode != 0 && h->cl_max_clusters > 0 && clusters <= h->cl_max_clusters &&
+                         (clusters + 7) / 8 * 64 <= (h->num_cus > 0 ? h->num_cus : 256);
+    // ... which also computes the policy-prior trajectories (cluster 0 of each plan, first launch) and needs no z0 products
+    const bool pi_fold = cluster && P > 0 && P <= 32;
+    if ((rc = launch_setup<NET>(h, E, z0, task_emb, prev_mean, t0, st, cluster))) return rc;
+    if (P > 0 && !pi_fold) {
         PiTrajParamsT<NET> p{};
         p.E = E; p.N = N; p.H = H; p.A = A; p.Apad = h->Apad; p.P = P; p.stride = h->stride; p.multitask = c.multitask;
         p.nnets = h->nnets; p.log_std_min = c.log_std_min; p.log_std_dif = c.log_std_dif;
@@ -980,10 +992,8 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
     RolloutParamsT<NET> rp{};
     fill_rollout<NET>(h, rp, E);
     rp.z0 = z0; rp.act_mask = act_mask; rp.disc_pow = disc_pow; rp.seed = seed; rp.call = call; rp.given_actions = 0;
-    // single-plan latency: 8 workgroups per 32-row tile when the whole call then still fits the chip in one round
-    const long clusters = (long)E * h->tiles * 2;
-    const bool cluster = h->cluster_mode != 0 && h->cl_max_clusters > 0 && clusters <= h->cl_max_clusters &&
-                         (clusters + 7) / 8 * 64 <= (h->num_cus > 0 ? h->num_cus : 256);
+    rp.pi_fold = pi_fold ? 1 : 0;
+    rp.pi_traj_eps = tape ? tape->pi_traj_eps : nullptr;
     const int nst = cluster ? 1 : Kern<NET>::sample_tiles(h, E, false), nw = Kern<NET>::waves(h, E, nst);
     rp.tiles = h->tiles * (2 / nst);
     rp.cl_xbuf = h->cl_xbuf; rp.cl_flags = h->cl_flags; rp.cl_err = h->cl_err_dev; rp.cl_zs = h->cl_zs;

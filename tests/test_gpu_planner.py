@@ -208,7 +208,11 @@ def test_cluster_path_runs_and_agrees_with_one_workgroup_per_tile(name):
     print(f"[{name}] cluster vs one workgroup per tile, iteration 0 values: rel err {err:.2e}")
     record_parity(f"{name}/fused/split/cluster_vs_single", value_rel=err)
     assert err < 2e-5
-    assert np.array_equal(a["actions"][:, 0], b["actions"][:, 0])  # the sampled actions do not depend on the kernel
+    # the sampled actions do not depend on the kernel; the policy-prior rows are computed by a different kernel on each path
+    # (ks_pitraj / cluster 0's first launch): the same arithmetic in a different summation order
+    P = c["cfg"].num_pi_trajs
+    assert np.array_equal(a["actions"][:, 0, :, P:], b["actions"][:, 0, :, P:])
+    assert np.abs(a["actions"][:, 0, :, :P] - b["actions"][:, 0, :, :P]).max() < 1e-5
 
 
 @PRECS
