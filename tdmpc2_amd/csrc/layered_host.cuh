@@ -40,7 +40,12 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             while (rt > 1 && (long)(rows_p / (32 * rt)) * q.ncolblk < slots * 3 / 4) rt >>= 1;
         }
         const int nblk = (int)(rows_p / (32 * rt)) * q.ncolblk;
+        // few workgroups per CU: row operand staged four chunks deep, weight ring of 8 / 16 blocks (g_gemm_s<.., .., 4>)
+        const bool deep = !wide && (long)nblk < 2 * slots && !getenv("TDMPC2_GEMM_SD1");
         if (wide) hipLaunchKernelGGL((g_gemm_s<2, 4>), dim3(nblk), dim3(GTHREADS), 0, st, q);
+        else if (deep && rt == 4) hipLaunchKernelGGL((g_gemm_s<1, 4, 4>), dim3(nblk), dim3(GTHREADS), 0, st, q);
+        else if (deep && rt == 2) hipLaunchKernelGGL((g_gemm_s<1, 2, 4>), dim3(nblk), dim3(GTHREADS), 0, st, q);
+        else if (deep) hipLaunchKernelGGL((g_gemm_s<1, 1, 4>), dim3(nblk), dim3(GTHREADS), 0, st, q);
         else if (rt == 4) hipLaunchKernelGGL((g_gemm_s<1, 4>), dim3(nblk), dim3(GTHREADS), 0, st, q);
         else if (rt == 2) hipLaunchKernelGGL((g_gemm_s<1, 2>), dim3(nblk), dim3(GTHREADS), 0, st, q);
         else hipLaunchKernelGGL((g_gemm_s<1, 1>), dim3(nblk), dim3(GTHREADS), 0, st, q);

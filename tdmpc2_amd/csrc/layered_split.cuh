@@ -39,7 +39,13 @@ struct GemmSParams {
 // RT = 32-row tiles per workgroup: 4 (128 rows, throughput) or 2 / 1 (64 / 32 rows: calls with few rows -- single-plan
 // latency of the 48M / 317M models, where 128-row tiles leave most of the chip idle: c3 at E = 1 is 4 x 14 = 56
 // workgroups on 512 slots; every weight fragment then feeds fewer MFMAs, which does not matter while the chip is not full).
-template <int NCT, int RT = 4>
+// SD = chunks of the row operand in flight (global -> registers -> LDS): 1 for the throughput tiles, whose neighbours on
+// the CU cover the latency; 4 -- together with a weight ring of 8 / 16 k16-blocks instead of 4 -- for calls with few rows (one
+// or two workgroups per CU: single-plan latency of the 48M / 317M models), where the k-loop ran at one L2 / Infinity-Cache
+// round trip per two chunks: c3 single plan 6.17 -> 5.25 ms, c4 24.6 -> 23.0 ms, bit-identical sums (profiles/README.md r03c).
+// (Measured and rejected there: split-K over 4 / 8 workgroups per tile with the consumer adding the slices -- slower: the
+// partial sums' traffic; one accumulator per product kind on the 32-row tile -- no change.)
+template <int NCT, int RT = 4, int SD = 1>
 __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     constexpr int TM = 32 * RT;  // rows of this workgroup's tile
     __shared__ __attribute__((aligned(16))) _Float16 As[2][2][TM * GS_LDH];  // [buffer][plane][row][k]
@@ -72,13 +78,18 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
         g_off[i] = r * p.lda * 4 + plane * p.lda * 2 + c16 * 16;
         l_off[i] = (plane * TM * GS_LDH + r * GS_LDH) * 2 + c16 * 16;
     }
-    f32x4 stage[RT];
+    const int nchunks = p.K / GBK;
+    f32x4 stage[SD][RT];
 #pragma unroll
-    for (int i = 0; i < RT; ++i) stage[i] = *reinterpret_cast<const f32x4 *>(ab + g_off[i]);
+    for (int d = 0; d < SD; ++d)
+        if (d < nchunks) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i) stage[d][i] = *reinterpret_cast<const f32x4 *>(ab + g_off[i] + (size_t)d * GBK * 2);
+        }
     char *lds = reinterpret_cast<char *>(&As[0][0][0]);
     constexpr int BUF_BYTES = 2 * TM * GS_LDH * 2;
 #pragma unroll
-    for (int i = 0; i < RT; ++i) *reinterpret_cast<f32x4 *>(lds + l_off[i]) = stage[i];
+    for (int i = 0; i < RT; ++i) *reinterpret_cast<f32x4 *>(lds + l_off[i]) = stage[0][i];
     __syncthreads();
 
     f32x16 acc[NCT][RT];
@@ -90,8 +101,8 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
             for (int e = 0; e < 16; ++e) acc[n][r][e] = 0.f;
 
     const int i32 = lane & 31, hh = lane >> 5;
-    const int nchunks = p.K / GBK;
-    constexpr int PFB = NCT == 1 ? 4 : 2;  // weight ring in k16-blocks (NCT x 8 VGPRs each)
+    // weight ring in k16-blocks (NCT x 8 VGPRs each); few-row variants (SD = 4): 8 ... 16 blocks
+    constexpr int PFB = SD > 2 ? (RT == 1 ? 16 : 8) : (NCT == 1 ? 4 : 2);
     f16x8 rh[PFB][NCT], rl[PFB][NCT];
 #pragma unroll
     for (int d = 0; d < PFB; ++d) {
@@ -103,16 +114,18 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    for (int c = 0; c < nchunks; c += 2) {  // two chunks (4 k16-blocks) per iteration: a whole number of ring turns
+    constexpr int U = SD > 2 ? PFB / 2 : 2;  // chunks per trip: a whole number of turns of the weight ring and of the staging ring
+    static_assert(U % SD == 0 && (2 * U) % PFB == 0, "staging depth 1, 2 or 4; ring turns per trip");
+    for (int c = 0; c < nchunks; c += U) {
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
+        for (int cc = 0; cc < U; ++cc) {
             const int ch = c + cc;
             if (ch < nchunks) {  // uniform
                 const bool more = ch + 1 < nchunks;
-                if (more) {
+                if (ch + SD < nchunks) {  // chunk ch's slot is free (its rows went to LDS one chunk ago): request chunk ch + SD
 #pragma unroll
                     for (int i = 0; i < RT; ++i)
-                        stage[i] = *reinterpret_cast<const f32x4 *>(ab + g_off[i] + (size_t)(ch + 1) * GBK * 2);
+                        stage[cc % SD][i] = *reinterpret_cast<const f32x4 *>(ab + g_off[i] + (size_t)(ch + SD) * GBK * 2);
                 }
                 const _Float16 *ah = &As[ch & 1][0][0] + i32 * GS_LDH + 8 * hh;
                 const _Float16 *al = &As[ch & 1][1][0] + i32 * GS_LDH + 8 * hh;
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
                 if (more) {
                     char *dst = lds + ((ch + 1) & 1) * BUF_BYTES;
 #pragma unroll
-                    for (int i = 0; i < RT; ++i) *reinterpret_cast<f32x4 *>(dst + l_off[i]) = stage[i];
+                    for (int i = 0; i < RT; ++i) *reinterpret_cast<f32x4 *>(dst + l_off[i]) = stage[(cc + 1) % SD][i];
                 }
                 __syncthreads();
             }
