@@ -279,7 +279,7 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
  * inside the rollout launch, one launch per CEM iteration; 0 = always a launch of its own (k_refit); 2 (default) = inside
  * the rollout launch when the call's workgroups fit the chip in one round (few plans: single-environment latency), a
  * launch of its own otherwise (many plans: the in-launch refits would delay the next round of workgroups).
- * key TDMPC2_TUNE_CLUSTER (fused family, f16x2-split arithmetic, non-episodic): single-plan latency path -- every 512-wide
+ * key TDMPC2_TUNE_CLUSTER (fused family, f16x2-split arithmetic): single-plan latency path -- every 512-wide
  * layer of a 32-row sample tile is split over a cluster of 8 workgroups on 8 CUs that exchange the layer's raw sums through
  * L2 (tdmpc2_amd/csrc/cluster_kernels.cuh); used when all of a call's clusters fit the chip at once (one or two plans of
  * 512 samples on 256 CUs).  0 = never, 1 / 2 (default) = whenever the call fits. */

@@ -34,18 +34,21 @@
 //   (cluster 0 of a plan, first launch: the policy-prior trajectories, tdmpc2.py:154-160, are the rollout of the tile's first
 //    P rows under a_t = pi(z_t): at the top of step t  pi.l0 -> S0, pi.l1 -> S3, policy head -> the P rows' action columns and
 //    `actions`, z_t back into the tile; two more hand-overs per step -- phases are only required to grow)
+//   (EP = 1, episodic models: termination(z_t), world_model.py:132-141 / tdmpc2.py:133-134, t >= 1: term.l0 -> S5 right behind the
+//    step's first layers -- same z_t columns --, its epilogue, term.l1 -> S3 and the one-logit head after the reward head;
+//    termination(z_H): term.l0 -> S5 in front of the policy layers, term.l1 -> S0 behind the policy head)
 //   value:    phase 4H+1  pi.l0 -> S0;  4H+2  pi.l1 -> S1;  policy head;  z_H back into the tile
 //             phase 4H+3  q1.l0 -> S2 (parked), q0.l0 -> S3;  4H+4  q0.l1 -> S0;  head;  epilogue q1.l0 <- S2
 //             phase 4H+5  q1.l1 -> S1;  head.
 #pragma once
 
 constexpr int CL = 8;                  // workgroups per cluster
-constexpr int CL_SLOTS = 5;            // exchange tiles per cluster (the fifth holds a head's logits, [32][128] fp32)
+constexpr int CL_SLOTS = 6;            // exchange tiles per cluster (S4 holds a head's logits, [32][128] fp32; S5: episodic models)
 constexpr int CL_TILE = 32 * WIDTH;    // floats per exchange tile
 constexpr int CL_FLAG_STRIDE = 16;     // arrival words reserved per cluster (64 B)
 constexpr int CL_MAXSPIN = 1 << 17;    // polls before a member gives up (~0.2 s; a healthy wait is microseconds)
-__host__ __device__ constexpr int cl_phases(int H) { return 6 * H + 5; }  // hand-overs per launch (upper bound: with the policy prior)
-__host__ __device__ constexpr int cl_heads(int H) { return 2 * H + 3; }  // narrow heads per launch: H reward (+ H policy prior), policy, two Q
+__host__ __device__ constexpr int cl_phases(int H) { return 8 * H + 7; }  // hand-overs per launch (upper bound: policy prior + termination)
+__host__ __device__ constexpr int cl_heads(int H) { return 3 * H + 4; }  // narrow heads per launch (upper bound): H reward, H policy prior, H + 1 termination, policy, two Q
 
 struct ClState {
     float *xbuf;       // this cluster's CL_SLOTS exchange tiles
@@ -401,7 +404,20 @@ __device__ __forceinline__ float cl_head_twohot(const CT &c, ClState &x, const L
     return r;
 }
 
-template <int APAD>
+// termination head (one logit): 1 if sigmoid(logit) > 0.5, on member 0 (the others get 0 and never use it)
+template <class CT>
+__device__ __forceinline__ float cl_head_term(const CT &c, ClState &x, const LayerS &ly) {
+    const bool consume = x.rank == 0;
+    cl_head_logits(c, x, ly, consume);
+    if (!consume) return 0.f;
+    const bool live = (c.tid >> 3) < CT::TROWS;
+    const float v = c.f32()[(live ? c.tid >> 3 : 0) * CT::RSF()];
+    const float pr = 1.f / (1.f + expf(-v));
+    __syncthreads();
+    return pr > 0.5f ? 1.f : 0.f;
+}
+
+template <int APAD, int EP>
 __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS> p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int s_is_last, s_dead, s_fast;
@@ -464,8 +480,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS
     epi_barrier(c);
 
     float G = 0.f;
+    float termv = 0.f;  // EP: 1 once any latent of this row's trajectory was classified terminal (tdmpc2.py:133-134)
     TIMER_START(c)
     for (int t = 0; t < p.H; ++t) {
+        const bool term_step = EP && t > 0;
         // ---- actions of step t (tdmpc2.py:176-181): every member fills its own tile; member 0 also writes them out
         {
             float *ag = p.actions + ((size_t)e * p.H + t) * p.N * p.A;
@@ -533,21 +551,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS
         // ---- first layers of dynamics (parked in S0) and reward (S1) over the same [z_t | a_t] tile
         gb_prefetch(c, p.rew.l[1].g, p.rew.l[1].b);
         cl_gemm(c, x, wref(p.dyn.l[0]), 0, wref(p.rew.l[0]), 1, 0, KBA);
+        if constexpr (EP) {
+            if (term_step) cl_gemm(c, x, wref(p.term.l[0]), 5, WRef{}, 0, 0, ZKB16);  // termination(z_t): same z columns, parked in S5
+        }
         cl_epi<0>(c, x, 1, CL_E(p.rew.l[0]), b_rew, GB{});
         // ---- reward: layer 2, two-hot head
-        cl_layer<0>(c, x, CL_L(p.rew.l[1]), p.rew.l[1].bias, 0, ZKB16, 2, gb_of(p.dyn.l[0]));
+        cl_layer<0>(c, x, CL_L(p.rew.l[1]), p.rew.l[1].bias, 0, ZKB16, 2, term_step ? gb_of(p.term.l[0]) : gb_of(p.dyn.l[0]));
         const float r = cl_head_twohot(c, x, p.rew.l[2], p.bins, p.num_bins);
         TIMER_MARK(c, T_HEAD)
-        G += disc[t] * r;
+        if constexpr (EP) {
+            if (term_step) {
+                cl_epi<0>(c, x, 5, CL_E(p.term.l[0]), p.term.l[0].bias, gb_of(p.term.l[1]));
+                cl_layer<0>(c, x, CL_L(p.term.l[1]), p.term.l[1].bias, 0, ZKB16, 3, gb_of(p.dyn.l[0]));
+                termv = fminf(termv + cl_head_term(c, x, p.term.l[2]), 1.f);
+            }
+        }
+        G += disc[t] * (1.f - termv) * r;
         // ---- dynamics: the parked first layer, layers 2 and 3 (SimNorm)
         cl_epi<0>(c, x, 0, CL_E(p.dyn.l[0]), b_dyn, gb_of(p.dyn.l[1]));
         cl_layer<0>(c, x, CL_L(p.dyn.l[1]), p.dyn.l[1].bias, 0, ZKB16, 1, gb_of(p.dyn.l[2]));
         cl_layer<1>(c, x, CL_L(p.dyn.l[2]), p.dyn.l[2].bias, 0, ZKB16, 2, (t == p.H - 1 || pifold) ? gb_of(p.pi.l[0]) : gb_of(p.rew.l[0]),
                     (t == p.H - 1 || pifold) ? zs : nullptr);
     }
-    // ---- a_H = pi(z_H) (tdmpc2.py:135); z_H was also saved to zs
+    // ---- a_H = pi(z_H) (tdmpc2.py:135); z_H was also saved to zs.  EP: termination(z_H)'s first layer from the same tile first.
+    if constexpr (EP) cl_gemm(c, x, wref(p.term.l[0]), 5, WRef{}, 0, 0, ZKB16);
     cl_layer<0>(c, x, CL_L(p.pi.l[0]), b_pi, 0, ZKB16, 0, gb_of(p.pi.l[1]));
-    cl_layer<0>(c, x, CL_L(p.pi.l[1]), p.pi.l[1].bias, 0, ZKB16, 1, gb_of(p.q[q0].l[0]));
+    cl_layer<0>(c, x, CL_L(p.pi.l[1]), p.pi.l[1].bias, 0, ZKB16, 1, EP ? gb_of(p.term.l[0]) : gb_of(p.q[q0].l[0]));
     {
         auto eps = [&](int row, int a) -> float {
             const unsigned ridx = (unsigned)((size_t)(row0 + row) * p.A + a);
@@ -556,6 +585,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS
         };
         cl_head_logits(c, x, p.pi.l[2], true);
         head_pi_rows_s(c, p.A, p.Apad, p.log_std_min, p.log_std_dif, mask, eps, nullptr, 0, nullptr);
+    }
+    if constexpr (EP) {  // termination(z_H) (tdmpc2.py:133-134, last loop iteration): the hidden layers overwrite z columns only
+        cl_epi<0>(c, x, 5, CL_E(p.term.l[0]), p.term.l[0].bias, gb_of(p.term.l[1]));
+        cl_layer<0>(c, x, CL_L(p.term.l[1]), p.term.l[1].bias, 0, ZKB16, 0, gb_of(p.q[q0].l[0]));
+        termv = fminf(termv + cl_head_term(c, x, p.term.l[2]), 1.f);
     }
     TIMER_MARK(c, T_HEAD)
     tile_from_global_s(c, zs);
@@ -574,7 +608,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS
     if (rank != 0) return;  // member 0 owns the values
     TIMER_MARK(c, T_HEAD)
     TIMER_FLUSH(c, p.timing)
-    const float val = G + disc[p.H] * ((qa + qb) / 2.f);
+    const float val = G + disc[p.H] * (1.f - termv) * ((qa + qb) / 2.f);
     if (!p.fold_refit) {
         if ((tid & 7) == 0 && live) p.value[(size_t)e * p.N + row0 + (tid >> 3)] = val;
         return;

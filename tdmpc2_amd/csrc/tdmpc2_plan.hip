@@ -893,7 +893,10 @@ template <> struct Kern<NetS> {
     // cluster path: `clusters` row tiles of 32 samples, 8 workgroups each, in groups of 8 clusters (one per XCD)
     static void rollout_cluster(const tdmpc2_plan *h, const RolloutParamsT<NetS> &p, int clusters, hipStream_t st) {
         const int grid = (clusters + 7) / 8 * 64;
-#define CALL_ROLL_CL(AP, AR) hipLaunchKernelGGL((ks_rollout_cl<AP>), dim3(grid), dim3(NTHREADS), h->cl_lds, st, p);
+        const bool ep = h->cfg.episodic != 0;
+#define CALL_ROLL_CL(AP, AR)                                                                              \
+    if (ep) hipLaunchKernelGGL((ks_rollout_cl<AP, 1>), dim3(grid), dim3(NTHREADS), h->cl_lds, st, p);    \
+    else hipLaunchKernelGGL((ks_rollout_cl<AP, 0>), dim3(grid), dim3(NTHREADS), h->cl_lds, st, p);
         FUSED_DISPATCH(h->Apad, 0, CALL_ROLL_CL)
 #undef CALL_ROLL_CL
     }
@@ -1273,8 +1276,8 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             return TDMPC2_ERR_HIP;
         }
     }
-    // cluster path (single-plan latency): split arithmetic, non-episodic, sized for the calls that fit the chip in one round
-    if (!h->lay.on && h->split && !c.episodic) {
+    // cluster path (single-plan latency): split arithmetic, sized for the calls that fit the chip in one round
+    if (!h->lay.on && h->split) {
         const long cus = h->num_cus > 0 ? h->num_cus : 256;
         const long per_env = (long)h->tiles * 2;                       // 32-row tiles = clusters per plan
         long envs = std::min<long>((long)c.max_envs, cus / (per_env * CL));
@@ -1299,7 +1302,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
                 return fail(TDMPC2_ERR_HIP, "hipHostGetDevicePointer failed");
             }
             int rcl = 0;
-#define CALL_SETLDS_CL(AP, AR) rcl = set_lds(ks_rollout_cl<AP>, h->cl_lds);
+#define CALL_SETLDS_CL(AP, AR) rcl = c.episodic ? set_lds(ks_rollout_cl<AP, 1>, h->cl_lds) : set_lds(ks_rollout_cl<AP, 0>, h->cl_lds);
             FUSED_DISPATCH(h->Apad, 0, CALL_SETLDS_CL)
 #undef CALL_SETLDS_CL
             if (rcl) {

@@ -168,7 +168,7 @@ def test_plan_matches_reference_golden(name, prec):
 _PN = {0: "auto", 1: "fp32", 2: "split"}
 
 
-@pytest.mark.parametrize("name", FUSED_CASES)
+@pytest.mark.parametrize("name", FUSED_CASES + ["c1_ep", "c2_ep"])
 def test_plan_without_cluster_path_matches_reference_golden(name):
     """The goldens above run one or two plans per call: the split arithmetic then takes the cluster path (8 workgroups per
     32-row tile, cluster_kernels.cuh).  The same cases with TDMPC2_TUNE_CLUSTER = 0: one workgroup per tile (ks_rollout)."""
@@ -184,7 +184,7 @@ def test_plan_without_cluster_path_matches_reference_golden(name):
     _compare_stages(name, c, got, g, g["action"], g["prev_mean_out"], tag="/fused/split/golden/no_cluster")
 
 
-@pytest.mark.parametrize("name", ["c1", "c2_i6", "mt5"])
+@pytest.mark.parametrize("name", ["c1", "c2_i6", "mt5", "c1_ep"])
 def test_cluster_path_runs_and_agrees_with_one_workgroup_per_tile(name):
     """Both kernels compute the same sums in a different order (the cluster splits every contraction in four quarters): the
     iteration-0 values -- identical actions -- agree to fp32 round-off but not bit for bit (which also proves that the
