@@ -74,7 +74,15 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
         const int idx = tid + 256 * i;
-        const int plane = idx / (4 * TM), r = (idx >> 2) % TM, c16 = idx & 3;
+        // a quad of lanes copies 64 contiguous bytes of one row; the two quads of an 8-lane LDS write phase take rows 4 apart:
+        // with the 80-byte row stride rows r and r + 1 overlap in 4 banks, rows r and r + 4 do not (r01k PMC: 25 % of the LDS
+        // cycles of g_gemm_s<2> were bank conflicts; the b128 fragment READS are conflict-free with this stride)
+        const int plane = idx / (4 * TM), q = (idx >> 2) % TM, c16 = idx & 3;
+#ifdef GEMM_LINEAR_STAGING
+        const int r = q;
+#else
+        const int r = (q & ~7) | ((q & 1) << 2) | ((q >> 1) & 3);
+#endif
         g_off[i] = r * p.lda * 4 + plane * p.lda * 2 + c16 * 16;
         l_off[i] = (plane * TM * GS_LDH + r * GS_LDH) * 2 + c16 * 16;
     }
