@@ -124,57 +124,67 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     __builtin_amdgcn_sched_barrier(0);
     constexpr int U = SD > 2 ? PFB / 2 : 2;  // chunks per trip: a whole number of turns of the weight ring and of the staging ring
     static_assert(U % SD == 0 && (2 * U) % PFB == 0, "staging depth 1, 2 or 4; ring turns per trip");
-    for (int c = 0; c < nchunks; c += U) {
+    // One chunk (32 of K = two k16-blocks).  `steady`: compile-time true in the main loop, whose trips contain NO conditional --
+    // with the "is there a next chunk / a chunk to request" tests inside, hipcc's wait-count insertion loses track of the
+    // vector-memory queue at every join and waits for (nearly) everything in front of the staging store: the deep weight ring
+    // then bought nothing (s_waitcnt vmcnt(4) where vmcnt(15) would do; 0.39 us per chunk, profiles/README.md r03d).
+    auto chunk = [&](const int ch, const int cc, const bool steady) __attribute__((always_inline)) {
+        const bool more = steady || ch + 1 < nchunks;
+        if (steady || ch + SD < nchunks) {  // chunk ch's slot is free (its rows went to LDS one chunk ago): request chunk ch + SD
 #pragma unroll
-        for (int cc = 0; cc < U; ++cc) {
-            const int ch = c + cc;
-            if (ch < nchunks) {  // uniform
-                const bool more = ch + 1 < nchunks;
-                if (ch + SD < nchunks) {  // chunk ch's slot is free (its rows went to LDS one chunk ago): request chunk ch + SD
-#pragma unroll
-                    for (int i = 0; i < RT; ++i)
-                        stage[cc % SD][i] = *reinterpret_cast<const f32x4 *>(ab + g_off[i] + (size_t)(ch + SD) * GBK * 2);
-                }
-                const _Float16 *ah = &As[ch & 1][0][0] + i32 * GS_LDH + 8 * hh;
-                const _Float16 *al = &As[ch & 1][1][0] + i32 * GS_LDH + 8 * hh;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
-                    const int d = (cc * 2 + kb) % PFB;
-                    f16x8 fh[RT], fl[RT];
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        fh[rt] = *reinterpret_cast<const f16x8 *>(ah + rt * 32 * GS_LDH + kb * 16);
-                        fl[rt] = *reinterpret_cast<const f16x8 *>(al + rt * 32 * GS_LDH + kb * 16);
-                    }
-#pragma unroll
-                    for (int n = 0; n < NCT; ++n)
-#pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) acc[n][rt] = SPLIT_MFMA(fh[rt], rh[d][n], acc[n][rt]);
-#pragma unroll
-                    for (int n = 0; n < NCT; ++n)
-#pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) acc[n][rt] = SPLIT_MFMA(fh[rt], rl[d][n], acc[n][rt]);
-#pragma unroll
-                    for (int n = 0; n < NCT; ++n)
-#pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) acc[n][rt] = SPLIT_MFMA(fl[rt], rh[d][n], acc[n][rt]);
-                    const int kn = ch * 2 + kb + PFB;
-                    const int knc = kn < KB ? kn : KB - 1;
-#pragma unroll
-                    for (int n = 0; n < NCT; ++n) {
-                        rh[d][n] = ldw(u[n] + (size_t)knc * 2048, voff, 0);
-                        rl[d][n] = ldw(u[n] + (size_t)knc * 2048, voff, 1024);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (more) {
-                    char *dst = lds + ((ch + 1) & 1) * BUF_BYTES;
-#pragma unroll
-                    for (int i = 0; i < RT; ++i) *reinterpret_cast<f32x4 *>(dst + l_off[i]) = stage[(cc + 1) % SD][i];
-                }
-                __syncthreads();
-            }
+            for (int i = 0; i < RT; ++i)
+                stage[cc % SD][i] = *reinterpret_cast<const f32x4 *>(ab + g_off[i] + (size_t)(ch + SD) * GBK * 2);
         }
+        const _Float16 *ah = &As[ch & 1][0][0] + i32 * GS_LDH + 8 * hh;
+        const _Float16 *al = &As[ch & 1][1][0] + i32 * GS_LDH + 8 * hh;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int d = (cc * 2 + kb) % PFB;
+            f16x8 fh[RT], fl[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                fh[rt] = *reinterpret_cast<const f16x8 *>(ah + rt * 32 * GS_LDH + kb * 16);
+                fl[rt] = *reinterpret_cast<const f16x8 *>(al + rt * 32 * GS_LDH + kb * 16);
+            }
+#pragma unroll
+            for (int n = 0; n < NCT; ++n)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[n][rt] = SPLIT_MFMA(fh[rt], rh[d][n], acc[n][rt]);
+#pragma unroll
+            for (int n = 0; n < NCT; ++n)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[n][rt] = SPLIT_MFMA(fh[rt], rl[d][n], acc[n][rt]);
+#pragma unroll
+            for (int n = 0; n < NCT; ++n)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[n][rt] = SPLIT_MFMA(fl[rt], rh[d][n], acc[n][rt]);
+            const int kn = ch * 2 + kb + PFB;
+            const int knc = kn < KB ? kn : KB - 1;
+#pragma unroll
+            for (int n = 0; n < NCT; ++n) {
+                rh[d][n] = ldw(u[n] + (size_t)knc * 2048, voff, 0);
+                rl[d][n] = ldw(u[n] + (size_t)knc * 2048, voff, 1024);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) {
+            char *dst = lds + ((ch + 1) & 1) * BUF_BYTES;
+#pragma unroll
+            for (int i = 0; i < RT; ++i) *reinterpret_cast<f32x4 *>(dst + l_off[i]) = stage[(cc + 1) % SD][i];
+        }
+        __syncthreads();
+    };
+    int c = 0;
+#ifndef GEMM_NO_STEADY_LOOP
+    for (; c + U + SD <= nchunks; c += U) {  // steady state: every chunk has a successor to store and a chunk to request
+#pragma unroll
+        for (int cc = 0; cc < U; ++cc) chunk(c + cc, cc, true);
+    }
+#endif
+    for (; c < nchunks; c += U) {  // the last trips (and short contractions)
+#pragma unroll
+        for (int cc = 0; cc < U; ++cc)
+            if (c + cc < nchunks) chunk(c + cc, cc, false);  // uniform
     }
 
     // epilogue: acc * oscale + bias -> fp32.  C fragment: lane holds column (l & 31), rows (reg&3) + 8 (reg>>2) + 4 (l>>5).
