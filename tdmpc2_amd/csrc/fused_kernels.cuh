@@ -241,7 +241,7 @@ __device__ __forceinline__ void kloop_f32(const CT &c, const LayerS &ly, int kb0
     for (int st = 0; st < NST; ++st) an[st] = *reinterpret_cast<const f32x4 *>(a0p + st * 32 * CT::RSF());
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
-    for (int k = 0; k < nk; k += PFD) {
+    for (int k = 0; k < nk; k += PFD) {  // (a branch-free steady-state trip as in kloop_tile_s / g_gemm_s was measured here: -0.5 %)
 #pragma unroll
         for (int d = 0; d < PFD; ++d) {
             const int kk = k + d;
@@ -555,26 +555,36 @@ __device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int 
     AFragT<CT::NST> an;
     load_a<CT>(an, a0p, 0);
     __builtin_amdgcn_sched_barrier(0);
+    // one k-block; `steady`: compile-time true in the main loop, whose trips contain no conditional (with the range tests
+    // inside, hipcc's wait-count insertion loses track of the queue at every join and waits for nearly all loads: the
+    // lesson of g_gemm_s, profiles/README.md r03h)
+    auto step = [&](const int kk, const int d, const bool steady) __attribute__((always_inline)) {
+        const AFragT<CT::NST> a = an;
+        load_a<CT>(an, a0p, (steady || kk + 1 < nk) ? kk + 1 : kk);
+#pragma unroll
+        for (int st = 0; st < CT::NST; ++st) acc[st][0] = SPLIT_MFMA(a.h[st], rh[d], acc[st][0]);
+#pragma unroll
+        for (int st = 0; st < CT::NST; ++st) acc[st][1] = SPLIT_MFMA(a.h[st], rl[d], acc[st][1]);
+#pragma unroll
+        for (int st = 0; st < CT::NST; ++st) acc[st][2] = SPLIT_MFMA(a.l[st], rh[d], acc[st][2]);
+        const int kn = (steady || kk + PFT < nk) ? kk + PFT : nk - 1;
+        rh[d] = ldw(u + (size_t)kn * 2048, voff, 0);
+        rl[d] = ldw(u + (size_t)kn * 2048, voff, 1024);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int k = 0;
+#ifndef HEAD_NO_STEADY_LOOP
 #pragma unroll 1
-    for (int k = 0; k < nk; k += PFT) {
+    for (; k + 2 * PFT <= nk; k += PFT) {  // every block has a successor and a block PFT ahead
 #pragma unroll
-        for (int d = 0; d < PFT; ++d) {
-            const int kk = k + d;
-            if (kk < nk) {
-                const AFragT<CT::NST> a = an;
-                load_a<CT>(an, a0p, kk + 1 < nk ? kk + 1 : kk);
+        for (int d = 0; d < PFT; ++d) step(k + d, d, true);
+    }
+#endif
+#pragma unroll 1
+    for (; k < nk; k += PFT) {
 #pragma unroll
-                for (int st = 0; st < CT::NST; ++st) acc[st][0] = SPLIT_MFMA(a.h[st], rh[d], acc[st][0]);
-#pragma unroll
-                for (int st = 0; st < CT::NST; ++st) acc[st][1] = SPLIT_MFMA(a.h[st], rl[d], acc[st][1]);
-#pragma unroll
-                for (int st = 0; st < CT::NST; ++st) acc[st][2] = SPLIT_MFMA(a.l[st], rh[d], acc[st][2]);
-                const int kn = kk + PFT < nk ? kk + PFT : nk - 1;
-                rh[d] = ldw(u + (size_t)kn * 2048, voff, 0);
-                rl[d] = ldw(u + (size_t)kn * 2048, voff, 1024);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        for (int d = 0; d < PFT; ++d)
+            if (k + d < nk) step(k + d, d, false);
     }
 #pragma unroll
     for (int r = 0; r < CT::NST; ++r)
