@@ -203,3 +203,42 @@ def test_planner_seed_differs_across_ranks(monkeypatch):
     monkeypatch.setenv("RANK", "3")
     s3 = (t._rank() << 32) ^ 7
     assert s0 != s3 and (s3 >> 32) == 3 and (s3 & 0xFFFFFFFF) == 7
+
+
+def test_task_tables_of_the_agent_match_the_embedding_lookup():
+    """TDMPC2._task_tables (what the training-side forwards index with `task`): rows equal what the model's own
+    nn.Embedding(max_norm=1) returns at lookup (world_model.py:88-101), masks and discounts are the model's tables."""
+    from tdmpc2_amd.config import named_config
+    from tdmpc2_amd.tdmpc2 import TDMPC2
+
+    cfg = named_config("small", task="mt30")
+    agent = TDMPC2(cfg, device=torch.device("cpu"))
+    with torch.no_grad():
+        agent.model._task_emb.weight.mul_(3.0)  # rows of norm > 1: the renorm must bite
+        agent.model._task_emb.weight[0].mul_(0.01)  # and one row that stays as it is
+    w_before = agent.model._task_emb.weight.detach().clone()
+    emb, mask, disc = agent._task_tables()
+    ids = torch.arange(w_before.shape[0])
+    looked_up = torch.nn.functional.embedding(ids, w_before.clone(), max_norm=1.0)
+    assert torch.allclose(emb, looked_up, atol=1e-7)
+    assert (emb.norm(dim=-1) <= 1.0 + 1e-5).all() and torch.equal(emb[0], w_before[0])
+    assert torch.equal(agent.model._task_emb.weight, w_before)  # the table is derived, the parameter untouched
+    assert torch.equal(mask, agent.model._action_masks.float()) and torch.equal(disc, agent.discount.float())
+
+
+def test_every_tuning_key_of_the_header_has_a_binding():
+    """include/tdmpc2_plan.h's enum tdmpc2_tuning <-> NativePlanner.set_* (rows per workgroup, in-launch refit, cluster path)."""
+    import os
+    import re
+
+    from tdmpc2_amd import native
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "tdmpc2_plan.h")).read()
+    keys = dict((k, int(v)) for k, v in re.findall(r"(TDMPC2_TUNE_[A-Z_]+) = (\d+)", hdr))
+    assert keys == {"TDMPC2_TUNE_ROWS_PER_WORKGROUP": 0, "TDMPC2_TUNE_FOLD_REFIT": 1, "TDMPC2_TUNE_CLUSTER": 2}
+    src = open(native.__file__).read()
+    for key_id, method in [(1, "set_fold_refit"), (2, "set_cluster")]:
+        body = src[src.index(f"def {method}("):]
+        body = body[:body.index("\n    def ", 10)]
+        assert f"tdmpc2_plan_set_tuning(self._h, {key_id}," in body, method
