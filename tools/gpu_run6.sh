@@ -25,6 +25,6 @@ cp $(find gpurun_out/prof_r02aa -name "*kernel_stats.csv" | head -1) gpurun_out/
 head -12 gpurun_out/r02aa_kernel_stats_by_grid.txt
 bash tools/gpu_pmc.sh r02aa
 python tools/pmc_summary.py gpurun_out/pmc_r02aa ks_rollout > gpurun_out/r02aa_pmc.txt 2>&1
-python tools/pmc_summary.py --json gpurun_out/r02aa_pmc.json ks_rollout gpurun_out/pmc_r02aa > /dev/null 2>&1 || python tools/pmc_summary.py gpurun_out/pmc_r02aa --json gpurun_out/r02aa_pmc.json ks_rollout
+python tools/pmc_summary.py gpurun_out/pmc_r02aa --json gpurun_out/r02aa_pmc.json 'ks_rollout<\d+, \d, 8, 0, 0>'
 head -40 gpurun_out/r02aa_pmc.txt
 rm -rf gpurun_out/pmc_r02aa/*/ 2>/dev/null; du -sh gpurun_out | tail -1

@@ -68,13 +68,22 @@ def emit_json(root, out_path, kernel="k_rollout"):
     for path in sorted(glob.glob(os.path.join(root, "*", "*_counter_collection.csv"))):
         with open(path) as f:
             for r in csv.DictReader(f):
-                name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
-                base = name.replace("void ", "").split("<")[0]
-                if base != kernel or r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
+                name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
+                base = name.split("<")[0]
+                # `kernel`: a base name ("ks_rollout": every instantiation) or a regular expression for the whole
+                # instantiation name ("ks_rollout<\\d+, \\d, 8, 0, 0>": the split-arithmetic ones only -- the exact-fp32
+                # instantiation runs on the same grid and would otherwise be averaged in)
+                if "<" in kernel or "\\" in kernel:
+                    import re
+                    if not re.fullmatch(kernel, name):
+                        continue
+                elif base != kernel:
+                    continue
+                if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
                     continue
                 wgs = str(int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1))
                 res.setdefault(wgs, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    out = {"kernel": kernel, "source": root, "note": "bytes per launch; fetch = FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read "
+    out = {"kernel": kernel.split("<")[0], "match": kernel, "source": root, "note": "bytes per launch; fetch = FETCH_SIZE KiB x 1024 x 2 (gfx950 wide-read "
            "correction, MI355X_MICROARCH.md HBM section), write = WRITE_SIZE KiB x 1024 (uncalibrated)", "by_workgroups": {}}
     for wgs, c in res.items():
         f_ = sum(c.get("FETCH_SIZE", [0])) / max(len(c.get("FETCH_SIZE", [])), 1)
@@ -86,7 +95,13 @@ def emit_json(root, out_path, kernel="k_rollout"):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 3 and sys.argv[2] == "--json":
-        emit_json(sys.argv[1], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "k_rollout")
+    if "--json" in sys.argv:  # pmc_summary.py <dir> --json <out> [kernel]  |  pmc_summary.py --json <out> [kernel] <dir>
+        i = sys.argv.index("--json")
+        rest = sys.argv[1:i] + sys.argv[i + 2:]
+        dirs = [a for a in rest if os.path.isdir(a)]
+        names = [a for a in rest if not os.path.isdir(a)]
+        if not dirs or i + 1 >= len(sys.argv):
+            sys.exit("usage: pmc_summary.py <dir> --json <out.json> [kernel]")
+        emit_json(dirs[0], sys.argv[i + 1], names[0] if names else "k_rollout")
     else:
         main()
