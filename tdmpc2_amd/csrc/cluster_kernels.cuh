@@ -46,7 +46,7 @@ constexpr int CL = 8;                  // workgroups per cluster
 constexpr int CL_SLOTS = 6;            // exchange tiles per cluster (S4 holds a head's logits, [32][128] fp32; S5: episodic models)
 constexpr int CL_TILE = 32 * WIDTH;    // floats per exchange tile
 constexpr int CL_FLAG_STRIDE = 16;     // arrival words reserved per cluster (64 B)
-constexpr int CL_MAXSPIN = 1 << 17;    // polls before a member gives up (~0.2 s; a healthy wait is microseconds)
+constexpr int CL_MAXSPIN = 1 << 20;    // polls before a member gives up (a few 100 ms: longer than any kernel that could hold a CU back; a healthy wait is microseconds)
 __host__ __device__ constexpr int cl_phases(int H) { return 8 * H + 7; }  // hand-overs per launch (upper bound: policy prior + termination)
 __host__ __device__ constexpr int cl_heads(int H) { return 3 * H + 4; }  // narrow heads per launch (upper bound): H reward, H policy prior, H + 1 termination, policy, two Q
 
@@ -62,6 +62,7 @@ struct ClState {
     unsigned phase;    // last phase this member arrived at
     unsigned hphase;   // narrow heads so far (arrival words 8..15 of the cluster)
     bool learned;      // the launch's first hand-over is behind us (x.fast is valid)
+    bool mute;         // test hook (TDMPC2_CLUSTER_FAULT): this member never signals -- the others must time out, not hang
 };
 
 __device__ __forceinline__ void cl_st16(float *p, f32x4 v, int fast) {
@@ -180,7 +181,7 @@ __device__ __forceinline__ void cl_barrier(const CT &c, ClState &x, bool learn) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores are acknowledged (by the L2 / the fabric)
     __syncthreads();
     x.phase += 1;
-    if (c.tid == 0) __hip_atomic_store(x.flags + x.rank, x.phase | (x.xcc << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c.tid == 0 && !x.mute) __hip_atomic_store(x.flags + x.rank, x.phase | (x.xcc << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (c.tid < CL && !*x.dead) {
         int spin = 0;
         unsigned v;
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS
     float *sm_std = sm_mean + p.H * p.A;
     ClState x{p.cl_xbuf + (size_t)cl * CL_SLOTS * CL_TILE, p.cl_flags + (size_t)cl * CL_FLAG_STRIDE, p.cl_err,
               smem + TROWS * CT::RSF() + 2048 + ((2 * p.H * p.A + 3) & ~3), &s_dead, &s_fast, rank, 0u,
-              (unsigned)(p.iter * cl_phases(p.H)), (unsigned)(p.iter * cl_heads(p.H)), false};
+              (unsigned)(p.iter * cl_phases(p.H)), (unsigned)(p.iter * cl_heads(p.H)), false, p.cl_fault != 0 && cl == 0 && rank == 7};
     {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));

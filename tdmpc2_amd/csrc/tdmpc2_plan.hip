@@ -124,6 +124,7 @@ struct RolloutParamsT {
     unsigned int *cl_flags;
     unsigned int *cl_err;
     float *cl_zs;
+    int cl_fault;              // test hook: member 7 of cluster 0 never signals (the bounded waits must report it)
     int pi_fold;               // the policy-prior trajectories (tdmpc2.py:154-160) are computed by cluster 0 of each plan in launch 0
     const float *pi_traj_eps;  // [E,H,P,A] or null (Philox)
 };
@@ -704,6 +705,7 @@ struct tdmpc2_plan {
     unsigned int *cl_flags = nullptr;
     unsigned int *cl_err_host = nullptr, *cl_err_dev = nullptr;  // host-mapped error word of the bounded waits
     size_t cl_lds = 0;
+    int cl_fault = 0;                // TDMPC2_CLUSTER_FAULT=1 at create: test hook of the bounded waits
     bool split = false;  // fused kernels on the f16 matrix pipe with hi/lo operand split (fused_kernels.cuh)
     int force_rows = 0;  // TDMPC2_TUNE_ROWS_PER_WORKGROUP: 0 auto, 32, 64
     size_t row_bytes = 0;  // bytes of one sample row of the fused kernels' LDS tile
@@ -1000,6 +1002,7 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
     const int nst = cluster ? 1 : Kern<NET>::sample_tiles(h, E, false), nw = Kern<NET>::waves(h, E, nst);
     rp.tiles = h->tiles * (2 / nst);
     rp.cl_xbuf = h->cl_xbuf; rp.cl_flags = h->cl_flags; rp.cl_err = h->cl_err_dev; rp.cl_zs = h->cl_zs;
+    rp.cl_fault = h->cl_fault;
     std::unique_lock<std::mutex> gate;
     bool gate_record = false;
     const int gdev = c.device >= 0 && c.device < 64 ? c.device : 0;
@@ -1313,6 +1316,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
         }
     }
     if (const char *cm = getenv("TDMPC2_CLUSTER")) h->cluster_mode = atoi(cm);
+    if (const char *cf = getenv("TDMPC2_CLUSTER_FAULT")) h->cl_fault = atoi(cf);
     if (getenv("TDMPC2_TIMING")) {
         if (dev_alloc(h, (void **)&h->timing, 16 * 8) == 0) (void)hipMemset(h->timing, 0, 16 * 8);
     }

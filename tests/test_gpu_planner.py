@@ -476,3 +476,37 @@ def test_action_statistics_over_32_seeds(prec):
     record_parity(f"c1x32seeds/fused/{_PN[prec]}/oracle", action_abs=worst, action_mse=mse, elite_swaps=int(boundary), plans=E)
     assert len(clean) >= E - 4
     assert worst < 1e-4 and mse < 1e-9
+
+
+def test_cluster_hand_over_that_never_arrives_is_reported_not_hung(monkeypatch):
+    """Every wait of the cluster path is bounded.  TDMPC2_CLUSTER_FAULT=1 (read at create) mutes one member of cluster 0: the
+    plan of that call is invalid but returns, the NEXT call on the handle fails loudly, and the handle then plans on the
+    one-workgroup-per-tile kernels -- bit for bit what a handle with the cluster path switched off returns."""
+    import time
+
+    from tdmpc2_amd.native import NativeError, NativePlanner
+    from tests.gpu_common import case_on_gpu, dev, plan_inputs
+
+    c, model, ref = case_on_gpu("c1", 1, 2)
+    monkeypatch.setenv("TDMPC2_CLUSTER_FAULT", "1")
+    planner = NativePlanner(c["cfg"], c["iterations"], dev(), max_envs=c["n_envs"], path=1, precision=2)
+    monkeypatch.delenv("TDMPC2_CLUSTER_FAULT")
+    planner.bind_state_dict(model.sd)
+    inp = plan_inputs(c, model)
+    kw = dict(eval_mode=c["eval_mode"], task_emb=inp["task_emb"], act_mask=inp["act_mask"], tape=inp["tape"])
+    t = time.perf_counter()
+    planner.plan(inp["z0"], inp["disc_pow"], inp["prev_mean"].clone(), inp["t0"], **kw)  # invalid result, but it comes back
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t < 60
+    with pytest.raises(NativeError, match="cluster hand-over"):
+        planner.plan(inp["z0"], inp["disc_pow"], inp["prev_mean"].clone(), inp["t0"], **kw)
+    pm_a, pm_b = inp["prev_mean"].clone(), inp["prev_mean"].clone()
+    a = planner.plan(inp["z0"], inp["disc_pow"], pm_a, inp["t0"], **kw).clone()
+    ref.set_cluster(0)
+    try:
+        b = ref.plan(inp["z0"], inp["disc_pow"], pm_b, inp["t0"], **kw).clone()
+    finally:
+        ref.set_cluster(2)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(pm_a, pm_b)
+    planner.close()
