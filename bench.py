@@ -423,6 +423,26 @@ def main():
     assert torch.isfinite(out).all()
 
     extra = {}
+    if rank == 0 and world == 1:
+        # What box is this?  The fused kernels are power-managed (profiles/README.md): boxes of the same pool differ by up to 15 %
+        # in EVERY figure of this line.  Outside the timed region: queue half a second of the same steps and read the
+        # clocks / socket power the driver reports while they run.
+        try:
+            import subprocess
+            for i in range(15):
+                step(500 + i, warm)
+            smi = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower"], capture_output=True, text=True, timeout=20)
+            torch.cuda.synchronize(device)
+            keep = {}
+            for line in smi.stdout.splitlines():
+                low = line.lower()
+                for key, pat in (("sclk", "sclk"), ("mclk", "mclk"), ("fclk", "fclk"), ("power_w", "current socket"),
+                                 ("power_cap_w", "max graphics package power")):
+                    if pat in low and ":" in line and key not in keep:  # "GPU[0]  : sclk clock level: S: (2100Mhz)"
+                        keep[key] = line.split(":", 1)[1].strip()[:90]
+            extra["box_under_load"] = keep or {"raw": smi.stdout[:300]}
+        except Exception as ex:  # no rocm-smi, no permission: the line is still valid
+            extra["box_under_load"] = {"error": repr(ex)[:120]}
     if rank == 0:
         # single-environment latency (the reference's E = 1 semantics), reported beside the throughput
         one = NativePlanner(cfg, I, device, max_envs=1, path=path, precision=prec)
