@@ -440,6 +440,11 @@ def main():
                                  ("power_cap_w", "max graphics package power")):
                     if pat in low and ":" in line and key not in keep:  # "GPU[0]  : sclk clock level: S: (2100Mhz)"
                         keep[key] = line.split(":", 1)[1].strip()[:90]
+            pr = torch.cuda.get_device_properties(device)
+            for k in ("name", "gcnArchName", "multi_processor_count", "clock_rate", "memory_clock_rate", "L2_cache_size"):
+                v = getattr(pr, k, None)
+                if v is not None:
+                    keep["prop_" + k] = v if isinstance(v, (int, float)) else str(v)[:60]
             extra["box_under_load"] = keep or {"raw": smi.stdout[:300]}
         except Exception as ex:  # no rocm-smi, no permission: the line is still valid
             extra["box_under_load"] = {"error": repr(ex)[:120]}
