@@ -1,0 +1,48 @@
+#!/bin/bash
+# Evidence run of a round (MI355X box, through gpurun): full -m gpu suite, the default bench line, the torchrun
+# (RCCL, 1 rank) leg, rocprofv3 kernel stats and the PMC passes of the same command.
+# usage: gpurun --timeout 2400 -- bash tools/gpu_evidence.sh <tag> [parts]     parts: any of "tests bench torchrun stats pmc" (default: all)
+cd "$(dirname "$0")/.."
+R=$PWD
+TAG="${1:-r03a}"; PARTS="${2:-tests bench torchrun stats pmc}"
+mkdir -p gpurun_out
+has() { [[ " $PARTS " == *" $1 "* ]]; }
+if has tests; then
+  (time timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider) > gpurun_out/${TAG}_pytest_gpu.log 2>&1
+  tail -8 gpurun_out/${TAG}_pytest_gpu.log
+fi
+if has bench; then
+  timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+  tail -5 gpurun_out/${TAG}_bench.err
+  python - <<PY
+import json
+d=json.loads(open("gpurun_out/${TAG}_bench.json").read().strip().splitlines()[-1])
+print("bench", d["value"], d["roofline"]["frac"], d["roofline"]["avg_launch_ms"], d["roofline"].get("traffic"), d["extra"].get("latency_ms_single_env"),
+      {k:(v.get("value"), v.get("roofline",{}).get("frac"), v.get("roofline",{}).get("traffic")) for k,v in d["extra"].get("configs",{}).items()}, d.get("cpu_baseline",{}).get("value"))
+PY
+fi
+if has torchrun; then
+  HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 5 --warmup 2 --skip-cpu-baseline --skip-extra-configs > gpurun_out/${TAG}_torchrun_n1.log 2>&1
+  tail -c 600 gpurun_out/${TAG}_torchrun_n1.log; echo
+  TDMPC2_BENCH_FORCE_C5=1 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 2 --warmup 1 --skip-cpu-baseline > gpurun_out/${TAG}_torchrun_c5_leg.log 2>&1
+  tail -c 400 gpurun_out/${TAG}_torchrun_c5_leg.log; echo
+fi
+if has stats; then
+  export TMPDIR=/tmp
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG} -o ${TAG} -- python $R/bench.py --steps 5 --warmup 2 --skip-cpu-baseline --skip-traffic > $R/gpurun_out/prof_${TAG}.stdout 2> $R/gpurun_out/prof_${TAG}.stderr
+  cd $R
+  KT=$(find gpurun_out/prof_${TAG} -name "*kernel_trace.csv" | head -1)
+  python tools/rocprof_summary.py $KT > gpurun_out/${TAG}_kernel_stats_by_grid.txt
+  cp $(find gpurun_out/prof_${TAG} -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_rocprofv3_kernel_stats.csv
+  head -14 gpurun_out/${TAG}_kernel_stats_by_grid.txt | cut -c1-160
+  rm -rf gpurun_out/prof_${TAG}
+fi
+if has pmc; then
+  bash tools/gpu_pmc.sh ${TAG}
+  python tools/pmc_summary.py gpurun_out/pmc_${TAG} ks_rollout > gpurun_out/${TAG}_pmc.txt 2>&1
+  python tools/pmc_summary.py gpurun_out/pmc_${TAG} --json gpurun_out/${TAG}_pmc.json 'ks_rollout<\d+, \d, 8, 0, 0>'
+  head -40 gpurun_out/${TAG}_pmc.txt
+  rm -rf gpurun_out/pmc_${TAG}/*/ 2>/dev/null
+fi
+du -sh gpurun_out | tail -1
