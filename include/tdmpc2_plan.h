@@ -20,6 +20,8 @@
  *   tdmpc2_plan_td_target[_mt]    <- TDMPC2._td_target                  tdmpc2/tdmpc2.py:239-254
  *   tdmpc2_plan_policy_value[_mt] <- forward half of TDMPC2.update_pi   tdmpc2/tdmpc2.py:208-225
  *   tdmpc2_plan_export_packed / import_packed <- TDMPC2.save / load of the planner's weights  tdmpc2/tdmpc2.py:72-95
+ *   tdmpc2_plan_export_noise  <- the six RNG draw sites of one plan    tdmpc2/tdmpc2.py:176,204, tdmpc2/common/world_model.py:156,212,
+ *                                (what torch.manual_seed pins there)   tdmpc2/common/math.py:90
  *
  * Conventions
  *   - plain C types only; every tensor is a DEVICE pointer to fp32 (or int32 /
@@ -46,7 +48,7 @@
 extern "C" {
 #endif
 
-#define TDMPC2_PLAN_ABI_VERSION 5
+#define TDMPC2_PLAN_ABI_VERSION 6
 
 typedef struct tdmpc2_plan tdmpc2_plan_t;
 
@@ -110,6 +112,16 @@ typedef struct tdmpc2_noise {
     const float *final_eps;    /* [E,A]          randn, tdmpc2.py:204 (unused when eval_mode) */
 } tdmpc2_noise;
 
+/* The same six tensors as OUTPUTS (tdmpc2_plan_export_noise): device pointers the library writes; any may be NULL. */
+typedef struct tdmpc2_noise_out {
+    float *pi_traj_eps;  /* [n,H,P,A] */
+    float *sample_eps;   /* [n,I,H,N-P,A] */
+    float *pi_eps;       /* [n,I,N,A] */
+    int32_t *qidx;       /* [n,I,2] */
+    float *gumbel_exp;   /* [n,K] */
+    float *final_eps;    /* [n,A] */
+} tdmpc2_noise_out;
+
 /* Optional stage-wise outputs (any pointer may be NULL). */
 typedef struct tdmpc2_debug {
     float *value;       /* [E,I,N]   value after nan_to_num, tdmpc2.py:184 */
@@ -161,6 +173,21 @@ int tdmpc2_plan_run(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *
                     const float *act_mask, const float *disc_pow, float *prev_mean, const uint8_t *t0,
                     int eval_mode, const tdmpc2_noise *tape, uint64_t seed, float *action,
                     const tdmpc2_debug *dbg, void *stream);
+
+/* The in-kernel generator, made visible (parity of the fast mode).  A plan run with tape = NULL draws its noise from
+ * Philox4x32-10 keyed by (seed, the handle's call counter at entry, draw site, CEM iteration, environment, element) --
+ * the six sites of the reference (tdmpc2/tdmpc2.py:176,204; tdmpc2/common/world_model.py:156,212; tdmpc2/common/math.py:90).
+ * export_noise writes exactly those draws, for environments [env_first, env_first + n_envs) of such a call, as the tensors
+ * of a noise tape: tdmpc2_plan_run(..., tape = the export, ...) then reproduces the tape = NULL plan bit for bit, and the
+ * same tape replays through a CPU restatement of the reference.  Every kernel family draws the same numbers.
+ *   call  = the value tdmpc2_plan_call_counter returned BEFORE the run being reproduced (run / run_obs / shard_begin /
+ *           policy_value / td_target each consume one count). */
+int tdmpc2_plan_export_noise(tdmpc2_plan_t *h, int env_first, int n_envs, uint64_t seed, uint32_t call,
+                             const tdmpc2_noise_out *out, void *stream);
+/* The per-handle call counter mixed into the Philox key (so that consecutive plans under one seed draw fresh noise).
+ * Ranks that shard ONE plan (tdmpc2_plan_shard_*) must agree on it: set it from one rank's value before shard_begin. */
+int tdmpc2_plan_call_counter(const tdmpc2_plan_t *h, uint32_t *next_call);
+int tdmpc2_plan_set_call_counter(tdmpc2_plan_t *h, uint32_t next_call);
 
 /* State-observation encoder: WorldModel.encode for cfg.obs == 'state'
  * (tdmpc2/common/world_model.py:103-112) with the network of layers.enc (tdmpc2/common/layers.py:153-164):
@@ -285,6 +312,13 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
  * 512 samples on 256 CUs).  0 = never, 1 / 2 (default) = whenever the call fits. */
 enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0, TDMPC2_TUNE_FOLD_REFIT = 1, TDMPC2_TUNE_CLUSTER = 2 };
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
+
+/* Fault report of the cluster path (TDMPC2_TUNE_CLUSTER).  Its hand-overs between workgroups wait a bounded time (about
+ * 0.13 s); when a wait gives up -- another process or a foreign kernel held the compute units -- the plan in flight is
+ * invalid: its action[E, A] comes back as NaN and its prev_mean is left as it was, so the step can simply be planned again.
+ * Call this after synchronising the stream of a tdmpc2_plan_run / run_obs: *faults = number of such plans since the last
+ * call (0 = none); the handle has then switched to one workgroup per tile (the path that cannot time out) for good. */
+int tdmpc2_plan_take_fault(tdmpc2_plan_t *h, int *faults);
 
 /* Live timing of the dominant (rollout) stage: after set_profiling(h, n > 0) every rollout launch
  * (FUSED: one ks_rollout kernel; LAYERED: the GEMM / row-kernel sequence of one CEM iteration's

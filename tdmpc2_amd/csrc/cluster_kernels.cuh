@@ -617,6 +617,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl(RolloutParamsT<NetS
     // ---- elite selection + refit by the last member-0 workgroup of the plan (the hand-over of ks_rollout)
     if ((tid & 7) == 0 && live)
         __hip_atomic_store(p.value + (size_t)e * p.N + row0 + (tid >> 3), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every wave's value stores must be ACKNOWLEDGED before the ticket moves: a workgroup-scope release fence does not wait
+    // for them on gfx950 (the emitted code is `global_store ... sc1; s_barrier; global_atomic_add`), so drain explicitly
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (tid == 0) {

@@ -1492,8 +1492,8 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
     // ---- elite selection + refit by the LAST workgroup of this plan to get here (tdmpc2.py:184-206): one launch per CEM
     // iteration.  Hand-over protocol (MI355X_MICROARCH.md, inter-workgroup visibility; a plan's workgroups sit on different
     // XCDs, whose L2s are not coherent): the only data another workgroup reads -- this workgroup's 32 / 64 values --
-    // leaves as agent-scope write-through (sc1) stores; every wave drains its stores (workgroup-scope release =
-    // s_waitcnt vmcnt(0)) before the barrier; one lane takes the plan's ticket with an agent-scope atomic; the last
+    // leaves as agent-scope write-through (sc1) stores; every wave drains its stores (an explicit s_waitcnt vmcnt(0): the
+    // workgroup-scope release fence alone emits no wait) before the barrier; one lane takes the plan's ticket with an agent-scope atomic; the last
     // arriver reads the values with agent-scope (sc1) loads, which bypass its L1 and find lines its XCD's L2 has not held
     // in this launch (refit_plan).  No cache maintenance instruction on either side.  The elite ACTIONS are not handed
     // over at all: the refit re-derives them (RefitParams::regen).  Measured and rejected: agent-scope release / acquire
@@ -1501,6 +1501,9 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
     // 32 neighbouring workgroups: +13 % on the launch, profiles/README.md r02b-r02d).
     if ((tid & 7) == 0 && live)
         __hip_atomic_store(p.value + (size_t)e * p.N + row0 + (tid >> 3), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // every wave's value stores must be ACKNOWLEDGED before the ticket moves: a workgroup-scope release fence does not wait
+    // for them on gfx950 (the emitted code is `global_store ... sc1; s_barrier; global_atomic_add`), so drain explicitly
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (tid == 0) {

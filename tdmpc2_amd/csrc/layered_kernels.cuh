@@ -361,18 +361,32 @@ struct SampleParams {
 };
 
 __global__ void l_sample(SampleParams p) {
-    const size_t total = (size_t)p.E * p.H * (p.N - p.P) * p.A;
+    // one work item per PAIR of action columns: the same Philox pairs (index, Box-Muller branches) as the fused family's
+    // rollout kernels draw, so that a seed means the same plan on every kernel family (tdmpc2_plan_export_noise)
+    const int hp = (p.A + 15) / 16 * 8, hpa = (p.A + 1) / 2;
+    const size_t total = (size_t)p.E * p.H * (p.N - p.P) * hpa;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int a = idx % p.A;
-        size_t r = idx / p.A;
+        const int a0 = 2 * (int)(idx % hpa);
+        size_t r = idx / hpa;
         const int n = r % (p.N - p.P);
         r /= (p.N - p.P);
         const int t = r % p.H, e = r / p.H;
-        const unsigned ridx = (unsigned)(((size_t)t * (p.N - p.P) + n) * p.A + a);
-        const float z = p.eps ? p.eps[(size_t)e * p.eps_estride + ridx] : rng_normal(p.seed, p.call, SITE_SAMPLE, p.iter, e, ridx);
-        float v = sample_action(p.mean[((size_t)e * p.H + t) * p.A + a], p.std[((size_t)e * p.H + t) * p.A + a], z);
-        if (p.mask) v *= p.mask[(size_t)e * p.A + a];
-        p.actions[(((size_t)e * p.H + t) * p.N + p.P + n) * p.A + a] = v;
+        float z[2] = {0.f, 0.f};
+        if (p.eps) {
+            const float *ep = p.eps + (size_t)e * p.eps_estride + (unsigned)(((size_t)t * (p.N - p.P) + n) * p.A + a0);
+            z[0] = ep[0];
+            if (a0 + 1 < p.A) z[1] = ep[1];
+        } else {
+            rng_normal2(p.seed, p.call, SITE_SAMPLE, p.iter, e, (unsigned)(((size_t)t * (p.N - p.P) + n) * hp + a0 / 2), z[0], z[1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int a = a0 + u;
+            if (a >= p.A) break;
+            float v = sample_action(p.mean[((size_t)e * p.H + t) * p.A + a], p.std[((size_t)e * p.H + t) * p.A + a], z[u]);
+            if (p.mask) v *= p.mask[(size_t)e * p.A + a];
+            p.actions[(((size_t)e * p.H + t) * p.N + p.P + n) * p.A + a] = v;
+        }
     }
 }
 

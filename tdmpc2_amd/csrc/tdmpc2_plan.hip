@@ -68,6 +68,10 @@ struct RefitParams {
     unsigned int call;
     float *prev_mean;  // [E,H,A]
     float *action;     // [E,A]
+    // cluster path: the handle's host-mapped error word (a bounded hand-over wait gave up somewhere in this plan).  When it is
+    // set the plan's numbers are garbage: the final pick then returns NaN actions and leaves prev_mean untouched, so that the
+    // caller can re-plan the same step (tdmpc2_plan_take_fault); null on every other path.
+    const unsigned int *err;
     // In-launch refit (fused family, ks_rollout's last-arriver epilogue): the elite actions are RE-DERIVED from the
     // iteration's sampling distribution and noise instead of being read back from `actions` -- the workgroups that sampled
     // them sit on other XCDs, and shipping 64 x H x A floats per workgroup through write-through stores cost 13 % of the
@@ -548,6 +552,16 @@ __device__ __forceinline__ void refit_plan(const RefitParams &p, int e, float *s
         if (ev[k] == ymax) atomicMin(s_pick, k);
     __syncthreads();
     const int pick = ei[*s_pick];
+    bool bad = false;
+    if (p.err) {  // uniform: one system-scope load of the host-mapped word, broadcast through LDS
+        if (tid == 0) s_pick[1] = (int)__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        bad = s_pick[1] != 0;
+    }
+    if (bad) {
+        for (int a = tid; a < p.A; a += nthr) p.action[(size_t)e * p.A + a] = __uint_as_float(0x7fc00000u);
+        return;
+    }
     for (int a = tid; a < p.A; a += nthr) {
         float x = p.stage ? ea[(size_t)*s_pick * HA + a] : acts[(size_t)pick * p.A + a];  // elite_actions[0, rand_idx]
         if (!p.eval_mode) {
@@ -615,6 +629,64 @@ __global__ void k_copy_pad(const float *src, int n, int npad, float *dst) {
 #include "layered_kernels.cuh"
 #include "layered_split.cuh"
 #include "encoder_kernels.cuh"
+
+// ================================================================ the in-kernel generator as a noise tape (tdmpc2_plan_export_noise)
+// Every draw of a tape = NULL plan, written with the index formulas and device functions of the kernels that consume them
+// (ks_rollout / ks_rollout_cl / ks_pitraj / l_sample / l_pi_head / l_qidx / refit_plan), for environments [e0, e0 + n).
+struct NoiseExportParams {
+    int e0, n, H, N, P, A, K, I, nq, hp;
+    unsigned long long seed;
+    unsigned int call;
+    tdmpc2_noise_out o;
+};
+__global__ void k_export_noise(NoiseExportParams p) {
+    const size_t gtid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
+    const int NS = p.N - p.P, hpa = (p.A + 1) / 2;
+    if (p.o.pi_traj_eps)  // [n,H,P,A]: rng_normal(SITE_PITRAJ, iter = t, row * A + a)
+        for (size_t i = gtid; i < (size_t)p.n * p.H * p.P * p.A; i += gsz) {
+            const unsigned ra = (unsigned)(i % ((size_t)p.P * p.A));
+            const size_t r = i / ((size_t)p.P * p.A);
+            const int t = (int)(r % p.H), e = (int)(r / p.H);
+            p.o.pi_traj_eps[i] = rng_normal(p.seed, p.call, SITE_PITRAJ, t, p.e0 + e, ra);
+        }
+    if (p.o.sample_eps)  // [n,I,H,N-P,A]: Philox pairs over (t, n, a / 2) with the fused tile's action padding
+        for (size_t i = gtid; i < (size_t)p.n * p.I * p.H * NS * hpa; i += gsz) {
+            const int a0 = 2 * (int)(i % hpa);
+            size_t r = i / hpa;
+            const int ns = (int)(r % NS);
+            r /= NS;
+            const int t = (int)(r % p.H);
+            r /= p.H;
+            const int it = (int)(r % p.I), e = (int)(r / p.I);
+            float z0, z1;
+            rng_normal2(p.seed, p.call, SITE_SAMPLE, it, p.e0 + e, (unsigned)(((size_t)t * NS + ns) * p.hp + a0 / 2), z0, z1);
+            float *dst = p.o.sample_eps + ((((size_t)e * p.I + it) * p.H + t) * NS + ns) * p.A + a0;
+            dst[0] = z0;
+            if (a0 + 1 < p.A) dst[1] = z1;
+        }
+    if (p.o.pi_eps)  // [n,I,N,A]: rng_normal(SITE_PI, iter, n * A + a)
+        for (size_t i = gtid; i < (size_t)p.n * p.I * p.N * p.A; i += gsz) {
+            const unsigned ra = (unsigned)(i % ((size_t)p.N * p.A));
+            const size_t r = i / ((size_t)p.N * p.A);
+            const int it = (int)(r % p.I), e = (int)(r / p.I);
+            p.o.pi_eps[i] = rng_normal(p.seed, p.call, SITE_PI, it, p.e0 + e, ra);
+        }
+    if (p.o.qidx)  // [n,I,2]: two distinct heads, uniform over ordered pairs (the randperm(nq)[:2] of world_model.py:212)
+        for (size_t i = gtid; i < (size_t)p.n * p.I; i += gsz) {
+            const int it = (int)(i % p.I), e = (int)(i / p.I);
+            const uint4 r = rng_raw(p.seed, p.call, SITE_QIDX, it, p.e0 + e, 0);
+            int q0 = (int)(r.x % (unsigned)p.nq), q1 = (int)(r.y % (unsigned)(p.nq - 1));
+            if (q1 >= q0) ++q1;
+            p.o.qidx[2 * i] = q0;
+            p.o.qidx[2 * i + 1] = q1;
+        }
+    if (p.o.gumbel_exp)  // [n,K]
+        for (size_t i = gtid; i < (size_t)p.n * p.K; i += gsz)
+            p.o.gumbel_exp[i] = rng_exponential(p.seed, p.call, SITE_GUMBEL, 0, p.e0 + (int)(i / p.K), (unsigned)(i % p.K));
+    if (p.o.final_eps)  // [n,A]
+        for (size_t i = gtid; i < (size_t)p.n * p.A; i += gsz)
+            p.o.final_eps[i] = rng_normal(p.seed, p.call, SITE_FINAL, 0, p.e0 + (int)(i / p.A), (unsigned)(i % p.A));
+}
 
 // ================================================================ host side
 thread_local std::string g_err;
@@ -706,6 +778,7 @@ struct tdmpc2_plan {
     unsigned int *cl_err_host = nullptr, *cl_err_dev = nullptr;  // host-mapped error word of the bounded waits
     size_t cl_lds = 0;
     int cl_fault = 0;                // TDMPC2_CLUSTER_FAULT=1 at create: test hook of the bounded waits
+    int faults = 0;                  // cluster plans that gave up since the last tdmpc2_plan_take_fault
     bool split = false;  // fused kernels on the f16 matrix pipe with hi/lo operand split (fused_kernels.cuh)
     int force_rows = 0;  // TDMPC2_TUNE_ROWS_PER_WORKGROUP: 0 auto, 32, 64
     size_t row_bytes = 0;  // bytes of one sample row of the fused kernels' LDS tile
@@ -956,11 +1029,12 @@ void fill_rollout(tdmpc2_plan *h, RolloutParamsT<NET> &p, int E) {
 int validate_envs(tdmpc2_plan *h, int E) {
     if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
     if (E < 1 || E > h->cfg.max_envs) return fail(TDMPC2_ERR_INVALID, "n_envs=%d outside [1, max_envs=%d]", E, h->cfg.max_envs);
-    if (h->cl_err_host && *(volatile unsigned int *)h->cl_err_host) {  // raised by a member of an EARLIER cluster launch
+    // a cluster hand-over of an EARLIER plan gave up (bounded wait): that plan returned NaN actions and kept its prev_mean
+    // (refit_plan); from here on the handle plans with one workgroup per tile.  tdmpc2_plan_take_fault reports it.
+    if (h->cl_err_host && *(volatile unsigned int *)h->cl_err_host) {
         *(volatile unsigned int *)h->cl_err_host = 0;
         h->cluster_mode = 0;
-        return fail(TDMPC2_ERR_HIP, "a cluster hand-over of an earlier plan timed out (its result was invalid); the cluster path "
-                                    "is now off for this handle");
+        h->faults++;
     }
     return check_ready(h);
 }
@@ -1050,6 +1124,7 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
         fp.value = h->value; fp.actions = h->actions; fp.act_mask = act_mask; fp.mean = h->mean; fp.std = h->std;
         fp.gumbel_exp = tape ? tape->gumbel_exp : nullptr; fp.final_eps = tape ? tape->final_eps : nullptr;
         fp.seed = seed; fp.call = call; fp.prev_mean = prev_mean; fp.action = action;
+        fp.err = cluster ? h->cl_err_dev : nullptr;
         if (dbg) {
             if (dbg->value) { fp.dbg_value = dbg->value + (size_t)it * N; fp.dbg_value_es = (long)I * N; }
             if (dbg->elite_idx) { fp.dbg_idx = dbg->elite_idx + (size_t)it * K; fp.dbg_idx_es = (long)I * K; }
@@ -1663,7 +1738,7 @@ int launch_value(tdmpc2_plan *h, int rows, const float *z, bool target, bool red
             for (int qh = 0; qh < c.num_q; ++qh)
                 if (!h->tq[qh].l[i].bound)
                     return fail(TDMPC2_ERR_STATE, "layer %d of target Q head %d is not bound (net TDMPC2_NET_TARGET_Q)", i, qh);
-    const unsigned call = ++h->call;
+    const unsigned call = h->call++;
     if (h->lay.on) {
         const size_t rows_p = round_up((size_t)rows, GBM), cap = round_up((size_t)c.max_envs * c.num_samples, GBM);
         if (rows_p > cap)
@@ -2002,13 +2077,27 @@ int tdmpc2_plan_import_packed(tdmpc2_plan_t *h, const void *host_buf, uint64_t b
         for (int l = 0; l < 3; ++l)
             if ((rc = ensure_layer_alloc(h, net, l, layer_shape(h, net, l)))) return rc;
     }
+    for (uint32_t l = 0; l < hdr.enc_layers; ++l) {  // untrusted header fields: range-check before anything is allocated
+        const int wmax = ENC_THREADS * ENC_MAX_PER_THREAD;
+        if (hdr.enc_in[l] < 1 || hdr.enc_in[l] > 1 << 20 || hdr.enc_out[l] < 1 || hdr.enc_out[l] > wmax)
+            return fail(TDMPC2_ERR_INVALID, "packed weights: encoder layer %u has shape [%d, %d]", l, hdr.enc_out[l], hdr.enc_in[l]);
+    }
     for (uint32_t l = 0; l < hdr.enc_layers; ++l)
         if ((rc = ensure_enc_alloc(h, (int)l, hdr.enc_in[l], hdr.enc_out[l]))) return rc;
     std::vector<Seg> segs;
     collect_segments(h, hdr.has_target != 0, (int)hdr.enc_layers, segs);
-    if (segs.size() != hdr.nseg || bytes < sizeof(PackHdr) + hdr.nseg * sizeof(uint64_t) + hdr.data_bytes)
-        return fail(TDMPC2_ERR_INVALID, "packed weights: %llu segments / %llu bytes, expected %zu segments", (unsigned long long)hdr.nseg,
-                    (unsigned long long)bytes, segs.size());
+    // the blob must hold exactly what this handle expects: header + size table + the sum of the EXPECTED segment sizes (the
+    // header's own data_bytes is only compared, never trusted; no addition can wrap)
+    uint64_t expect = 0;
+    for (const Seg &sg : segs) {
+        if (sg.bytes > (uint64_t)1 << 40 || expect > (uint64_t)1 << 41) return fail(TDMPC2_ERR_INVALID, "packed weights: implausible segment size");
+        expect += sg.bytes;
+    }
+    const uint64_t need = sizeof(PackHdr) + (uint64_t)segs.size() * sizeof(uint64_t) + expect;
+    if (segs.size() != hdr.nseg || hdr.data_bytes != expect || bytes < need)
+        return fail(TDMPC2_ERR_INVALID, "packed weights: %llu segments / %llu data bytes in a buffer of %llu bytes; this handle expects %zu segments / "
+                    "%llu data bytes (%llu in all)", (unsigned long long)hdr.nseg, (unsigned long long)hdr.data_bytes, (unsigned long long)bytes,
+                    segs.size(), (unsigned long long)expect, (unsigned long long)need);
     const char *src = static_cast<const char *>(host_buf);
     const uint64_t *sizes = reinterpret_cast<const uint64_t *>(src + sizeof hdr);
     for (size_t i = 0; i < segs.size(); ++i)
@@ -2028,6 +2117,47 @@ int tdmpc2_plan_import_packed(tdmpc2_plan_t *h, const void *host_buf, uint64_t b
     }
     for (uint32_t l = 0; l < hdr.enc_layers; ++l) h->enc[l].bound = true;
     if (hdr.enc_layers) h->enc_layers = (int)hdr.enc_layers;
+    return TDMPC2_OK;
+}
+
+int tdmpc2_plan_export_noise(tdmpc2_plan_t *h, int env_first, int n_envs, uint64_t seed, uint32_t call,
+                             const tdmpc2_noise_out *out, void *stream) {
+    if (!h || !out) return fail(TDMPC2_ERR_INVALID, "null argument");
+    if (env_first < 0 || n_envs < 1) return fail(TDMPC2_ERR_INVALID, "environment range [%d, +%d)", env_first, n_envs);
+    ENTER(h);
+    const tdmpc2_plan_cfg &c = h->cfg;
+    NoiseExportParams p{};
+    p.e0 = env_first; p.n = n_envs; p.H = c.horizon; p.N = c.num_samples; p.P = c.num_pi_trajs; p.A = c.action_dim;
+    p.K = c.num_elites; p.I = c.iterations; p.nq = c.num_q; p.hp = (c.action_dim + 15) / 16 * 8;
+    p.seed = seed; p.call = call; p.o = *out;
+    hipLaunchKernelGGL(k_export_noise, dim3(2048), dim3(256), 0, (hipStream_t)stream, p);
+    HIP_TRY(hipGetLastError());
+    return TDMPC2_OK;
+}
+
+int tdmpc2_plan_call_counter(const tdmpc2_plan_t *h, uint32_t *next_call) {
+    if (!h || !next_call) return fail(TDMPC2_ERR_INVALID, "null argument");
+    *next_call = h->call;
+    return TDMPC2_OK;
+}
+
+int tdmpc2_plan_set_call_counter(tdmpc2_plan_t *h, uint32_t next_call) {
+    if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
+    ENTER(h);
+    h->call = next_call;
+    return TDMPC2_OK;
+}
+
+int tdmpc2_plan_take_fault(tdmpc2_plan_t *h, int *faults) {
+    if (!h || !faults) return fail(TDMPC2_ERR_INVALID, "null argument");
+    ENTER(h);
+    if (h->cl_err_host && *(volatile unsigned int *)h->cl_err_host) {
+        *(volatile unsigned int *)h->cl_err_host = 0;
+        h->cluster_mode = 0;
+        h->faults++;
+    }
+    *faults = h->faults;
+    h->faults = 0;
     return TDMPC2_OK;
 }
 

@@ -78,6 +78,25 @@ def gather_actions(local_actions: torch.Tensor, n_envs: int) -> torch.Tensor:
     return torch.cat([o[: b - a] for o, (a, b) in zip(out, sizes)], dim=0)
 
 
+def _agree_on_stream(backend, seed: int, device, group=None):
+    """Make the ranks of a sharded plan draw identical noise: compare the seeds (raise on mismatch) and adopt rank 0's call
+    counter (NativePlanner.call_counter / set_call_counter; stand-ins without a counter have no hidden state to align)."""
+    seed = int(seed) & (2**64 - 1)
+    has_counter = hasattr(backend, "call_counter") and hasattr(backend, "set_call_counter")
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    # int64 cannot hold a u64 seed: ship it as two 32-bit halves
+    mine = torch.tensor([seed >> 32, seed & 0xFFFFFFFF, backend.call_counter() if has_counter else 0], dtype=torch.int64, device=device)
+    ref = mine.clone()
+    dist.broadcast(ref, src=src, group=group)
+    bad = torch.tensor([int(not torch.equal(mine[:2], ref[:2]))], dtype=torch.int64, device=device)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+    if int(bad.item()):
+        raise ValueError("sharded_plan: the Philox seed differs between ranks (it must not depend on the rank: every rank has to "
+                         f"sample the same actions); this rank passed {seed:#x}")
+    if has_counter:
+        backend.set_call_counter(int(ref[2].item()))
+
+
 def sharded_plan(backend, z0, disc_pow, prev_mean, t0, eval_mode: bool = False, task_emb=None, act_mask=None, tape=None,
                  seed: int = 0, group=None, stages: Optional[dict] = None) -> torch.Tensor:
     """ONE plan per environment with its sample rows split over the ranks of `group` (last row:
@@ -100,6 +119,8 @@ def sharded_plan(backend, z0, disc_pow, prev_mean, t0, eval_mode: bool = False, 
     r0, r1 = rank * per, (rank + 1) * per
     value = torch.zeros(E, N, dtype=torch.float32, device=z0.device)
     action = torch.empty(E, cfg.action_dim, dtype=torch.float32, device=z0.device)
+    if world > 1 and tape is None:
+        _agree_on_stream(backend, seed, z0.device, group)
     backend.shard_begin(z0, prev_mean, t0, task_emb=task_emb, act_mask=act_mask, tape=tape, seed=seed)
     for it in range(backend.iterations):
         backend.shard_values(it, r0, r1, z0, disc_pow, value, act_mask=act_mask, seed=seed)

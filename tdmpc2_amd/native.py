@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("TDMPC2_PLAN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtdmpc2_plan.so")
 _lib = None
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/tdmpc2_plan.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "tdmpc2_plan_policy_value", "tdmpc2_plan_td_target", "tdmpc2_plan_policy_value_mt", "tdmpc2_plan_td_target_mt",
     "tdmpc2_plan_packed_size", "tdmpc2_plan_export_packed", "tdmpc2_plan_import_packed",
     "tdmpc2_plan_shard_begin", "tdmpc2_plan_shard_values", "tdmpc2_plan_shard_refit",
+    "tdmpc2_plan_export_noise", "tdmpc2_plan_call_counter", "tdmpc2_plan_set_call_counter", "tdmpc2_plan_take_fault",
 ]
 
 NET_DYNAMICS, NET_REWARD, NET_PI, NET_Q, NET_TERMINATION, NET_TARGET_Q = range(6)
@@ -127,6 +128,14 @@ def load_library():
     lib.tdmpc2_plan_estimate_value_trace.restype = i32
     lib.tdmpc2_plan_refit.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tdmpc2_plan_refit.restype = i32
+    lib.tdmpc2_plan_export_noise.argtypes = [vp, i32, i32, u64, C.c_uint32, C.POINTER(Noise), vp]
+    lib.tdmpc2_plan_export_noise.restype = i32
+    lib.tdmpc2_plan_call_counter.argtypes = [vp, C.POINTER(C.c_uint32)]
+    lib.tdmpc2_plan_call_counter.restype = i32
+    lib.tdmpc2_plan_set_call_counter.argtypes = [vp, C.c_uint32]
+    lib.tdmpc2_plan_set_call_counter.restype = i32
+    lib.tdmpc2_plan_take_fault.argtypes = [vp, C.POINTER(i32)]
+    lib.tdmpc2_plan_take_fault.restype = i32
     lib.tdmpc2_plan_set_tuning.argtypes = [vp, i32, i32]
     lib.tdmpc2_plan_set_tuning.restype = i32
     lib.tdmpc2_plan_set_profiling.argtypes = [vp, i32]
@@ -317,14 +326,46 @@ class NativePlanner:
         return action
 
     def _noise(self, tape, E):
-        cfg, dev = self.cfg, self.device
-        H, N, K, P, A, I = cfg.horizon, cfg.num_samples, cfg.num_elites, cfg.num_pi_trajs, cfg.action_dim, self.iterations
-        shapes = {"pi_traj_eps": ((E, H, P, A), torch.float32), "sample_eps": ((E, I, H, N - P, A), torch.float32),
-                  "pi_eps": ((E, I, N, A), torch.float32), "qidx": ((E, I, 2), torch.int32),
-                  "gumbel_exp": ((E, K), torch.float32), "final_eps": ((E, A), torch.float32)}
+        shapes = self.noise_shapes(E)
         for k, (shp, dt) in shapes.items():
-            _chk_tensor(f"tape[{k}]", tape[k], dt, shp, dev)
+            _chk_tensor(f"tape[{k}]", tape[k], dt, shp, self.device)
         return Noise(**{k: tape[k].data_ptr() for k in shapes})
+
+    def noise_shapes(self, E):
+        """Shapes / dtypes of the six tensors of a noise tape for E environments (struct tdmpc2_noise)."""
+        cfg = self.cfg
+        H, N, K, P, A, I = cfg.horizon, cfg.num_samples, cfg.num_elites, cfg.num_pi_trajs, cfg.action_dim, self.iterations
+        return {"pi_traj_eps": ((E, H, P, A), torch.float32), "sample_eps": ((E, I, H, N - P, A), torch.float32),
+                "pi_eps": ((E, I, N, A), torch.float32), "qidx": ((E, I, 2), torch.int32),
+                "gumbel_exp": ((E, K), torch.float32), "final_eps": ((E, A), torch.float32)}
+
+    def call_counter(self) -> int:
+        """The handle's call counter: the value the NEXT plan / td_target / policy_value call mixes into its Philox key."""
+        n = C.c_uint32()
+        self._check(self.lib.tdmpc2_plan_call_counter(self._h, C.byref(n)))
+        return int(n.value)
+
+    def set_call_counter(self, value: int):
+        self._check(self.lib.tdmpc2_plan_set_call_counter(self._h, C.c_uint32(int(value) & 0xFFFFFFFF)))
+
+    def export_noise(self, seed: int, call: int, n_envs: int, env_first: int = 0, fields=None):
+        """The draws a tape = None plan makes under (seed, call = call_counter() read BEFORE that plan) for environments
+        [env_first, env_first + n_envs), as a noise-tape dict: feeding it back as `tape` reproduces the plan bit for bit,
+        and the same tensors replay through the CPU oracle (tdmpc2_plan_export_noise)."""
+        shapes = self.noise_shapes(n_envs)
+        out = {k: torch.empty(shp, dtype=dt, device=self.device) for k, (shp, dt) in shapes.items() if fields is None or k in fields}
+        noise = Noise(**{k: v.data_ptr() for k, v in out.items()})
+        with torch.cuda.device(self.device):
+            self._check(self.lib.tdmpc2_plan_export_noise(self._h, int(env_first), int(n_envs), C.c_uint64(int(seed) & (2**64 - 1)),
+                                                          C.c_uint32(int(call) & 0xFFFFFFFF), C.byref(noise), self._stream()))
+        return out
+
+    def take_fault(self) -> int:
+        """Number of cluster-path plans that gave up (bounded hand-over wait) since the last call; such a plan returned NaN
+        actions and kept its prev_mean, and the handle now plans with one workgroup per tile.  Call after a sync."""
+        n = C.c_int()
+        self._check(self.lib.tdmpc2_plan_take_fault(self._h, C.byref(n)))
+        return int(n.value)
 
     # ------------------------------------------------------------------ training-side forward pieces
     def _task_tables(self, R, task_ids, task_emb_table, act_mask_table, discount_table=None):

@@ -78,19 +78,18 @@ class TDMPC2(torch.nn.Module):
 
     # ------------------------------------------------------------------ native planner
     def planner(self) -> NativePlanner:
-        if self._planner is not None and self._planner_log_std != self._log_std():
-            self._planner.close()  # log_std_min / log_std_dif are constants of the handle: a load() changed them
-            self._planner = None
+        # (log_std_min / log_std_dif are constants of the handle; they can only change in load() / sync_planner_weights(),
+        # which drop a stale handle -- no device read, hence no stream sync, on the planning path)
         if self._planner is None:
             self._planner_log_std = self._log_std()
             self._planner = NativePlanner(self.cfg, self.cfg.iterations, self.device, max_envs=self.max_envs,
-                                          log_std_min=float(self.model.log_std_min),
-                                          log_std_dif=float(self.model.log_std_dif))
+                                          log_std_min=self._planner_log_std[0], log_std_dif=self._planner_log_std[1])
             self._planner.bind_state_dict(self.model.planner_state_dict())
             self._bind_encoder()
         return self._planner
 
     def _log_std(self):
+        """(log_std_min, log_std_dif) as host floats: two device reads -- only where the weights can change."""
         return float(self.model.log_std_min), float(self.model.log_std_dif)
 
     def _bind_encoder(self):
@@ -139,7 +138,12 @@ class TDMPC2(torch.nn.Module):
         if task is not None:
             task = torch.tensor([task], device=self.device)
         if self.cfg.mpc:
-            return self.plan(obs, t0=t0, eval_mode=eval_mode, task=task).cpu()
+            a = self.plan(obs, t0=t0, eval_mode=eval_mode, task=task).cpu()
+            if self._planner is not None and self._planner.take_fault():
+                # a cluster hand-over of THIS plan gave up (another process / kernel held the compute units): the library
+                # returned NaN and left _prev_mean alone; it has switched to the path without hand-overs -- plan again
+                a = self.plan(obs, t0=t0, eval_mode=eval_mode, task=task).cpu()
+            return a
         z = self.model.encode(obs, task)
         action, info = self.model.pi(z, task)
         if eval_mode:
@@ -180,7 +184,10 @@ class TDMPC2(torch.nn.Module):
 
     @torch.no_grad()
     def act_batch(self, obs, t0, eval_mode=False, tasks=None):
-        return self.plan_batch(obs, t0, eval_mode, tasks).cpu()
+        a = self.plan_batch(obs, t0, eval_mode, tasks).cpu()
+        if self._planner is not None and self._planner.take_fault():  # see act()
+            a = self.plan_batch(obs, t0, eval_mode, tasks).cpu()
+        return a
 
     def _plan_inputs(self, E, tasks):
         planner = self.planner()

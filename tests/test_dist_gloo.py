@@ -227,3 +227,45 @@ def _bcast_worker(rank, world, port):
 
 def test_broadcast_streams_in_buckets():
     mp.spawn(_bcast_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+class _CounterBackend:
+    """Only the hidden state sharded_plan has to align across ranks (NativePlanner.call_counter / set_call_counter)."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def call_counter(self):
+        return self.n
+
+    def set_call_counter(self, v):
+        self.n = int(v)
+
+
+def _stream_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tdmpc2_amd.dist import _agree_on_stream
+
+        # rank 1's handle has planned on its own in the meantime (ADVICE r2): its counter ran ahead
+        be = _CounterBackend(5 if rank == 0 else 9)
+        _agree_on_stream(be, (1 << 40) + 7, torch.device("cpu"))
+        assert be.n == 5
+        # a seed that carries the rank (what TDMPC2._seed does) must be refused on EVERY rank, not diverge silently
+        raised = False
+        try:
+            _agree_on_stream(be, (rank << 32) ^ 3, torch.device("cpu"))
+        except ValueError as ex:
+            raised = "seed differs between ranks" in str(ex)
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write(str(int(raised)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_plan_ranks_agree_on_the_philox_stream(tmp_path):
+    """Without a tape the ranks of a sharded plan must draw identical noise: rank 0's call counter is adopted, a
+    rank-dependent seed raises everywhere."""
+    mp.spawn(_stream_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").read_text() == "1" and (tmp_path / "ok1").read_text() == "1"

@@ -206,3 +206,29 @@ def test_pixel_observation_agent_plans():
     b = ref.plan(z, disc, torch.zeros(1, cfg.horizon, cfg.action_dim, device=agent.device),
                  torch.ones(1, dtype=torch.uint8, device=agent.device), seed=agent._seed)
     assert torch.equal(a, b[0].cpu())
+
+
+def test_act_replans_a_step_whose_cluster_plan_gave_up(monkeypatch):
+    """a cluster hand-over that times out must not leak a garbage action into env.step.  The library returns NaN
+    and keeps `_prev_mean`; `act()` sees the fault after its `.cpu()` sync and plans the step again on the path without
+    hand-overs.  With a noise tape the re-planned action is exactly what a cluster-less agent returns."""
+    from oracle import planner_oracle as po
+    from tdmpc2_amd import synth
+
+    monkeypatch.setenv("TDMPC2_CLUSTER_FAULT", "1")
+    c, faulty = _agent("c1")
+    faulty.planner()  # the handle reads the test hook at create
+    monkeypatch.delenv("TDMPC2_CLUSTER_FAULT")
+    monkeypatch.setenv("TDMPC2_CLUSTER", "0")
+    _, plain = _agent("c1")
+    plain.planner()
+    monkeypatch.delenv("TDMPC2_CLUSTER")
+    obs = torch.as_tensor(synth.make_obs(c["cfg"], 1, seed=3)[0])
+    tape = {k: v.unsqueeze(0).to(faulty.device).contiguous() for k, v in po.env_tape(c["tape"], 0).items()}
+    faulty.noise_tape = plain.noise_tape = tape
+    for t0 in (True, False):
+        x = faulty.act(obs, t0=t0, eval_mode=False)
+        y = plain.act(obs, t0=t0, eval_mode=False)
+        assert torch.isfinite(x).all() and torch.equal(x, y)
+        assert torch.equal(faulty._prev_mean, plain._prev_mean)
+    assert faulty.planner().take_fault() == 0  # act() consumed the report

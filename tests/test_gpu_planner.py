@@ -479,12 +479,13 @@ def test_action_statistics_over_32_seeds(prec):
 
 
 def test_cluster_hand_over_that_never_arrives_is_reported_not_hung(monkeypatch):
-    """Every wait of the cluster path is bounded.  TDMPC2_CLUSTER_FAULT=1 (read at create) mutes one member of cluster 0: the
-    plan of that call is invalid but returns, the NEXT call on the handle fails loudly, and the handle then plans on the
-    one-workgroup-per-tile kernels -- bit for bit what a handle with the cluster path switched off returns."""
+    """Every wait of the cluster path is bounded, and the fault is reported by the call it happened in.
+    TDMPC2_CLUSTER_FAULT=1 (read at create) mutes one member of cluster 0: that call comes back with NaN actions and an
+    UNTOUCHED prev_mean, `take_fault()` reports it after the sync, and the handle then plans on the one-workgroup-per-tile
+    kernels -- bit for bit what a handle with the cluster path switched off returns.  No later call fails for it."""
     import time
 
-    from tdmpc2_amd.native import NativeError, NativePlanner
+    from tdmpc2_amd.native import NativePlanner
     from tests.gpu_common import case_on_gpu, dev, plan_inputs
 
     c, model, ref = case_on_gpu("c1", 1, 2)
@@ -494,14 +495,18 @@ def test_cluster_hand_over_that_never_arrives_is_reported_not_hung(monkeypatch):
     planner.bind_state_dict(model.sd)
     inp = plan_inputs(c, model)
     kw = dict(eval_mode=c["eval_mode"], task_emb=inp["task_emb"], act_mask=inp["act_mask"], tape=inp["tape"])
+    assert planner.take_fault() == 0
     t = time.perf_counter()
-    planner.plan(inp["z0"], inp["disc_pow"], inp["prev_mean"].clone(), inp["t0"], **kw)  # invalid result, but it comes back
+    pm_bad = inp["prev_mean"].clone()
+    bad = planner.plan(inp["z0"], inp["disc_pow"], pm_bad, inp["t0"], **kw)  # invalid plan, but it comes back ...
     torch.cuda.synchronize()
     assert time.perf_counter() - t < 60
-    with pytest.raises(NativeError, match="cluster hand-over"):
-        planner.plan(inp["z0"], inp["disc_pow"], inp["prev_mean"].clone(), inp["t0"], **kw)
+    assert torch.isnan(bad).all()                      # ... as NaN, never as a plausible action,
+    assert torch.equal(pm_bad, inp["prev_mean"])       # with the warm-start state of the step intact,
+    assert planner.take_fault() == 1                   # and the fault is visible right after the sync
+    assert planner.take_fault() == 0
     pm_a, pm_b = inp["prev_mean"].clone(), inp["prev_mean"].clone()
-    a = planner.plan(inp["z0"], inp["disc_pow"], pm_a, inp["t0"], **kw).clone()
+    a = planner.plan(inp["z0"], inp["disc_pow"], pm_a, inp["t0"], **kw).clone()  # the same step, planned again: healthy
     ref.set_cluster(0)
     try:
         b = ref.plan(inp["z0"], inp["disc_pow"], pm_b, inp["t0"], **kw).clone()
@@ -509,4 +514,5 @@ def test_cluster_hand_over_that_never_arrives_is_reported_not_hung(monkeypatch):
         ref.set_cluster(2)
     torch.cuda.synchronize()
     assert torch.equal(a, b) and torch.equal(pm_a, pm_b)
+    assert planner.take_fault() == 0
     planner.close()
