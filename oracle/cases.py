@@ -26,6 +26,9 @@ CASES = {
     "small": ("small", {}, 3, False, 0.06),
     "small_ep": ("small", dict(episodic=True), 2, False, 0.06),
     "small_mt": ("small", dict(task="mt30"), 3, False, 0.06),
+    # the same episodic model with a termination head that FIRES (a tenth to a half of the sample rows per step; with the plain
+    # synthetic weights of "small_ep" sigmoid(.) never crosses 0.5, so the layered family's (1 - term) masking was idle there)
+    "small_ep_fire": ("small", dict(episodic=True), 2, False, 0.06),
     "c1_ep": ("c1", dict(episodic=True), 1, False, 0.06),
     "c3": ("c3", {}, 2, False, 0.03),                   # mt30 48M: L768 M1792 T64
     "c4": ("c4", dict(iterations=2), 1, False, 0.02),   # mt80 317M: L1376 M4096 nq8 T96, H5 N1024 (2 CEM iterations)
@@ -57,6 +60,9 @@ def build_custom(cfg, E: int, eval_mode: bool = False, head_std: float = 0.06, n
         cfg.episode_lengths = [500 if i % 2 == 0 else 1000 for i in range(n)]
     I = planner_iterations(cfg)
     sd = synth.make_state_dict(cfg, seed=0, head_std=head_std)
+    if name == "small_ep_fire":  # spread the termination logits around 0 (world_model.py:132-141: sigmoid(.) > 0.5 terminates)
+        sd["_termination.2.weight"] = sd["_termination.2.weight"] * 12.0
+        sd["_termination.2.bias"] = sd["_termination.2.bias"] * 0.0 + 3.3
     z0 = synth.make_latents(cfg, E, seed=1)
     tape = synth.make_noise_tape(cfg, E, I, seed=2)
     prev = np.random.default_rng(5).uniform(-0.5, 0.5, (E, cfg.horizon, cfg.action_dim)).astype(np.float32)

@@ -40,7 +40,7 @@ def pytest_sessionfinish(session, exitstatus):
         return
     import json
 
-    out = os.environ.get("TDMPC2_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "parity_r02.json"))
+    out = os.environ.get("TDMPC2_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "parity_r03.json"))
     try:
         os.makedirs(os.path.dirname(out), exist_ok=True)
         with open(out, "w") as f:
@@ -48,3 +48,25 @@ def pytest_sessionfinish(session, exitstatus):
                        "exit_status": int(exitstatus), "cases": helpers.PARITY}, f, indent=1, sort_keys=True)
     except OSError:
         pass
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The parity table goes to STDOUT as well, so that the log of whoever runs `pytest -m gpu` carries the numbers (the
+    JSON above is a file on the GPU box)."""
+    try:
+        from tests import helpers
+    except Exception:
+        return
+    if not helpers.PARITY:
+        return
+    tr = terminalreporter
+    tr.write_sep("=", "parity report: worst |HIP - reference/oracle| per case (gates: value_rel, action_abs, prev_mean_abs < 1e-4)")
+    cols = ("value_rel", "mean_abs", "std_abs", "action_abs", "prev_mean_abs", "elite_swaps", "plans")
+    tr.write_line(f"{'case':58s} " + " ".join(f"{c:>13s}" for c in cols))
+    for key in sorted(helpers.PARITY):
+        m = helpers.PARITY[key]
+        cells = []
+        for c in cols:
+            v = m.get(c)
+            cells.append(f"{'':>13s}" if v is None else (f"{v:13d}" if isinstance(v, int) else f"{v:13.2e}"))
+        tr.write_line(f"{key[:58]:58s} " + " ".join(cells))

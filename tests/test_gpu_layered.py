@@ -14,7 +14,7 @@ from tests.test_gpu_planner import _compare_stages, _oracle_stage_inputs, _run_n
 pytestmark = pytest.mark.gpu
 
 PATH_FUSED, PATH_LAYERED = 1, 2
-LAYERED_CASES = ["small", "small_ep", "small_mt", "c1_ep", "c3", "c4", "c4_l1024"]
+LAYERED_CASES = ["small", "small_ep", "small_ep_fire", "small_mt", "c1_ep", "c3", "c4", "c4_l1024"]
 _PN = {1: "fp32", 2: "split"}
 # both arithmetic modes of the layered family: exact-fp32 MFMA GEMMs (1) and the f16x2 split (2)
 PRECS = pytest.mark.parametrize("prec", [1, 2], ids=["fp32", "split"])
@@ -54,7 +54,7 @@ def test_layered_family_on_fused_size_class(name, prec):
 
 
 @PRECS
-@pytest.mark.parametrize("name", ["small", "small_ep", "small_mt", "c1_ep", "c3"])
+@pytest.mark.parametrize("name", ["small", "small_ep", "small_ep_fire", "small_mt", "c1_ep", "c3"])
 def test_layered_estimate_value_matches_oracle(name, prec):
     """_estimate_value (tdmpc2.py:122-136, incl. the termination head when episodic) on identical actions."""
     from tests.gpu_common import case_on_gpu, dev, plan_inputs

@@ -69,7 +69,7 @@ GEOMETRIES = [
     ("c2_ep", 1, 1, dict(cluster=1)),
     ("mt5", 1, 5, dict()),
     ("small_mt", 2, 3, dict()),
-    ("small_ep", 2, 2, dict()),
+    ("small_ep_fire", 2, 2, dict()),
     ("c1", 2, 2, dict()),
 ]
 

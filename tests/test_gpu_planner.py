@@ -13,12 +13,14 @@ from tests.helpers import ACT_ATOL, VALUE_RTOL, boundary_gap, elite_sets_equal, 
 pytestmark = pytest.mark.gpu
 
 FUSED_CASES = ["c1", "c1_wide", "c2", "c2_i6", "mt5"]
-MID_ATOL = 2.5e-4  # cap of the conditioning slack on the per-iteration mean / std (the final action is held to ACT_ATOL)
-# Chained comparison: the values of iteration it > 0 are taken on actions sampled from OUR refits of the earlier iterations,
-# the reference's on ITS refits; the two differ by the propagated fp32 differences of two correct implementations
-# (c2: |v| ~ 126, 8 iterations, temperature 0.5 -> the refit amplifies value round-off).  Iteration 0 -- identical actions --
-# and the identical-action stage test (test_estimate_value_matches_oracle) hold VALUE_RTOL; later iterations of the chained
-# run hold twice that.  The FINAL action (north_star: "within 1e-4") is gated at ACT_ATOL without slack.
+# Gates (north_star: "within 1e-4 fp32").  The DEFAULT arithmetic (f16x2 split) and everything the bench runs is held to 1e-4
+# on every quantity a plan returns or chains through: trajectory values of every iteration (relative to max(1, |v|)), the
+# per-iteration mean / std, the final action and the new _prev_mean -- no slack.
+# Only the exact-fp32 MFMA mode keeps a conditioning allowance on the INTERMEDIATE quantities of a chained plan (its
+# sequential-fmaf sums differ more from torch's blocked sums than the split mode's: c2 at I = 8, |v| ~ 126, temperature 0.5:
+# values 1.3e-4, mean 1.4e-4): values of iterations >= 1 within 2e-4, mean / std / _prev_mean within
+# min(1e-4 + 4 * temperature * eps_v, 2.5e-4).  Its returned action is gated at 1e-4 like everything else.
+MID_ATOL = 2.5e-4
 CHAIN_VALUE_RTOL = 2 * VALUE_RTOL
 # the fused family in both arithmetic modes: exact-fp32 MFMA (1) and the f16x2 split on the f16 matrix pipe (2)
 PRECS = pytest.mark.parametrize("prec", [1, 2], ids=["fp32", "split"])
@@ -98,11 +100,12 @@ def test_refit_matches_oracle(name):
 def _compare_stages(name, c, got, ref_stages, ref_action, ref_prev, tag=""):
     """Stage-wise comparison until (if ever) a legitimate elite-boundary swap.  Gates: every trajectory value within
     VALUE_RTOL (relative to max(1, |v|)); elite SETS identical unless the reference's own k-th / (k+1)-th values are closer
-    than 1e-4 (top-k is discontinuous); per-iteration mean / std within ACT_ATOL plus the first-order conditioning of the
-    softmax refit, capped at MID_ATOL; the final action and the new _prev_mean within ACT_ATOL, no slack (north_star:
-    "within 1e-4").  The worst numbers go to the parity report (tests/helpers.py)."""
+    than 1e-4 (top-k is discontinuous); per-iteration mean / std, the final action and the new _prev_mean within ACT_ATOL,
+    no slack (north_star: "within 1e-4"); the exact-fp32 mode alone (tag ".../fp32/...") keeps the capped conditioning
+    allowance on the intermediate quantities described at the top of this file.  The worst numbers go to the parity report (tests/helpers.py)."""
     cfg = c["cfg"]
     K = cfg.num_elites
+    exact_mode = "/fp32/" in tag  # the only mode with an allowance (see the gate table above)
     worst = dict(value=0.0, mean=0.0, std=0.0, action=0.0, prev_mean=0.0)
     swaps = 0
     for e in range(c["n_envs"]):
@@ -112,7 +115,7 @@ def _compare_stages(name, c, got, ref_stages, ref_action, ref_prev, tag=""):
                 break
             err = value_err(got["value"][e, it], ref_stages["value"][e, it])
             worst["value"] = max(worst["value"], err)
-            assert err < (VALUE_RTOL if it == 0 else CHAIN_VALUE_RTOL), (name, e, it, err)
+            assert err < (CHAIN_VALUE_RTOL if (exact_mode and it > 0) else VALUE_RTOL), (name, e, it, err)
             if not elite_sets_equal(got["elite_idx"][e, it], ref_stages["elite_idx"][e, it]):
                 assert boundary_gap(ref_stages["value"][e, it], K) < 1e-4, (name, e, it)
                 diverged = True
@@ -124,7 +127,7 @@ def _compare_stages(name, c, got, ref_stages, ref_action, ref_prev, tag=""):
             # first-order conditioning of the refit: score_k = exp(temperature * (v_k - v_max)), so an absolute
             # value error eps_v moves mean/std (actions are in [-1, 1]) by up to ~4 * temperature * eps_v.
             eps_v = np.abs(got["value"][e, it].astype(np.float64) - ref_stages["value"][e, it]).max()
-            tol = min(ACT_ATOL + 4.0 * cfg.temperature * eps_v, MID_ATOL)
+            tol = min(ACT_ATOL + 4.0 * cfg.temperature * eps_v, MID_ATOL) if exact_mode else ACT_ATOL
             assert dm < tol and ds < tol, (name, e, it, dm, ds, tol)
         if not diverged:
             da = np.abs(got["action"][e] - ref_action[e]).max()

@@ -89,7 +89,7 @@ def _task_rows(tb, H):
 
 
 # (case, kernel family): every family / task mode combination against the reference's own `_td_target` output
-TD_CASES = [("mt5", 1), ("mt5", 2), ("small", 2), ("small_ep", 2), ("small_mt", 2), ("c1", 2), ("c2", 2), ("c3", 2), ("c4", 2),
+TD_CASES = [("mt5", 1), ("mt5", 2), ("small", 2), ("small_ep", 2), ("small_ep_fire", 2), ("small_mt", 2), ("c1", 2), ("c2", 2), ("c3", 2), ("c4", 2),
             ("c1_ep", 1)]
 
 

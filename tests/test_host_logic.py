@@ -242,3 +242,48 @@ def test_every_tuning_key_of_the_header_has_a_binding():
         body = src[src.index(f"def {method}("):]
         body = body[:body.index("\n    def ", 10)]
         assert f"tdmpc2_plan_set_tuning(self._h, {key_id}," in body, method
+
+
+@pytest.mark.parametrize("cfg_name,over", [("tiny", {}), ("tiny", dict(task="mt30")), ("c1", {})])
+def test_checkpoint_conversion_agrees_with_the_references_own(cfg_name, over):
+    """`checkpoint.convert_state_dict` + the WorldModel load hook against the reference's `api_model_conversion`
+    (tdmpc2/common/layers.py:167-221), imported and run as it is (needs /root/reference: build container only).  An
+    old-API checkpoint as released (flat-numbered Q keys, no log_std_* / _action_masks) goes through both; every key the
+    reference produces must exist here with the same tensor, and no Q key may be left over."""
+    from oracle import ref_runner
+
+    if not ref_runner.available():
+        pytest.skip("the reference tree is not on this machine")
+    api_model_conversion = ref_runner._import_reference().layers.api_model_conversion
+    cfg = named_config(cfg_name, **over)
+    src = WorldModel(cfg)
+    syn = {k: torch.as_tensor(v) for k, v in synth.make_state_dict(cfg, 0).items()}
+    src.load_state_dict(dict(syn))
+    old = checkpoint.to_old_format(src.state_dict())
+    for k in ("log_std_min", "log_std_dif", "_action_masks"):
+        old.pop(k, None)
+    assert checkpoint.is_old_format(old)
+    # reference: target_state_dict = the freshly built model's state dict (tdmpc2.py:92-94)
+    fresh = WorldModel(cfg)
+    want = api_model_conversion(fresh.state_dict(), dict(old))
+    # here: strict load of the same old dict (the pre-hook converts), then read the model back
+    mine = WorldModel(cfg)
+    mine.load_state_dict(dict(old))
+    got = mine.state_dict()
+    assert set(want) == set(got), (sorted(set(want) - set(got)), sorted(set(got) - set(want)))
+    for k, v in want.items():
+        if torch.is_tensor(v):
+            assert torch.equal(v, got[k]), k
+        else:
+            assert str(v) == str(got[k]) or k.endswith("__device"), (k, v, got[k])
+    # ... and the function-level converter maps the Q keys exactly like the reference's renaming block
+    conv = checkpoint.convert_state_dict(dict(old))
+    for k, v in want.items():
+        if "Qs" in k and torch.is_tensor(v) and not checkpoint.is_meta_key(k):
+            assert torch.equal(conv[k], v), k
+    # a new-format dict passes through both unchanged (layers.py:171-173)
+    new = src.state_dict()
+    assert api_model_conversion(fresh.state_dict(), dict(new)).keys() == new.keys()
+    again = WorldModel(cfg)
+    again.load_state_dict(dict(new))
+    assert all(torch.equal(v, again.state_dict()[k]) for k, v in new.items() if torch.is_tensor(v))
