@@ -70,18 +70,103 @@ def disc_pow_rows(cfg, n_envs, device):
     return torch.tensor(vals, dtype=torch.float32, device=device).repeat(n_envs, 1).contiguous()
 
 
-def pmc_traffic(workgroups, kernel="ks_rollout"):
-    """HBM-side bytes per rollout-kernel launch from the committed rocprofv3 --pmc passes (FETCH_SIZE with the gfx950
-    x2 correction + WRITE_SIZE; tools/gpu_pmc.sh -> tools/pmc_summary.py --json).  bench.py cannot read PMC
-    counters from inside its own process, so the figure comes from the profile of the same launch geometry;
-    None if no profile of that geometry is committed."""
-    path = os.path.join(ROOT, "profiles", f"pmc_{kernel}.json")
+def _planner_for(name, E, I, device):
+    """(cfg, planner with synthetic weights bound, plan inputs) of workload `name` -- what the timed legs build."""
+    from tdmpc2_amd.native import NativePlanner
+
+    cfg = named_config(name)
+    sd_np = synth.make_state_dict(cfg, seed=0)
+    sd = {k: torch.as_tensor(v).to(device) for k, v in sd_np.items() if not k.startswith("_encoder.")}
+    planner = NativePlanner(cfg, I, device, max_envs=E)
+    planner.bind_state_dict(sd)
+    z0 = torch.as_tensor(synth.make_latents(cfg, E, seed=1000)).to(device)
+    emb = mask = None
+    if cfg.multitask:
+        tasks = torch.arange(E) % len(cfg.tasks)
+        w = torch.as_tensor(sd_np["_task_emb.weight"])[tasks]
+        n = w.norm(dim=1, keepdim=True)
+        emb = torch.where(n > 1.0, w / (n + 1e-7), w).to(device).contiguous()
+        mask = torch.as_tensor(sd_np["_action_masks"])[tasks].to(device).contiguous()
+    return cfg, planner, dict(z0=z0, disc=disc_pow_rows(cfg, E, device), emb=emb, mask=mask)
+
+
+def traffic_child(name, E, I, steps):
+    """Child mode (run under `rocprofv3 --pmc` by measured_traffic): the same workload, a few untimed steps, no output.
+    Fused family: whole plans (the parent reads the ks_rollout launches of the throughput grid).  Layered family: the
+    rollout STAGE alone (tdmpc2_plan_estimate_value = the GEMM / row-kernel sequence of one CEM iteration's
+    _estimate_value, which is what `roofline` times), so that every g_gemm* / l_* dispatch of the trace belongs to a stage."""
+    device = torch.device("cuda", 0)
+    cfg, planner, x = _planner_for(name, E, I, device)
+    prev = torch.zeros(E, cfg.horizon, cfg.action_dim, device=device)
+    warm = torch.zeros(E, dtype=torch.uint8, device=device)
+    if planner.path == 1:
+        for i in range(steps + 1):
+            planner.plan(x["z0"], x["disc"], prev, warm, task_emb=x["emb"], act_mask=x["mask"], seed=i)
+    else:
+        acts = torch.rand(E, cfg.horizon, cfg.num_samples, cfg.action_dim, device=device) * 2 - 1
+        eps = torch.randn(E, cfg.num_samples, cfg.action_dim, device=device)
+        qidx = torch.tensor([[0, 1]] * E, dtype=torch.int32, device=device)
+        for i in range(steps):
+            planner.estimate_value(x["z0"], x["disc"], acts, eps, qidx, task_emb=x["emb"], act_mask=x["mask"])
+    torch.cuda.synchronize(device)
+    planner.close()
+
+
+def measured_traffic(name, E, I, fused, workgroups, steps=2, timeout=420):
+    """HBM-side bytes per rollout launch / stage of THIS workload on THIS box: two `rocprofv3 --kernel-trace --pmc` children of
+    this script (FETCH_SIZE and WRITE_SIZE need separate passes: TCC has 4 slots, MI355X_MICROARCH.md), run after the timed
+    region.  FETCH_SIZE is in KiB and under-reports wide coalesced reads by 2x on gfx950 (same guide, HBM section): x 1024 x 2;
+    WRITE_SIZE KiB x 1024 (uncalibrated).  Returns (bytes per launch or None, detail dict)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return None, {"error": "rocprofv3 not on PATH"}
+    tmp = tempfile.mkdtemp(prefix="tdmpc2_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    per = {}
     try:
-        with open(path) as f:
-            d = json.load(f)
-        return float(d["by_workgroups"][str(workgroups)]["traffic_bytes"]), d.get("source")
-    except Exception:
-        return None, None
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "t", "--",
+                   sys.executable, os.path.abspath(__file__), "--traffic-child", name, "--envs", str(E), "--iterations", str(I),
+                   "--steps", str(steps)]
+            p = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if p.returncode != 0 or not files:
+                return None, {"error": f"rocprofv3 --pmc {counter} rc={p.returncode}: {(p.stderr or p.stdout)[-200:]}"}
+            total, launches = 0.0, set()
+            with open(files[0]) as f:
+                for r in csv.DictReader(f):
+                    if r["Counter_Name"] != counter:
+                        continue
+                    kn = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").strip()
+                    wgs = int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)
+                    if fused:
+                        if not (kn.startswith("ks_rollout<") and wgs == workgroups):
+                            continue
+                        launches.add(r["Dispatch_Id"])
+                    else:
+                        if not (kn.startswith("g_gemm") or kn.startswith("l_")):
+                            continue
+                    total += float(r["Counter_Value"])
+            n = len(launches) if fused else steps
+            if n == 0:
+                return None, {"error": f"no matching dispatches in the {counter} pass"}
+            per[counter] = total / n * 1024.0
+        fetch, write = 2.0 * per["FETCH_SIZE"], per["WRITE_SIZE"]
+        return fetch + write, {"fetch_bytes": round(fetch), "write_bytes": round(write), "launches_per_pass": n,
+                               "source": "this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE children of bench.py "
+                                         "on the same box after the timed region"}
+    except Exception as ex:
+        return None, {"error": repr(ex)[:200]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def action_mse_vs_reference(device, path, prec):
@@ -137,6 +222,66 @@ def torch_eager_gpu_baseline(cfg, iterations, sd_np, device, n_plans=5):
     return {"value": round(n_plans / el, 2), "unit": "plans/s", "ms_per_plan": round(1e3 * el / n_plans, 2),
             "what": f"oracle restatement of the reference planner as PyTorch-ROCm {torch.__version__} eager ops on this GPU, "
                     f"1 env, {n_plans} sequential plans"}
+
+
+def torch_compile_child(name, iterations, n_plans=20):
+    """Child mode: the reference's DEFAULT execution mode (config.yaml:74 `compile: true`; tdmpc2.py:41-55:
+    torch.compile(self._plan, mode="reduce-overhead")) applied to the oracle restatement of `_plan` on this GPU; prints one
+    JSON object.  Reported baseline only."""
+    from oracle import planner_oracle as po
+
+    device = torch.device("cuda", 0)
+    cfg = named_config(name)
+    sd_np = synth.make_state_dict(cfg, seed=0)
+    model = po.OracleModel(cfg, {k: torch.as_tensor(v) for k, v in sd_np.items()}, device=device)
+    z0 = torch.as_tensor(synth.make_latents(cfg, 1, seed=1)).to(device)
+    tape = {k: v.to(device) for k, v in po.env_tape(synth.make_noise_tape(cfg, 1, iterations, seed=2), 0).items()}
+    disc = get_discount(cfg, cfg.episode_length)
+
+    def plan_fn(z, prev):
+        a, pm, _ = po.plan(model, z0=z, tape=tape, prev_mean=prev, t0=False, eval_mode=False, task=None, discount=disc,
+                           iterations=iterations)
+        return a, pm
+
+    t_c = time.perf_counter()
+    fn = torch.compile(plan_fn, mode="reduce-overhead")
+    prev = torch.zeros(cfg.horizon, cfg.action_dim, device=device)
+    with torch.no_grad():
+        for _ in range(3):  # compile + CUDA-graph capture
+            torch.compiler.cudagraph_mark_step_begin()
+            a, pm = fn(z0, prev)
+            prev = pm.clone()
+        torch.cuda.synchronize(device)
+        compile_s = time.perf_counter() - t_c
+        t0 = time.perf_counter()
+        for _ in range(n_plans):
+            torch.compiler.cudagraph_mark_step_begin()
+            a, pm = fn(z0, prev)
+            prev = pm.clone()
+        torch.cuda.synchronize(device)
+        el = time.perf_counter() - t0
+    print(json.dumps({"value": round(n_plans / el, 2), "unit": "plans/s", "ms_per_plan": round(1e3 * el / n_plans, 3),
+                      "compile_s": round(compile_s, 1), "finite": bool(torch.isfinite(a).all()),
+                      "what": f"torch.compile(mode='reduce-overhead') of the oracle restatement of the reference planner "
+                              f"(torch {torch.__version__}, Inductor / Triton-ROCm, graph replay), 1 env, {n_plans} sequential plans"}))
+
+
+def torch_compile_baseline(name, iterations, timeout=240):
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--compile-child", name, "--iterations", str(iterations)],
+                           env=env, capture_output=True, text=True, timeout=timeout)
+        for line in reversed(p.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "status": "unavailable", "error": (p.stderr or p.stdout)[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "status": f"no result within {timeout} s (compilation of the 6-iteration plan did not finish)"}
+    except Exception as ex:
+        return {"value": None, "status": "unavailable", "error": repr(ex)[:200]}
 
 
 def cpu_baseline(cfg, iterations, sd_np, budget_s=12.0):
@@ -327,7 +472,15 @@ def main():
     ap.add_argument("--skip-extra-configs", action="store_true",
                     help="do not append the short c3 / c4 legs (extra.configs) to the default c2 line")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
+    ap.add_argument("--skip-traffic", action="store_true",
+                    help="do not launch the rocprofv3 --pmc children that measure roofline.traffic (use when bench.py itself runs under a profiler)")
+    ap.add_argument("--traffic-child", default=None, metavar="CONFIG", help=argparse.SUPPRESS)
+    ap.add_argument("--compile-child", default=None, metavar="CONFIG", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.traffic_child:
+        return traffic_child(args.traffic_child, args.envs, args.iterations, args.steps)
+    if args.compile_child:
+        return torch_compile_child(args.compile_child, args.iterations)
 
     t_boot = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -583,8 +736,17 @@ def main():
     split = planner.precision == 2
     kernel = ("ks_rollout" if family == "fused"
               else ("g_gemm_s" if split else "g_gemm") + " + row kernels of one _estimate_value")
-    # the committed PMC passes are of the default (split-arithmetic) rollout kernel at 64 rows per workgroup
-    traffic, traffic_src = pmc_traffic(E * cfg.num_samples // 64, kernel) if (family == "fused" and split) else (None, None)
+    traffic, traffic_info = None, {"skipped": True}
+    if world == 1 and not args.skip_traffic and args.path == "auto" and args.precision == "auto":
+        log("measuring roofline.traffic (rocprofv3 --pmc children)")
+        traffic, traffic_info = measured_traffic(args.config, E, I, family == "fused", E * cfg.num_samples // 64)
+        for nm, leg in extra.get("configs", {}).items():
+            if nm in ("c3", "c4") and "roofline" in leg:
+                tb, ti = measured_traffic(nm, leg["config"]["envs"], leg["config"]["iterations"], leg["config"]["kernel_family"] == "fused",
+                                          leg["config"]["envs"] * named_config(nm).num_samples // 64)
+                leg["roofline"]["traffic"] = None if tb is None else round(tb)
+                leg["roofline"]["traffic_detail"] = ti
+    traffic = None if traffic is None else round(traffic)
     peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
     line = {
         "metric": "plan() calls/sec (H=3, 512 samples, 6 iters)",
@@ -597,7 +759,9 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",  # inputs, outputs, accumulation and all non-GEMM math; the products' arithmetic is in config.arithmetic
+        # inputs, outputs, accumulation and all non-GEMM math are fp32; what the label must not hide is how the PRODUCTS of the
+        # nn.Linear contractions are formed (extra.exact_fp32_mode carries the strict-fp32 figure of the same run)
+        "dtype": "f32 (f16x2-split products: 22-bit operands, fp32 accumulate)" if split else "f32",
         "data": "synthetic",
         "config": {
             "workload": f"{args.config}: {cfg.task} world model (L{cfg.latent_dim} M{cfg.mlp_dim} A{cfg.action_dim} "
@@ -614,7 +778,7 @@ def main():
             "mfma_issue_executed": round(executed * (3 if split else 1), 2),
             "frac_mfma_issue_executed": round(executed * (3 if split else 1) / peak, 4),
             "traffic_unit": "bytes per launch (HBM/fabric side of L2: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)",
-            "traffic_source": traffic_src,
+            "traffic_detail": traffic_info,
             "kernel": kernel,
             "launches_timed": roll_n, "avg_launch_ms": round(1e3 * launch_s, 4),
             "note": "achieved = ALGORITHMIC (as-written) FLOPs of one CEM iteration (all num_q Q heads, SURVEY 8(d)) x envs / "
@@ -637,6 +801,9 @@ def main():
             line["extra"]["torch_rocm_eager_same_gpu"] = torch_eager_gpu_baseline(cfg, I, sd_np, device)
         except Exception as ex:
             line["extra"]["torch_rocm_eager_same_gpu"] = {"error": repr(ex)}
+        if args.config in ("c1", "c2"):
+            log("torch.compile(reduce-overhead) baseline (child process)")
+            line["extra"]["torch_compile_same_gpu"] = torch_compile_baseline(args.config, I)
         try:
             line["cpu_baseline"] = cpu_baseline(cfg, I, sd_np, args.cpu_budget)
         except Exception as ex:  # the baseline is a reported number, never a reason to lose the measurement

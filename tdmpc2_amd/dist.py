@@ -71,11 +71,17 @@ def gather_actions(local_actions: torch.Tensor, n_envs: int) -> torch.Tensor:
     world = dist.get_world_size()
     sizes = [shard_range(n_envs, world, r) for r in range(world)]
     mx = max(b - a for a, b in sizes)
-    pad = torch.zeros(mx, local_actions.shape[1], dtype=local_actions.dtype, device=local_actions.device)
-    pad[: local_actions.shape[0]] = local_actions
+    stage = torch.device("cpu") if _host_staged() else local_actions.device
+    pad = torch.zeros(mx, local_actions.shape[1], dtype=local_actions.dtype, device=stage)
+    pad[: local_actions.shape[0]] = local_actions.to(stage)
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
-    return torch.cat([o[: b - a] for o, (a, b) in zip(out, sizes)], dim=0)
+    return torch.cat([o[: b - a] for o, (a, b) in zip(out, sizes)], dim=0).to(local_actions.device)
+
+
+def _host_staged(group=None) -> bool:
+    """True when the group's collectives must see host tensors (gloo)."""
+    return dist.get_backend(group) == "gloo"
 
 
 def _agree_on_stream(backend, seed: int, device, group=None):
@@ -84,6 +90,8 @@ def _agree_on_stream(backend, seed: int, device, group=None):
     seed = int(seed) & (2**64 - 1)
     has_counter = hasattr(backend, "call_counter") and hasattr(backend, "set_call_counter")
     src = dist.get_global_rank(group, 0) if group is not None else 0
+    if _host_staged(group):
+        device = torch.device("cpu")
     # int64 cannot hold a u64 seed: ship it as two 32-bit halves
     mine = torch.tensor([seed >> 32, seed & 0xFFFFFFFF, backend.call_counter() if has_counter else 0], dtype=torch.int64, device=device)
     ref = mine.clone()
@@ -126,8 +134,11 @@ def sharded_plan(backend, z0, disc_pow, prev_mean, t0, eval_mode: bool = False, 
         backend.shard_values(it, r0, r1, z0, disc_pow, value, act_mask=act_mask, seed=seed)
         if world > 1:
             local = value[:, r0:r1].contiguous()
-            gathered = torch.empty(world, E, per, dtype=value.dtype, device=value.device)
-            dist.all_gather_into_tensor(gathered.view(-1), local.view(-1), group=group)
+            # RCCL gathers device tensors in place; gloo (CPU tests, and ranks that SHARE one GPU -- RCCL refuses two ranks
+            # on one device) takes the 4 KB slices through host memory
+            stage = torch.device("cpu") if _host_staged(group) else value.device
+            gathered = torch.empty(world, E, per, dtype=value.dtype, device=stage)
+            dist.all_gather_into_tensor(gathered.view(-1), local.to(stage).view(-1), group=group)
             value.copy_(gathered.permute(1, 0, 2).reshape(E, N))
         backend.shard_refit(it, value, prev_mean, action, act_mask=act_mask, eval_mode=eval_mode, seed=seed, stages=stages)
     return action

@@ -93,3 +93,103 @@ def test_row_ranges_compose(name, path, rccl_group):
     planner.shard_values(0, N // 2, N, inp["z0"], inp["disc_pow"], halves)
     torch.cuda.synchronize()
     assert torch.equal(full, halves)
+
+
+# ---------------------------------------------------------------- two PROCESSES sharing the one MI355X
+# RCCL refuses two ranks on one device, so the ranks talk over gloo (value slices and actions staged through host memory,
+# tdmpc2_amd/dist.py) -- everything else is the real thing: two processes, two library handles on the same GPU, the HIP
+# planner as the compute leg of dist.sharded_plan and of the env-sharded batch path.
+def _two_proc_worker(rank, world, port, out_dir, name, path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import cases
+        from oracle import planner_oracle as po
+        from tdmpc2_amd.dist import gather_actions, shard_range, sharded_plan
+        from tdmpc2_amd.native import NativePlanner
+
+        d = torch.device("cuda", 0)
+        c = cases.build_case(name)
+        cfg, E = c["cfg"], c["n_envs"]
+        model = po.OracleModel(cfg, {k: torch.as_tensor(v) for k, v in c["sd"].items()})
+        planner = NativePlanner(cfg, c["iterations"], d, max_envs=max(E, 2), path=path)
+        planner.bind_state_dict(model.sd)
+        inp = plan_inputs(c, model)
+        kw = dict(task_emb=inp["task_emb"], act_mask=inp["act_mask"])
+        # (1) ONE plan, its sample rows split over the two processes; no tape: in-kernel Philox.  Rank 1's handle has planned
+        # on its own before (its call counter ran ahead): sharded_plan must re-align the streams.
+        if rank == 1:
+            planner.plan(inp["z0"], inp["disc_pow"], inp["prev_mean"].clone(), inp["t0"], seed=5, **kw)
+        pm = inp["prev_mean"].clone()
+        stages = planner.debug_buffers(E)
+        a = sharded_plan(planner, inp["z0"], inp["disc_pow"], pm, inp["t0"], eval_mode=c["eval_mode"], tape=None, seed=77,
+                         stages=stages, **kw)
+        torch.cuda.synchronize()
+        torch.save({"action": a.cpu(), "prev_mean": pm.cpu(), "value": stages["value"].cpu(), "elite_idx": stages["elite_idx"].cpu()},
+                   os.path.join(out_dir, f"shard{rank}.pt"))
+        # (2) env-sharded batch: each process plans its share of the environments (recorded tape), actions gathered
+        a0, a1 = shard_range(E, world, rank)
+        if a1 > a0:
+            loc = planner.plan(inp["z0"][a0:a1].contiguous(), inp["disc_pow"][a0:a1].contiguous(), inp["prev_mean"][a0:a1].clone(),
+                               inp["t0"][a0:a1].contiguous(), eval_mode=c["eval_mode"],
+                               task_emb=None if inp["task_emb"] is None else inp["task_emb"][a0:a1].contiguous(),
+                               act_mask=None if inp["act_mask"] is None else inp["act_mask"][a0:a1].contiguous(),
+                               tape={k: v[a0:a1].contiguous() for k, v in inp["tape"].items()})
+        else:
+            loc = torch.empty(0, cfg.action_dim, device=d)
+        full = gather_actions(loc, E)
+        torch.save(full.cpu(), os.path.join(out_dir, f"envs{rank}.pt"))
+        planner.close()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,path", [("c1", 1), ("c4", 2)])
+def test_two_processes_on_one_gpu_shard_a_plan_bit_identically(name, path, tmp_path):
+    """2-rank `dist.sharded_plan` with the HIP planner in both ranks == the 1-rank sharded plan, bit for bit (values, elite
+    sets, action, _prev_mean), in-kernel Philox, on the 5M fused model and on the 317M layered model (the case the sharding is
+    for); the env-sharded batch gathers the actions one process computes alone.  Two handles of two processes coexist."""
+    import torch.multiprocessing as mp
+
+    from tdmpc2_amd.dist import sharded_plan
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    saved = {k: os.environ.get(k) for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE")}
+    try:
+        mp.spawn(_two_proc_worker, args=(2, port, str(tmp_path), name, path), nprocs=2, join=True)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    r0, r1 = torch.load(tmp_path / "shard0.pt"), torch.load(tmp_path / "shard1.pt")
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), k  # every rank holds the same plan
+    # one rank, same seed, fresh handle (call counter 0, like rank 0's)
+    from tdmpc2_amd.native import NativePlanner
+
+    c, model, _ = case_on_gpu(name, path, 2)
+    planner = NativePlanner(c["cfg"], c["iterations"], dev(), max_envs=max(c["n_envs"], 2), path=path)
+    planner.bind_state_dict(model.sd)
+    inp = plan_inputs(c, model)
+    pm = inp["prev_mean"].clone()
+    stages = planner.debug_buffers(c["n_envs"])
+    assert not (dist.is_initialized() and dist.get_world_size() > 1)
+    a = sharded_plan(planner, inp["z0"], inp["disc_pow"], pm, inp["t0"], eval_mode=c["eval_mode"], tape=None, seed=77, stages=stages,
+                     task_emb=inp["task_emb"], act_mask=inp["act_mask"])
+    torch.cuda.synchronize()
+    assert torch.equal(stages["value"].cpu(), r0["value"]) and torch.equal(stages["elite_idx"].cpu(), r0["elite_idx"])
+    assert torch.equal(a.cpu(), r0["action"]) and torch.equal(pm.cpu(), r0["prev_mean"])
+    want = planner.plan(inp["z0"], inp["disc_pow"], inp["prev_mean"].clone(), inp["t0"], eval_mode=c["eval_mode"], tape=inp["tape"],
+                        task_emb=inp["task_emb"], act_mask=inp["act_mask"])
+    e0, e1 = torch.load(tmp_path / "envs0.pt"), torch.load(tmp_path / "envs1.pt")
+    assert torch.equal(e0, e1)
+    # (a one-env share and the two-env call may take different kernels of the fused family -- cluster path or not: same
+    # plan to fp32 round-off, not bit for bit)
+    assert torch.allclose(e0, want.cpu(), atol=1e-4)
+    planner.close()
