@@ -309,8 +309,12 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
  * key TDMPC2_TUNE_CLUSTER (fused family, f16x2-split arithmetic): single-plan latency path -- every 512-wide
  * layer of a 32-row sample tile is split over a cluster of 8 workgroups on 8 CUs that exchange the layer's raw sums through
  * L2 (tdmpc2_amd/csrc/cluster_kernels.cuh); used when all of a call's clusters fit the chip at once (one or two plans of
- * 512 samples on 256 CUs).  0 = never, 1 / 2 (default) = whenever the call fits. */
-enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0, TDMPC2_TUNE_FOLD_REFIT = 1, TDMPC2_TUNE_CLUSTER = 2 };
+ * 512 samples on 256 CUs).  0 = never, 1 / 2 (default) = whenever the call fits.
+ * key TDMPC2_TUNE_FUSE_LN (layered family, f16x2-split arithmetic): 1 (default) = the LayerNorm + Mish / SimNorm + operand split
+ * of every NormedLinear (tdmpc2/common/layers.py:94-118) runs in the epilogue of its GEMM -- the column blocks of a row block
+ * exchange per-row (mean, M2) partials through L2, a bounded wait like the cluster path's (tdmpc2_plan_take_fault) --;
+ * 0 = fp32 pre-activations to HBM and a row kernel per layer. */
+enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0, TDMPC2_TUNE_FOLD_REFIT = 1, TDMPC2_TUNE_CLUSTER = 2, TDMPC2_TUNE_FUSE_LN = 3 };
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
 
 /* Fault report of the cluster path (TDMPC2_TUNE_CLUSTER).  Its hand-overs between workgroups wait a bounded time (about

@@ -10,9 +10,37 @@
 
 inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
+// LayerNorm + activation fused into the GEMM's epilogue (g_gemm_s<.., EPI>, split arithmetic): which NormedLinear's
+// LayerNorm parameters / output scale, and whether the activation is Mish (0) or SimNorm (1).
+struct LnFuse {
+    int act;
+    long gb_sel_stride;
+    int width;
+};
+
+// the arrival counters of the fused launches of one stage: zeroed once per stage (stream-ordered), a fresh slice per launch
+int lay_arrive_reset(tdmpc2_plan *h, hipStream_t st) {
+    Layered &L = h->lay;
+    if (!L.arrive) return 0;
+    if (L.arrive_off) HIP_TRY(hipMemsetAsync(L.arrive, 0, L.arrive_off * sizeof(unsigned int), st));
+    L.arrive_off = 0;
+    return 0;
+}
+
+#define GEMM_S_LAUNCH(NCTV, RTV, SDV)                                                                         \
+    do {                                                                                                      \
+        if (epi == 0) hipLaunchKernelGGL((g_gemm_s<NCTV, RTV, SDV, 0>), dim3(nblk), dim3(GTHREADS), 0, st, q); \
+        else if (epi == 1) hipLaunchKernelGGL((g_gemm_s<NCTV, RTV, SDV, 1>), dim3(nblk), dim3(GTHREADS), 0, st, q); \
+        else hipLaunchKernelGGL((g_gemm_s<NCTV, RTV, SDV, 2>), dim3(nblk), dim3(GTHREADS), 0, st, q);          \
+    } while (0)
+
 // One nn.Linear over `rows_p` (padded) rows.  `slot` = index of the net in beff (multitask first layers), -1 otherwise.
+// `ln` != null asks for the NormedLinear epilogue inside the GEMM; *fused tells the caller whether that happened (if not,
+// `out` holds fp32 pre-activations and the row kernel has to follow).
 int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t rows_p, int rows_per_env,
-             const HostLayer &ly, long w_sel_stride, long bias_sel_stride, int slot, const int *sel, float *out, int ldo) {
+             const HostLayer &ly, long w_sel_stride, long bias_sel_stride, int slot, const int *sel, float *out, int ldo,
+             const LnFuse *ln = nullptr, bool *fused = nullptr) {
+    if (fused) *fused = false;
     if (h->split) {
         GemmSParams q{};
         q.A = reinterpret_cast<const _Float16 *>(A); q.lda = lda; q.K = ly.KB * 16; q.wp = ly.wps;
@@ -39,16 +67,31 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         if (!wide && !getenv("TDMPC2_GEMM_RT4")) {
             while (rt > 1 && (long)(rows_p / (32 * rt)) * q.ncolblk < slots * 3 / 4) rt >>= 1;
         }
-        const int nblk = (int)(rows_p / (32 * rt)) * q.ncolblk;
+        const int nrowblk = (int)(rows_p / (32 * rt));
+        const int nblk = nrowblk * q.ncolblk;
         // few workgroups per CU: row operand staged four chunks deep, weight ring of 8 / 16 blocks (g_gemm_s<.., .., 4>)
         const bool deep = !wide && (long)nblk < 2 * slots && !getenv("TDMPC2_GEMM_SD1");
-        if (wide) hipLaunchKernelGGL((g_gemm_s<2, 4>), dim3(nblk), dim3(GTHREADS), 0, st, q);
-        else if (deep && rt == 4) hipLaunchKernelGGL((g_gemm_s<1, 4, 4>), dim3(nblk), dim3(GTHREADS), 0, st, q);
-        else if (deep && rt == 2) hipLaunchKernelGGL((g_gemm_s<1, 2, 4>), dim3(nblk), dim3(GTHREADS), 0, st, q);
-        else if (deep) hipLaunchKernelGGL((g_gemm_s<1, 1, 4>), dim3(nblk), dim3(GTHREADS), 0, st, q);
-        else if (rt == 4) hipLaunchKernelGGL((g_gemm_s<1, 4>), dim3(nblk), dim3(GTHREADS), 0, st, q);
-        else if (rt == 2) hipLaunchKernelGGL((g_gemm_s<1, 2>), dim3(nblk), dim3(GTHREADS), 0, st, q);
-        else hipLaunchKernelGGL((g_gemm_s<1, 1>), dim3(nblk), dim3(GTHREADS), 0, st, q);
+        int epi = 0;
+        Layered &L = h->lay;
+        if (ln && L.fuse_ln && L.arrive && L.stats && (size_t)nrowblk * q.ncolblk * 32 * rt * 2 <= L.stats_cap) {
+            if (L.arrive_off + (size_t)nrowblk > L.arrive_cap) {  // (more fused launches in one stage than sized for)
+                HIP_TRY(hipMemsetAsync(L.arrive, 0, L.arrive_cap * sizeof(unsigned int), st));
+                L.arrive_off = 0;
+            }
+            epi = 1 + ln->act;
+            q.ln_g = ly.g; q.ln_b = ly.b; q.gb_sel_stride = sel ? ln->gb_sel_stride : 0;
+            q.ascale = ly.ascale; q.asc_sel_stride = sel ? (long)(3 * sizeof(LayerScal) / sizeof(float)) : 0;
+            q.width = ln->width; q.stats = L.stats; q.arrive = L.arrive + L.arrive_off; q.err = h->cl_err_dev; q.fault = h->cl_fault;
+            L.arrive_off += (size_t)nrowblk;
+            if (fused) *fused = true;
+        }
+        if (wide) GEMM_S_LAUNCH(2, 4, 1);
+        else if (deep && rt == 4) GEMM_S_LAUNCH(1, 4, 4);
+        else if (deep && rt == 2) GEMM_S_LAUNCH(1, 2, 4);
+        else if (deep) GEMM_S_LAUNCH(1, 1, 4);
+        else if (rt == 4) GEMM_S_LAUNCH(1, 4, 1);
+        else if (rt == 2) GEMM_S_LAUNCH(1, 2, 1);
+        else GEMM_S_LAUNCH(1, 1, 1);
         LAUNCH_CHECK();
         return 0;
     }
@@ -106,11 +149,14 @@ int lay_hidden(tdmpc2_plan *h, hipStream_t st, const HostNet &net, int slot, siz
                const int *sel, bool is_q) {
     const Layered &L = h->lay;
     int rc;
+    bool fused = false;
+    const LnFuse f0{0, is_q ? q_gstride(h, 0) : 0, h->cfg.mlp_dim}, f1{0, is_q ? q_gstride(h, 1) : 0, h->cfg.mlp_dim};
     if ((rc = lay_gemm(h, st, L.X, L.Kin, rows_p, rpe, net.l[0], is_q ? q_wstride(h, 0) : 0, is_q ? q_bstride(h, 0) : 0, slot,
-                       sel, L.HA, L.Mp))) return rc;
-    if ((rc = lay_ln(h, st, 0, L.HA, L.Mp, h->cfg.mlp_dim, rows, rpe, net.l[0], is_q ? q_gstride(h, 0) : 0, sel))) return rc;
+                       sel, L.HA, L.Mp, &f0, &fused))) return rc;
+    if (!fused && (rc = lay_ln(h, st, 0, L.HA, L.Mp, h->cfg.mlp_dim, rows, rpe, net.l[0], is_q ? q_gstride(h, 0) : 0, sel))) return rc;
     if ((rc = lay_gemm(h, st, L.HA, L.Mp, rows_p, rpe, net.l[1], is_q ? q_wstride(h, 1) : 0, is_q ? q_bstride(h, 1) : 0, -1,
-                       sel, L.HB, L.Mp))) return rc;
+                       sel, L.HB, L.Mp, &f1, &fused))) return rc;
+    if (fused) return 0;
     return lay_ln(h, st, 0, L.HB, L.Mp, h->cfg.mlp_dim, rows, rpe, net.l[1], is_q ? q_gstride(h, 1) : 0, sel);
 }
 
@@ -119,7 +165,11 @@ int lay_dynamics(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int
     const Layered &L = h->lay;
     int rc;
     if ((rc = lay_hidden(h, st, h->dyn, BE_DYN, rows, rows_p, rpe, nullptr, false))) return rc;
-    if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, rpe, h->dyn.l[2], 0, 0, -1, nullptr, L.X, L.Kin))) return rc;
+    bool fused = false;
+    const LnFuse f2{1, 0, h->cfg.latent_dim};
+    // fused: the SimNorm latent goes straight into X's z columns in operand form (action / padding columns untouched)
+    if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, rpe, h->dyn.l[2], 0, 0, -1, nullptr, L.X, L.Kin, &f2, &fused))) return rc;
+    if (fused) return 0;
     return lay_ln(h, st, 1, L.X, L.Kin, h->cfg.latent_dim, rows, rpe, h->dyn.l[2], 0, nullptr);
 }
 
@@ -193,6 +243,7 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
     const bool ranged = N != NF;
     const size_t rows = (size_t)E * N, rows_p = round_up(rows, GBM);
     int rc;
+    if ((rc = lay_arrive_reset(h, st))) return rc;
     if (h->split) hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM);
     else hipLaunchKernelGGL(l_init_x, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM);
     LAUNCH_CHECK();
@@ -238,6 +289,7 @@ int lay_pitraj(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const flo
     const int P = c.num_pi_trajs, H = c.horizon, A = c.action_dim, rpe = L.Ppad;
     const size_t rows = (size_t)E * rpe, rows_p = round_up(rows, GBM);
     int rc;
+    if ((rc = lay_arrive_reset(h, st))) return rc;
     if (h->split)
         hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, rpe, z0, (float *)nullptr,
                            (float *)nullptr);
@@ -296,6 +348,7 @@ int lay_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float 
         fp.value = h->value; fp.actions = h->actions; fp.act_mask = act_mask; fp.mean = h->mean; fp.std = h->std;
         fp.gumbel_exp = tape ? tape->gumbel_exp : nullptr; fp.final_eps = tape ? tape->final_eps : nullptr;
         fp.seed = seed; fp.call = call; fp.prev_mean = prev_mean; fp.action = action;
+        fp.err = h->lay.fuse_ln ? h->cl_err_dev : nullptr;  // a fused-epilogue wait that gave up: NaN action, prev_mean kept
         if (dbg) {
             if (dbg->value) { fp.dbg_value = dbg->value + (size_t)it * N; fp.dbg_value_es = (long)I * N; }
             if (dbg->elite_idx) { fp.dbg_idx = dbg->elite_idx + (size_t)it * K; fp.dbg_idx_es = (long)I * K; }
@@ -319,6 +372,10 @@ int lay_value(tdmpc2_plan *h, hipStream_t st, int rows, const float *z, bool tar
     Layered &L = h->lay;
     const size_t rows_p = round_up((size_t)rows, GBM);
     const int rpe = (int)rows_p;  // one "plan" spanning the call: sel index 0, noise / action index = row
+    {
+        int rc0 = lay_arrive_reset(h, st);
+        if (rc0) return rc0;
+    }
     if (h->split) hipLaunchKernelGGL(l_init_rows_s, dim3((unsigned)rows_p), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, z, rows);
     else hipLaunchKernelGGL(l_init_rows, dim3((unsigned)rows_p), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, z, rows);
     LAUNCH_CHECK();

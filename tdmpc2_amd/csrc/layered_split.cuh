@@ -28,9 +28,21 @@ struct GemmSParams {
     long sel_stride;
     int rows_per_env;
     const int *row_env; // optional per-row env of the bias lookup (see GemmParams)
-    float *out;         // fp32 [Rp, ldo]
+    float *out;         // fp32 [Rp, ldo]  (EPI != 0: operand form, the same ldo * 4 bytes per row)
     int ldo;
+    // ---- EPI != 0: LayerNorm + activation + hi / lo split in the epilogue (no fp32 round trip, no row kernel)
+    const float *ln_g, *ln_b;  // LayerNorm weight / bias [width], + sel * gb_sel_stride
+    long gb_sel_stride;
+    const float *ascale;       // operand scale of a Mish layer's output (LayerScal::ascale), + sel * asc_sel_stride
+    long asc_sel_stride;
+    int width;                 // LayerNorm width = out_features (a multiple of 32)
+    float *stats;              // [row block][column block][rows of the tile][2]: (mean, M2) of a workgroup's columns
+    unsigned int *arrive;      // [row block] arrival counters of this launch (zero on entry)
+    unsigned int *err;         // the handle's host-mapped error word (bounded wait gave up)
+    int fault;                 // test hook (TDMPC2_CLUSTER_FAULT at create): column block 0 of row block 0 never arrives
 };
+
+constexpr int GLN_MAXSPIN = 1 << 20;  // x s_sleep(2) ~ 0.1 s: peers of a row block are dispatched back to back
 
 // NCT = 32-wide output column tiles per wave: 1 -> 128 x 128 workgroup tile (narrow outputs: heads, small models),
 // 2 -> 128 x 256 (a wave owns 64 columns x 128 rows = 8 accumulators: per k16-block 4 KB of weight fragments and 8 KB of
@@ -45,14 +57,28 @@ struct GemmSParams {
 // round trip per two chunks: c3 single plan 6.17 -> 5.25 ms, c4 24.6 -> 23.0 ms, bit-identical sums (profiles/README.md r03c).
 // (Measured and rejected there: split-K over 4 / 8 workgroups per tile with the consumer adding the slices -- slower: the
 // partial sums' traffic; one accumulator per product kind on the 32-row tile -- no change.)
-template <int NCT, int RT = 4, int SD = 1>
+// EPI = 0: out <- acc * oscale + bias (fp32 pre-activation, head logits).
+// EPI = 1 / 2: the NormedLinear epilogue (layers.py:94-118) -- LayerNorm over the WHOLE output row, then Mish (1) or SimNorm
+// (2), then the hi / lo operand split -- inside the GEMM.  A row's columns are spread over the `ncolblk` workgroups of its
+// row block, so these exchange per-row (mean, M2) of their own columns through L2 / HBM: agent-scope stores, one arrival
+// counter per row block, a bounded wait, agent-scope loads, Chan's parallel combination (as exact as a two-pass variance).
+// The MFMA runs with the weight fragment as the A operand here, so that a lane holds 16 NCT FEATURES of one row (thread-local
+// row sums, one lane ^ 32 exchange) and writes 4 consecutive features per store.  The workgroups of a row block must be
+// dispatched together: row-major tile order (never the strip order of gemm_tile_of_block), in-order dispatch per XCD; a wait
+// that gives up raises the handle's error word (the plan then returns NaN, tdmpc2_plan_take_fault).
+template <int NCT, int RT = 4, int SD = 1, int EPI = 0>
 __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     constexpr int TM = 32 * RT;  // rows of this workgroup's tile
     __shared__ __attribute__((aligned(16))) _Float16 As[2][2][TM * GS_LDH];  // [buffer][plane][row][k]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rb, cb;
-    gemm_tile_of_block(blockIdx.x, gridDim.x, p.ncolblk, rb, cb);
+    if (EPI == 0) {
+        gemm_tile_of_block(blockIdx.x, gridDim.x, p.ncolblk, rb, cb);
+    } else {  // column blocks of a row block on consecutive block ids
+        rb = blockIdx.x / p.ncolblk;
+        cb = blockIdx.x % p.ncolblk;
+    }
     const int row0 = rb * TM;
     const int sel = p.sel ? p.sel[(size_t)(row0 / p.rows_per_env) * p.sel_stride] : 0;
     const int KB = p.K / 16;
@@ -146,18 +172,22 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
                 fh[rt] = *reinterpret_cast<const f16x8 *>(ah + rt * 32 * GS_LDH + kb * 16);
                 fl[rt] = *reinterpret_cast<const f16x8 *>(al + rt * 32 * GS_LDH + kb * 16);
             }
+            // EPI != 0: weight fragment as the A operand -> C[feature][row] (same sums, transposed accumulator tile)
 #pragma unroll
             for (int n = 0; n < NCT; ++n)
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[n][rt] = SPLIT_MFMA(fh[rt], rh[d][n], acc[n][rt]);
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[n][rt] = EPI ? SPLIT_MFMA(rh[d][n], fh[rt], acc[n][rt]) : SPLIT_MFMA(fh[rt], rh[d][n], acc[n][rt]);
 #pragma unroll
             for (int n = 0; n < NCT; ++n)
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[n][rt] = SPLIT_MFMA(fh[rt], rl[d][n], acc[n][rt]);
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[n][rt] = EPI ? SPLIT_MFMA(rl[d][n], fh[rt], acc[n][rt]) : SPLIT_MFMA(fh[rt], rl[d][n], acc[n][rt]);
 #pragma unroll
             for (int n = 0; n < NCT; ++n)
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[n][rt] = SPLIT_MFMA(fl[rt], rh[d][n], acc[n][rt]);
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[n][rt] = EPI ? SPLIT_MFMA(rh[d][n], fl[rt], acc[n][rt]) : SPLIT_MFMA(fl[rt], rh[d][n], acc[n][rt]);
             const int kn = ch * 2 + kb + PFB;
             const int knc = kn < KB ? kn : KB - 1;
 #pragma unroll
@@ -187,9 +217,165 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
             if (c + cc < nchunks) chunk(c + cc, cc, false);  // uniform
     }
 
-    // epilogue: acc * oscale + bias -> fp32.  C fragment: lane holds column (l & 31), rows (reg&3) + 8 (reg>>2) + 4 (l>>5).
     const float osc = p.oscale[(size_t)sel * p.osc_sel_stride];
     const float *bsel = p.bias + (size_t)sel * p.bias_sel_stride;
+    if constexpr (EPI != 0) {
+        // transposed C fragment: lane holds row (l & 31) of row tile rt and features (reg & 3) + 8 (reg >> 2) + 4 (l >> 5) of
+        // column tile ct0 + n.  LDS (the staging buffers are idle now): per-wave partials, then the rows' (mean, rstd).
+        __syncthreads();  // every wave is done with the last chunk's fragments
+        float *red = reinterpret_cast<float *>(&As[0][0][0]);         // [4 waves][TM][2]
+        float *rs = red + 4 * TM * 2;                                  // [TM][2]
+        int nval = 0;                                                  // valid features of this wave (whole column tiles)
+#pragma unroll
+        for (int n = 0; n < NCT; ++n) nval += (ct0 + n < p.CT) ? 32 : 0;
+        // (1) v = acc * oscale + bias, in place
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int row = row0 + rt * 32 + i32;
+            const float *bp = bsel;
+            if (p.bias_env_stride != 0) bp += (size_t)(p.row_env ? p.row_env[row] : row / p.rows_per_env) * p.bias_env_stride;
+#pragma unroll
+            for (int n = 0; n < NCT; ++n) {
+                const int ct = ct0 + n < p.CT ? ct0 + n : p.CT - 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bp + ct * 32 + 8 * j + 4 * hh);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[n][rt][4 * j + r] = fmaf(acc[n][rt][4 * j + r], osc, b4[r]);
+                }
+            }
+        }
+        // (2) this wave's (mean, M2) of every row over its own features: thread-local sums + the lane ^ 32 half
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int n = 0; n < NCT; ++n)
+                if (ct0 + n < p.CT) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) s1 += acc[n][rt][e];
+                }
+            s1 += __shfl_xor(s1, 32);
+            const float mw = nval ? s1 / (float)nval : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int n = 0; n < NCT; ++n)
+                if (ct0 + n < p.CT) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const float d = acc[n][rt][e] - mw;
+                        q = fmaf(d, d, q);
+                    }
+                }
+            q += __shfl_xor(q, 32);
+            if (hh == 0) {
+                red[(wave * TM + rt * 32 + i32) * 2 + 0] = mw;
+                red[(wave * TM + rt * 32 + i32) * 2 + 1] = q;
+            }
+        }
+        __syncthreads();
+        // (3) workgroup partial per row (Chan's combination over the 4 waves) -> this (row block, column block)'s slot
+        float *slot = p.stats + ((size_t)rb * p.ncolblk + cb) * TM * 2;
+        if (tid < TM) {
+            float n_acc = 0.f, m_acc = 0.f, q_acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                int nw = p.CT - (cb * 4 + w) * NCT;
+                nw = nw < 0 ? 0 : (nw > NCT ? NCT : nw);
+                if (nw == 0) continue;
+                const float nb = 32.f * (float)nw, mb = red[(w * TM + tid) * 2], qb = red[(w * TM + tid) * 2 + 1];
+                const float nt = n_acc + nb, dl = mb - m_acc;
+                m_acc += dl * (nb / nt);
+                q_acc += qb + dl * dl * (n_acc * nb / nt);
+                n_acc = nt;
+            }
+            __hip_atomic_store(slot + 2 * tid, m_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + 2 * tid + 1, q_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (4) arrive (stores acknowledged first), wait for the row block's other column blocks -- bounded
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (!(p.fault && rb == 0 && cb == 0)) __hip_atomic_fetch_add(p.arrive + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spin = 0;
+            while (__hip_atomic_load(p.arrive + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.ncolblk) {
+                if (++spin > GLN_MAXSPIN) {
+                    if (p.err) __hip_atomic_store(p.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        // (5) the row's statistics over all column blocks
+        if (tid < TM) {
+            float n_acc = 0.f, m_acc = 0.f, q_acc = 0.f;
+            const float *all = p.stats + (size_t)rb * p.ncolblk * TM * 2;
+            for (int c = 0; c < p.ncolblk; ++c) {
+                int ncol = p.CT - c * 4 * NCT;
+                ncol = ncol > 4 * NCT ? 4 * NCT : ncol;
+                const float nb = 32.f * (float)ncol;
+                const float mb = __hip_atomic_load(all + ((size_t)c * TM + tid) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float qb = __hip_atomic_load(all + ((size_t)c * TM + tid) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float nt = n_acc + nb, dl = mb - m_acc;
+                m_acc += dl * (nb / nt);
+                q_acc += qb + dl * dl * (n_acc * nb / nt);
+                n_acc = nt;
+            }
+            rs[2 * tid] = m_acc;
+            rs[2 * tid + 1] = 1.0f / sqrtf(q_acc / n_acc + LN_EPS);
+        }
+        __syncthreads();
+        // (6) normalise, activate, split, store operand form: 4 consecutive features = 8 bytes per plane per store
+        const float *gsel = p.ln_g + (size_t)sel * p.gb_sel_stride, *besel = p.ln_b + (size_t)sel * p.gb_sel_stride;
+        const float oscl = EPI == 1 ? p.ascale[(size_t)sel * p.asc_sel_stride] : ACT_SCALE;
+#pragma unroll
+        for (int n = 0; n < NCT; ++n) {
+            if (ct0 + n >= p.CT) continue;
+            f32x4 g4[4], be4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                g4[j] = *reinterpret_cast<const f32x4 *>(gsel + (ct0 + n) * 32 + 8 * j + 4 * hh);
+                be4[j] = *reinterpret_cast<const f32x4 *>(besel + (ct0 + n) * 32 + 8 * j + 4 * hh);
+            }
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const int row = row0 + rt * 32 + i32;
+                const float mean = rs[2 * (rt * 32 + i32)], rstd = rs[2 * (rt * 32 + i32) + 1];
+                _Float16 *hp = reinterpret_cast<_Float16 *>(p.out + (size_t)row * p.ldo);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 y;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = fmaf((acc[n][rt][4 * j + r] - mean) * rstd, g4[j][r], be4[j][r]);
+                    if (EPI == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = mish_fast(y[r]);
+                    } else {  // SimNorm: groups of 8 consecutive features = this lane's 4 + lane ^ 32's 4
+                        float m = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
+                        m = fmaxf(m, __shfl_xor(m, 32));
+                        float es = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            y[r] = __expf(y[r] - m);
+                            es += y[r];
+                        }
+                        es += __shfl_xor(es, 32);
+                        const float inv = 1.0f / es;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] *= inv;
+                    }
+                    f16x4 hi, lo;
+                    split4(y, hi, lo, oscl);
+                    const int f = (ct0 + n) * 32 + 8 * j + 4 * hh;
+                    *reinterpret_cast<f16x4 *>(hp + f) = hi;
+                    *reinterpret_cast<f16x4 *>(hp + p.ldo + f) = lo;
+                }
+            }
+        }
+        return;
+    }
+    // epilogue: acc * oscale + bias -> fp32.  C fragment: lane holds column (l & 31), rows (reg&3) + 8 (reg>>2) + 4 (l>>5).
 #pragma unroll
     for (int n = 0; n < NCT; ++n) {
         if (ct0 + n >= p.CT) continue;

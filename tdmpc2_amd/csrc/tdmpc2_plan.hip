@@ -755,6 +755,13 @@ struct Layered {
     const HostNet *qarr = nullptr;   // the Q ensemble in use: online (planning) or target (td_target)
     const float *bias_tab = nullptr; // effective first-layer biases: per plan (h->beff) or per task (h->beff_tab)
     const int *row_env = nullptr;    // per-row env of the bias / mask lookups, or null: row / rows_per_env
+    // LayerNorm + activation inside the GEMM epilogue (split arithmetic, g_gemm_s<.., EPI>): the exchange of per-row
+    // (mean, M2) partials between the column blocks of a row block, and the arrival counters of a stage's fused launches
+    bool fuse_ln = false;
+    float *stats = nullptr;
+    size_t stats_cap = 0;            // floats
+    unsigned int *arrive = nullptr;
+    size_t arrive_cap = 0, arrive_off = 0;  // counters; the next free one (zeroed at the start of every stage)
 };
 
 struct tdmpc2_plan {
@@ -1034,6 +1041,7 @@ int validate_envs(tdmpc2_plan *h, int E) {
     if (h->cl_err_host && *(volatile unsigned int *)h->cl_err_host) {
         *(volatile unsigned int *)h->cl_err_host = 0;
         h->cluster_mode = 0;
+        h->lay.fuse_ln = false;
         h->faults++;
     }
     return check_ready(h);
@@ -1329,6 +1337,27 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             return rc;
         }
         L.bias_tab = h->beff;
+        if (h->split) {  // fused NormedLinear epilogue: exchange buffer, counters, error word
+            const size_t maxct = (size_t)(std::max(c.mlp_dim, c.latent_dim) + 31) / 32;
+            L.stats_cap = Rp * ((maxct + 3) / 4) * 2;
+            L.arrive_cap = 64 * (Rp / 32);
+            if ((rc = dev_alloc(h, (void **)&L.stats, L.stats_cap * 4)) || (rc = dev_alloc(h, (void **)&L.arrive, L.arrive_cap * 4))) {
+                tdmpc2_plan_destroy(h);
+                return rc;
+            }
+            if (hipMemset(L.arrive, 0, L.arrive_cap * 4) != hipSuccess ||
+                hipHostMalloc((void **)&h->cl_err_host, 64, hipHostMallocMapped) != hipSuccess) {
+                tdmpc2_plan_destroy(h);
+                return fail(TDMPC2_ERR_HIP, "allocating the fused-epilogue counters / error word failed");
+            }
+            *h->cl_err_host = 0;
+            if (hipHostGetDevicePointer((void **)&h->cl_err_dev, h->cl_err_host, 0) != hipSuccess) {
+                tdmpc2_plan_destroy(h);
+                return fail(TDMPC2_ERR_HIP, "hipHostGetDevicePointer failed");
+            }
+            L.fuse_ln = true;
+            if (const char *fl = getenv("TDMPC2_FUSE_LN")) L.fuse_ln = atoi(fl) != 0;
+        }
         // stale rows of padded tiles are computed but never read back; start them finite
         if (hipMemset(L.X, 0, Rp * L.Kin * 4) != hipSuccess || hipMemset(L.HA, 0, Rp * L.Mp * 4) != hipSuccess ||
             hipMemset(L.HB, 0, Rp * L.Mp * 4) != hipSuccess || hipMemset(h->beff, 0, (E + 4) * h->nnets * L.Mp * 4) != hipSuccess) {
@@ -2154,6 +2183,7 @@ int tdmpc2_plan_take_fault(tdmpc2_plan_t *h, int *faults) {
     if (h->cl_err_host && *(volatile unsigned int *)h->cl_err_host) {
         *(volatile unsigned int *)h->cl_err_host = 0;
         h->cluster_mode = 0;
+        h->lay.fuse_ln = false;
         h->faults++;
     }
     *faults = h->faults;
@@ -2171,6 +2201,11 @@ int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value) {
     if (key == TDMPC2_TUNE_CLUSTER) {
         if (value < 0 || value > 2) return fail(TDMPC2_ERR_INVALID, "cluster must be 0 (never), 1 (whenever the call fits) or 2 (auto)");
         h->cluster_mode = value;
+        return TDMPC2_OK;
+    }
+    if (key == TDMPC2_TUNE_FUSE_LN) {
+        if (value < 0 || value > 1) return fail(TDMPC2_ERR_INVALID, "fuse_ln must be 0 or 1");
+        h->lay.fuse_ln = value != 0 && h->lay.stats != nullptr;
         return TDMPC2_OK;
     }
     if (key == TDMPC2_TUNE_FOLD_REFIT) {

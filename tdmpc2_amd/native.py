@@ -610,6 +610,11 @@ class NativePlanner:
         0 never, 1 / 2 (default) whenever all of a call's clusters fit the chip at once."""
         self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 2, int(mode)))
 
+    def set_fuse_ln(self, on):
+        """Layered family, split arithmetic: LayerNorm + Mish / SimNorm + operand split inside the GEMM epilogue (1, default)
+        or as a row kernel over fp32 pre-activations (0)."""
+        self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 3, int(bool(on))))
+
     def set_profiling(self, max_launches: int):
         """Bracket up to `max_launches` rollout-kernel launches with HIP events (0 = off)."""
         self._check(self.lib.tdmpc2_plan_set_profiling(self._h, int(max_launches)))

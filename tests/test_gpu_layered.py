@@ -157,3 +157,68 @@ def test_layered_errors_are_loud():
         NativePlanner(named_config("c3"), 6, torch.device("cuda", 0), path=PATH_FUSED)
     with pytest.raises(NativeError):  # termination head with task ids: the reference asserts the same
         NativePlanner(named_config("c3", episodic=True), 6, torch.device("cuda", 0))
+
+
+@pytest.mark.parametrize("name", ["small", "small_ep_fire", "small_mt", "c1", "c3", "c4"])
+def test_normed_linear_epilogue_inside_the_gemm_agrees_with_the_row_kernel(name):
+    """Split arithmetic: by default every NormedLinear's LayerNorm + Mish / SimNorm + operand split runs in the epilogue of
+    its GEMM (column blocks of a row block exchange per-row (mean, M2) partials, g_gemm_s<.., EPI>); TDMPC2_TUNE_FUSE_LN = 0
+    restores fp32 pre-activations + one row kernel per layer.  Both must reproduce the reference golden, and they agree with
+    each other to fp32 round-off (the LayerNorm sums are combined in a different order)."""
+    from tests.gpu_common import case_on_gpu
+
+    c, model, planner = case_on_gpu(name, PATH_LAYERED, 2)
+    g = load_golden(name)
+    fused = _run_native(c, model, planner)
+    again = _run_native(c, model, planner)
+    planner.set_fuse_ln(0)
+    try:
+        plain = _run_native(c, model, planner)
+    finally:
+        planner.set_fuse_ln(1)
+    for k in fused:
+        assert np.array_equal(fused[k], again[k]), (name, k)  # the exchange is deterministic
+    _compare_stages(name, c, plain, g, g["action"], g["prev_mean_out"], tag="/layered/split/golden/ln_row_kernel")
+    _compare_stages(name, c, fused, g, g["action"], g["prev_mean_out"], tag="/layered/split/golden/ln_in_gemm")
+    err = value_err(fused["value"][:, 0], plain["value"][:, 0])
+    print(f"[{name}] LayerNorm in the GEMM epilogue vs row kernel, iteration-0 values: rel err {err:.2e}, "
+          f"bit-identical: {np.array_equal(fused['value'][:, 0], plain['value'][:, 0])}")
+    assert err < 2e-5
+    assert planner.take_fault() == 0
+
+
+def test_fused_epilogue_wait_that_never_completes_is_reported_not_hung(monkeypatch):
+    """The wait for the other column blocks of a row block is bounded: with one workgroup muted (TDMPC2_CLUSTER_FAULT=1, read
+    at create) the plan comes back -- as NaN, with prev_mean untouched --, take_fault() reports it, and the handle continues
+    on the row-kernel path, bit for bit like a handle that had the fused epilogue switched off."""
+    import time
+
+    import torch
+
+    from tdmpc2_amd.native import NativePlanner
+    from tests.gpu_common import case_on_gpu, dev, plan_inputs
+
+    c, model, ref = case_on_gpu("small", PATH_LAYERED, 2)
+    monkeypatch.setenv("TDMPC2_CLUSTER_FAULT", "1")
+    planner = NativePlanner(c["cfg"], c["iterations"], dev(), max_envs=c["n_envs"], path=PATH_LAYERED, precision=2)
+    monkeypatch.delenv("TDMPC2_CLUSTER_FAULT")
+    planner.bind_state_dict(model.sd)
+    inp = plan_inputs(c, model)
+    kw = dict(eval_mode=c["eval_mode"], task_emb=inp["task_emb"], act_mask=inp["act_mask"], tape=inp["tape"])
+    t = time.perf_counter()
+    pm = inp["prev_mean"].clone()
+    bad = planner.plan(inp["z0"], inp["disc_pow"], pm, inp["t0"], **kw)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t < 120
+    assert torch.isnan(bad).all() and torch.equal(pm, inp["prev_mean"])
+    assert planner.take_fault() == 1
+    pm_a, pm_b = inp["prev_mean"].clone(), inp["prev_mean"].clone()
+    a = planner.plan(inp["z0"], inp["disc_pow"], pm_a, inp["t0"], **kw).clone()
+    ref.set_fuse_ln(0)
+    try:
+        b = ref.plan(inp["z0"], inp["disc_pow"], pm_b, inp["t0"], **kw).clone()
+    finally:
+        ref.set_fuse_ln(1)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(pm_a, pm_b) and planner.take_fault() == 0
+    planner.close()
