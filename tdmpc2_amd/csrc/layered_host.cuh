@@ -18,6 +18,18 @@ struct LnFuse {
     int width;
 };
 
+// Hidden-activation / logit buffers a chain of GEMMs runs through, and the exchange buffer of its fused epilogues: the
+// handle holds two sets so that two independent chains (reward || dynamics of one step, the two Q heads) can be in flight on
+// two streams at once -- the second chain's workgroups fill the slots the first one's last, partly filled round leaves idle
+// (c3: 840 workgroups on 512 slots) and the launch gaps of one chain hide behind the other's kernels.
+struct LayBufs {
+    float *HA, *HB, *LG, *stats;
+};
+inline LayBufs lay_bufs(const tdmpc2_plan *h, int set) {
+    const Layered &L = h->lay;
+    return set == 0 ? LayBufs{L.HA, L.HB, L.LG, L.stats} : LayBufs{L.HA2, L.HB2, L.LG2, L.stats2};
+}
+
 // the arrival counters of the fused launches of one stage: zeroed once per stage (stream-ordered), a fresh slice per launch
 int lay_arrive_reset(tdmpc2_plan *h, hipStream_t st) {
     Layered &L = h->lay;
@@ -39,7 +51,7 @@ int lay_arrive_reset(tdmpc2_plan *h, hipStream_t st) {
 // `out` holds fp32 pre-activations and the row kernel has to follow).
 int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t rows_p, int rows_per_env,
              const HostLayer &ly, long w_sel_stride, long bias_sel_stride, int slot, const int *sel, float *out, int ldo,
-             const LnFuse *ln = nullptr, bool *fused = nullptr) {
+             const LnFuse *ln = nullptr, bool *fused = nullptr, float *stats = nullptr) {
     if (fused) *fused = false;
     if (h->split) {
         GemmSParams q{};
@@ -73,7 +85,10 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         const bool deep = !wide && (long)nblk < 2 * slots && !getenv("TDMPC2_GEMM_SD1");
         int epi = 0;
         Layered &L = h->lay;
-        if (ln && L.fuse_ln && L.arrive && L.stats && (size_t)nrowblk * q.ncolblk * 32 * rt * 2 <= L.stats_cap) {
+        if (!stats) stats = L.stats;
+        // (beyond 16 column blocks per row block -- single plans of the 317M model on 128-column tiles -- the exchange costs
+        // more than the row kernel it replaces: measured, profiles/README.md r03d)
+        if (ln && L.fuse_ln && L.arrive && stats && q.ncolblk <= 16 && (size_t)nrowblk * q.ncolblk * 32 * rt * 2 <= L.stats_cap) {
             if (L.arrive_off + (size_t)nrowblk > L.arrive_cap) {  // (more fused launches in one stage than sized for)
                 HIP_TRY(hipMemsetAsync(L.arrive, 0, L.arrive_cap * sizeof(unsigned int), st));
                 L.arrive_off = 0;
@@ -81,7 +96,7 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             epi = 1 + ln->act;
             q.ln_g = ly.g; q.ln_b = ly.b; q.gb_sel_stride = sel ? ln->gb_sel_stride : 0;
             q.ascale = ly.ascale; q.asc_sel_stride = sel ? (long)(3 * sizeof(LayerScal) / sizeof(float)) : 0;
-            q.width = ln->width; q.stats = L.stats; q.arrive = L.arrive + L.arrive_off; q.err = h->cl_err_dev; q.fault = h->cl_fault;
+            q.width = ln->width; q.stats = stats; q.arrive = L.arrive + L.arrive_off; q.err = h->cl_err_dev; q.fault = h->cl_fault;
             L.arrive_off += (size_t)nrowblk;
             if (fused) *fused = true;
         }
@@ -145,26 +160,31 @@ inline long q_bstride(const tdmpc2_plan *h, int l) { return h->cfg.num_q > 1 ? (
 inline long q_gstride(const tdmpc2_plan *h, int l) { return h->cfg.num_q > 1 ? (long)(h->lay.qarr[1].l[l].g - h->lay.qarr[0].l[l].g) : 0; }
 
 // X -> hidden 1 (HA) -> hidden 2 (HB): the two NormedLinear(Mish) layers of a reference `mlp` (layers.py:121-133).
+// `after_l0` (optional): recorded on `st` once the first layer -- the only reader of X in the chain -- has been launched.
 int lay_hidden(tdmpc2_plan *h, hipStream_t st, const HostNet &net, int slot, size_t rows, size_t rows_p, int rpe,
-               const int *sel, bool is_q) {
+               const int *sel, bool is_q, const LayBufs *bufs = nullptr, hipEvent_t after_l0 = nullptr) {
     const Layered &L = h->lay;
+    const LayBufs b = bufs ? *bufs : lay_bufs(h, 0);
     int rc;
     bool fused = false;
     const LnFuse f0{0, is_q ? q_gstride(h, 0) : 0, h->cfg.mlp_dim}, f1{0, is_q ? q_gstride(h, 1) : 0, h->cfg.mlp_dim};
     if ((rc = lay_gemm(h, st, L.X, L.Kin, rows_p, rpe, net.l[0], is_q ? q_wstride(h, 0) : 0, is_q ? q_bstride(h, 0) : 0, slot,
-                       sel, L.HA, L.Mp, &f0, &fused))) return rc;
-    if (!fused && (rc = lay_ln(h, st, 0, L.HA, L.Mp, h->cfg.mlp_dim, rows, rpe, net.l[0], is_q ? q_gstride(h, 0) : 0, sel))) return rc;
-    if ((rc = lay_gemm(h, st, L.HA, L.Mp, rows_p, rpe, net.l[1], is_q ? q_wstride(h, 1) : 0, is_q ? q_bstride(h, 1) : 0, -1,
-                       sel, L.HB, L.Mp, &f1, &fused))) return rc;
+                       sel, b.HA, L.Mp, &f0, &fused, b.stats))) return rc;
+    if (after_l0) HIP_TRY(hipEventRecord(after_l0, st));
+    if (!fused && (rc = lay_ln(h, st, 0, b.HA, L.Mp, h->cfg.mlp_dim, rows, rpe, net.l[0], is_q ? q_gstride(h, 0) : 0, sel))) return rc;
+    if ((rc = lay_gemm(h, st, b.HA, L.Mp, rows_p, rpe, net.l[1], is_q ? q_wstride(h, 1) : 0, is_q ? q_bstride(h, 1) : 0, -1,
+                       sel, b.HB, L.Mp, &f1, &fused, b.stats))) return rc;
     if (fused) return 0;
-    return lay_ln(h, st, 0, L.HB, L.Mp, h->cfg.mlp_dim, rows, rpe, net.l[1], is_q ? q_gstride(h, 1) : 0, sel);
+    return lay_ln(h, st, 0, b.HB, L.Mp, h->cfg.mlp_dim, rows, rpe, net.l[1], is_q ? q_gstride(h, 1) : 0, sel);
 }
 
 // z <- next(z, a): dynamics MLP with SimNorm output written back into X[:, 0:L)  (world_model.py:114-121)
-int lay_dynamics(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rpe) {
+// `x_free` (optional): an event of another stream after which X may be overwritten (a concurrent chain still reading z_t).
+int lay_dynamics(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rpe, hipEvent_t x_free = nullptr) {
     const Layered &L = h->lay;
     int rc;
     if ((rc = lay_hidden(h, st, h->dyn, BE_DYN, rows, rows_p, rpe, nullptr, false))) return rc;
+    if (x_free) HIP_TRY(hipStreamWaitEvent(st, x_free, 0));
     bool fused = false;
     const LnFuse f2{1, 0, h->cfg.latent_dim};
     // fused: the SimNorm latent goes straight into X's z columns in operand form (action / padding columns untouched)
@@ -197,10 +217,10 @@ int lay_policy(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int r
 }
 
 int lay_twohot(tdmpc2_plan *h, hipStream_t st, size_t rows, int rpe, int mode, int t, const float *disc_pow, float *value,
-               float *trace, int n_full = 0, int n_off = 0) {
+               float *trace, int n_full = 0, int n_off = 0, const float *lg = nullptr) {
     const Layered &L = h->lay;
     TwoHotParams p{};
-    p.lg = L.LG; p.ld = L.ldl; p.rows = (int)rows; p.rows_per_env = rpe; p.num_bins = h->cfg.num_bins; p.mode = mode;
+    p.lg = lg ? lg : L.LG; p.ld = L.ldl; p.rows = (int)rows; p.rows_per_env = rpe; p.num_bins = h->cfg.num_bins; p.mode = mode;
     p.t = t; p.H = h->cfg.horizon; p.bins = h->bins; p.disc_pow = disc_pow; p.G = L.G; p.qtmp = L.QT; p.value = value;
     p.term = h->cfg.episodic ? L.TERM : nullptr; p.trace = trace; p.trace_ld = h->cfg.horizon + 2 + h->cfg.action_dim;
     p.n_full = n_full; p.n_off = n_off;
@@ -247,6 +267,13 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
     if (h->split) hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM);
     else hipLaunchKernelGGL(l_init_x, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM);
     LAUNCH_CHECK();
+    // Two chains at a time (h->lay.side: a second stream + a second buffer set): the reward chain of step t runs beside the
+    // dynamics chain, the second Q head beside the first.  Hazards: reward.l0 is the side chain's only reader of X -- the
+    // dynamics' last layer (the writer of z_{t+1}) waits for it; the termination update waits for the reward's two-hot (which
+    // reads TERM); everything is joined before the value is formed, i.e. inside the stage.
+    const bool two = L.side != nullptr && !getenv("TDMPC2_ONE_STREAM");
+    hipStream_t sd = two ? L.side : st;
+    const LayBufs b2 = lay_bufs(h, two ? 1 : 0);
     for (int t = 0; t < H; ++t) {
         const int total = (int)rows * A;
         if (h->split)
@@ -256,15 +283,21 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
             hipLaunchKernelGGL(l_set_action, dim3((total + 255) / 256), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, A, NF, H, t,
                                (int)rows, actions, N, n_off);
         LAUNCH_CHECK();
+        if (two) {  // fork: the side stream sees [z_t | a_t]
+            HIP_TRY(hipEventRecord(L.ev_fork, st));
+            HIP_TRY(hipStreamWaitEvent(sd, L.ev_fork, 0));
+        }
         // reward(z, a_t) -> two_hot_inv -> G += disc * (1 - term) * r
-        if ((rc = lay_hidden(h, st, h->rew, BE_REW, rows, rows_p, N, nullptr, false))) return rc;
-        if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, N, h->rew.l[2], 0, 0, -1, nullptr, L.LG, L.ldl))) return rc;
-        if ((rc = lay_twohot(h, st, rows, N, 0, t, disc_pow, value, trace))) return rc;
+        if ((rc = lay_hidden(h, sd, h->rew, BE_REW, rows, rows_p, N, nullptr, false, &b2, two ? L.ev_xread : nullptr))) return rc;
+        if ((rc = lay_gemm(h, sd, b2.HB, L.Mp, rows_p, N, h->rew.l[2], 0, 0, -1, nullptr, b2.LG, L.ldl))) return rc;
+        if ((rc = lay_twohot(h, sd, rows, N, 0, t, disc_pow, value, trace, 0, 0, b2.LG))) return rc;
+        if (two) HIP_TRY(hipEventRecord(L.ev_side, sd));
         // z = next(z, a_t)
-        if ((rc = lay_dynamics(h, st, rows, rows_p, N))) return rc;
+        if ((rc = lay_dynamics(h, st, rows, rows_p, N, two ? L.ev_xread : nullptr))) return rc;
         if (c.episodic) {  // termination head on the new latent (tdmpc2.py:133-134)
             if ((rc = lay_hidden(h, st, h->term, -1, rows, rows_p, N, nullptr, false))) return rc;
             if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, N, h->term.l[2], 0, 0, -1, nullptr, L.LG, L.ldl))) return rc;
+            if (two) HIP_TRY(hipStreamWaitEvent(st, L.ev_side, 0));  // the reward's two-hot has read TERM
             hipLaunchKernelGGL(l_term, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, L.LG, L.ldl, (int)rows, L.TERM);
             LAUNCH_CHECK();
         }
@@ -272,13 +305,22 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
     // a_H = pi(z_H); value = G + disc^H (1 - term) avg of the two selected Q heads
     if ((rc = lay_policy(h, st, rows, rows_p, N, N, act_mask, pi_eps, pi_eps_estride, seed, call, SITE_PI, iter, nullptr, 0,
                          trace, n_off))) return rc;
-    for (int j = 0; j < 2; ++j) {
-        if ((rc = lay_hidden(h, st, h->q[0], BE_Q0, rows, rows_p, N, qidx + j, true))) return rc;
-        if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, N, h->q[0].l[2], q_wstride(h, 2), q_bstride(h, 2), -1, qidx + j, L.LG,
-                           L.ldl))) return rc;
-        if ((rc = lay_twohot(h, st, rows, N, 1 + j, 0, disc_pow, value, trace, ranged ? NF : 0, n_off))) return rc;
+    if (two) {
+        HIP_TRY(hipEventRecord(L.ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(sd, L.ev_fork, 0));
     }
-    return 0;
+    // head 0 on the main stream, head 1 beside it
+    if ((rc = lay_hidden(h, st, h->q[0], BE_Q0, rows, rows_p, N, qidx, true))) return rc;
+    if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, N, h->q[0].l[2], q_wstride(h, 2), q_bstride(h, 2), -1, qidx, L.LG, L.ldl))) return rc;
+    if ((rc = lay_twohot(h, st, rows, N, 1, 0, disc_pow, value, trace, ranged ? NF : 0, n_off))) return rc;
+    if ((rc = lay_hidden(h, sd, h->q[0], BE_Q0, rows, rows_p, N, qidx + 1, true, &b2))) return rc;
+    if ((rc = lay_gemm(h, sd, b2.HB, L.Mp, rows_p, N, h->q[0].l[2], q_wstride(h, 2), q_bstride(h, 2), -1, qidx + 1, b2.LG,
+                       L.ldl))) return rc;
+    if (two) {  // join: G (all reward two-hots) and the second head's logits are complete
+        HIP_TRY(hipEventRecord(L.ev_side, sd));
+        HIP_TRY(hipStreamWaitEvent(st, L.ev_side, 0));
+    }
+    return lay_twohot(h, st, rows, N, 2, 0, disc_pow, value, trace, ranged ? NF : 0, n_off, b2.LG);
 }
 
 // The P policy-prior trajectories (tdmpc2/tdmpc2.py:154-160): rows n < P of actions[E, H, N, A].

@@ -70,6 +70,12 @@ template <int NCT, int RT = 4, int SD = 1, int EPI = 0>
 __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     constexpr int TM = 32 * RT;  // rows of this workgroup's tile
     __shared__ __attribute__((aligned(16))) _Float16 As[2][2][TM * GS_LDH];  // [buffer][plane][row][k]
+    // EPI != 0: the epilogue's output stage (one 32-row tile in operand form) -- the idle staging buffers when they are large
+    // enough (128-row tiles), memory of its own otherwise
+    constexpr int EPI_STAGE_BYTES = EPI ? 2 * 32 * (128 * NCT + 4) * 2 : 0;
+    constexpr bool EPI_ALIAS = EPI_STAGE_BYTES <= (int)sizeof(As);
+    __shared__ __attribute__((aligned(16))) char epi_own[EPI_ALIAS ? 16 : EPI_STAGE_BYTES];
+    char *epi_lds = EPI_ALIAS ? reinterpret_cast<char *>(&As[0][0][0]) : epi_own;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rb, cb;
@@ -326,28 +332,36 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
             rs[2 * tid + 1] = 1.0f / sqrtf(q_acc / n_acc + LN_EPS);
         }
         __syncthreads();
-        // (6) normalise, activate, split, store operand form: 4 consecutive features = 8 bytes per plane per store
+        // (6) normalise, activate, split -> operand form.  A lane holds 4 consecutive features of 32 different rows: stored
+        // directly that is 16 bytes per row per instruction (8 192 partial-line writes per 128 x 256 tile -- measured: + 31 us
+        // on a 242 us GEMM).  So each 32-row tile goes through LDS ([plane][row][features], row stride + 4 halfs: the b64
+        // writes of a wave spread over all banks) and leaves as 16-byte pieces, 512 contiguous bytes per row and plane.
         const float *gsel = p.ln_g + (size_t)sel * p.gb_sel_stride, *besel = p.ln_b + (size_t)sel * p.gb_sel_stride;
         const float oscl = EPI == 1 ? p.ascale[(size_t)sel * p.asc_sel_stride] : ACT_SCALE;
+        constexpr int WF = 128 * NCT;          // features of the workgroup's column block
+        constexpr int SROW = WF + 4;           // halfs
+        constexpr int PIECES = WF / 8;         // 16-byte pieces per row and plane
+        float rmean[RT], rrstd[RT];
 #pragma unroll
-        for (int n = 0; n < NCT; ++n) {
-            if (ct0 + n >= p.CT) continue;
-            f32x4 g4[4], be4[4];
+        for (int rt = 0; rt < RT; ++rt) {
+            rmean[rt] = rs[2 * (rt * 32 + i32)];
+            rrstd[rt] = rs[2 * (rt * 32 + i32) + 1];
+        }
+        __syncthreads();  // rs is consumed: the stage may overwrite it
+        _Float16 *stg = reinterpret_cast<_Float16 *>(epi_lds);
+        const int nvalid_pieces = (p.CT * 32 - cb * WF < WF ? p.CT * 32 - cb * WF : WF) / 8;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                g4[j] = *reinterpret_cast<const f32x4 *>(gsel + (ct0 + n) * 32 + 8 * j + 4 * hh);
-                be4[j] = *reinterpret_cast<const f32x4 *>(besel + (ct0 + n) * 32 + 8 * j + 4 * hh);
-            }
+        for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const int row = row0 + rt * 32 + i32;
-                const float mean = rs[2 * (rt * 32 + i32)], rstd = rs[2 * (rt * 32 + i32) + 1];
-                _Float16 *hp = reinterpret_cast<_Float16 *>(p.out + (size_t)row * p.ldo);
+            for (int n = 0; n < NCT; ++n) {
+                if (ct0 + n >= p.CT) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gsel + (ct0 + n) * 32 + 8 * j + 4 * hh);
+                    const f32x4 be4 = *reinterpret_cast<const f32x4 *>(besel + (ct0 + n) * 32 + 8 * j + 4 * hh);
                     f32x4 y;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[r] = fmaf((acc[n][rt][4 * j + r] - mean) * rstd, g4[j][r], be4[j][r]);
+                    for (int r = 0; r < 4; ++r) y[r] = fmaf((acc[n][rt][4 * j + r] - rmean[rt]) * rrstd[rt], g4[r], be4[r]);
                     if (EPI == 1) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) y[r] = mish_fast(y[r]);
@@ -367,11 +381,22 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
                     }
                     f16x4 hi, lo;
                     split4(y, hi, lo, oscl);
-                    const int f = (ct0 + n) * 32 + 8 * j + 4 * hh;
-                    *reinterpret_cast<f16x4 *>(hp + f) = hi;
-                    *reinterpret_cast<f16x4 *>(hp + p.ldo + f) = lo;
+                    const int fl = (wave * NCT + n) * 32 + 8 * j + 4 * hh;  // feature inside the column block
+                    *reinterpret_cast<f16x4 *>(stg + (0 * 32 + i32) * SROW + fl) = hi;
+                    *reinterpret_cast<f16x4 *>(stg + (1 * 32 + i32) * SROW + fl) = lo;
                 }
             }
+            __syncthreads();
+            char *obase = reinterpret_cast<char *>(p.out) + (size_t)(row0 + rt * 32) * p.ldo * 4 + (size_t)cb * WF * 2;
+#pragma unroll
+            for (int c = tid; c < 2 * 32 * PIECES; c += GTHREADS) {
+                const int piece = c % PIECES, row = (c / PIECES) % 32, plane = c / (PIECES * 32);
+                if (piece < nvalid_pieces) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(stg + (plane * 32 + row) * SROW + piece * 8);
+                    *reinterpret_cast<f32x4 *>(obase + (size_t)row * p.ldo * 4 + (size_t)plane * p.ldo * 2 + piece * 16) = v;
+                }
+            }
+            if (rt + 1 < RT) __syncthreads();
         }
         return;
     }

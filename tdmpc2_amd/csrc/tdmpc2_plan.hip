@@ -757,6 +757,10 @@ struct Layered {
     const int *row_env = nullptr;    // per-row env of the bias / mask lookups, or null: row / rows_per_env
     // LayerNorm + activation inside the GEMM epilogue (split arithmetic, g_gemm_s<.., EPI>): the exchange of per-row
     // (mean, M2) partials between the column blocks of a row block, and the arrival counters of a stage's fused launches
+    // a second stream + buffer set for a second chain of GEMMs in flight (lay_estimate_value)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_side = nullptr, ev_xread = nullptr;
+    float *HA2 = nullptr, *HB2 = nullptr, *LG2 = nullptr, *stats2 = nullptr;
     bool fuse_ln = false;
     float *stats = nullptr;
     size_t stats_cap = 0;            // floats
@@ -1337,11 +1341,29 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             return rc;
         }
         L.bias_tab = h->beff;
+        // second chain (reward || dynamics, Q head || Q head): buffers, stream, events
+        if (!getenv("TDMPC2_ONE_STREAM")) {
+            if ((rc = dev_alloc(h, (void **)&L.HA2, Rp * L.Mp * 4)) || (rc = dev_alloc(h, (void **)&L.HB2, Rp * L.Mp * 4)) ||
+                (rc = dev_alloc(h, (void **)&L.LG2, Rp * L.ldl * 4))) {
+                tdmpc2_plan_destroy(h);
+                return rc;
+            }
+            if (hipMemset(L.HA2, 0, Rp * L.Mp * 4) != hipSuccess || hipMemset(L.HB2, 0, Rp * L.Mp * 4) != hipSuccess ||
+                hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&L.ev_side, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&L.ev_xread, hipEventDisableTiming) != hipSuccess) {
+                tdmpc2_plan_destroy(h);
+                return fail(TDMPC2_ERR_HIP, "creating the second stream of the layered path failed");
+            }
+        }
         if (h->split) {  // fused NormedLinear epilogue: exchange buffer, counters, error word
             const size_t maxct = (size_t)(std::max(c.mlp_dim, c.latent_dim) + 31) / 32;
             L.stats_cap = Rp * ((maxct + 3) / 4) * 2;
             L.arrive_cap = 64 * (Rp / 32);
-            if ((rc = dev_alloc(h, (void **)&L.stats, L.stats_cap * 4)) || (rc = dev_alloc(h, (void **)&L.arrive, L.arrive_cap * 4))) {
+            L.arrive_cap *= 2;  // two chains
+            if ((rc = dev_alloc(h, (void **)&L.stats, L.stats_cap * 4)) || (rc = dev_alloc(h, (void **)&L.stats2, L.stats_cap * 4)) ||
+                (rc = dev_alloc(h, (void **)&L.arrive, L.arrive_cap * 4))) {
                 tdmpc2_plan_destroy(h);
                 return rc;
             }
@@ -1442,6 +1464,12 @@ void tdmpc2_plan_destroy(tdmpc2_plan_t *h) {
             fprintf(stderr, "\n");
         }
     }
+    if (h->lay.side) {
+        (void)hipStreamSynchronize(h->lay.side);
+        (void)hipStreamDestroy(h->lay.side);
+    }
+    for (hipEvent_t e : {h->lay.ev_fork, h->lay.ev_side, h->lay.ev_xread})
+        if (e) (void)hipEventDestroy(e);
     for (void *p : h->allocs) (void)hipFree(p);
     if (h->cl_err_host) (void)hipHostFree(h->cl_err_host);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
