@@ -46,16 +46,28 @@ int lay_arrive_reset(tdmpc2_plan *h, hipStream_t st) {
         else hipLaunchKernelGGL((g_gemm_s<NCTV, RTV, SDV, 2>), dim3(nblk), dim3(GTHREADS), 0, st, q);          \
     } while (0)
 
+// A k-range of a layer with a per-environment bias of the caller's: the action columns of a first layer at t = 0, where the
+// z columns' product is one vector per plan (lay_cvec).
+struct GemmRange {
+    int kb0, kblocks;        // first k16-block, number of blocks (a multiple of 2)
+    const float *bias_env;   // [env, Mp]
+    long bias_env_stride;
+    int col_off;             // A's first column (halfs into the hi plane)
+};
+
 // One nn.Linear over `rows_p` (padded) rows.  `slot` = index of the net in beff (multitask first layers), -1 otherwise.
 // `ln` != null asks for the NormedLinear epilogue inside the GEMM; *fused tells the caller whether that happened (if not,
 // `out` holds fp32 pre-activations and the row kernel has to follow).
 int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t rows_p, int rows_per_env,
              const HostLayer &ly, long w_sel_stride, long bias_sel_stride, int slot, const int *sel, float *out, int ldo,
-             const LnFuse *ln = nullptr, bool *fused = nullptr, float *stats = nullptr) {
+             const LnFuse *ln = nullptr, bool *fused = nullptr, float *stats = nullptr, const GemmRange *range = nullptr) {
     if (fused) *fused = false;
     if (h->split) {
         GemmSParams q{};
         q.A = reinterpret_cast<const _Float16 *>(A); q.lda = lda; q.K = ly.KB * 16; q.wp = ly.wps;
+        if (range) {
+            q.A += range->col_off; q.K = range->kblocks * 16; q.kb0 = range->kb0; q.kbs = ly.KB;
+        }
         q.w_sel_stride = sel ? w_sel_stride : 0; q.oscale = ly.oscale;
         q.osc_sel_stride = sel ? (long)(3 * sizeof(LayerScal) / sizeof(float)) : 0;  // the net's [heads][3] scalar table
         q.row_env = h->lay.row_env;
@@ -70,6 +82,9 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             q.bias = ly.bias;
             q.bias_env_stride = 0;
             q.bias_sel_stride = sel ? bias_sel_stride : 0;
+        }
+        if (range && range->bias_env) {
+            q.bias = range->bias_env; q.bias_env_stride = range->bias_env_stride; q.bias_sel_stride = 0;
         }
         q.sel = sel; q.sel_stride = 2; q.rows_per_env = rows_per_env; q.out = out; q.ldo = ldo;
         // rows per workgroup tile: 128 when that fills the chip (two workgroups per CU), else 64 or 32 -- few rows mean
@@ -162,14 +177,15 @@ inline long q_gstride(const tdmpc2_plan *h, int l) { return h->cfg.num_q > 1 ? (
 // X -> hidden 1 (HA) -> hidden 2 (HB): the two NormedLinear(Mish) layers of a reference `mlp` (layers.py:121-133).
 // `after_l0` (optional): recorded on `st` once the first layer -- the only reader of X in the chain -- has been launched.
 int lay_hidden(tdmpc2_plan *h, hipStream_t st, const HostNet &net, int slot, size_t rows, size_t rows_p, int rpe,
-               const int *sel, bool is_q, const LayBufs *bufs = nullptr, hipEvent_t after_l0 = nullptr) {
+               const int *sel, bool is_q, const LayBufs *bufs = nullptr, hipEvent_t after_l0 = nullptr,
+               const GemmRange *l0_range = nullptr) {
     const Layered &L = h->lay;
     const LayBufs b = bufs ? *bufs : lay_bufs(h, 0);
     int rc;
     bool fused = false;
     const LnFuse f0{0, is_q ? q_gstride(h, 0) : 0, h->cfg.mlp_dim}, f1{0, is_q ? q_gstride(h, 1) : 0, h->cfg.mlp_dim};
     if ((rc = lay_gemm(h, st, L.X, L.Kin, rows_p, rpe, net.l[0], is_q ? q_wstride(h, 0) : 0, is_q ? q_bstride(h, 0) : 0, slot,
-                       sel, b.HA, L.Mp, &f0, &fused, b.stats))) return rc;
+                       sel, b.HA, L.Mp, &f0, &fused, b.stats, l0_range))) return rc;
     if (after_l0) HIP_TRY(hipEventRecord(after_l0, st));
     if (!fused && (rc = lay_ln(h, st, 0, b.HA, L.Mp, h->cfg.mlp_dim, rows, rpe, net.l[0], is_q ? q_gstride(h, 0) : 0, sel))) return rc;
     if ((rc = lay_gemm(h, st, b.HA, L.Mp, rows_p, rpe, net.l[1], is_q ? q_wstride(h, 1) : 0, is_q ? q_bstride(h, 1) : 0, -1,
@@ -180,10 +196,11 @@ int lay_hidden(tdmpc2_plan *h, hipStream_t st, const HostNet &net, int slot, siz
 
 // z <- next(z, a): dynamics MLP with SimNorm output written back into X[:, 0:L)  (world_model.py:114-121)
 // `x_free` (optional): an event of another stream after which X may be overwritten (a concurrent chain still reading z_t).
-int lay_dynamics(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rpe, hipEvent_t x_free = nullptr) {
+int lay_dynamics(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rpe, hipEvent_t x_free = nullptr,
+                 const GemmRange *l0_range = nullptr) {
     const Layered &L = h->lay;
     int rc;
-    if ((rc = lay_hidden(h, st, h->dyn, BE_DYN, rows, rows_p, rpe, nullptr, false))) return rc;
+    if ((rc = lay_hidden(h, st, h->dyn, BE_DYN, rows, rows_p, rpe, nullptr, false, nullptr, nullptr, l0_range))) return rc;
     if (x_free) HIP_TRY(hipStreamWaitEvent(st, x_free, 0));
     bool fused = false;
     const LnFuse f2{1, 0, h->cfg.latent_dim};
@@ -249,6 +266,30 @@ int lay_setup(tdmpc2_plan *h, hipStream_t st, int E, const float *task_emb, cons
     return 0;
 }
 
+// At t = 0 every sample row of a plan starts from the same latent (z.repeat(num_samples, 1), tdmpc2.py:163): the z columns'
+// product of the reward / dynamics first layers is ONE vector per plan, cvec[net][e] = W[:, :L] z0_e + b_eff(e), computed here
+// once per plan (E rows instead of E x N); the t = 0 GEMMs of every CEM iteration then contract the action columns only
+// (K = 32 instead of L + 32).  Split arithmetic; same products, the z / action partial sums are added in fp32.
+int lay_cvec(tdmpc2_plan *h, hipStream_t st, int E, const float *z0) {
+    Layered &L = h->lay;
+    L.cvec_ready = false;
+    if (!h->split || !L.Z0X || getenv("TDMPC2_Z0_SHARED_OFF")) return 0;
+    const tdmpc2_plan_cfg &c = h->cfg;
+    const size_t rows_p = round_up((size_t)E, GBM);
+    hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)E), dim3(256), 0, st, L.Z0X, L.Kin, c.latent_dim, 1, z0, (float *)nullptr, (float *)nullptr);
+    LAUNCH_CHECK();
+    const HostNet *nets[2] = {&h->rew, &h->dyn};
+    const int slots[2] = {BE_REW, BE_DYN};
+    int rc;
+    for (int i = 0; i < 2; ++i) {
+        GemmRange r{0, c.latent_dim / 16, nullptr, 0, 0};
+        if ((rc = lay_gemm(h, st, L.Z0X, L.Kin, rows_p, 1, nets[i]->l[0], 0, 0, slots[i], nullptr, L.cvec + (size_t)i * L.cvec_rows * L.Mp, L.Mp,
+                           nullptr, nullptr, nullptr, &r))) return rc;
+    }
+    L.cvec_ready = true;
+    return 0;
+}
+
 // TDMPC2._estimate_value (tdmpc2/tdmpc2.py:122-136) for E plans with the step actions in `actions` [E,H,N,A].
 int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float *act_mask, const float *disc_pow,
                        const float *actions, const float *pi_eps, long pi_eps_estride, const int *qidx /* dense [E,2] */,
@@ -287,13 +328,19 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
             HIP_TRY(hipEventRecord(L.ev_fork, st));
             HIP_TRY(hipStreamWaitEvent(sd, L.ev_fork, 0));
         }
+        // t = 0: the z columns' products come from lay_cvec; contract the action columns only
+        GemmRange r_rew{c.latent_dim / 16, (L.Kin - c.latent_dim) / 16, L.cvec, (long)L.Mp, c.latent_dim};
+        GemmRange r_dyn = r_rew;
+        r_dyn.bias_env = L.cvec + (size_t)L.cvec_rows * L.Mp;
+        const bool shortk = t == 0 && L.cvec_ready;
         // reward(z, a_t) -> two_hot_inv -> G += disc * (1 - term) * r
-        if ((rc = lay_hidden(h, sd, h->rew, BE_REW, rows, rows_p, N, nullptr, false, &b2, two ? L.ev_xread : nullptr))) return rc;
+        if ((rc = lay_hidden(h, sd, h->rew, BE_REW, rows, rows_p, N, nullptr, false, &b2, two ? L.ev_xread : nullptr,
+                             shortk ? &r_rew : nullptr))) return rc;
         if ((rc = lay_gemm(h, sd, b2.HB, L.Mp, rows_p, N, h->rew.l[2], 0, 0, -1, nullptr, b2.LG, L.ldl))) return rc;
         if ((rc = lay_twohot(h, sd, rows, N, 0, t, disc_pow, value, trace, 0, 0, b2.LG))) return rc;
         if (two) HIP_TRY(hipEventRecord(L.ev_side, sd));
         // z = next(z, a_t)
-        if ((rc = lay_dynamics(h, st, rows, rows_p, N, two ? L.ev_xread : nullptr))) return rc;
+        if ((rc = lay_dynamics(h, st, rows, rows_p, N, two ? L.ev_xread : nullptr, shortk ? &r_dyn : nullptr))) return rc;
         if (c.episodic) {  // termination head on the new latent (tdmpc2.py:133-134)
             if ((rc = lay_hidden(h, st, h->term, -1, rows, rows_p, N, nullptr, false))) return rc;
             if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, N, h->term.l[2], 0, 0, -1, nullptr, L.LG, L.ldl))) return rc;
@@ -359,6 +406,7 @@ int lay_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float 
     const unsigned call = h->call++;
     int rc;
     if ((rc = lay_setup(h, st, E, task_emb, prev_mean, t0, true))) return rc;
+    if ((rc = lay_cvec(h, st, E, z0))) return rc;
     if (P > 0 && (rc = lay_pitraj(h, st, E, z0, act_mask, tape ? tape->pi_traj_eps : nullptr, seed, call))) return rc;
     int refit_stage = 0;
     const size_t refit_lds = refit_lds_bytes(N, K, H, A, &refit_stage);

@@ -17,6 +17,7 @@ struct GemmSParams {
     const _Float16 *A;  // operand form [Rp, lda]: row r at (char*)A + r * lda * 4: [hi lda halfs | lo lda halfs]
     int lda;
     int K;              // contraction length, multiple of GBK
+    int kb0, kbs;       // a k-range of the packed matrix: first k16-block and blocks per column tile (0: K / 16 = the whole matrix)
     const _Float16 *wp; // split-packed [CT][K/16][2][64][8] (k_pack_split), + sel * w_sel_stride (in halfs)
     long w_sel_stride;
     const float *oscale; // device scalar(s): 2^-(kw + 5), + sel * osc_sel_stride
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
 #pragma unroll
     for (int n = 0; n < NCT; ++n) {
         const int ct = ct0 + n < p.CT ? ct0 + n : p.CT - 1;
-        u[n] = reinterpret_cast<const char *>(p.wp + (size_t)sel * p.w_sel_stride) + (size_t)ct * KB * 2048;
+        u[n] = reinterpret_cast<const char *>(p.wp + (size_t)sel * p.w_sel_stride) + ((size_t)ct * (p.kbs ? p.kbs : KB) + p.kb0) * 2048;
     }
     unsigned voff = (unsigned)lane * 16u;
     asm volatile("" : "+v"(voff));

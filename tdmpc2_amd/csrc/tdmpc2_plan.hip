@@ -761,6 +761,10 @@ struct Layered {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_side = nullptr, ev_xread = nullptr;
     float *HA2 = nullptr, *HB2 = nullptr, *LG2 = nullptr, *stats2 = nullptr;
+    // t = 0 of every rollout: the z0 products of the reward / dynamics first layers, one vector per plan (lay_cvec)
+    float *Z0X = nullptr, *cvec = nullptr;
+    size_t cvec_rows = 0;
+    bool cvec_ready = false;
     bool fuse_ln = false;
     float *stats = nullptr;
     size_t stats_cap = 0;            // floats
@@ -1336,11 +1340,22 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             (rc = dev_alloc(h, (void **)&L.HB, Rp * L.Mp * 4)) || (rc = dev_alloc(h, (void **)&L.LG, Rp * L.ldl * 4)) ||
             (rc = dev_alloc(h, (void **)&L.G, Rp * 4)) || (rc = dev_alloc(h, (void **)&L.QT, Rp * 4)) ||
             (rc = dev_alloc(h, (void **)&L.TERM, Rp * 4)) || (rc = dev_alloc(h, (void **)&L.qidx, E * 2 * 4)) ||
-            (rc = dev_alloc(h, (void **)&h->beff, (E + 4) * h->nnets * L.Mp * 4))) {
+            (rc = dev_alloc(h, (void **)&h->beff, (round_up(E, GBM) + 4) * h->nnets * L.Mp * 4))) {
             tdmpc2_plan_destroy(h);
             return rc;
         }
         L.bias_tab = h->beff;
+        if (h->split) {  // lay_cvec: z0 rows in operand form (one per plan, padded to a GEMM tile), cvec [2][rows][Mp]
+            L.cvec_rows = round_up(E, GBM);
+            if ((rc = dev_alloc(h, (void **)&L.Z0X, L.cvec_rows * L.Kin * 4)) || (rc = dev_alloc(h, (void **)&L.cvec, 2 * L.cvec_rows * L.Mp * 4))) {
+                tdmpc2_plan_destroy(h);
+                return rc;
+            }
+            if (hipMemset(L.Z0X, 0, L.cvec_rows * L.Kin * 4) != hipSuccess) {
+                tdmpc2_plan_destroy(h);
+                return fail(TDMPC2_ERR_HIP, "hipMemset(workspace) failed");
+            }
+        }
         // second chain (reward || dynamics, Q head || Q head): buffers, stream, events
         if (!getenv("TDMPC2_ONE_STREAM")) {
             if ((rc = dev_alloc(h, (void **)&L.HA2, Rp * L.Mp * 4)) || (rc = dev_alloc(h, (void **)&L.HB2, Rp * L.Mp * 4)) ||
@@ -1382,7 +1397,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
         }
         // stale rows of padded tiles are computed but never read back; start them finite
         if (hipMemset(L.X, 0, Rp * L.Kin * 4) != hipSuccess || hipMemset(L.HA, 0, Rp * L.Mp * 4) != hipSuccess ||
-            hipMemset(L.HB, 0, Rp * L.Mp * 4) != hipSuccess || hipMemset(h->beff, 0, (E + 4) * h->nnets * L.Mp * 4) != hipSuccess) {
+            hipMemset(L.HB, 0, Rp * L.Mp * 4) != hipSuccess || hipMemset(h->beff, 0, (round_up(E, GBM) + 4) * h->nnets * L.Mp * 4) != hipSuccess) {
             tdmpc2_plan_destroy(h);
             return fail(TDMPC2_ERR_HIP, "hipMemset(workspace) failed");
         }
@@ -1910,6 +1925,7 @@ int tdmpc2_plan_shard_begin(tdmpc2_plan_t *h, int n_envs, const float *z0, const
     const int E = n_envs, P = c.num_pi_trajs;
     if (h->lay.on) {
         if ((rc = lay_setup(h, st, E, task_emb, prev_mean, t0, true))) return rc;
+        if ((rc = lay_cvec(h, st, E, z0))) return rc;
         if (P > 0 && (rc = lay_pitraj(h, st, E, z0, act_mask, tape ? tape->pi_traj_eps : nullptr, seed, call))) return rc;
         return TDMPC2_OK;
     }
@@ -2327,6 +2343,7 @@ int tdmpc2_plan_estimate_value_trace(tdmpc2_plan_t *h, int n_envs, const float *
     if (h->lay.on) {
         if (trace_tiles) return fail(TDMPC2_ERR_UNSUPPORTED, "the layered path dumps trace_scalars only");
         if ((rc = lay_setup(h, st, E, task_emb, nullptr, nullptr, false))) return rc;
+        if ((rc = lay_cvec(h, st, E, z0))) return rc;
         hipLaunchKernelGGL(l_copy_qidx, dim3((E + 255) / 256), dim3(256), 0, st, E, qidx, 2L, h->lay.qidx);
         HIP_TRY(hipGetLastError());
         return lay_estimate_value(h, st, E, z0, act_mask, disc_pow, actions, pi_eps, (long)N * A, h->lay.qidx, 0, 0, 0, value,
