@@ -1281,8 +1281,13 @@ __device__ __forceinline__ void first_layers_s(const CT &c, const LayerS &la, co
 // the later rewards and the terminal value (tdmpc2.py:128-136).  Its first layer reads the same z_t columns as the step's
 // reward / dynamics first layers, so it runs at the top of step t (t >= 1; after the loop next to the policy prior's):
 // the raw dynamics sums wait in the workgroup's L2 scratch tile, the raw termination sums in the held registers.
-template <int APAD, int ST, int NW, int AR, int EP>
+// TR = 1: the instantiation behind tdmpc2_plan_estimate_value_trace (activation dumps after every phase); the planning
+// instantiations (TR = 0) carry no trace code -- 66 fewer spilled SGPRs, 7 fewer VGPRs, +0.6 % (A/B r03h).  Episodic kernels
+// keep the dumps inside the one instantiation (TRACE = TR || EP).
+#define DUMP_TILE(...) do { if constexpr (TRACE) dump_tile_s(__VA_ARGS__); } while (0)
+template <int APAD, int ST, int NW, int AR, int EP, int TR = 0>
 __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p) {
+    constexpr bool TRACE = TR || EP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int s_is_last;
     const int e = blockIdx.x / p.tiles, tile = p.tile_off + blockIdx.x % p.tiles;  // tile_off: a row range of the plan (shard_values)
@@ -1301,7 +1306,8 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
     float *zs = p.zscratch + (size_t)blockIdx.x * TROWS * WIDTH;
     const int NSLOT = 5 * p.H + 7;
     const bool live = (tid >> 3) < TROWS;  // ST = 1: threads 256..511 own no sample row in the row-per-8-lanes phases
-    float *tsc = p.trace_scalars && live ? p.trace_scalars + ((size_t)e * p.N + row0 + (tid >> 3)) * (p.H + 2 + p.A) : nullptr;
+    float *tsc = nullptr;
+    if constexpr (TRACE) tsc = p.trace_scalars && live ? p.trace_scalars + ((size_t)e * p.N + row0 + (tid >> 3)) * (p.H + 2 + p.A) : nullptr;
 
     for (int idx = tid; idx < p.H * p.A; idx += NTHR) {
         sm_mean[idx] = p.mean[(size_t)e * p.H * p.A + idx];
@@ -1387,10 +1393,10 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
         }
         epi_barrier(c);
         TIMER_MARK(c, T_EPI)
-        dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 0, p.rew.l[0].ascale);
+        DUMP_TILE(c, p.trace_tiles, NSLOT, 5 * t + 0, p.rew.l[0].ascale);
         // ---- reward: layer 2, two-hot head
         layer_full_s<0>(c, p.rew.l[1], p.rew.l[1].bias, 0, ZKB16, term_step ? gb_of(p.term.l[0]) : gb_of(p.dyn.l[0]));
-        dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 1, p.rew.l[1].ascale);
+        DUMP_TILE(c, p.trace_tiles, NSLOT, 5 * t + 1, p.rew.l[1].ascale);
         // for the held epilogue below; in flight behind the head
         if (term_step) gb_prefetch(c, p.term.l[1].g, p.term.l[1].b);
         else gb_prefetch(c, p.dyn.l[1].g, p.dyn.l[1].b);
@@ -1413,12 +1419,12 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
                  gb_of(p.dyn.l[1]), nullptr);
         epi_barrier(c);
         TIMER_MARK(c, T_EPI)
-        dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 2, p.dyn.l[0].ascale);
+        DUMP_TILE(c, p.trace_tiles, NSLOT, 5 * t + 2, p.dyn.l[0].ascale);
         layer_full_s<0>(c, p.dyn.l[1], p.dyn.l[1].bias, 0, ZKB16, gb_of(p.dyn.l[2]));
-        dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 3, p.dyn.l[1].ascale);
+        DUMP_TILE(c, p.trace_tiles, NSLOT, 5 * t + 3, p.dyn.l[1].ascale);
         layer_full_s<1>(c, p.dyn.l[2], p.dyn.l[2].bias, 0, ZKB16, t == p.H - 1 ? gb_of(p.pi.l[0]) : gb_of(p.rew.l[0]),
                         t == p.H - 1 ? zs : nullptr);
-        dump_tile_s(c, p.trace_tiles, NSLOT, 5 * t + 4);
+        DUMP_TILE(c, p.trace_tiles, NSLOT, 5 * t + 4);
     }
     // ---- a_H = pi(z_H) (tdmpc2.py:135); z_H was also saved to zs.  EP: termination(z_H) first layer from the same tile.
     f32x16 acch[ST][FT];  // held raw sums: termination first layer (EP), then the second Q head's
@@ -1427,9 +1433,9 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
         kloop_s(c, p.term.l[0], 0, ZKB16, acch);
     }
     layer_full_s<0>(c, p.pi.l[0], b_pi, 0, ZKB16, gb_of(p.pi.l[1]));
-    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 0, p.pi.l[0].ascale);
+    DUMP_TILE(c, p.trace_tiles, NSLOT, 5 * p.H + 0, p.pi.l[0].ascale);
     layer_full_s<0>(c, p.pi.l[1], p.pi.l[1].bias, 0, ZKB16, EP ? gb_of(p.term.l[0]) : gb_of(p.q[q0].l[0]));
-    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 1, p.pi.l[1].ascale);
+    DUMP_TILE(c, p.trace_tiles, NSLOT, 5 * p.H + 1, p.pi.l[1].ascale);
     if constexpr (EP) gb_prefetch(c, p.term.l[1].g, p.term.l[1].b);
     {
         auto eps = [&](int row, int a) -> float {
@@ -1450,7 +1456,7 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
     tile_from_global_s(c, zs);
     __syncthreads();
     TIMER_MARK(c, T_TILE)
-    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 2);
+    DUMP_TILE(c, p.trace_tiles, NSLOT, 5 * p.H + 2);
     // ---- Q(z_H, a_H): the two selected heads, first layers in one pass (world_model.py:186-216)
     {
         f32x16 acc[ST][FT];
@@ -1461,18 +1467,18 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
     }
     epi_barrier(c);
     TIMER_MARK(c, T_EPI)
-    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 3, p.q[q0].l[0].ascale);
+    DUMP_TILE(c, p.trace_tiles, NSLOT, 5 * p.H + 3, p.q[q0].l[0].ascale);
     layer_full_s<0>(c, p.q[q0].l[1], p.q[q0].l[1].bias, 0, ZKB16, gb_of(p.q[q1].l[0]));
-    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 4, p.q[q0].l[1].ascale);
+    DUMP_TILE(c, p.trace_tiles, NSLOT, 5 * p.H + 4, p.q[q0].l[1].ascale);
     gb_prefetch(c, p.q[q1].l[1].g, p.q[q1].l[1].b);  // for the held second-head epilogue below
     const float qa = head_twohot_s(c, p.q[q0].l[2], p.bins, p.num_bins);
     TIMER_MARK(c, T_HEAD)
     epi_t<0>(c, acch, *p.q[q1].l[0].oscale, *p.q[q1].l[0].ascale, b_q1, gb_of(p.q[q1].l[1]), nullptr);
     epi_barrier(c);
     TIMER_MARK(c, T_EPI)
-    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 5, p.q[q1].l[0].ascale);
+    DUMP_TILE(c, p.trace_tiles, NSLOT, 5 * p.H + 5, p.q[q1].l[0].ascale);
     layer_full_s<0>(c, p.q[q1].l[1], p.q[q1].l[1].bias, 0, ZKB16, GB{});
-    dump_tile_s(c, p.trace_tiles, NSLOT, 5 * p.H + 6, p.q[q1].l[1].ascale);
+    DUMP_TILE(c, p.trace_tiles, NSLOT, 5 * p.H + 6, p.q[q1].l[1].ascale);
     const float qb = head_twohot_s(c, p.q[q1].l[2], p.bins, p.num_bins);
     TIMER_MARK(c, T_HEAD)
     TIMER_FLUSH(c, p.timing)

@@ -968,10 +968,12 @@ template <> struct Kern<NetS> {
         (void)nw;
         const int ar = h->split ? 0 : 1;
         const bool ep = h->cfg.episodic != 0;
+        const bool tracing = p.trace_tiles || p.trace_scalars;  // (the host forces 64-row workgroups for a trace call)
         const size_t lds = nst == 2 ? h->lds_bytes : h->lds_bytes - (size_t)32 * h->row_bytes;
 #define CALL_ROLL(AP, AR)                                                                                                       \
     if (nst == 2) {                                                                                                             \
         if (ep) hipLaunchKernelGGL((ks_rollout<AP, 2, 8, AR, 1>), dim3(grid), dim3(NTHREADS), lds, st, p);                        \
+        else if (tracing) hipLaunchKernelGGL((ks_rollout<AP, 2, 8, AR, 0, 1>), dim3(grid), dim3(NTHREADS), lds, st, p);           \
         else hipLaunchKernelGGL((ks_rollout<AP, 2, 8, AR, 0>), dim3(grid), dim3(NTHREADS), lds, st, p);                           \
     } else {                                                                                                                    \
         if (ep) hipLaunchKernelGGL((ks_rollout<AP, 1, 8, AR, 1>), dim3(grid), dim3(NTHREADS), lds, st, p);                        \
@@ -1197,7 +1199,7 @@ int fused_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0,
     rp.pi_eps = pi_eps; rp.pi_eps_estride = (long)N * A;
     rp.qidx = qidx; rp.qidx_estride = 2;
     rp.trace_tiles = trace_tiles; rp.trace_scalars = trace_scalars;
-    const int nst = Kern<NET>::sample_tiles(h, E, trace_tiles != nullptr), nw = Kern<NET>::waves(h, E, nst);
+    const int nst = Kern<NET>::sample_tiles(h, E, trace_tiles != nullptr || trace_scalars != nullptr), nw = Kern<NET>::waves(h, E, nst);
     rp.tiles = h->tiles * (2 / nst);
     Kern<NET>::rollout(h, rp, E * rp.tiles, st, nst, nw);
     HIP_TRY(hipGetLastError());
@@ -1412,7 +1414,8 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
     rc = set_lds(ks_setup<AP, AR>, h->lds_bytes) || set_lds(ks_pitraj<AP, 2, AR>, h->lds_bytes) ||                   \
          set_lds(ks_pitraj<AP, 1, AR>, h->lds_bytes) || set_lds(ks_value<AP, AR>, h->lds_bytes) ||                    \
          (c.episodic ? (set_lds(ks_rollout<AP, 2, 8, AR, 1>, h->lds_bytes) || set_lds(ks_rollout<AP, 1, 8, AR, 1>, h->lds_bytes)) \
-                     : (set_lds(ks_rollout<AP, 2, 8, AR, 0>, h->lds_bytes) || set_lds(ks_rollout<AP, 1, 8, AR, 0>, h->lds_bytes)));
+                     : (set_lds(ks_rollout<AP, 2, 8, AR, 0>, h->lds_bytes) || set_lds(ks_rollout<AP, 1, 8, AR, 0>, h->lds_bytes) || \
+                        set_lds(ks_rollout<AP, 2, 8, AR, 0, 1>, h->lds_bytes)));
         FUSED_DISPATCH(h->Apad, ar, CALL_SETLDS)
 #undef CALL_SETLDS
         if (rc) {
