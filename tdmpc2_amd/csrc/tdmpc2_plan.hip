@@ -772,6 +772,43 @@ struct Layered {
     size_t arrive_cap = 0, arrive_off = 0;  // counters; the next free one (zeroed at the start of every stage)
 };
 
+// The layered path's second stream and its three events come from a process-wide pool and go back to it when a handle is
+// destroyed; they are never destroyed.  Measured on ROCm 7.0 / MI355X (profiles/README.md r03k): after hipStreamDestroy /
+// hipEventDestroy of a stream the NULL stream had waited on, kernels launched back to back on the NULL stream by the NEXT
+// handle overlapped (garbage plans; gone with GPU_MAX_HW_QUEUES=1, AMD_SERIALIZE_KERNEL=3, or without the destroys).
+struct SideRes {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+};
+struct SidePool {
+    std::mutex mu;
+    std::vector<SideRes> free_list[64];
+};
+static SidePool g_side_pool;
+static bool side_acquire(int dev, SideRes *out) {
+    const int d = dev >= 0 && dev < 64 ? dev : 0;
+    {
+        std::lock_guard<std::mutex> lk(g_side_pool.mu);
+        if (!g_side_pool.free_list[d].empty()) {
+            *out = g_side_pool.free_list[d].back();
+            g_side_pool.free_list[d].pop_back();
+            return true;
+        }
+    }
+    SideRes r;
+    if (hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess) return false;
+    for (int i = 0; i < 3; ++i)
+        if (hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) != hipSuccess) return false;  // (a failed create leaks what it made)
+    *out = r;
+    return true;
+}
+static void side_release(int dev, const SideRes &r) {
+    if (!r.stream) return;
+    (void)hipStreamSynchronize(r.stream);
+    std::lock_guard<std::mutex> lk(g_side_pool.mu);
+    g_side_pool.free_list[dev >= 0 && dev < 64 ? dev : 0].push_back(r);
+}
+
 struct tdmpc2_plan {
     tdmpc2_plan_cfg cfg;
     Layered lay;
@@ -854,6 +891,10 @@ int dev_alloc(tdmpc2_plan *h, void **p, size_t bytes) {
     HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
     h->allocs.push_back(*p);
     h->bytes += bytes;
+    // TDMPC2_POISON=1 (tests): every allocation starts as NaN bit patterns instead of whatever the allocator hands out
+    // (fresh pages read as zero and hide a read of memory that was never written; recycled memory does not)
+    static const bool poison = getenv("TDMPC2_POISON") != nullptr;
+    if (poison) HIP_TRY(hipMemset(*p, 0xFF, bytes ? bytes : 16));
     return 0;
 }
 
@@ -1365,14 +1406,13 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
                 tdmpc2_plan_destroy(h);
                 return rc;
             }
+            SideRes sr;
             if (hipMemset(L.HA2, 0, Rp * L.Mp * 4) != hipSuccess || hipMemset(L.HB2, 0, Rp * L.Mp * 4) != hipSuccess ||
-                hipStreamCreateWithFlags(&L.side, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&L.ev_side, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&L.ev_xread, hipEventDisableTiming) != hipSuccess) {
+                !side_acquire(c.device, &sr)) {
                 tdmpc2_plan_destroy(h);
                 return fail(TDMPC2_ERR_HIP, "creating the second stream of the layered path failed");
             }
+            L.side = sr.stream; L.ev_fork = sr.ev[0]; L.ev_side = sr.ev[1]; L.ev_xread = sr.ev[2];
         }
         if (h->split) {  // fused NormedLinear epilogue: exchange buffer, counters, error word
             const size_t maxct = (size_t)(std::max(c.mlp_dim, c.latent_dim) + 31) / 32;
@@ -1482,12 +1522,11 @@ void tdmpc2_plan_destroy(tdmpc2_plan_t *h) {
             fprintf(stderr, "\n");
         }
     }
-    if (h->lay.side) {
-        (void)hipStreamSynchronize(h->lay.side);
-        (void)hipStreamDestroy(h->lay.side);
+    if (h->lay.side) {  // back to the pool, never destroyed (see SidePool)
+        SideRes sr;
+        sr.stream = h->lay.side; sr.ev[0] = h->lay.ev_fork; sr.ev[1] = h->lay.ev_side; sr.ev[2] = h->lay.ev_xread;
+        side_release(h->cfg.device, sr);
     }
-    for (hipEvent_t e : {h->lay.ev_fork, h->lay.ev_side, h->lay.ev_xread})
-        if (e) (void)hipEventDestroy(e);
     for (void *p : h->allocs) (void)hipFree(p);
     if (h->cl_err_host) (void)hipHostFree(h->cl_err_host);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
