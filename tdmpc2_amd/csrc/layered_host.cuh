@@ -71,8 +71,12 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         q.w_sel_stride = sel ? w_sel_stride : 0; q.oscale = ly.oscale;
         q.osc_sel_stride = sel ? (long)(3 * sizeof(LayerScal) / sizeof(float)) : 0;  // the net's [heads][3] scalar table
         q.row_env = h->lay.row_env;
-        // wide outputs (>= 256 columns) take the 128 x 256 tile as long as that still leaves the chip two waves of workgroups
-        const bool wide = ly.CT >= 8 && (rows_p / GBM) * ((ly.CT + 7) / 8) >= (size_t)(getenv("TDMPC2_GEMM_NCT1") ? (1 << 30) : 512);
+        // wide outputs (>= 256 columns) take the 128 x 256 tile ...
+        // ... from 128 such workgroups on: with a second chain in flight (lay_estimate_value) a partly filled round is not idle,
+        // and the 128 x 256 tile does 1.7 x the MFMAs per operand byte (A/B r3n: threshold 512 -> 256: c3 +2.0 %, c4 +2.3 %;
+        // 128: single plans of the 317M model 20.8 -> 18.7 ms; below that single plans of the 48M model lose)
+        static const size_t wide_min = getenv("TDMPC2_GEMM_NCT1") ? (size_t)1 << 30 : getenv("TDMPC2_GEMM_WIDE_MIN") ? (size_t)atoi(getenv("TDMPC2_GEMM_WIDE_MIN")) : 128;
+        const bool wide = ly.CT >= 8 && (rows_p / GBM) * ((ly.CT + 7) / 8) >= wide_min;
         q.CT = ly.CT; q.ncolblk = wide ? (ly.CT + 7) / 8 : (ly.CT + 3) / 4;
         if (slot >= 0 && h->cfg.multitask) {
             q.bias = h->lay.bias_tab + (size_t)slot * h->lay.Mp;

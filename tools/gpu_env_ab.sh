@@ -4,11 +4,12 @@
 #   e.g. bash tools/gpu_env_ab.sh r3e "c3 30 8;c4 8 4" "TDMPC2_ONE_STREAM=1" "A=0"
 cd "$(dirname "$0")/.."
 TAG=$1; SPECS=$2; shift 2
+ENVSETS=("$@")
 mkdir -p gpurun_out
 out=gpurun_out/${TAG}_ab.txt; : > $out
 IFS=';' read -r -a SP <<< "$SPECS"
 for rep in 1 2; do
-  for envset in "$@"; do
+  for envset in "${ENVSETS[@]}"; do
     for spec in "${SP[@]}"; do
       set -- $spec
       echo "== [$envset] $1 E=$2" >> $out
