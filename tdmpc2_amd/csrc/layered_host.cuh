@@ -105,9 +105,9 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         int epi = 0;
         Layered &L = h->lay;
         if (!stats) stats = L.stats;
-        // (beyond 16 column blocks per row block -- single plans of the 317M model on 128-column tiles -- the exchange costs
-        // more than the row kernel it replaces: measured, profiles/README.md r03d)
-        if (ln && L.fuse_ln && L.arrive && stats && q.ncolblk <= 16 && (size_t)nrowblk * q.ncolblk * 32 * rt * 2 <= L.stats_cap) {
+        // (always, whatever the tile: the statistics' combination order is tile-independent, so a plan's bits do not depend
+        // on the size of the call it is part of)
+        if (ln && L.fuse_ln && L.arrive && stats && (size_t)nrowblk * 32 * rt * ((ly.CT + 3) / 4) * 2 <= L.stats_cap) {
             if (L.arrive_off + (size_t)nrowblk > L.arrive_cap) {  // (more fused launches in one stage than sized for)
                 HIP_TRY(hipMemsetAsync(L.arrive, 0, L.arrive_cap * sizeof(unsigned int), st));
                 L.arrive_off = 0;

@@ -230,11 +230,12 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
         // transposed C fragment: lane holds row (l & 31) of row tile rt and features (reg & 3) + 8 (reg >> 2) + 4 (l >> 5) of
         // column tile ct0 + n.  LDS (the staging buffers are idle now): per-wave partials, then the rows' (mean, rstd).
         __syncthreads();  // every wave is done with the last chunk's fragments
-        float *red = reinterpret_cast<float *>(&As[0][0][0]);         // [4 waves][TM][2]
-        float *rs = red + 4 * TM * 2;                                  // [TM][2]
-        int nval = 0;                                                  // valid features of this wave (whole column tiles)
-#pragma unroll
-        for (int n = 0; n < NCT; ++n) nval += (ct0 + n < p.CT) ? 32 : 0;
+        // The combination ORDER is a function of the layer alone, never of the tile shape, the row count or the number of
+        // plans in the call: per 32-column tile (mean, M2); tiles folded left to right inside groups of 128 columns; groups
+        // folded left to right over the row.  A plan therefore computes the same bits alone, inside a batch and when its
+        // rows are split over ranks, whichever g_gemm_s variant the call size selects.
+        float *red = reinterpret_cast<float *>(&As[0][0][0]);         // [4 NCT tiles of the column block][TM][2]
+        float *rs = red + 4 * NCT * TM * 2;                            // [TM][2]
         // (1) v = acc * oscale + bias, in place
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -252,52 +253,47 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
                 }
             }
         }
-        // (2) this wave's (mean, M2) of every row over its own features: thread-local sums + the lane ^ 32 half
+        // (2) (mean, M2) of every row over each 32-column tile: 16 thread-local values + the lane ^ 32 half
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            float s1 = 0.f;
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int n = 0; n < NCT; ++n)
-                if (ct0 + n < p.CT) {
+            for (int n = 0; n < NCT; ++n) {
+                float s1 = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) s1 += acc[n][rt][e];
+                for (int e = 0; e < 16; ++e) s1 += acc[n][rt][e];
+                s1 += __shfl_xor(s1, 32);
+                const float mw = s1 * (1.f / 32.f);
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float d = acc[n][rt][e] - mw;
+                    q = fmaf(d, d, q);
                 }
-            s1 += __shfl_xor(s1, 32);
-            const float mw = nval ? s1 / (float)nval : 0.f;
-            float q = 0.f;
-#pragma unroll
-            for (int n = 0; n < NCT; ++n)
-                if (ct0 + n < p.CT) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const float d = acc[n][rt][e] - mw;
-                        q = fmaf(d, d, q);
-                    }
+                q += __shfl_xor(q, 32);
+                if (hh == 0) {
+                    red[((wave * NCT + n) * TM + rt * 32 + i32) * 2 + 0] = mw;
+                    red[((wave * NCT + n) * TM + rt * 32 + i32) * 2 + 1] = q;
                 }
-            q += __shfl_xor(q, 32);
-            if (hh == 0) {
-                red[(wave * TM + rt * 32 + i32) * 2 + 0] = mw;
-                red[(wave * TM + rt * 32 + i32) * 2 + 1] = q;
             }
-        }
         __syncthreads();
-        // (3) workgroup partial per row (Chan's combination over the 4 waves) -> this (row block, column block)'s slot
-        float *slot = p.stats + ((size_t)rb * p.ncolblk + cb) * TM * 2;
-        if (tid < TM) {
+        // (3) fold the tiles of each 128-column group left to right -> stats[row block][group][row]
+        const int NG = (p.CT + 3) / 4;  // groups of the whole row
+        for (int idx = tid; idx < NCT * TM; idx += GTHREADS) {
+            const int g = idx / TM, r = idx - g * TM, G = cb * NCT + g;  // group g of this column block = group G of the row
+            if (G >= NG) continue;
             float n_acc = 0.f, m_acc = 0.f, q_acc = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                int nw = p.CT - (cb * 4 + w) * NCT;
-                nw = nw < 0 ? 0 : (nw > NCT ? NCT : nw);
-                if (nw == 0) continue;
-                const float nb = 32.f * (float)nw, mb = red[(w * TM + tid) * 2], qb = red[(w * TM + tid) * 2 + 1];
-                const float nt = n_acc + nb, dl = mb - m_acc;
-                m_acc += dl * (nb / nt);
-                q_acc += qb + dl * dl * (n_acc * nb / nt);
+            for (int t = 0; t < 4; ++t) {
+                if (G * 4 + t >= p.CT) break;
+                const float mb = red[((g * 4 + t) * TM + r) * 2], qb = red[((g * 4 + t) * TM + r) * 2 + 1];
+                const float nt = n_acc + 32.f, dl = mb - m_acc;
+                m_acc += dl * (32.f / nt);
+                q_acc += qb + dl * dl * (n_acc * 32.f / nt);
                 n_acc = nt;
             }
-            __hip_atomic_store(slot + 2 * tid, m_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(slot + 2 * tid + 1, q_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float *slot = p.stats + (((size_t)rb * NG + G) * TM + r) * 2;
+            __hip_atomic_store(slot, m_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + 1, q_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // (4) arrive (stores acknowledged first), wait for the row block's other column blocks -- bounded
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -314,20 +310,29 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
             }
         }
         __syncthreads();
-        // (5) the row's statistics over all column blocks
+        // (5) the row's statistics: the groups folded left to right (loads eight at a time, the fold in order)
         if (tid < TM) {
             float n_acc = 0.f, m_acc = 0.f, q_acc = 0.f;
-            const float *all = p.stats + (size_t)rb * p.ncolblk * TM * 2;
-            for (int c = 0; c < p.ncolblk; ++c) {
-                int ncol = p.CT - c * 4 * NCT;
-                ncol = ncol > 4 * NCT ? 4 * NCT : ncol;
-                const float nb = 32.f * (float)ncol;
-                const float mb = __hip_atomic_load(all + ((size_t)c * TM + tid) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float qb = __hip_atomic_load(all + ((size_t)c * TM + tid) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float nt = n_acc + nb, dl = mb - m_acc;
-                m_acc += dl * (nb / nt);
-                q_acc += qb + dl * dl * (n_acc * nb / nt);
-                n_acc = nt;
+            const float *all = p.stats + ((size_t)rb * NG * TM + tid) * 2;
+            for (int g0 = 0; g0 < NG; g0 += 8) {
+                float mb[8], qb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int G = g0 + u < NG ? g0 + u : NG - 1;
+                    mb[u] = __hip_atomic_load(all + (size_t)G * TM * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    qb[u] = __hip_atomic_load(all + (size_t)G * TM * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (g0 + u >= NG) break;
+                    int nt4 = p.CT - (g0 + u) * 4;
+                    nt4 = nt4 > 4 ? 4 : nt4;
+                    const float nb = 32.f * (float)nt4;
+                    const float nt = n_acc + nb, dl = mb[u] - m_acc;
+                    m_acc += dl * (nb / nt);
+                    q_acc += qb[u] + dl * dl * (n_acc * nb / nt);
+                    n_acc = nt;
+                }
             }
             rs[2 * tid] = m_acc;
             rs[2 * tid + 1] = 1.0f / sqrtf(q_acc / n_acc + LN_EPS);
