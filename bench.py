@@ -457,8 +457,10 @@ def config_leg(name, E, steps, device, rank=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # 80 steps of 256 plans = a timed region of about two seconds (20 steps were half a second: too short for an outside
+    # observer's GPU-activity sampler to see)
+    ap.add_argument("--steps", type=int, default=80)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--envs", type=int, default=256, help="independent environments planned per GPU per step")
     ap.add_argument("--config", default="c2", help="c1 cheetah-run 5M | c2 dog-run 5M (BASELINE configs[1])")
     ap.add_argument("--iterations", type=int, default=6, help="CEM iterations (the metric is quoted at 6)")

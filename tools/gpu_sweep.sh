@@ -10,7 +10,7 @@ OUT="$R/gpurun_out/sweep_${TAG}.jsonl"
 mkdir -p "$R/gpurun_out"; : > "$OUT"
 run() {
   echo "== bench.py $*" >&2
-  timeout 600 python "$R/bench.py" --skip-cpu-baseline "$@" 2>/dev/null | tail -1 >> "$OUT" || echo "{\"error\": \"$*\"}" >> "$OUT"
+  timeout 600 python "$R/bench.py" --skip-cpu-baseline --skip-traffic --skip-extra-configs "$@" 2>/dev/null | tail -1 >> "$OUT" || echo "{\"error\": \"$*\"}" >> "$OUT"
 }
 run --config c1 --envs 1 --steps 20 --warmup 3
 run --config c1 --envs 16 --steps 20 --warmup 3
