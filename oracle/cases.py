@@ -19,6 +19,8 @@ CASES = {
     "tiny_eval": ("tiny", {}, 2, True, 0.06),
     "tiny_mt": ("tiny", dict(task="mt30", model_size=None), 3, False, 0.06),
     "c1": ("c1", {}, 2, False, 0.06),
+    # more plans per fixture: eight environments of the 5M model, the reference's 6 iterations each
+    "c1_x8": ("c1", {}, 8, False, 0.06),
     "c1_wide": ("c1", {}, 1, False, 0.1),
     "c2": ("c2", {}, 2, False, 0.06),
     "mt5": ("mt5", {}, 2, False, 0.06),
