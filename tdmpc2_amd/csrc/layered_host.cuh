@@ -96,7 +96,10 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         const long slots = 2L * (h->num_cus > 0 ? h->num_cus : 256);
         int rt = 4;
         if (!wide && !getenv("TDMPC2_GEMM_RT4")) {
-            while (rt > 1 && (long)(rows_p / (32 * rt)) * q.ncolblk < slots * 3 / 4) rt >>= 1;
+            static const double fill = getenv("TDMPC2_GEMM_FILL") ? atof(getenv("TDMPC2_GEMM_FILL")) : 0.75;
+            static const double fill_head = getenv("TDMPC2_GEMM_FILL_HEAD") ? atof(getenv("TDMPC2_GEMM_FILL_HEAD")) : 0.75;
+            const double f = ly.CT <= 4 ? fill_head : fill;  // narrow outputs (two-hot / policy heads): one column block
+            while (rt > 1 && (double)((long)(rows_p / (32 * rt)) * q.ncolblk) < (double)slots * f) rt >>= 1;
         }
         const int nrowblk = (int)(rows_p / (32 * rt));
         const int nblk = nrowblk * q.ncolblk;

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Evidence run of a round (MI355X box, through gpurun): full -m gpu suite, the default bench line, the torchrun
 # (RCCL, 1 rank) leg, rocprofv3 kernel stats and the PMC passes of the same command.
-# usage: gpurun --timeout 2400 -- bash tools/gpu_evidence.sh <tag> [parts]     parts: any of "tests bench torchrun stats pmc" (default: all)
+# usage: gpurun --timeout 2400 -- bash tools/gpu_evidence.sh <tag> [parts]     parts: any of "tests bench torchrun stats pmc pmc_layered" (default: all)
 cd "$(dirname "$0")/.."
 R=$PWD
-TAG="${1:-r03a}"; PARTS="${2:-tests bench torchrun stats pmc}"
+TAG="${1:-r3z}"; PARTS="${2:-tests bench torchrun stats pmc pmc_layered}"
 mkdir -p gpurun_out
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 if has tests; then
@@ -44,5 +44,13 @@ if has pmc; then
   python tools/pmc_summary.py gpurun_out/pmc_${TAG} --json gpurun_out/${TAG}_pmc.json 'ks_rollout<\d+, \d, 8, 0, 0>'
   head -40 gpurun_out/${TAG}_pmc.txt
   rm -rf gpurun_out/pmc_${TAG}/*/ 2>/dev/null
+fi
+if has pmc_layered; then  # the layered family's GEMMs at the c3 / c4 geometry of the bench legs
+  bash tools/gpu_pmc.sh ${TAG}_c3 --config c3 --envs 30 --steps 2 --warmup 1 --skip-cpu-baseline --skip-extra-configs --skip-traffic
+  python tools/pmc_summary.py gpurun_out/pmc_${TAG}_c3 g_gemm_s > gpurun_out/${TAG}_c3_pmc.txt 2>&1
+  bash tools/gpu_pmc.sh ${TAG}_c4 --config c4 --envs 8 --steps 1 --warmup 1 --skip-cpu-baseline --skip-extra-configs --skip-traffic
+  python tools/pmc_summary.py gpurun_out/pmc_${TAG}_c4 g_gemm_s > gpurun_out/${TAG}_c4_pmc.txt 2>&1
+  grep -A3 "g_gemm_s<2, 4, 1, 1>  workgroups=840\|g_gemm_s<2, 4, 1, 1>  workgroups=1024" gpurun_out/${TAG}_c3_pmc.txt gpurun_out/${TAG}_c4_pmc.txt | head -20
+  rm -rf gpurun_out/pmc_${TAG}_c3/*/ gpurun_out/pmc_${TAG}_c4/*/ 2>/dev/null
 fi
 du -sh gpurun_out | tail -1
