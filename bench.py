@@ -580,7 +580,9 @@ def main():
         elapsed = float(t.item())
     assert faults > 0 or torch.isfinite(out).all()
 
-    extra = {"bounded_wait_faults": faults}
+    # (digest of the last timed step's actions: same seed, same inputs -> A/B variants that claim identical sums can be compared)
+    import hashlib
+    extra = {"bounded_wait_faults": faults, "action_sha1": hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:16]}
     if rank == 0 and world == 1:
         # What box is this?  The fused kernels are power-managed (profiles/README.md): boxes of the same pool differ by up to 15 %
         # in EVERY figure of this line.  Outside the timed region: queue half a second of the same steps and read the

@@ -122,7 +122,10 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             L.arrive_off += (size_t)nrowblk;
             if (fused) *fused = true;
         }
-        if (wide) GEMM_S_LAUNCH(2, 4, 1);
+        // (TDMPC2_GEMM_WIDE_SD=2: the throughput tile with the row operand staged two chunks ahead -- same sums, 16 more VGPRs)
+        static const int wide_sd = getenv("TDMPC2_GEMM_WIDE_SD") ? atoi(getenv("TDMPC2_GEMM_WIDE_SD")) : 1;
+        if (wide && wide_sd == 2) GEMM_S_LAUNCH(2, 4, 2);
+        else if (wide) GEMM_S_LAUNCH(2, 4, 1);
         else if (deep && rt == 4) GEMM_S_LAUNCH(1, 4, 4);
         else if (deep && rt == 2) GEMM_S_LAUNCH(1, 2, 4);
         else if (deep) GEMM_S_LAUNCH(1, 1, 4);
