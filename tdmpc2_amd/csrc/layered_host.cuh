@@ -39,12 +39,13 @@ int lay_arrive_reset(tdmpc2_plan *h, hipStream_t st) {
     return 0;
 }
 
-#define GEMM_S_LAUNCH(NCTV, RTV, SDV)                                                                         \
+#define GEMM_S_LAUNCH_PF(NCTV, RTV, SDV, PFV)                                                                  \
     do {                                                                                                      \
-        if (epi == 0) hipLaunchKernelGGL((g_gemm_s<NCTV, RTV, SDV, 0>), dim3(nblk), dim3(GTHREADS), 0, st, q); \
-        else if (epi == 1) hipLaunchKernelGGL((g_gemm_s<NCTV, RTV, SDV, 1>), dim3(nblk), dim3(GTHREADS), 0, st, q); \
-        else hipLaunchKernelGGL((g_gemm_s<NCTV, RTV, SDV, 2>), dim3(nblk), dim3(GTHREADS), 0, st, q);          \
+        if (epi == 0) hipLaunchKernelGGL((g_gemm_s<NCTV, RTV, SDV, 0, PFV>), dim3(nblk), dim3(GTHREADS), 0, st, q); \
+        else if (epi == 1) hipLaunchKernelGGL((g_gemm_s<NCTV, RTV, SDV, 1, PFV>), dim3(nblk), dim3(GTHREADS), 0, st, q); \
+        else hipLaunchKernelGGL((g_gemm_s<NCTV, RTV, SDV, 2, PFV>), dim3(nblk), dim3(GTHREADS), 0, st, q);     \
     } while (0)
+#define GEMM_S_LAUNCH(NCTV, RTV, SDV) GEMM_S_LAUNCH_PF(NCTV, RTV, SDV, 0)
 
 // A k-range of a layer with a per-environment bias of the caller's: the action columns of a first layer at t = 0, where the
 // z columns' product is one vector per plan (lay_cvec).
@@ -124,7 +125,9 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         }
         // (TDMPC2_GEMM_WIDE_SD=2: the throughput tile with the row operand staged two chunks ahead -- same sums, 16 more VGPRs)
         static const int wide_sd = getenv("TDMPC2_GEMM_WIDE_SD") ? atoi(getenv("TDMPC2_GEMM_WIDE_SD")) : 1;
-        if (wide && wide_sd == 2) GEMM_S_LAUNCH(2, 4, 2);
+        static const int wide_pf = getenv("TDMPC2_GEMM_WIDE_PF") ? atoi(getenv("TDMPC2_GEMM_WIDE_PF")) : 2;
+        if (wide && wide_pf == 3) GEMM_S_LAUNCH_PF(2, 4, 1, 3);
+        else if (wide && wide_sd == 2) GEMM_S_LAUNCH(2, 4, 2);
         else if (wide) GEMM_S_LAUNCH(2, 4, 1);
         else if (deep && rt == 4) GEMM_S_LAUNCH(1, 4, 4);
         else if (deep && rt == 2) GEMM_S_LAUNCH(1, 2, 4);

@@ -67,7 +67,9 @@ constexpr int GLN_MAXSPIN = 1 << 20;  // x s_sleep(2) ~ 0.1 s: peers of a row bl
 // row sums, one lane ^ 32 exchange) and writes 4 consecutive features per store.  The workgroups of a row block must be
 // dispatched together: row-major tile order (never the strip order of gemm_tile_of_block), in-order dispatch per XCD; a wait
 // that gives up raises the handle's error word (the plan then returns NaN, tdmpc2_plan_take_fault).
-template <int NCT, int RT = 4, int SD = 1, int EPI = 0>
+// PF = k16-blocks of the weight ring (0: the rule below).  PF = 3 on the throughput tile: three chunks per trip, weight
+// fragments requested 1.5 chunks ahead instead of 1 (16 more VGPRs).
+template <int NCT, int RT = 4, int SD = 1, int EPI = 0, int PF = 0>
 __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     constexpr int TM = 32 * RT;  // rows of this workgroup's tile
     __shared__ __attribute__((aligned(16))) _Float16 As[2][2][TM * GS_LDH];  // [buffer][plane][row][k]
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
 
     const int i32 = lane & 31, hh = lane >> 5;
     // weight ring in k16-blocks (NCT x 8 VGPRs each); few-row variants (SD = 4): 8 ... 16 blocks
-    constexpr int PFB = SD > 2 ? (RT == 1 ? 16 : 8) : (NCT == 1 ? 4 : 2);
+    constexpr int PFB = PF ? PF : SD > 2 ? (RT == 1 ? 16 : 8) : (NCT == 1 ? 4 : 2);
     f16x8 rh[PFB][NCT], rl[PFB][NCT];
 #pragma unroll
     for (int d = 0; d < PFB; ++d) {
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    constexpr int U = SD > 2 ? PFB / 2 : 2;  // chunks per trip: a whole number of turns of the weight ring and of the staging ring
+    constexpr int U = SD > 2 ? PFB / 2 : (PFB % 2 ? 2 * PFB : 2);  // chunks per trip (even: the LDS buffer of a chunk is then a compile-time choice): a whole number of turns of the weight ring and of the staging ring
     static_assert(U % SD == 0 && (2 * U) % PFB == 0, "staging depth 1, 2 or 4; ring turns per trip");
     // One chunk (32 of K = two k16-blocks).  `steady`: compile-time true in the main loop, whose trips contain NO conditional --
     // with the "is there a next chunk / a chunk to request" tests inside, hipcc's wait-count insertion loses track of the

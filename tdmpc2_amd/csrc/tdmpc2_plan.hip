@@ -72,6 +72,9 @@ struct RefitParams {
     // set the plan's numbers are garbage: the final pick then returns NaN actions and leaves prev_mean untouched, so that the
     // caller can re-plan the same step (tdmpc2_plan_take_fault); null on every other path.
     const unsigned int *err;
+    // sharded plans (one API call per CEM iteration): the sticky word the host raises when it consumes `err` between two
+    // iterations of the plan in flight -- checked like `err` by the final pick; null on every other path.
+    const unsigned int *err2;
     // In-launch refit (fused family, ks_rollout's last-arriver epilogue): the elite actions are RE-DERIVED from the
     // iteration's sampling distribution and noise instead of being read back from `actions` -- the workgroups that sampled
     // them sit on other XCDs, and shipping 64 x H x A floats per workgroup through write-through stores cost 13 % of the
@@ -553,8 +556,13 @@ __device__ __forceinline__ void refit_plan(const RefitParams &p, int e, float *s
     __syncthreads();
     const int pick = ei[*s_pick];
     bool bad = false;
-    if (p.err) {  // uniform: one system-scope load of the host-mapped word, broadcast through LDS
-        if (tid == 0) s_pick[1] = (int)__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (p.err || p.err2) {  // uniform: one system-scope load of the host-mapped word(s), broadcast through LDS
+        if (tid == 0) {
+            unsigned int w = 0;
+            if (p.err) w |= __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (p.err2) w |= __hip_atomic_load(p.err2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            s_pick[1] = w != 0;
+        }
         __syncthreads();
         bad = s_pick[1] != 0;
     }
@@ -817,6 +825,7 @@ struct tdmpc2_plan {
     unsigned int *ticket = nullptr;  // [max_envs] arrival counters of that hand-over
     int *qidx_buf = nullptr;         // [max_envs, 2] the two Q heads of the current iteration (shard_values)
     unsigned int shard_call = 0;     // call counter captured by shard_begin (Philox stream of the sharded plan)
+    bool in_shard = false;           // between shard_begin and the last shard_refit: a consumed fault marks the plan in flight (cl_err_host[4])
     // per-task tables of policy_value / td_target on multitask batches (grown on demand)
     float *beff_tab = nullptr, *mask_tab = nullptr, *disc_tab = nullptr;
     int *task_rows = nullptr;  // [rows] copy of the row -> task map, padded to whole GEMM tiles (layered family)
@@ -1091,6 +1100,7 @@ int validate_envs(tdmpc2_plan *h, int E) {
     // (refit_plan); from here on the handle plans with one workgroup per tile.  tdmpc2_plan_take_fault reports it.
     if (h->cl_err_host && *(volatile unsigned int *)h->cl_err_host) {
         *(volatile unsigned int *)h->cl_err_host = 0;
+        if (h->in_shard) ((volatile unsigned int *)h->cl_err_host)[4] = 1;  // the sharded plan in flight is invalid: its final pick says so
         h->cluster_mode = 0;
         h->lay.fuse_ln = false;
         h->faults++;
@@ -1940,6 +1950,10 @@ void fill_refit(tdmpc2_plan *h, RefitParams &fp, int E, int it, int eval_mode, f
     fp.value = value; fp.actions = h->actions; fp.act_mask = act_mask; fp.mean = h->mean; fp.std = h->std;
     fp.gumbel_exp = tape ? tape->gumbel_exp : nullptr; fp.final_eps = tape ? tape->final_eps : nullptr;
     fp.seed = seed; fp.call = call; fp.prev_mean = prev_mean; fp.action = action;
+    // a bounded inter-workgroup wait (fused NormedLinear epilogue) that gave up in ANY iteration of this sharded plan: NaN
+    // action, prev_mean kept -- word 0: raised by this iteration's kernels; word 4: raised by validate_envs when it consumed
+    // word 0 between two iterations
+    fp.err = h->cl_err_dev; fp.err2 = h->cl_err_dev ? h->cl_err_dev + 4 : nullptr;
     if (dbg) {
         if (dbg->value) { fp.dbg_value = dbg->value + (size_t)it * N; fp.dbg_value_es = (long)I * N; }
         if (dbg->elite_idx) { fp.dbg_idx = dbg->elite_idx + (size_t)it * K; fp.dbg_idx_es = (long)I * K; }
@@ -1964,6 +1978,8 @@ int tdmpc2_plan_shard_begin(tdmpc2_plan_t *h, int n_envs, const float *z0, const
     hipStream_t st = (hipStream_t)stream;
     const unsigned call = h->call++;
     h->shard_call = call;
+    h->in_shard = true;  // (after validate_envs: a fault it consumed belonged to an earlier plan)
+    if (h->cl_err_host) ((volatile unsigned int *)h->cl_err_host)[4] = 0;
     const int E = n_envs, P = c.num_pi_trajs;
     if (h->lay.on) {
         if ((rc = lay_setup(h, st, E, task_emb, prev_mean, t0, true))) return rc;
@@ -2050,6 +2066,7 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
     fill_refit(h, fp, n_envs, iter, eval_mode, value, c.multitask ? act_mask : nullptr, tape, seed, h->shard_call, prev_mean, action, dbg, stage);
     hipLaunchKernelGGL(k_refit, dim3(n_envs), dim3(refit_threads(c.num_samples)), lds, st, fp);
     HIP_TRY(hipGetLastError());
+    if (fp.last) h->in_shard = false;
     if (dbg && dbg->actions)
         HIP_TRY(hipMemcpy2DAsync(dbg->actions + (size_t)iter * c.horizon * c.num_samples * c.action_dim,
                                  (size_t)c.iterations * c.horizon * c.num_samples * c.action_dim * 4, h->actions,

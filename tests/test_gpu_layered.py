@@ -224,6 +224,43 @@ def test_fused_epilogue_wait_that_never_completes_is_reported_not_hung(monkeypat
     planner.close()
 
 
+def test_sharded_plan_reports_a_wait_that_gave_up_in_an_earlier_iteration(monkeypatch):
+    """dist.sharded_plan makes one API call per CEM iteration, and every call consumes the handle's error word: a fused-epilogue
+    wait that gives up in iteration 0 must still invalidate the plan's FINAL pick (NaN action, prev_mean kept), not vanish
+    between two iterations.  One workgroup muted (TDMPC2_CLUSTER_FAULT=1, read at create); single process."""
+    import torch
+
+    from tdmpc2_amd.dist import sharded_plan
+    from tdmpc2_amd.native import NativePlanner
+    from tests.gpu_common import case_on_gpu, dev, plan_inputs
+
+    c, model, ref = case_on_gpu("small", PATH_LAYERED, 2)
+    monkeypatch.setenv("TDMPC2_CLUSTER_FAULT", "1")
+    planner = NativePlanner(c["cfg"], c["iterations"], dev(), max_envs=c["n_envs"], path=PATH_LAYERED, precision=2)
+    monkeypatch.delenv("TDMPC2_CLUSTER_FAULT")
+    planner.bind_state_dict(model.sd)
+    inp = plan_inputs(c, model)
+    kw = dict(eval_mode=c["eval_mode"], task_emb=inp["task_emb"], act_mask=inp["act_mask"], tape=inp["tape"])
+    pm = inp["prev_mean"].clone()
+    bad = sharded_plan(planner, inp["z0"], inp["disc_pow"], pm, inp["t0"], **kw)
+    torch.cuda.synchronize()
+    assert torch.isnan(bad).all() and torch.equal(pm, inp["prev_mean"])
+    assert planner.take_fault() >= 1
+    # the handle has switched to the row-kernel path: the next sharded plan is valid and equals the plain plan of a handle
+    # with the fused epilogue off
+    pm_a, pm_b = inp["prev_mean"].clone(), inp["prev_mean"].clone()
+    a = sharded_plan(planner, inp["z0"], inp["disc_pow"], pm_a, inp["t0"], **kw).clone()
+    ref.set_fuse_ln(0)
+    try:
+        b = ref.plan(inp["z0"], inp["disc_pow"], pm_b, inp["t0"], **kw).clone()
+    finally:
+        ref.set_fuse_ln(1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all() and torch.allclose(a, b, atol=1e-6) and torch.allclose(pm_a, pm_b, atol=1e-6)
+    assert planner.take_fault() == 0
+    planner.close()
+
+
 def test_a_plan_computes_the_same_bits_alone_and_in_a_batch_that_switches_tiles():
     """Six plans of the 48M model in one call run on the 128 x 256 GEMM tile with the NormedLinear epilogue exchanging over 7
     column blocks; one plan alone runs on 32-row x 128-column tiles with 14.  The LayerNorm statistics are combined in an
