@@ -112,7 +112,8 @@ def sharded_plan(backend, z0, disc_pow, prev_mean, t0, eval_mode: bool = False, 
     the prologue, the action sampling and the elite selection + refit are replicated; a rank evaluates only rows
     [rank * N / G, (rank + 1) * N / G) of every plan and the value slices are all-gathered once per CEM iteration
     (N / G * 4 bytes per plan per rank over RCCL / xGMI).  Returns action [E, A] -- the same on every rank; `prev_mean` is
-    updated in place.
+    updated in place.  If a bounded inter-workgroup wait of the kernels gave up on any rank (NativePlanner.take_fault), all
+    ranks re-plan the step on the kernels without such waits (`backend.last_shard_retries`).
 
     `backend` is a `NativePlanner` (or anything with its shard_begin / shard_values / shard_refit / shard_granularity /
     cfg / iterations: the CPU tests drive this function over gloo with an oracle-backed stand-in)."""
@@ -127,18 +128,39 @@ def sharded_plan(backend, z0, disc_pow, prev_mean, t0, eval_mode: bool = False, 
     r0, r1 = rank * per, (rank + 1) * per
     value = torch.zeros(E, N, dtype=torch.float32, device=z0.device)
     action = torch.empty(E, cfg.action_dim, dtype=torch.float32, device=z0.device)
-    if world > 1 and tape is None:
-        _agree_on_stream(backend, seed, z0.device, group)
-    backend.shard_begin(z0, prev_mean, t0, task_emb=task_emb, act_mask=act_mask, tape=tape, seed=seed)
-    for it in range(backend.iterations):
-        backend.shard_values(it, r0, r1, z0, disc_pow, value, act_mask=act_mask, seed=seed)
+    can_fault = hasattr(backend, "take_fault")
+    prev_in = prev_mean.clone() if can_fault else None
+    backend.last_shard_retries = 0
+    for attempt in range(2):
+        if world > 1 and tape is None:
+            _agree_on_stream(backend, seed, z0.device, group)
+        backend.shard_begin(z0, prev_mean, t0, task_emb=task_emb, act_mask=act_mask, tape=tape, seed=seed)
+        for it in range(backend.iterations):
+            backend.shard_values(it, r0, r1, z0, disc_pow, value, act_mask=act_mask, seed=seed)
+            if world > 1:
+                local = value[:, r0:r1].contiguous()
+                # RCCL gathers device tensors in place; gloo (CPU tests, and ranks that SHARE one GPU -- RCCL refuses two ranks
+                # on one device) takes the 4 KB slices through host memory
+                stage = torch.device("cpu") if _host_staged(group) else value.device
+                gathered = torch.empty(world, E, per, dtype=value.dtype, device=stage)
+                dist.all_gather_into_tensor(gathered.view(-1), local.to(stage).view(-1), group=group)
+                value.copy_(gathered.permute(1, 0, 2).reshape(E, N))
+            backend.shard_refit(it, value, prev_mean, action, act_mask=act_mask, eval_mode=eval_mode, seed=seed, stages=stages)
+        if not can_fault:
+            break
+        # A bounded inter-workgroup wait of the planner kernels that gave up on ANY rank (another process or kernel held the
+        # compute units) made that rank's value slice garbage, and every rank has refitted on it: the ranks agree on the
+        # verdict, switch to the kernels without inter-workgroup waits and plan the step again (once: those cannot fault).
+        if z0.is_cuda:
+            torch.cuda.synchronize(z0.device)
+        bad = torch.tensor([int(backend.take_fault() > 0)], dtype=torch.int64,
+                           device=torch.device("cpu") if (world > 1 and _host_staged(group)) else z0.device)
         if world > 1:
-            local = value[:, r0:r1].contiguous()
-            # RCCL gathers device tensors in place; gloo (CPU tests, and ranks that SHARE one GPU -- RCCL refuses two ranks
-            # on one device) takes the 4 KB slices through host memory
-            stage = torch.device("cpu") if _host_staged(group) else value.device
-            gathered = torch.empty(world, E, per, dtype=value.dtype, device=stage)
-            dist.all_gather_into_tensor(gathered.view(-1), local.to(stage).view(-1), group=group)
-            value.copy_(gathered.permute(1, 0, 2).reshape(E, N))
-        backend.shard_refit(it, value, prev_mean, action, act_mask=act_mask, eval_mode=eval_mode, seed=seed, stages=stages)
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+        if not int(bad.item()) or attempt == 1:
+            break
+        backend.last_shard_retries += 1
+        backend.set_fuse_ln(0)
+        backend.set_cluster(0)
+        prev_mean.copy_(prev_in)
     return action

@@ -127,20 +127,30 @@ def _two_proc_worker(rank, world, port, out_dir, name, path):
         torch.cuda.synchronize()
         torch.save({"action": a.cpu(), "prev_mean": pm.cpu(), "value": stages["value"].cpu(), "elite_idx": stages["elite_idx"].cpu()},
                    os.path.join(out_dir, f"shard{rank}.pt"))
-        # bounded inter-workgroup waits that gave up while the two processes competed for the compute units (0 on a healthy run)
-        torch.save(torch.tensor([planner.take_fault()]), os.path.join(out_dir, f"faults{rank}.pt"))
+        # did sharded_plan have to re-plan (a bounded inter-workgroup wait gave up while the two processes competed for the
+        # compute units; the verdict is collective, so both ranks report the same number)?
+        retries = int(planner.last_shard_retries)
         # (2) env-sharded batch: each process plans its share of the environments (recorded tape), actions gathered
         a0, a1 = shard_range(E, world, rank)
+        replans = 0
         if a1 > a0:
-            loc = planner.plan(inp["z0"][a0:a1].contiguous(), inp["disc_pow"][a0:a1].contiguous(), inp["prev_mean"][a0:a1].clone(),
-                               inp["t0"][a0:a1].contiguous(), eval_mode=c["eval_mode"],
-                               task_emb=None if inp["task_emb"] is None else inp["task_emb"][a0:a1].contiguous(),
-                               act_mask=None if inp["act_mask"] is None else inp["act_mask"][a0:a1].contiguous(),
-                               tape={k: v[a0:a1].contiguous() for k, v in inp["tape"].items()})
+            def own_share():
+                return planner.plan(inp["z0"][a0:a1].contiguous(), inp["disc_pow"][a0:a1].contiguous(), inp["prev_mean"][a0:a1].clone(),
+                                    inp["t0"][a0:a1].contiguous(), eval_mode=c["eval_mode"],
+                                    task_emb=None if inp["task_emb"] is None else inp["task_emb"][a0:a1].contiguous(),
+                                    act_mask=None if inp["act_mask"] is None else inp["act_mask"][a0:a1].contiguous(),
+                                    tape={k: v[a0:a1].contiguous() for k, v in inp["tape"].items()})
+            loc = own_share()
+            torch.cuda.synchronize()
+            if planner.take_fault():  # what TDMPC2.act() does: the plan came back NaN, the handle has switched kernels -- plan again
+                replans = 1
+                loc = own_share()
+                torch.cuda.synchronize()
         else:
             loc = torch.empty(0, cfg.action_dim, device=d)
         full = gather_actions(loc, E)
         torch.save(full.cpu(), os.path.join(out_dir, f"envs{rank}.pt"))
+        torch.save(torch.tensor([retries, replans]), os.path.join(out_dir, f"faults{rank}.pt"))
         planner.close()
         dist.barrier()
     finally:
@@ -182,11 +192,16 @@ def test_two_processes_on_one_gpu_shard_a_plan_bit_identically(name, path, tmp_p
     pm = inp["prev_mean"].clone()
     stages = planner.debug_buffers(c["n_envs"])
     assert not (dist.is_initialized() and dist.get_world_size() > 1)
+    f0, f1 = (torch.load(tmp_path / f"faults{r}.pt").tolist() for r in (0, 1))
+    assert f0[0] == f1[0], "the re-plan verdict is collective"
+    print(f"two processes on one GPU: sharded_plan re-planned {f0[0]} time(s); env-sharded re-plans per rank {f0[1]}, {f1[1]}")
+    if f0[0]:  # the two ranks finished on the kernels without inter-workgroup waits: compare with the same kernels
+        planner.set_fuse_ln(0)
+        planner.set_cluster(0)
     a = sharded_plan(planner, inp["z0"], inp["disc_pow"], pm, inp["t0"], eval_mode=c["eval_mode"], tape=None, seed=77, stages=stages,
                      task_emb=inp["task_emb"], act_mask=inp["act_mask"])
     torch.cuda.synchronize()
-    faults = [int(torch.load(tmp_path / f"faults{r}.pt")[0]) for r in (0, 1)] + [planner.take_fault()]
-    assert faults == [0, 0, 0], f"bounded waits gave up (rank 0, rank 1, single process): {faults}"
+    assert planner.last_shard_retries == 0, "a single process on the GPU: no wait can give up"
     v1, v2 = stages["value"].cpu(), r0["value"]
     if not torch.equal(v1, v2):  # say where: [env, iteration, row]
         bad = (v1 != v2).nonzero()
