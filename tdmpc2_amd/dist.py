@@ -131,9 +131,12 @@ def sharded_plan(backend, z0, disc_pow, prev_mean, t0, eval_mode: bool = False, 
     can_fault = hasattr(backend, "take_fault")
     prev_in = prev_mean.clone() if can_fault else None
     backend.last_shard_retries = 0
+    call0 = None
     for attempt in range(2):
         if world > 1 and tape is None:
             _agree_on_stream(backend, seed, z0.device, group)
+        if can_fault and hasattr(backend, "call_counter"):
+            call0 = backend.call_counter()  # (after the ranks agreed) a re-plan draws the noise of the attempt it replaces
         backend.shard_begin(z0, prev_mean, t0, task_emb=task_emb, act_mask=act_mask, tape=tape, seed=seed)
         for it in range(backend.iterations):
             backend.shard_values(it, r0, r1, z0, disc_pow, value, act_mask=act_mask, seed=seed)
@@ -163,4 +166,6 @@ def sharded_plan(backend, z0, disc_pow, prev_mean, t0, eval_mode: bool = False, 
         backend.set_fuse_ln(0)
         backend.set_cluster(0)
         prev_mean.copy_(prev_in)
+        if call0 is not None:
+            backend.set_call_counter(call0)
     return action

@@ -225,9 +225,11 @@ def test_fused_epilogue_wait_that_never_completes_is_reported_not_hung(monkeypat
 
 
 def test_sharded_plan_reports_a_wait_that_gave_up_in_an_earlier_iteration(monkeypatch):
-    """dist.sharded_plan makes one API call per CEM iteration, and every call consumes the handle's error word: a fused-epilogue
-    wait that gives up in iteration 0 must still invalidate the plan's FINAL pick (NaN action, prev_mean kept), not vanish
-    between two iterations.  One workgroup muted (TDMPC2_CLUSTER_FAULT=1, read at create); single process."""
+    """A sharded plan is one API call per CEM iteration, and every call consumes the handle's error word: a fused-epilogue
+    wait that gives up in the prologue must still invalidate the plan's FINAL pick (NaN action, prev_mean kept) instead of
+    vanishing between two iterations; dist.sharded_plan turns that verdict into ONE re-plan on the kernels without
+    inter-workgroup waits, with the noise of the attempt it replaces.  One workgroup muted (TDMPC2_CLUSTER_FAULT=1, read at
+    create); single process."""
     import torch
 
     from tdmpc2_amd.dist import sharded_plan
@@ -235,29 +237,44 @@ def test_sharded_plan_reports_a_wait_that_gave_up_in_an_earlier_iteration(monkey
     from tests.gpu_common import case_on_gpu, dev, plan_inputs
 
     c, model, ref = case_on_gpu("small", PATH_LAYERED, 2)
-    monkeypatch.setenv("TDMPC2_CLUSTER_FAULT", "1")
-    planner = NativePlanner(c["cfg"], c["iterations"], dev(), max_envs=c["n_envs"], path=PATH_LAYERED, precision=2)
-    monkeypatch.delenv("TDMPC2_CLUSTER_FAULT")
-    planner.bind_state_dict(model.sd)
     inp = plan_inputs(c, model)
-    kw = dict(eval_mode=c["eval_mode"], task_emb=inp["task_emb"], act_mask=inp["act_mask"], tape=inp["tape"])
+    kw = dict(task_emb=inp["task_emb"], act_mask=inp["act_mask"])
+    N, E = c["cfg"].num_samples, c["n_envs"]
+
+    def faulty():
+        monkeypatch.setenv("TDMPC2_CLUSTER_FAULT", "1")
+        p = NativePlanner(c["cfg"], c["iterations"], dev(), max_envs=E, path=PATH_LAYERED, precision=2)
+        monkeypatch.delenv("TDMPC2_CLUSTER_FAULT")
+        p.bind_state_dict(model.sd)
+        return p
+
+    # (a) the entry points by hand, with a sync after every call so that the NEXT call's validation consumes the error word
+    planner = faulty()
     pm = inp["prev_mean"].clone()
-    bad = sharded_plan(planner, inp["z0"], inp["disc_pow"], pm, inp["t0"], **kw)
+    value = torch.zeros(E, N, device=dev())
+    action = torch.zeros(E, c["cfg"].action_dim, device=dev())
+    planner.shard_begin(inp["z0"], pm, inp["t0"], tape=inp["tape"], **kw)
     torch.cuda.synchronize()
-    assert torch.isnan(bad).all() and torch.equal(pm, inp["prev_mean"])
+    for it in range(c["iterations"]):
+        planner.shard_values(it, 0, N, inp["z0"], inp["disc_pow"], value, act_mask=inp["act_mask"])
+        torch.cuda.synchronize()
+        planner.shard_refit(it, value, pm, action, act_mask=inp["act_mask"], eval_mode=c["eval_mode"])
+        torch.cuda.synchronize()
+    assert torch.isnan(action).all() and torch.equal(pm, inp["prev_mean"])
     assert planner.take_fault() >= 1
-    # the handle has switched to the row-kernel path: the next sharded plan is valid and equals the plain plan of a handle
-    # with the fused epilogue off
+    planner.close()
+    # (b) the same through dist.sharded_plan: re-planned once, valid, equal to a handle that never used the fused epilogue
+    planner = faulty()
     pm_a, pm_b = inp["prev_mean"].clone(), inp["prev_mean"].clone()
-    a = sharded_plan(planner, inp["z0"], inp["disc_pow"], pm_a, inp["t0"], **kw).clone()
+    a = sharded_plan(planner, inp["z0"], inp["disc_pow"], pm_a, inp["t0"], eval_mode=c["eval_mode"], tape=inp["tape"], **kw).clone()
+    assert planner.last_shard_retries == 1 and planner.take_fault() == 0
     ref.set_fuse_ln(0)
     try:
-        b = ref.plan(inp["z0"], inp["disc_pow"], pm_b, inp["t0"], **kw).clone()
+        b = ref.plan(inp["z0"], inp["disc_pow"], pm_b, inp["t0"], eval_mode=c["eval_mode"], tape=inp["tape"], **kw).clone()
     finally:
         ref.set_fuse_ln(1)
     torch.cuda.synchronize()
     assert torch.isfinite(a).all() and torch.allclose(a, b, atol=1e-6) and torch.allclose(pm_a, pm_b, atol=1e-6)
-    assert planner.take_fault() == 0
     planner.close()
 
 
