@@ -103,7 +103,7 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             while (rt > 1 && (double)((long)(rows_p / (32 * rt)) * q.ncolblk) < (double)slots * f) rt >>= 1;
         }
         const int nrowblk = (int)(rows_p / (32 * rt));
-        const int nblk = nrowblk * q.ncolblk;
+        int nblk = nrowblk * q.ncolblk;
         // few workgroups per CU: row operand staged four chunks deep, weight ring of 8 / 16 blocks (g_gemm_s<.., .., 4>)
         const bool deep = !wide && (long)nblk < 2 * slots && !getenv("TDMPC2_GEMM_SD1");
         int epi = 0;
@@ -122,6 +122,11 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             q.width = ln->width; q.stats = stats; q.arrive = L.arrive + L.arrive_off; q.err = h->cl_err_dev; q.fault = h->cl_fault;
             L.arrive_off += (size_t)nrowblk;
             if (fused) *fused = true;
+            static const int xcd_rows = getenv("TDMPC2_GEMM_XCD_ROWS") ? atoi(getenv("TDMPC2_GEMM_XCD_ROWS")) : 0;
+            if (xcd_rows) {
+                q.xcd_rows = 1; q.nrowblk = nrowblk;
+                nblk = 8 * ((nrowblk + 7) / 8) * q.ncolblk;
+            }
         }
         // The throughput tile stages its row operand TWO chunks ahead (same sums; 242 VGPRs in the main loop instead of 226, the
         // epilogue's 255 are the kernel's maximum either way): c3 +0.4 ... 0.7 %, c4 +0.5 % in three same-call A/Bs (profiles/README.md

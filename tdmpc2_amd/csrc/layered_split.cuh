@@ -41,6 +41,13 @@ struct GemmSParams {
     unsigned int *arrive;      // [row block] arrival counters of this launch (zero on entry)
     unsigned int *err;         // the handle's host-mapped error word (bounded wait gave up)
     int fault;                 // test hook (TDMPC2_CLUSTER_FAULT at create): column block 0 of row block 0 never arrives
+    // EPI != 0 tile order.  0: row-major over the grid (block b = row block b / ncolblk): the column blocks of a row block sit on
+    // `ncolblk` consecutive block ids, i.e. on that many DIFFERENT XCDs (block b runs on XCD b % 8).  1: XCD-local row blocks --
+    // XCD x's t-th workgroup is column block t % ncolblk of row block (t / ncolblk) * 8 + x: the peers of a row block are
+    // consecutive in ONE XCD's dispatch order (at most one partly dispatched row block per XCD and launch, whatever the other
+    // XCDs and other launches do), they read the same A rows through one L2 and exchange their statistics inside it.  The
+    // grid is padded to 8 * ceil(nrowblk / 8) * ncolblk blocks; a row block >= nrowblk leaves as a whole.
+    int xcd_rows, nrowblk;
 };
 
 constexpr int GLN_MAXSPIN = 1 << 20;  // x s_sleep(2) ~ 0.1 s: peers of a row block are dispatched back to back
@@ -84,6 +91,12 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     int rb, cb;
     if (EPI == 0) {
         gemm_tile_of_block(blockIdx.x, gridDim.x, p.ncolblk, rb, cb);
+    } else if (p.xcd_rows) {  // column blocks of a row block consecutive in ONE XCD's dispatch order (GemmSParams::xcd_rows)
+        const int x = blockIdx.x & 7, t = blockIdx.x >> 3;
+        const int rbl = t / p.ncolblk;
+        cb = t - rbl * p.ncolblk;
+        rb = rbl * 8 + x;
+        if (rb >= p.nrowblk) return;  // (the whole row block: every one of its workgroups takes this exit)
     } else {  // column blocks of a row block on consecutive block ids
         rb = blockIdx.x / p.ncolblk;
         cb = blockIdx.x % p.ncolblk;
