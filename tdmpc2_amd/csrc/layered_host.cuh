@@ -122,7 +122,14 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             q.width = ln->width; q.stats = stats; q.arrive = L.arrive + L.arrive_off; q.err = h->cl_err_dev; q.fault = h->cl_fault;
             L.arrive_off += (size_t)nrowblk;
             if (fused) *fused = true;
-            static const int xcd_rows = getenv("TDMPC2_GEMM_XCD_ROWS") ? atoi(getenv("TDMPC2_GEMM_XCD_ROWS")) : 0;
+            // Tile order of the fused launches (GemmSParams::xcd_rows).  Row-major puts block b = rb * ncolblk + cb on XCD b % 8:
+            // when ncolblk is a multiple of 8 (317M: 16) an XCD sees two column blocks only -- 1/8 of the weights, every A row --,
+            // otherwise (48M: 7, SimNorm layers: 3 / 6) it sees every column block AND nearly every row block.  XCD-local row blocks
+            // read each A row through ONE L2.  Measured (profiles/README.md r3v, same call, identical bits): c3 E = 30 980 -> 1 060
+            // plans/s, fabric-side traffic of a stage 19.8 -> 11.0 GB; with ncolblk = 16 it loses (c4 93.2 -> 90.0: the weights'
+            // locality goes), and calls with few row blocks (single plans) lose 3-4 %.  TDMPC2_GEMM_XCD_ROWS = 0 / 1: never / always.
+            static const int xcd_rows_env = getenv("TDMPC2_GEMM_XCD_ROWS") ? atoi(getenv("TDMPC2_GEMM_XCD_ROWS")) : -1;
+            const bool xcd_rows = xcd_rows_env >= 0 ? xcd_rows_env != 0 : (q.ncolblk % 8 != 0 && nrowblk >= 64);
             if (xcd_rows) {
                 q.xcd_rows = 1; q.nrowblk = nrowblk;
                 nblk = 8 * ((nrowblk + 7) / 8) * q.ncolblk;
