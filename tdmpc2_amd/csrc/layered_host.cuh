@@ -130,9 +130,13 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             // locality goes), and calls with few row blocks (single plans) lose 3-4 %.  TDMPC2_GEMM_XCD_ROWS = 0 / 1: never / always.
             static const int xcd_rows_env = getenv("TDMPC2_GEMM_XCD_ROWS") ? atoi(getenv("TDMPC2_GEMM_XCD_ROWS")) : -1;
             const bool xcd_rows = xcd_rows_env >= 0 ? xcd_rows_env != 0 : (q.ncolblk % 8 != 0 && nrowblk >= 64);
+            static const int col_pad_env = getenv("TDMPC2_GEMM_COL_PAD") ? atoi(getenv("TDMPC2_GEMM_COL_PAD")) : 0;
             if (xcd_rows) {
                 q.xcd_rows = 1; q.nrowblk = nrowblk;
                 nblk = 8 * ((nrowblk + 7) / 8) * q.ncolblk;
+            } else if (col_pad_env && q.ncolblk % 8 != 0 && q.ncolblk > 8) {
+                q.ncol_grid = (q.ncolblk + 7) / 8 * 8;
+                nblk = nrowblk * q.ncol_grid;
             }
         }
         // The throughput tile stages its row operand TWO chunks ahead (same sums; 242 VGPRs in the main loop instead of 226, the

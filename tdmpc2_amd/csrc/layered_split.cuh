@@ -48,6 +48,10 @@ struct GemmSParams {
     // XCDs and other launches do), they read the same A rows through one L2 and exchange their statistics inside it.  The
     // grid is padded to 8 * ceil(nrowblk / 8) * ncolblk blocks; a row block >= nrowblk leaves as a whole.
     int xcd_rows, nrowblk;
+    // Row-major order with the row padded to `ncol_grid` = a multiple of 8 column blocks (0: no padding): block b = rb * ncol_grid
+    // + cb then runs on XCD cb % 8 -- an XCD streams ITS column blocks' weights only (calls with few rows, where the weights are
+    // the traffic: c3 single plan, 14 column blocks: every XCD read all 12.8 MB of a layer, 102 MB per GEMM); cb >= ncolblk leaves.
+    int ncol_grid;
 };
 
 constexpr int GLN_MAXSPIN = 1 << 20;  // x s_sleep(2) ~ 0.1 s: peers of a row block are dispatched back to back
@@ -98,8 +102,10 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
         rb = rbl * 8 + x;
         if (rb >= p.nrowblk) return;  // (the whole row block: every one of its workgroups takes this exit)
     } else {  // column blocks of a row block on consecutive block ids
-        rb = blockIdx.x / p.ncolblk;
-        cb = blockIdx.x % p.ncolblk;
+        const int ncg = p.ncol_grid ? p.ncol_grid : p.ncolblk;
+        rb = blockIdx.x / ncg;
+        cb = blockIdx.x % ncg;
+        if (cb >= p.ncolblk) return;
     }
     const int row0 = rb * TM;
     const int sel = p.sel ? p.sel[(size_t)(row0 / p.rows_per_env) * p.sel_stride] : 0;
