@@ -130,7 +130,11 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             // locality goes), and calls with few row blocks (single plans) lose 3-4 %.  TDMPC2_GEMM_XCD_ROWS = 0 / 1: never / always.
             static const int xcd_rows_env = getenv("TDMPC2_GEMM_XCD_ROWS") ? atoi(getenv("TDMPC2_GEMM_XCD_ROWS")) : -1;
             const bool xcd_rows = xcd_rows_env >= 0 ? xcd_rows_env != 0 : (q.ncolblk % 8 != 0 && nrowblk >= 64);
-            static const int col_pad_env = getenv("TDMPC2_GEMM_COL_PAD") ? atoi(getenv("TDMPC2_GEMM_COL_PAD")) : 0;
+            // Launches that keep the row-major order and have more than 8 column blocks, not a multiple of 8 (single plans and the
+            // prologue of the 48M model: 14): pad the row of blocks to a multiple of 8, so that XCD x only ever runs column blocks
+            // x and x + 8 and streams THEIR weights (GemmSParams::ncol_grid).  c3 single plan 3.81 -> 3.49 ms, throughput legs
+            // unchanged, identical bits (profiles/README.md r3s).  TDMPC2_GEMM_COL_PAD=0: off.
+            static const int col_pad_env = getenv("TDMPC2_GEMM_COL_PAD") ? atoi(getenv("TDMPC2_GEMM_COL_PAD")) : 1;
             if (xcd_rows) {
                 q.xcd_rows = 1; q.nrowblk = nrowblk;
                 nblk = 8 * ((nrowblk + 7) / 8) * q.ncolblk;
