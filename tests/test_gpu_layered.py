@@ -278,11 +278,13 @@ def test_sharded_plan_reports_a_wait_that_gave_up_in_an_earlier_iteration(monkey
     planner.close()
 
 
-def test_a_plan_computes_the_same_bits_alone_and_in_a_batch_that_switches_tiles():
+@pytest.mark.parametrize("E", [6, 16])
+def test_a_plan_computes_the_same_bits_alone_and_in_a_batch_that_switches_tiles(E):
     """Six plans of the 48M model in one call run on the 128 x 256 GEMM tile with the NormedLinear epilogue exchanging over 7
-    column blocks; one plan alone runs on 32-row x 128-column tiles with 14.  The LayerNorm statistics are combined in an
-    order that depends on the layer only (32-column tiles -> 128-column groups -> the row, left to right), so the values
-    agree BIT FOR BIT (and so do the rows of a plan split over ranks, test_gpu_dist.py)."""
+    column blocks; one plan alone runs on 32-row x 128-column tiles with 14 (in a row of blocks padded to 16).  The LayerNorm
+    statistics are combined in an order that depends on the layer only (32-column tiles -> 128-column groups -> the row, left
+    to right), so the values agree BIT FOR BIT (and so do the rows of a plan split over ranks, test_gpu_dist.py).  Sixteen
+    plans are 64 row blocks: the fused launches then take the XCD-local tile order -- same bits again."""
     from oracle import cases
     from oracle import planner_oracle as po
     from tdmpc2_amd import synth
@@ -292,7 +294,7 @@ def test_a_plan_computes_the_same_bits_alone_and_in_a_batch_that_switches_tiles(
     c = cases.build_case("c3")
     cfg = c["cfg"]
     sd = {k: torch.as_tensor(v) for k, v in c["sd"].items()}
-    E, H, N, A = 6, cfg.horizon, cfg.num_samples, cfg.action_dim
+    H, N, A = cfg.horizon, cfg.num_samples, cfg.action_dim
     planner = NativePlanner(cfg, c["iterations"], dev(), max_envs=E, path=PATH_LAYERED, precision=2)
     planner.bind_state_dict(sd)
     z0 = torch.as_tensor(synth.make_latents(cfg, E, seed=11)).to(dev())
@@ -308,10 +310,10 @@ def test_a_plan_computes_the_same_bits_alone_and_in_a_batch_that_switches_tiles(
     g = torch.Generator().manual_seed(5)
     actions = ((torch.rand(E, H, N, A, generator=g) * 2 - 1) * sd["_action_masks"][torch.tensor(tasks)].view(E, 1, 1, A)).to(dev()).contiguous()
     eps = torch.randn(E, N, A, generator=g).to(dev())
-    qidx = torch.tensor([[0, 4], [3, 1], [2, 0], [1, 2], [4, 3], [0, 1]], dtype=torch.int32, device=dev())
+    qidx = torch.tensor(([[0, 4], [3, 1], [2, 0], [1, 2], [4, 3], [0, 1]] * 3)[:E], dtype=torch.int32, device=dev())
     v = planner.estimate_value(z0, disc, actions, eps, qidx, task_emb=emb, act_mask=mask)
     assert torch.isfinite(v).all() and v.std() > 0
-    for e in (0, 3, 5):
+    for e in (0, 3, E - 1):
         ve = planner.estimate_value(z0[e:e + 1].contiguous(), disc[e:e + 1].contiguous(), actions[e:e + 1].contiguous(),
                                     eps[e:e + 1].contiguous(), qidx[e:e + 1].contiguous(), task_emb=emb[e:e + 1].contiguous(),
                                     act_mask=mask[e:e + 1].contiguous())
