@@ -122,26 +122,13 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             q.width = ln->width; q.stats = stats; q.arrive = L.arrive + L.arrive_off; q.err = h->cl_err_dev; q.fault = h->cl_fault;
             L.arrive_off += (size_t)nrowblk;
             if (fused) *fused = true;
-            // Tile order of the fused launches (GemmSParams::xcd_rows).  Row-major puts block b = rb * ncolblk + cb on XCD b % 8:
-            // when ncolblk is a multiple of 8 (317M: 16) an XCD sees two column blocks only -- 1/8 of the weights, every A row --,
-            // otherwise (48M: 7, SimNorm layers: 3 / 6) it sees every column block AND nearly every row block.  XCD-local row blocks
-            // read each A row through ONE L2.  Measured (profiles/README.md r3v, same call, identical bits): c3 E = 30 980 -> 1 060
-            // plans/s, fabric-side traffic of a stage 19.8 -> 11.0 GB; with ncolblk = 16 it loses (c4 93.2 -> 90.0: the weights'
-            // locality goes), and calls with few row blocks (single plans) lose 3-4 %.  TDMPC2_GEMM_XCD_ROWS = 0 / 1: never / always.
+            // tile order (tile_order.h); TDMPC2_GEMM_XCD_ROWS = 0 / 1: never / always XCD-local row blocks, TDMPC2_GEMM_COL_PAD = 0:
+            // no padding of the row-major order
             static const int xcd_rows_env = getenv("TDMPC2_GEMM_XCD_ROWS") ? atoi(getenv("TDMPC2_GEMM_XCD_ROWS")) : -1;
-            const bool xcd_rows = xcd_rows_env >= 0 ? xcd_rows_env != 0 : (q.ncolblk % 8 != 0 && nrowblk >= 64);
-            // Launches that keep the row-major order and have more than 8 column blocks, not a multiple of 8 (single plans and the
-            // prologue of the 48M model: 14): pad the row of blocks to a multiple of 8, so that XCD x only ever runs column blocks
-            // x and x + 8 and streams THEIR weights (GemmSParams::ncol_grid).  c3 single plan 3.81 -> 3.49 ms, throughput legs
-            // unchanged, identical bits (profiles/README.md r3s).  TDMPC2_GEMM_COL_PAD=0: off.
             static const int col_pad_env = getenv("TDMPC2_GEMM_COL_PAD") ? atoi(getenv("TDMPC2_GEMM_COL_PAD")) : 1;
-            if (xcd_rows) {
-                q.xcd_rows = 1; q.nrowblk = nrowblk;
-                nblk = 8 * ((nrowblk + 7) / 8) * q.ncolblk;
-            } else if (col_pad_env && q.ncolblk % 8 != 0 && q.ncolblk > 8) {
-                q.ncol_grid = (q.ncolblk + 7) / 8 * 8;
-                nblk = nrowblk * q.ncol_grid;
-            }
+            const GemmSOrder ord = gemm_s_order(nrowblk, q.ncolblk, xcd_rows_env, col_pad_env);
+            q.xcd_rows = ord.xcd_rows; q.ncol_grid = ord.ncol_grid; q.nrowblk = nrowblk;
+            nblk = ord.nblk;
         }
         // The throughput tile stages its row operand TWO chunks ahead (same sums; 242 VGPRs in the main loop instead of 226, the
         // epilogue's 255 are the kernel's maximum either way): c3 +0.4 ... 0.7 %, c4 +0.5 % in three same-call A/Bs (profiles/README.md

@@ -41,17 +41,8 @@ struct GemmSParams {
     unsigned int *arrive;      // [row block] arrival counters of this launch (zero on entry)
     unsigned int *err;         // the handle's host-mapped error word (bounded wait gave up)
     int fault;                 // test hook (TDMPC2_CLUSTER_FAULT at create): column block 0 of row block 0 never arrives
-    // EPI != 0 tile order.  0: row-major over the grid (block b = row block b / ncolblk): the column blocks of a row block sit on
-    // `ncolblk` consecutive block ids, i.e. on that many DIFFERENT XCDs (block b runs on XCD b % 8).  1: XCD-local row blocks --
-    // XCD x's t-th workgroup is column block t % ncolblk of row block (t / ncolblk) * 8 + x: the peers of a row block are
-    // consecutive in ONE XCD's dispatch order (at most one partly dispatched row block per XCD and launch, whatever the other
-    // XCDs and other launches do), they read the same A rows through one L2 and exchange their statistics inside it.  The
-    // grid is padded to 8 * ceil(nrowblk / 8) * ncolblk blocks; a row block >= nrowblk leaves as a whole.
-    int xcd_rows, nrowblk;
-    // Row-major order with the row padded to `ncol_grid` = a multiple of 8 column blocks (0: no padding): block b = rb * ncol_grid
-    // + cb then runs on XCD cb % 8 -- an XCD streams ITS column blocks' weights only (calls with few rows, where the weights are
-    // the traffic: c3 single plan, 14 column blocks: every XCD read all 12.8 MB of a layer, 102 MB per GEMM); cb >= ncolblk leaves.
-    int ncol_grid;
+    // EPI != 0: the tile order (tile_order.h: gemm_s_order / gemm_s_tile)
+    int xcd_rows, nrowblk, ncol_grid;
 };
 
 constexpr int GLN_MAXSPIN = 1 << 20;  // x s_sleep(2) ~ 0.1 s: peers of a row block are dispatched back to back
@@ -95,17 +86,8 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     int rb, cb;
     if (EPI == 0) {
         gemm_tile_of_block(blockIdx.x, gridDim.x, p.ncolblk, rb, cb);
-    } else if (p.xcd_rows) {  // column blocks of a row block consecutive in ONE XCD's dispatch order (GemmSParams::xcd_rows)
-        const int x = blockIdx.x & 7, t = blockIdx.x >> 3;
-        const int rbl = t / p.ncolblk;
-        cb = t - rbl * p.ncolblk;
-        rb = rbl * 8 + x;
-        if (rb >= p.nrowblk) return;  // (the whole row block: every one of its workgroups takes this exit)
-    } else {  // column blocks of a row block on consecutive block ids
-        const int ncg = p.ncol_grid ? p.ncol_grid : p.ncolblk;
-        rb = blockIdx.x / ncg;
-        cb = blockIdx.x % ncg;
-        if (cb >= p.ncolblk) return;
+    } else {  // tile_order.h: XCD-local row blocks, or (padded) row-major
+        if (!gemm_s_tile(blockIdx.x, p.nrowblk, p.ncolblk, p.xcd_rows, p.ncol_grid, rb, cb)) return;
     }
     const int row0 = rb * TM;
     const int sel = p.sel ? p.sel[(size_t)(row0 / p.rows_per_env) * p.sel_stride] : 0;

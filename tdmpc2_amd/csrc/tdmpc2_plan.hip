@@ -634,6 +634,7 @@ __global__ void k_copy_pad(const float *src, int n, int npad, float *dst) {
 
 #include "fused_kernels.cuh"
 #include "cluster_kernels.cuh"
+#include "tile_order.h"
 #include "layered_kernels.cuh"
 #include "layered_split.cuh"
 #include "encoder_kernels.cuh"
