@@ -126,10 +126,8 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             // no padding of the row-major order
             static const int xcd_rows_env = getenv("TDMPC2_GEMM_XCD_ROWS") ? atoi(getenv("TDMPC2_GEMM_XCD_ROWS")) : -1;
             static const int col_pad_env = getenv("TDMPC2_GEMM_COL_PAD") ? atoi(getenv("TDMPC2_GEMM_COL_PAD")) : 1;
-            // (TDMPC2_GEMM_XCD_COLS = 2 | 4, read per call so that one process can A/B it: a row block on 2 / 4 XCDs, tile_order.h)
-            const char *xc_env = getenv("TDMPC2_GEMM_XCD_COLS");
-            const GemmSOrder ord = gemm_s_order(nrowblk, q.ncolblk, xcd_rows_env, col_pad_env, xc_env ? atoi(xc_env) : 0);
-            q.xcd_rows = ord.xcd_rows; q.ncol_grid = ord.ncol_grid; q.nrowblk = nrowblk; q.xcd_cols = ord.xcd_cols;
+            const GemmSOrder ord = gemm_s_order(nrowblk, q.ncolblk, xcd_rows_env, col_pad_env);
+            q.xcd_rows = ord.xcd_rows; q.ncol_grid = ord.ncol_grid; q.nrowblk = nrowblk;
             nblk = ord.nblk;
         }
         // The throughput tile stages its row operand TWO chunks ahead (same sums; 242 VGPRs in the main loop instead of 226, the

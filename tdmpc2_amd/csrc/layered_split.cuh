@@ -42,7 +42,7 @@ struct GemmSParams {
     unsigned int *err;         // the handle's host-mapped error word (bounded wait gave up)
     int fault;                 // test hook (TDMPC2_CLUSTER_FAULT at create): column block 0 of row block 0 never arrives
     // EPI != 0: the tile order (tile_order.h: gemm_s_order / gemm_s_tile)
-    int xcd_rows, nrowblk, ncol_grid, xcd_cols;
+    int xcd_rows, nrowblk, ncol_grid;
 };
 
 constexpr int GLN_MAXSPIN = 1 << 20;  // x s_sleep(2) ~ 0.1 s: peers of a row block are dispatched back to back
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     if (EPI == 0) {
         gemm_tile_of_block(blockIdx.x, gridDim.x, p.ncolblk, rb, cb);
     } else {  // tile_order.h: XCD-local row blocks, or (padded) row-major
-        if (!gemm_s_tile(blockIdx.x, p.nrowblk, p.ncolblk, p.xcd_rows, p.ncol_grid, rb, cb, p.xcd_cols)) return;
+        if (!gemm_s_tile(blockIdx.x, p.nrowblk, p.ncolblk, p.xcd_rows, p.ncol_grid, rb, cb)) return;
     }
     const int row0 = rb * TM;
     const int sel = p.sel ? p.sel[(size_t)(row0 / p.rows_per_env) * p.sel_stride] : 0;

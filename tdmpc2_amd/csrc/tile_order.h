@@ -16,24 +16,13 @@
 
 struct GemmSOrder {
     int xcd_rows;   // 1: XCD-local row blocks
-    int xcd_cols;   // with xcd_rows: XCDs a row block's column blocks are spread over (1: all on one XCD; 2 / 4: see below)
     int ncol_grid;  // row-major: blocks per row of the grid (>= ncolblk, a multiple of 8 when padded); 0 with xcd_rows
     int nblk;       // workgroups to launch
 };
 
 // The rule (measured: profiles/README.md r3v, r3u, r3s).  `force_xcd_rows` / `col_pad`: -1 = automatic, 0 / 1 = never / always.
-// `split_cols` = g in {2, 4} (experimental, off by default): launches with ncolblk a multiple of 8 and >= 64 row blocks put a row
-// block on g XCDs (ncolblk / g column blocks each) and give an XCD the row blocks of one of 8 / g groups -- fabric-side reads
-// A * g + W * 8 / g per round instead of A * 8 + W (row-major) or A + W * 8 (g = 1).
-__host__ __device__ inline GemmSOrder gemm_s_order(int nrowblk, int ncolblk, int force_xcd_rows = -1, int col_pad = 1, int split_cols = 0) {
+__host__ __device__ inline GemmSOrder gemm_s_order(int nrowblk, int ncolblk, int force_xcd_rows = -1, int col_pad = 1) {
     GemmSOrder o;
-    o.xcd_cols = 1;
-    if ((split_cols == 2 || split_cols == 4) && force_xcd_rows != 0 && ncolblk % 8 == 0 && nrowblk >= 64) {
-        o.xcd_rows = 1; o.xcd_cols = split_cols; o.ncol_grid = 0;
-        const int nrg = 8 / split_cols;
-        o.nblk = 8 * ((nrowblk + nrg - 1) / nrg) * (ncolblk / split_cols);
-        return o;
-    }
     // Row-major puts block rb * ncolblk + cb on XCD (rb * ncolblk + cb) % 8.  With ncolblk a multiple of 8 (317M model: 16) an
     // XCD only ever sees column blocks x and x + 8 -- 1/8 of the weights, every A row.  Otherwise (48M: 7; SimNorm layers: 3, 6)
     // it sees every column block and nearly every row block; XCD-local row blocks then read each A row through ONE L2.
@@ -52,16 +41,7 @@ __host__ __device__ inline GemmSOrder gemm_s_order(int nrowblk, int ncolblk, int
 }
 
 // Block b -> (row block, column block); false: the block has no tile (padding) and leaves at once.
-__host__ __device__ inline bool gemm_s_tile(int b, int nrowblk, int ncolblk, int xcd_rows, int ncol_grid, int &rb, int &cb, int xcd_cols = 1) {
-    if (xcd_rows && xcd_cols > 1) {  // XCD x = (row group x % nrg, column group x / nrg); its t-th workgroup: the group's column block
-        const int x = b & 7, t = b >> 3;  // t % cpl of the group's row block t / cpl
-        const int nrg = 8 / xcd_cols, cpl = ncolblk / xcd_cols;
-        const int xr = x % nrg, xc = x / nrg;
-        const int rbl = t / cpl;
-        cb = xc * cpl + (t - rbl * cpl);
-        rb = rbl * nrg + xr;
-        return rb < nrowblk;
-    }
+__host__ __device__ inline bool gemm_s_tile(int b, int nrowblk, int ncolblk, int xcd_rows, int ncol_grid, int &rb, int &cb) {
     if (xcd_rows) {  // XCD x's t-th workgroup: column block t % ncolblk of row block (t / ncolblk) * 8 + x
         const int x = b & 7, t = b >> 3;
         const int rbl = t / ncolblk;

@@ -21,12 +21,12 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = r"""
 #include "tile_order.h"
-extern "C" void order(int nrowblk, int ncolblk, int force_xcd_rows, int col_pad, int split_cols, int *out) {
-    const GemmSOrder o = gemm_s_order(nrowblk, ncolblk, force_xcd_rows, col_pad, split_cols);
-    out[0] = o.xcd_rows; out[1] = o.ncol_grid; out[2] = o.nblk; out[3] = o.xcd_cols;
+extern "C" void order(int nrowblk, int ncolblk, int force_xcd_rows, int col_pad, int *out) {
+    const GemmSOrder o = gemm_s_order(nrowblk, ncolblk, force_xcd_rows, col_pad);
+    out[0] = o.xcd_rows; out[1] = o.ncol_grid; out[2] = o.nblk;
 }
-extern "C" int tile(int b, int nrowblk, int ncolblk, int xcd_rows, int ncol_grid, int xcd_cols, int *rb, int *cb) {
-    return gemm_s_tile(b, nrowblk, ncolblk, xcd_rows, ncol_grid, *rb, *cb, xcd_cols) ? 1 : 0;
+extern "C" int tile(int b, int nrowblk, int ncolblk, int xcd_rows, int ncol_grid, int *rb, int *cb) {
+    return gemm_s_tile(b, nrowblk, ncolblk, xcd_rows, ncol_grid, *rb, *cb) ? 1 : 0;
 }
 """
 
@@ -42,13 +42,10 @@ def lib(tmp_path_factory):
     return ctypes.CDLL(str(so))
 
 
-def order(lib, nrowblk, ncolblk, force=-1, col_pad=1, split=0):
-    out = (ctypes.c_int * 4)()
-    lib.order(nrowblk, ncolblk, force, col_pad, split, out)
-    o = {"xcd_rows": out[0], "ncol_grid": out[1], "nblk": out[2]}
-    if out[3] != 1:
-        o["xcd_cols"] = out[3]
-    return o
+def order(lib, nrowblk, ncolblk, force=-1, col_pad=1):
+    out = (ctypes.c_int * 3)()
+    lib.order(nrowblk, ncolblk, force, col_pad, out)
+    return {"xcd_rows": out[0], "ncol_grid": out[1], "nblk": out[2]}
 
 
 def tiles(lib, nrowblk, ncolblk, o):
@@ -56,7 +53,7 @@ def tiles(lib, nrowblk, ncolblk, o):
     rb, cb = ctypes.c_int(), ctypes.c_int()
     res = []
     for b in range(o["nblk"]):
-        if lib.tile(b, nrowblk, ncolblk, o["xcd_rows"], o["ncol_grid"], o.get("xcd_cols", 1), ctypes.byref(rb), ctypes.byref(cb)):
+        if lib.tile(b, nrowblk, ncolblk, o["xcd_rows"], o["ncol_grid"], ctypes.byref(rb), ctypes.byref(cb)):
             res.append((b, rb.value, cb.value))
     return res
 
@@ -107,27 +104,3 @@ def test_the_rule_is_the_measured_one(lib):
     assert order(lib, 24, 7)["ncol_grid"] == 7 and order(lib, 16, 14, col_pad=0)["ncol_grid"] == 14
     # the switches
     assert order(lib, 120, 7, force=0)["xcd_rows"] == 0 and order(lib, 8, 16, force=1)["xcd_rows"] == 1
-
-
-@pytest.mark.parametrize("g", [2, 4])
-@pytest.mark.parametrize("nrowblk,ncolblk", [(64, 16), (65, 16), (512, 16), (120, 8), (64, 32)])
-def test_a_row_block_on_g_xcds(lib, nrowblk, ncolblk, g):
-    """The experimental split (TDMPC2_GEMM_XCD_COLS): every tile once; a row block's column blocks sit on exactly g XCDs, ncolblk / g
-    consecutive ones in each of those XCDs' dispatch orders; an XCD walks its row blocks in order."""
-    o = order(lib, nrowblk, ncolblk, split=g)
-    assert o["xcd_rows"] == 1 and o["xcd_cols"] == g
-    t = tiles(lib, nrowblk, ncolblk, o)
-    assert sorted((rb, cb) for _, rb, cb in t) == [(r, c) for r in range(nrowblk) for c in range(ncolblk)]
-    by_rb = {}
-    for b, rb, cb in t:
-        by_rb.setdefault(rb, {}).setdefault(b % 8, []).append(b // 8)
-    for rb, per_xcd in by_rb.items():
-        assert len(per_xcd) == g
-        for local in per_xcd.values():
-            local.sort()
-            assert local == list(range(local[0], local[0] + ncolblk // g))
-    for x in range(8):
-        seq = [rb for b, rb, _ in t if b % 8 == x]
-        assert seq == sorted(seq)
-    # not applicable (falls back to the rule) when the column blocks do not split over 8 XCDs or the launch is small
-    assert "xcd_cols" not in order(lib, 120, 7, split=g) and "xcd_cols" not in order(lib, 8, 16, split=g)
