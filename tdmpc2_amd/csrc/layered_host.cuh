@@ -130,15 +130,11 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             q.xcd_rows = ord.xcd_rows; q.ncol_grid = ord.ncol_grid; q.nrowblk = nrowblk;
             nblk = ord.nblk;
         }
-        // The throughput tile stages its row operand TWO chunks ahead (same sums; 242 VGPRs in the main loop instead of 226, the
-        // epilogue's 255 are the kernel's maximum either way): c3 +0.4 ... 0.7 %, c4 +0.5 % in three same-call A/Bs (profiles/README.md
-        // r3z / r3y).  TDMPC2_GEMM_WIDE_SD=1: one chunk ahead; TDMPC2_GEMM_WIDE_PF=3: one chunk ahead with the weight ring three
-        // k16-blocks deep instead (+0.3 ... 0.5 %; both together do not fit the register file).
-        static const int wide_sd = getenv("TDMPC2_GEMM_WIDE_SD") ? atoi(getenv("TDMPC2_GEMM_WIDE_SD")) : 2;
-        static const int wide_pf = getenv("TDMPC2_GEMM_WIDE_PF") ? atoi(getenv("TDMPC2_GEMM_WIDE_PF")) : 2;
-        if (wide && wide_pf == 3) GEMM_S_LAUNCH_PF(2, 4, 1, 3);
-        else if (wide && wide_sd == 2) GEMM_S_LAUNCH(2, 4, 2);
-        else if (wide) GEMM_S_LAUNCH(2, 4, 1);
+        // The throughput tile stages its row operand TWO chunks ahead (g_gemm_s<2, 4, 2, ..>: same sums; 242 VGPRs in the main loop
+        // instead of 226, the epilogue's 255 are the kernel's maximum either way): c3 +0.4 ... 0.7 %, c4 +0.5 % over one chunk ahead
+        // in three same-call A/Bs; a weight ring three k16-blocks deep instead (template parameter PF = 3) bought +0.3 ... 0.5 %, and
+        // both together do not fit the register file (profiles/README.md r3z / r3y / r3x).  Only the adopted variant is instantiated.
+        if (wide) GEMM_S_LAUNCH(2, 4, 2);
         else if (deep && rt == 4) GEMM_S_LAUNCH(1, 4, 4);
         else if (deep && rt == 2) GEMM_S_LAUNCH(1, 2, 4);
         else if (deep) GEMM_S_LAUNCH(1, 1, 4);

@@ -43,7 +43,7 @@ if has pmc_layered; then  # the layered family's GEMMs at the c3 / c4 geometry o
   grep -A3 "g_gemm_s<2, 4, 1, 1>  workgroups=840\|g_gemm_s<2, 4, 1, 1>  workgroups=1024" gpurun_out/${TAG}_c3_pmc.txt gpurun_out/${TAG}_c4_pmc.txt | head -20
   rm -rf gpurun_out/pmc_${TAG}_c3/*/ gpurun_out/pmc_${TAG}_c4/*/ 2>/dev/null
 fi
-if has ab; then  # environment-switch A/B of the in-tree library (interleaved twice), e.g. AB_SPEC="c3 30 8" AB_ENVS="A=0|TDMPC2_GEMM_WIDE_SD=2"
+if has ab; then  # environment-switch A/B of the in-tree library (interleaved twice), e.g. AB_SPEC="c3 30 8" AB_ENVS="A=0|TDMPC2_GEMM_XCD_ROWS=0"
   IFS='|' read -r -a ABE <<< "${AB_ENVS:-A=0}"
   bash tools/gpu_env_ab.sh ${TAG} "${AB_SPEC:-c3 30 8}" "${ABE[@]}" > /dev/null
   cat gpurun_out/${TAG}_ab.txt
