@@ -2286,6 +2286,7 @@ int tdmpc2_plan_take_fault(tdmpc2_plan_t *h, int *faults) {
     ENTER(h);
     if (h->cl_err_host && *(volatile unsigned int *)h->cl_err_host) {
         *(volatile unsigned int *)h->cl_err_host = 0;
+        if (h->in_shard) ((volatile unsigned int *)h->cl_err_host)[4] = 1;  // (asked in the middle of a sharded plan: its final pick still says so)
         h->cluster_mode = 0;
         h->lay.fuse_ln = false;
         h->faults++;
