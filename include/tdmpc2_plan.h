@@ -289,7 +289,12 @@ int tdmpc2_plan_refit(tdmpc2_plan_t *h, int n_envs, float *value, const float *a
  * [row_begin, row_end) (a multiple of 64 rows, FUSED, or 128, LAYERED) writing value[E, N] at those rows only, then the
  * HOST all-gathers the value slices (RCCL, N * 4 bytes per plan), then shard_refit on the complete value[E, N]
  * (tdmpc2.py:184-197; at iter == iterations - 1 also the final pick, tdmpc2.py:199-206).  With one rank and the full row
- * range the three calls compute what tdmpc2_plan_run computes.  tdmpc2_amd/dist.py: sharded_plan. */
+ * range the three calls compute what tdmpc2_plan_run computes.  tdmpc2_amd/dist.py: sharded_plan.
+ * Faults: a bounded inter-workgroup wait that gave up in ANY of the plan's calls makes the final pick return NaN actions and
+ * keep prev_mean (every call consumes the handle's error word, so the library keeps a second, sticky word per plan in flight);
+ * tdmpc2_plan_take_fault after a sync reports it, and every rank has to plan the step again (dist.sharded_plan all-reduces the
+ * verdict).  The sticky word is written by the host: synchronise with the final shard_refit (the caller needs its action
+ * anyway) before the next shard_begin on the same handle. */
 int tdmpc2_plan_shard_begin(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *task_emb, const float *act_mask,
                             const float *prev_mean, const uint8_t *t0, const tdmpc2_noise *tape, uint64_t seed, void *stream);
 int tdmpc2_plan_shard_values(tdmpc2_plan_t *h, int n_envs, int iter, int row_begin, int row_end, const float *z0,
