@@ -197,6 +197,90 @@ def test_plan_sharded_over_two_ranks_is_bit_identical_to_one_rank(tmp_path):
     assert torch.allclose(a[0], wa, atol=1e-5) and torch.allclose(prev[0], wpm, atol=1e-5)
 
 
+class FaultyShardBackend(OracleShardBackend):
+    """The stand-in with NativePlanner's fault interface: on `faulty_rank` the first attempt's value slice is garbage (what a
+    bounded inter-workgroup wait that gave up leaves behind) and take_fault() reports it once; set_fuse_ln(0) -- which
+    sharded_plan calls on EVERY rank before it re-plans -- switches to the kernels that cannot fault."""
+
+    def __init__(self, case, faulty):
+        super().__init__(case)
+        self.faulty, self.fused, self.pending, self.counter, self.log = faulty, True, 0, 7, []
+
+    def shard_begin(self, *a, **kw):
+        self.log.append(("begin", self.counter, self.fused))
+        self.counter += 1
+        return super().shard_begin(*a, **kw)
+
+    def shard_values(self, it, r0, r1, z0, disc_pow, value, **kw):
+        super().shard_values(it, r0, r1, z0, disc_pow, value, **kw)
+        if self.faulty and self.fused and it == 1:
+            value[0, r0:r1] = 123.0
+            self.pending += 1
+
+    def take_fault(self):
+        n, self.pending = self.pending, 0
+        return n
+
+    def call_counter(self):
+        return self.counter
+
+    def set_call_counter(self, v):
+        self.counter = int(v)
+
+    def set_fuse_ln(self, on):
+        self.fused = bool(on)
+
+    def set_cluster(self, mode):
+        pass
+
+
+def _fault_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import cases
+        from tdmpc2_amd.dist import sharded_plan
+
+        c = cases.build_case("tiny")
+        be = FaultyShardBackend(c, faulty=(rank == 1))
+        prev = torch.as_tensor(c["prev_mean"][:1]).clone()
+        tape = {k: v[:1] for k, v in c["tape"].items()}
+        a = sharded_plan(be, torch.as_tensor(c["z0"][:1]), None, prev, torch.tensor([0], dtype=torch.uint8), tape=tape, seed=3)
+        torch.save({"action": a, "prev_mean": prev, "retries": torch.tensor(be.last_shard_retries),
+                    "log": be.log, "fused": be.fused}, os.path.join(out_dir, f"fault{rank}.pt"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_fault_on_one_rank_makes_every_rank_replan_once(tmp_path):
+    """dist.sharded_plan: rank 1's slice of iteration 1 is garbage and only rank 1 knows.  The verdict is all-reduced, BOTH
+    ranks switch kernels, restore prev_mean and the Philox call counter and plan the step again; the result is the plan of a
+    run that never faulted."""
+    from oracle import cases
+    from tdmpc2_amd.dist import sharded_plan
+
+    mp.spawn(_fault_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "fault0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "fault1.pt", weights_only=False)
+    assert int(r0["retries"]) == 1 and int(r1["retries"]) == 1
+    assert not r0["fused"] and not r1["fused"]
+    # two attempts on each rank, the second with the first one's call counter and the safe kernels
+    for r in (r0, r1):
+        assert [e[0] for e in r["log"]] == ["begin", "begin"]
+        assert r["log"][0][1] == r["log"][1][1] and r["log"][0][2] and not r["log"][1][2]
+    assert r0["log"][0][1] == r1["log"][0][1]  # (rank 0's counter, adopted by rank 1)
+    assert torch.equal(r0["action"], r1["action"]) and torch.equal(r0["prev_mean"], r1["prev_mean"])
+    c = cases.build_case("tiny")
+    be = FaultyShardBackend(c, faulty=False)
+    prev = torch.as_tensor(c["prev_mean"][:1]).clone()
+    tape = {k: v[:1] for k, v in c["tape"].items()}
+    a = sharded_plan(be, torch.as_tensor(c["z0"][:1]), None, prev, torch.tensor([0], dtype=torch.uint8), tape=tape, seed=3)
+    assert be.last_shard_retries == 0
+    assert torch.equal(a, r0["action"]) and torch.equal(prev, r0["prev_mean"])
+
+
 def test_sharded_plan_rejects_ragged_splits():
     from oracle import cases
     from tdmpc2_amd.dist import sharded_plan
