@@ -41,6 +41,9 @@ CASES = {
     "c2_i6": ("c2", dict(iterations=4), 2, False, 0.06),
     # episodic (termination head) at the dog-run dims: A = 38 exercises the 48-column action padding of the fused family
     "c2_ep": ("c2", dict(iterations=2, episodic=True), 1, False, 0.06),
+    # fatter pins of the large models: the benched c4 leg runs 6 CEM iterations, "c4" pins two of them
+    "c3_x4": ("c3", {}, 4, False, 0.03),                # mt30 48M, four plans (tasks 3, 10, 17, 24), 6 iterations
+    "c4_x2": ("c4", {}, 2, False, 0.02),                # mt80 317M, two plans x the full 6 iterations, H5 N1024
 }
 
 
@@ -51,7 +54,7 @@ def build_case(name: str):
 
 def build_custom(cfg, E: int, eval_mode: bool = False, head_std: float = 0.06, name: str = "", t0=None):
     """A case from an arbitrary config (edge-case tests build these on the fly; no golden fixture)."""
-    if cfg.multitask and name in ("tiny_mt", "small_mt", "c3", "c4", "c4_l1024"):
+    if cfg.multitask and name in ("tiny_mt", "small_mt", "c3", "c4", "c4_l1024", "c3_x4", "c4_x2"):
         # heterogeneous action dims / episode lengths to exercise masks and per-task discounts
         n = len(cfg.tasks)
         cfg.action_dims = [cfg.action_dim - (i % 3) for i in range(n)]

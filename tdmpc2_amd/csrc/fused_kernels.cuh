@@ -43,29 +43,7 @@
 enum { T_KLOOP = 0, T_EPI = 1, T_HEAD = 2, T_ACT = 3, T_PARK = 4, T_TILE = 5, T_EPI_PRE = 6, T_EPI_SYNC = 7, T_EPI_BIAS = 8,
        T_EPI_COMB = 9, T_EPI_MATH = 10, T_CL_WAIT = 11 };
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-// Scale of bounded operands (SimNorm latents in [0, 1], actions in [-1, 1]) and the LARGEST scale of a hidden activation.
-// A hidden layer's own scale is chosen at bind time from its LayerNorm affine parameters (k_ascale: the largest power
-// of two <= 2^5 that keeps |Mish(LayerNorm(.))| * scale below the f16 maximum for ANY input), so that a checkpoint with a
-// huge LayerNorm gain cannot overflow the hi piece into Inf -> NaN -> nan_to_num(0).  The consuming layer's output
-// scale (LayerS::oscale) carries the matching 2^-(kw + log2 scale_in).
-constexpr float ACT_SCALE = 32.f;  // 2^5
-constexpr int ACT_SCALE_LOG2 = 5;
-
-struct LayerS {
-    const _Float16 *wp;  // split: packed [CT][KB16][2 planes][64 lanes][8] f16; exact fp32: [CT][KB8][64 lanes][4] fp32
-    const float *bias;   // [CT*32] zero padded
-    const float *g, *b;  // LayerNorm affine (null for plain output layers)
-    const float *oscale; // device scalar: 2^-(kw + log2 of the input's scale) (split) or 1 (exact fp32)
-    const float *ascale; // device scalar: scale of THIS layer's output in operand form (split: 2^ka <= 32; exact fp32: 1)
-    int KB;              // k-blocks: of 16 (split) or of 8 (exact fp32)
-    int CT;
-};
-struct NetS {
-    LayerS l[3];
-};
 
 // The action padding (16, 32, 48 or 64 columns) is a template parameter: with compile-time row strides every LDS
 // address of the unrolled epilogues is base + immediate; with a run-time stride the compiler pre-computes hundreds of
@@ -136,16 +114,6 @@ __device__ __forceinline__ void split4(const f32x4 y, f16x4 &hi, f16x4 &lo, cons
     }
 }
 
-// Two standard normals from ONE Philox4x32-10 call (Box-Muller, both branches) with the hardware log / sin / cos:
-// the sampled distribution only has to be N(0,1) to sampling accuracy (fast mode; parity runs replay a noise tape).
-__device__ __forceinline__ void rng_normal2(unsigned long long seed, unsigned call, int site, int iter, int env, unsigned pair,
-                                            float &n0, float &n1) {
-    const uint4 r = rng_raw(seed, call, site, iter, env, pair);
-    const float u1 = u01(r.x), u2 = u01(r.y);
-    const float rad = __builtin_amdgcn_sqrtf(-2.f * __logf(u1));
-    n0 = rad * __builtin_amdgcn_cosf(u2);  // v_cos_f32 / v_sin_f32 take the angle in revolutions
-    n1 = rad * __builtin_amdgcn_sinf(u2);
-}
 
 // ---------------------------------------------------------------- contraction loops
 // v_mfma_f32_32x32x16_f16: lane l supplies A[i = l & 31][k = 8 (l >> 5) .. +7] and B[k = 8 (l >> 5) .. +7][j = l & 31].
@@ -1606,105 +1574,3 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_value(ValueParamsT<NetS> p) {
     }
 }
 
-// beff_tab[task][net][WIDTH] = b + W[:, L:L+T] . task_emb[task] for the policy and the Q heads (online or target):
-// the per-task effective first-layer biases ks_value indexes per row.  grid = n_tasks, block = WIDTH threads.
-struct TaskBiasParams {
-    int T, nq, nnets;
-    const float *task_emb;            // [n_tasks, T] (max_norm renorm applied by the caller, world_model.py:21)
-    const float *wemb[3 + MAXQ];      // [WIDTH][T] per net slot (null: skipped)
-    const float *bias[3 + MAXQ];      // [WIDTH]
-    float *beff_tab;
-};
-__global__ void ks_task_bias(TaskBiasParams p) {
-    const int task = blockIdx.x, f = threadIdx.x;
-    const float *emb = p.task_emb + (size_t)task * p.T;
-    for (int net = 0; net < p.nnets; ++net) {
-        if (!p.wemb[net]) continue;
-        const float *w = p.wemb[net] + (size_t)f * p.T;
-        float sacc = 0.f;
-        for (int k = 0; k < p.T; ++k) sacc = fmaf(w[k], emb[k], sacc);
-        p.beff_tab[((size_t)task * p.nnets + net) * WIDTH + f] = p.bias[net][f] + sacc;
-    }
-}
-
-// ================================================================ weight scaling + packing
-// max |W| of one matrix -> bits (atomicMax on the uint pattern of a non-negative float is order preserving)
-__global__ void k_absmax(const float *W, size_t n, unsigned int *out) {
-    float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float a = fabsf(W[i]);
-        if (a == a && a < INFINITY) m = fmaxf(m, a);
-    }
-    m = group_max<64>(m);
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
-}
-// Per-layer scalars of the split arithmetic, device resident (one record per layer and ensemble member).
-struct LayerScal {
-    float wscale;          // 2^kw: applied to the weights when they are packed
-    float oscale;          // 2^-(kw + log2 of the INPUT's operand scale): applied to the fp32 accumulator
-    unsigned int maxbits;  // max |W| as bits (k_absmax)
-    int kw;
-    float ascale;          // 2^ka: operand scale of this layer's OUTPUT (hidden layers; <= ACT_SCALE)
-    int ka;
-    unsigned int gmax, bmax;  // max |LayerNorm weight|, max |LayerNorm bias| as bits
-};
-// kw such that max|W| 2^kw in [2^13, 2^14); wscale = 2^kw (for packing)
-__global__ void k_wscale(LayerScal *s) {
-    const float m = __uint_as_float(s->maxbits);
-    int ex = 0;
-    if (m > 0.f) frexpf(m, &ex);  // m = f 2^ex, f in [0.5, 1)
-    int kw = 14 - ex;
-    kw = kw > 40 ? 40 : (kw < -40 ? -40 : kw);
-    s->kw = kw;
-    s->wscale = ldexpf(1.f, kw);
-}
-// Output scale of a LayerNorm + Mish layer of `width` features: |LayerNorm(x)_i| <= sqrt(width - 1) for any x, so
-// |Mish(g x + b)| <= sqrt(width - 1) max|g| + max|b| =: B.  ka = the largest exponent <= 5 with B 2^ka < 2^15 (half of
-// the f16 maximum: rounding of the hi piece cannot reach Inf).  Trained checkpoints (g ~ 1) keep ka = 5.
-__global__ void k_ascale(LayerScal *s, int width, int has_ln) {
-    int ka = ACT_SCALE_LOG2;
-    if (has_ln) {
-        const float bound = sqrtf((float)(width > 1 ? width - 1 : 1)) * __uint_as_float(s->gmax) + __uint_as_float(s->bmax);
-        if (bound > 0.f) {
-            int ex = 0;
-            frexpf(bound, &ex);  // bound < 2^ex
-            ka = 15 - ex < ka ? 15 - ex : ka;
-        }
-        ka = ka < -24 ? -24 : ka;
-    }
-    s->ka = ka;
-    s->ascale = ldexpf(1.f, ka);
-}
-// oscale of the three layers of one net: layer 0 reads [z | a] (scale 2^5), layer l > 0 reads layer l - 1's output
-__global__ void k_net_scales(LayerScal *s3) {
-    for (int l = 0; l < 3; ++l) {
-        const int kin = l == 0 ? ACT_SCALE_LOG2 : s3[l - 1].ka;
-        s3[l].oscale = ldexpf(1.f, -(s3[l].kw + kin));
-    }
-}
-// dst[ct][kb][plane][lane][e]: W[row = ct*32 + (lane & 31)][k = kb*16 + 8 (lane >> 5) + e] * wscale, hi / lo pieces;
-// packed k axis [z columns (nz) | action columns (na, zero padded)], source columns [z | task_emb (nt) | action].
-__global__ void k_pack_split(const float *W, int out, int in, int nz, int nt, int na, int CT, int KB, const float *wscale,
-                             _Float16 *dst) {
-    const size_t total = (size_t)CT * KB * 512;  // (lane, e) pairs per (ct, kb)
-    const float sc = *wscale;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int e = idx & 7, lane = (idx >> 3) & 63;
-        const size_t blk = idx >> 9;
-        const int kb = blk % KB, ct = blk / KB;
-        const int row = ct * 32 + (lane & 31);
-        const int k = kb * 16 + 8 * (lane >> 5) + e;
-        float v = 0.f;
-        if (row < out) {
-            int src = -1;
-            if (k < nz) src = k;
-            else if (k - nz < na) src = nz + nt + (k - nz);
-            if (src >= 0 && src < in) v = W[(size_t)row * in + src] * sc;
-        }
-        const _Float16 h = (_Float16)v;
-        const _Float16 l = (_Float16)(v - (float)h);
-        _Float16 *base = dst + blk * 1024;  // 2 planes x 64 lanes x 8
-        base[lane * 8 + e] = h;
-        base[512 + lane * 8 + e] = l;
-    }
-}

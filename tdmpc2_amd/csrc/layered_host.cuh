@@ -1,14 +1,7 @@
-// Host orchestration of the layer-at-a-time planner path (kernels: layered_kernels.cuh).
-// Included by tdmpc2_plan.hip inside its anonymous namespace, after `struct tdmpc2_plan`.
+// Host orchestration of the layer-at-a-time planner path (kernels: layered_kernels.cuh, layered_split.cuh).
+// Included by k_layered.hip inside namespace tdk (the functions declared in launch.h are the family's interface).
 #pragma once
 
-#define LAUNCH_CHECK()                                                                       \
-    do {                                                                                     \
-        hipError_t _e = hipGetLastError();                                                   \
-        if (_e != hipSuccess) return fail(TDMPC2_ERR_HIP, "launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
-    } while (0)
-
-inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
 // LayerNorm + activation fused into the GEMM's epilogue (g_gemm_s<.., EPI>, split arithmetic): which NormedLinear's
 // LayerNorm parameters / output scale, and whether the activation is Mish (0) or SimNorm (1).
@@ -267,7 +260,7 @@ int lay_twohot(tdmpc2_plan *h, hipStream_t st, size_t rows, int rpe, int mode, i
 }
 
 int lay_setup(tdmpc2_plan *h, hipStream_t st, int E, const float *task_emb, const float *prev_mean, const unsigned char *t0,
-              bool init_dist, float *beff_out = nullptr, const HostNet *qarr = nullptr) {
+              bool init_dist, float *beff_out, const HostNet *qarr) {
     const tdmpc2_plan_cfg &c = h->cfg;
     if (!c.multitask && !init_dist) return 0;
     if (!qarr) qarr = h->q;
@@ -312,8 +305,7 @@ int lay_cvec(tdmpc2_plan *h, hipStream_t st, int E, const float *z0) {
 // TDMPC2._estimate_value (tdmpc2/tdmpc2.py:122-136) for E plans with the step actions in `actions` [E,H,N,A].
 int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float *act_mask, const float *disc_pow,
                        const float *actions, const float *pi_eps, long pi_eps_estride, const int *qidx /* dense [E,2] */,
-                       unsigned long long seed, unsigned call, int iter, float *value, float *trace, int n_off = 0,
-                       int n_sub = 0) {
+                       unsigned long long seed, unsigned call, int iter, float *value, float *trace, int n_off, int n_sub) {
     // rows n_off .. n_off + n_sub of every plan (default: all num_samples rows): the sample-row range of one rank when a
     // plan is sharded over GPUs (tdmpc2_plan_shard_values); n_sub is a multiple of the GEMM row tile
     const tdmpc2_plan_cfg &c = h->cfg;
@@ -416,6 +408,29 @@ int lay_pitraj(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const flo
     return 0;
 }
 
+// One CEM iteration's sampled actions (tdmpc2.py:176-181: rows n >= P of h->actions, every step) and its two Q heads per plan.
+int lay_sample_iteration(tdmpc2_plan *h, hipStream_t st, int E, int iter, const float *act_mask, const tdmpc2_noise *tape,
+                         uint64_t seed, unsigned call, int *qbuf) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    const int H = c.horizon, N = c.num_samples, A = c.action_dim, P = c.num_pi_trajs, I = c.iterations;
+    SampleParams sp{};
+    sp.E = E; sp.H = H; sp.N = N; sp.A = A; sp.P = P; sp.iter = iter; sp.mean = h->mean; sp.std = h->std; sp.mask = act_mask;
+    sp.eps = tape ? tape->sample_eps + (size_t)iter * H * (N - P) * A : nullptr;
+    sp.eps_estride = (long)I * H * (N - P) * A;
+    sp.seed = seed; sp.call = call; sp.actions = h->actions;
+    hipLaunchKernelGGL(l_sample, dim3(1024), dim3(256), 0, st, sp);
+    LAUNCH_CHECK();
+    return lay_set_qidx(h, st, E, tape ? tape->qidx + (size_t)iter * 2 : nullptr, (long)I * 2, c.num_q, iter, seed, call, qbuf);
+}
+
+int lay_set_qidx(tdmpc2_plan *, hipStream_t st, int E, const int *qidx, long stride, int nq, int iter, uint64_t seed, unsigned call,
+                 int *dst) {
+    if (qidx) hipLaunchKernelGGL(l_copy_qidx, dim3((E + 255) / 256), dim3(256), 0, st, E, qidx, stride, dst);
+    else hipLaunchKernelGGL(l_qidx, dim3((E + 255) / 256), dim3(256), 0, st, E, nq, iter, (unsigned long long)seed, call, dst);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 // Everything of TDMPC2._plan after encode() (tdmpc2/tdmpc2.py:154-206) on the layered path.
 int lay_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float *task_emb, const float *act_mask,
             const float *disc_pow, float *prev_mean, const uint8_t *t0, int eval_mode, const tdmpc2_noise *tape,
@@ -430,16 +445,7 @@ int lay_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float 
     int refit_stage = 0;
     const size_t refit_lds = refit_lds_bytes(N, K, H, A, &refit_stage);
     for (int it = 0; it < I; ++it) {
-        SampleParams sp{};
-        sp.E = E; sp.H = H; sp.N = N; sp.A = A; sp.P = P; sp.iter = it; sp.mean = h->mean; sp.std = h->std; sp.mask = act_mask;
-        sp.eps = tape ? tape->sample_eps + (size_t)it * H * (N - P) * A : nullptr;
-        sp.eps_estride = (long)I * H * (N - P) * A;
-        sp.seed = seed; sp.call = call; sp.actions = h->actions;
-        hipLaunchKernelGGL(l_sample, dim3(1024), dim3(256), 0, st, sp);
-        LAUNCH_CHECK();
-        if (tape) hipLaunchKernelGGL(l_copy_qidx, dim3((E + 255) / 256), dim3(256), 0, st, E, tape->qidx + (size_t)it * 2, (long)I * 2, h->lay.qidx);
-        else hipLaunchKernelGGL(l_qidx, dim3((E + 255) / 256), dim3(256), 0, st, E, c.num_q, it, (unsigned long long)seed, call, h->lay.qidx);
-        LAUNCH_CHECK();
+        if ((rc = lay_sample_iteration(h, st, E, it, act_mask, tape, seed, call, h->lay.qidx))) return rc;
         if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
         if ((rc = lay_estimate_value(h, st, E, z0, act_mask, disc_pow, h->actions,
                                      tape ? tape->pi_eps + (size_t)it * N * A : nullptr, (long)I * N * A, h->lay.qidx, seed, call,
@@ -465,8 +471,7 @@ int lay_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float 
             if (dbg->mean) { fp.dbg_mean = dbg->mean + (size_t)it * H * A; fp.dbg_mean_es = (long)I * H * A; }
             if (dbg->std) { fp.dbg_std = dbg->std + (size_t)it * H * A; fp.dbg_std_es = (long)I * H * A; }
         }
-        hipLaunchKernelGGL(k_refit, dim3(E), dim3(refit_threads(N)), refit_lds, st, fp);
-        LAUNCH_CHECK();
+        if ((rc = launch_refit(fp, E, N, refit_lds, st))) return rc;
     }
     return TDMPC2_OK;
 }

@@ -10,11 +10,6 @@
 // defined there).
 #pragma once
 
-constexpr int GBM = 128;          // rows per GEMM workgroup
-constexpr int GBN = 128;          // output columns per GEMM workgroup (4 column tiles of 32)
-constexpr int GBK = 32;           // k-chunk staged through LDS
-constexpr int GLD = GBK + 4;      // LDS row stride in floats (stride/4 = 9, odd -> conflict-free ds_read_b128)
-constexpr int GTHREADS = 256;     // 4 wavefronts: 2 (rows) x 2 (cols), each 64 x 64 = 2x2 MFMA tiles
 
 // out[r, c] = sum_k A[r, k] * W[c, k] + bias(r)[c]          (pre-activation of one nn.Linear)
 #ifndef TDMPC2_GEMM_ROWMAJOR_TILES
@@ -155,7 +150,6 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm(GemmParams p) {
 }
 
 // ---------------------------------------------------------------- row-wise kernels: one wavefront per row
-constexpr int RW_THREADS = 256;  // 4 rows per workgroup
 
 // In place: x <- ACT(LayerNorm(x)) over `width` columns of each row (width % 4 == 0).  ACT 0 Mish, 1 SimNorm(8).
 // Per-plan ensemble member selection for the LayerNorm affine parameters like g_gemm.

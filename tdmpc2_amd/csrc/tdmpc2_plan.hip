@@ -21,581 +21,27 @@
 // Weights are re-packed once (bind) into MFMA fragment order so that a wave's global_load_dwordx4 reads 1 KiB
 // contiguous; one small workgroup per plan does nan_to_num + top-k + score + mean/std refit (+ the final Gumbel pick)
 // between rollout launches (k_refit below).  DESIGN.md has the full account.
-#include <hip/hip_runtime.h>
-
-#include <atomic>
-#include <cmath>
 #include <cstdarg>
-#include <cstdint>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
 #include <new>
-#include <string>
-#include <vector>
 
-#include "../../include/tdmpc2_plan.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "handle.h"
+#include "launch.h"
 
 namespace {
-
-constexpr int ROWS = 64;        // sample rows per rollout workgroup
-constexpr int NTHREADS = 512;   // 8 wavefronts
-constexpr int WIDTH = 512;      // latent_dim == mlp_dim of the fused size class
-constexpr int MAXQ = 8;
-constexpr int MAXH = 8;
-constexpr float LN_EPS = 1e-5f;
-
-// ---------------------------------------------------------------- kernel parameter blocks (NET = NetS, fused_kernels.cuh)
-// elite select + refit (tdmpc2/tdmpc2.py:184-206): refit_plan() below
-struct RefitParams {
-    int E, N, H, A, K, iter, last, eval_mode;
-    int stage;             // elite actions are staged in LDS ([K][H*A] floats after the other arrays): see refit_lds_bytes
-    float temperature, min_std, max_std;
-    float *value;          // [E,N] in/out (nan_to_num)
-    const float *actions;  // [E,H,N,A]
-    const float *act_mask; // [E,A] or null
-    float *mean, *std;     // [E,H,A] out
-    float *score;          // [E,K] out (may be null)
-    int *elite_idx;        // [E,K] out (may be null)
-    // last iteration only
-    const float *gumbel_exp;  // [E,K] or null -> Philox
-    const float *final_eps;   // [E,A] or null -> Philox
-    unsigned long long seed;
-    unsigned int call;
-    float *prev_mean;  // [E,H,A]
-    float *action;     // [E,A]
-    // cluster path: the handle's host-mapped error word (a bounded hand-over wait gave up somewhere in this plan).  When it is
-    // set the plan's numbers are garbage: the final pick then returns NaN actions and leaves prev_mean untouched, so that the
-    // caller can re-plan the same step (tdmpc2_plan_take_fault); null on every other path.
-    const unsigned int *err;
-    // sharded plans (one API call per CEM iteration): the sticky word the host raises when it consumes `err` between two
-    // iterations of the plan in flight -- checked like `err` by the final pick; null on every other path.
-    const unsigned int *err2;
-    // In-launch refit (fused family, ks_rollout's last-arriver epilogue): the elite actions are RE-DERIVED from the
-    // iteration's sampling distribution and noise instead of being read back from `actions` -- the workgroups that sampled
-    // them sit on other XCDs, and shipping 64 x H x A floats per workgroup through write-through stores cost 13 % of the
-    // launch (profiles/README.md r02c).  regen = 1: rows n >= P: clamp(old_mean + old_std * eps) * mask with eps from the tape
-    // slice or Philox (the rollout kernel's own formula and indices); rows n < P: the policy-prior actions written by an
-    // earlier launch.
-    int regen, P, Apad;
-    const float *sample_eps;   // tape slice of this iteration (or null: Philox)
-    long sample_eps_estride;
-    // debug copies (per iteration slices already offset by the host; env stride given)
-    float *dbg_value; long dbg_value_es;
-    int *dbg_idx; long dbg_idx_es;
-    float *dbg_score; long dbg_score_es;
-    float *dbg_mean; long dbg_mean_es;
-    float *dbg_std; long dbg_std_es;
-};
-
-template <class NET>
-struct RolloutParamsT {
-    int E, N, H, A, Apad, P, stride, tiles, nq, num_bins, multitask, given_actions, iter, iters_total;
-    int tile_off;  // first row tile of the range this launch covers (tiles = tiles in the range)
-    int nnets;  // vectors per plan in `beff`
-    float log_std_min, log_std_dif;
-    NET dyn, rew, pi, term;
-    NET q[MAXQ];
-    const float *bins;
-    const float *z0;        // [E,L]
-    const float *beff;      // [E,nnets,WIDTH] effective first-layer biases (multitask) or null
-    const float *cvec;      // [E,2,WIDTH]: z0-part (+bias) of reward / dynamics layer 1
-    const float *act_mask;  // [E,A] or null
-    const float *disc_pow;  // [E,H+1]
-    const float *mean;      // [E,H,A]
-    const float *std;       // [E,H,A]
-    const float *sample_eps;  // tape slice for this iteration: env stride given below
-    long sample_eps_estride;
-    const float *pi_eps;
-    long pi_eps_estride;
-    const int *qidx;
-    long qidx_estride;
-    unsigned long long seed;
-    unsigned int call;
-    float *actions;   // [E,H,N,A]
-    float *value;     // [E,N]
-    float *zscratch;  // [E*tiles,64,WIDTH]
-    float *trace_tiles;    // optional [E*tiles, 5H+7, 64, WIDTH] activations after each phase
-    float *trace_scalars;  // optional [E, N, H+2+A]: r_0..r_{H-1}, Q_a, Q_b, a_H[A]
-    unsigned long long *timing;  // profiling builds (-DSPLIT_TIMING): 16 cycle counters summed over workgroups, else null
-    // elite selection + refit by the last workgroup of each plan to finish (one launch per CEM iteration)
-    int fold_refit;
-    unsigned int *ticket;   // [E] arrival counters, zero between launches
-    RefitParams rf;
-    // cluster path (cluster_kernels.cuh): exchange tiles, arrival words, the handle's error word, per-member z_H scratch
-    float *cl_xbuf;
-    unsigned int *cl_flags;
-    unsigned int *cl_err;
-    float *cl_zs;
-    int cl_fault;              // test hook: member 7 of cluster 0 never signals (the bounded waits must report it)
-    int pi_fold;               // the policy-prior trajectories (tdmpc2.py:154-160) are computed by cluster 0 of each plan in launch 0
-    const float *pi_traj_eps;  // [E,H,P,A] or null (Philox)
-};
-
-// pi + two Q heads on a batch of latent rows (fused_kernels.cuh: ks_value)
-template <class NET>
-struct ValueParamsT {
-    int rows, A, Apad, nq, num_bins, reduce_min;
-    float log_std_min, log_std_dif, discount;
-    NET pi;
-    NET q[MAXQ];
-    const float *bins;
-    const float *z;        // [rows, L]
-    const float *pi_eps;   // [rows, A] or null (Philox)
-    const int *qidx;       // [2] or null (Philox)
-    unsigned long long seed;
-    unsigned int call;
-    const float *reward, *terminated;  // [rows] or null
-    float *action;         // [rows, A] or null
-    float *out;            // [rows]
-    // multitask batches: one task per row
-    int nnets;
-    const int *task_ids;     // [rows] or null (single task)
-    const float *beff_tab;   // [n_tasks, nnets, WIDTH] effective first-layer biases (ks_task_bias)
-    const float *mask_tab;   // [n_tasks, A]
-    const float *disc_tab;   // [n_tasks] or null (scalar `discount`)
-};
-
-// net slots inside `beff`
-enum { BE_DYN = 0, BE_REW = 1, BE_PI = 2, BE_Q0 = 3 };
-
-// ---------------------------------------------------------------- small math
-__device__ __forceinline__ float mish_f(float x) {
-    // x * tanh(softplus(x)) == x * n / (n + 2),  n = e^x (e^x + 2); no cancellation for x << 0.
-    // reference: nn.Mish in NormedLinear, tdmpc2/common/layers.py:103
-    if (x > 20.f) return x;
-    const float e = expf(x);
-    const float n = e * (e + 2.f);
-    return x * (n / (n + 2.f));
-}
-
-__device__ __forceinline__ float symexp_f(float x) {
-    // tdmpc2/common/math.py:50-55: sign(x) * (exp(|x|) - 1)
-    const float m = expf(fabsf(x)) - 1.f;
-    return x > 0.f ? m : (x < 0.f ? -m : 0.f);
-}
-
-// One sampled action (tdmpc2/tdmpc2.py:176-178): (mean + std * r).clamp(-1, 1) with the reference's two roundings (torch
-// does not fuse the multiply-add); used by every kernel that draws or re-derives a sample, so that they agree bit for bit.
-__device__ __forceinline__ float sample_action(float mean, float std, float r) {
-    return fminf(fmaxf(__fadd_rn(mean, __fmul_rn(std, r)), -1.f), 1.f);
-}
-
-template <int W>
-__device__ __forceinline__ float group_sum(float v) {  // sum over aligned groups of W lanes
-#pragma unroll
-    for (int m = 1; m < W; m <<= 1) v += __shfl_xor(v, m);
-    return v;
-}
-template <int W>
-__device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-    for (int m = 1; m < W; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
-    return v;
-}
-
-// ---------------------------------------------------------------- Philox4x32-10 (fast mode RNG)
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-        k.x += 0x9E3779B9u;
-        k.y += 0xBB67AE85u;
-    }
-    return c;
-}
-enum { SITE_PITRAJ = 1, SITE_SAMPLE = 2, SITE_PI = 3, SITE_QIDX = 4, SITE_GUMBEL = 5, SITE_FINAL = 6 };
-
-__device__ __forceinline__ uint4 rng_raw(unsigned long long seed, unsigned call, int site, int iter, int env,
-                                         unsigned idx) {
-    return philox4x32_10(make_uint4(idx, (unsigned)(site | (iter << 8)), (unsigned)env, call),
-                         make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
-}
-__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
-__device__ __forceinline__ float rng_normal(unsigned long long seed, unsigned call, int site, int iter, int env,
-                                            unsigned idx) {
-    const uint4 r = rng_raw(seed, call, site, iter, env, idx);
-    const float u1 = u01(r.x), u2 = u01(r.y);
-    return sqrtf(-2.f * logf(u1)) * cospif(2.f * u2);
-}
-__device__ __forceinline__ float rng_exponential(unsigned long long seed, unsigned call, int site, int iter,
-                                                 int env, unsigned idx) {
-    return -logf(u01(rng_raw(seed, call, site, iter, env, idx).x));
-}
-
-// per-plan setup: (1) effective first-layer biases b + W[:, L:L+T] . task_emb (multitask); (2) cvec = z0-part (+ bias) of
-// the reward / dynamics first layers (all rows share z0 at t = 0, tdmpc2/tdmpc2.py:163); (3) mean / std initialisation
-// and warm start (tdmpc2.py:164-167)
-template <class NET>
-struct SetupParamsT {
-    int E, H, A, T, multitask, nq, nnets, stride;
-    float max_std;
-    NET dyn, rew, pi;
-    NET q[MAXQ];
-    const float *wemb[3 + MAXQ];  // [out=WIDTH][T] task-embedding columns of each first layer
-    const float *z0, *task_emb, *prev_mean;
-    const unsigned char *t0;
-    float *beff, *cvec, *mean, *std;
-    unsigned int *cl_flags;  // cluster path: arrival words, zeroed at the start of every plan ([E][cl_flag_words]) or null
-    int cl_flag_words;
-    int skip_cvec;           // cluster path: no z0 products (cvec unused)
-};
-
-// policy-prior trajectories (tdmpc2/tdmpc2.py:154-160): rows < P of one tile per plan
-template <class NET>
-struct PiTrajParamsT {
-    int E, N, H, A, Apad, P, stride, multitask, nnets;
-    float log_std_min, log_std_dif;
-    NET dyn, pi;
-    const float *z0, *beff, *act_mask;
-    const float *pi_traj_eps;  // [E,H,P,A] or null
-    unsigned long long seed;
-    unsigned int call;
-    float *actions;   // [E,H,N,A]
-    float *zscratch;  // [E,64,WIDTH] (tile 0 of each plan)
-    long zscratch_estride;
-};
-
-// ================================================================ kernel: elite select + refit (struct RefitParams: above)
-// dynamic LDS of the refit; `stage` out: whether the K x H x A elite actions fit next to the rest (they are then gathered
-// by the whole workgroup in one round of loads instead of 2 K dependent global loads per (t, a) thread: 35 -> 12 us)
-inline size_t refit_lds_bytes(int N, int K, int H, int A, int *stage, size_t budget = 48 * 1024) {
-    size_t M = 64;
-    while (M < (size_t)N) M <<= 1;  // sort keys: 8 bytes per padded sample
-    const size_t base = (2 * M + 3 * (size_t)K + 4 * H * A + 48) * 4 + 64;
-    const size_t elite = (size_t)K * H * A * 4;
-    *stage = base + elite <= budget;
-    return *stage ? base + elite : base;
-}
-
-__device__ __forceinline__ void rng_normal2(unsigned long long seed, unsigned call, int site, int iter, int env, unsigned pair,
-                                            float &n0, float &n1);  // fused_kernels.cuh
-
-// block-wide sum / max over `n` floats in LDS: strided thread-local partials, wavefront shuffle reduction, one LDS slot per
-// wave, every thread reads the slots back (fixed order -> deterministic, the same value in every thread)
-__device__ __forceinline__ float block_sum_lds(const float *x, int n, float *slots, int tid, int nthr) {
-    float s = 0.f;
-    for (int i = tid; i < n; i += nthr) s += x[i];
-    s = group_sum<64>(s);
-    __syncthreads();  // slots may still be read from a previous reduction
-    if ((tid & 63) == 0) slots[tid >> 6] = s;
-    __syncthreads();
-    float t = 0.f;
-    for (int w = 0; w < (nthr >> 6); ++w) t += slots[w];
-    return t;
-}
-__device__ __forceinline__ float block_max_lds(const float *x, int n, float *slots, int tid, int nthr) {
-    float s = -INFINITY;
-    for (int i = tid; i < n; i += nthr) s = fmaxf(s, x[i]);
-    s = group_max<64>(s);
-    __syncthreads();
-    if ((tid & 63) == 0) slots[tid >> 6] = s;
-    __syncthreads();
-    float t = -INFINITY;
-    for (int w = 0; w < (nthr >> 6); ++w) t = fmaxf(t, slots[w]);
-    return t;
-}
-
-// Elite selection + refit (+ final pick) of plan `e` by one workgroup of `nthr` threads (a multiple of 64; any N <= 1024).
-// tdmpc2/tdmpc2.py:184-206.  Called by k_refit (one workgroup per plan) and by the last workgroup of a plan to finish
-// its rollouts (ks_rollout, fused family): the elite statistics are wavefront-shuffle reductions.
-// monotone map float -> uint (larger float <-> larger uint) and back; -0.0 has been folded into +0.0 by the caller
-__device__ __forceinline__ unsigned ordered_of(float v) {
-    const unsigned u = __float_as_uint(v);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float float_of_ordered(unsigned o) {
-    return __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);
-}
-#ifdef REFIT_TIMING  // probe builds: thread 0 leaves the cycle count of every phase in score[e][phase] (tools/probes)
-#define RT_MARK(i) { if (tid == 0 && p.score) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); p.score[(size_t)e * p.K + (i)] = (float)(t_ - rt_last); rt_last = t_; } }
-#define RT_INIT unsigned long long rt_last = __builtin_amdgcn_s_memtime();
-#else
-#define RT_MARK(i)
-#define RT_INIT
-#endif
-
-// forceinline: as a real call it takes the ADDRESS of the caller's kernel-argument member (`p.rf`), which makes the compiler
-// copy the caller's whole 2.5 KB argument struct to scratch and read every parameter from there (seen when the inliner's
-// budget ran out in ks_rollout_cl: 1.47 -> 2.1 ms per plan).
-__device__ __forceinline__ void refit_plan(const RefitParams &p, int e, float *smem, int tid, int nthr) {
-    int M = 64;  // sort width: the power of two >= N
-    while (M < p.N) M <<= 1;
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);  // [M] sort keys (or: [N] floats, counting path)
-    float *sv = smem;
-    float *ev = smem + 2 * M;                   // [K]
-    float *sc = ev + p.K;                       // [K]
-    int *ei = reinterpret_cast<int *>(sc + p.K);  // [K]
-    float *smean = reinterpret_cast<float *>(ei + p.K);  // [H*A]
-    float *sstd = smean + p.H * p.A;                     // [H*A]
-    float *slots = sstd + p.H * p.A;                     // [16] per-wave partials + [16] scratch scalars
-    int *s_pick = reinterpret_cast<int *>(slots + 32);
-    float *omean = slots + 48;                           // [H*A] the distribution this iteration sampled from (regen)
-    float *ostd = omean + p.H * p.A;                     // [H*A]
-    float *ea = ostd + p.H * p.A;                        // [K][H*A] elite_actions (tdmpc2.py:186) when staged
-    RT_INIT
-    const bool sorted_path = M <= nthr;  // one key per thread
-    // value.nan_to_num(0): nan -> 0, +-inf -> +-FLT_MAX (tdmpc2.py:184)
-    unsigned long long key = 0ull;  // padding keys sort last
-    for (int i = tid; i < p.N; i += nthr) {
-        // in-launch refit: the values of the plan's other workgroups arrive as write-through stores from other XCDs; read
-        // them with agent-scope (sc1) loads -- past the L1, from lines this XCD's L2 cannot hold yet -- and do NOT
-        // invalidate caches (an agent-scope acquire here, buffer_inv sc1, drops the XCD's L2-resident weights: +13 %)
-        float v = p.regen ? __hip_atomic_load(p.value + (size_t)e * p.N + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                          : p.value[(size_t)e * p.N + i];
-        if (v != v) v = 0.f;
-        else if (v == INFINITY) v = 3.402823466e+38f;
-        else if (v == -INFINITY) v = -3.402823466e+38f;
-        p.value[(size_t)e * p.N + i] = v;
-        if (p.dbg_value) p.dbg_value[(size_t)e * p.dbg_value_es + i] = v;
-        if (sorted_path) key = ((unsigned long long)ordered_of(v + 0.f) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
-        else sv[i] = v;
-    }
-    RT_MARK(0)
-    if (sorted_path) {
-        // torch.topk(..., sorted=True) order (value desc, index asc on ties; tdmpc2.py:185) = descending order of the 64-bit
-        // keys (ordered value | ~index): a bitonic sort with one key per thread -- the 39 of 45 stages (N = 512) whose
-        // partner sits in the same wavefront are register shuffles, the rest go through LDS.
-        for (int k = 2; k <= M; k <<= 1) {
-            const bool desc = (tid & k) == 0;  // this k-block ends up descending (the last level: everyone)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                unsigned long long other;
-                if (j >= 64) {
-                    if (tid < M) keys[tid] = key;
-                    __syncthreads();
-                    other = tid < M ? keys[tid ^ j] : 0ull;
-                    __syncthreads();
-                } else {
-                    const unsigned lo = __shfl_xor((unsigned)key, j), hi = __shfl_xor((unsigned)(key >> 32), j);
-                    other = ((unsigned long long)hi << 32) | lo;
-                }
-                const bool lower = (tid & j) == 0;
-                const bool keep_max = lower == desc;
-                key = keep_max ? (key > other ? key : other) : (key < other ? key : other);
-            }
-        }
-        if (tid < p.K) {
-            ei[tid] = (int)(0xFFFFFFFFu - (unsigned)key);
-            ev[tid] = float_of_ordered((unsigned)(key >> 32));
-        }
-        __syncthreads();
-    } else {
-        __syncthreads();
-        // rank = position in (value desc, index asc) order by counting: every thread compares its value with the whole LDS
-        // array (broadcast reads, no bank conflicts).  Only when N exceeds the workgroup (N = 1024 inside the 512-thread
-        // rollout kernel).
-        for (int i = tid; i < p.N; i += nthr) {
-            const float v = sv[i];
-            int rank = 0;
-            for (int j = 0; j < p.N; j += 4) {
-                const f32x4 u = *reinterpret_cast<const f32x4 *>(sv + j);  // N is a multiple of 64
-#pragma unroll
-                for (int q = 0; q < 4; ++q) rank += (u[q] > v) || (u[q] == v && j + q < i);
-            }
-            if (rank < p.K) {
-                ei[rank] = i;
-                ev[rank] = v;
-            }
-        }
-        __syncthreads();
-    }
-    RT_MARK(1)
-    const float vmax = ev[0];  // max(elite_value)
-    for (int k = tid; k < p.K; k += nthr) sc[k] = expf(p.temperature * (ev[k] - vmax));
-    const float s1 = block_sum_lds(sc, p.K, slots, tid, nthr);
-    for (int k = tid; k < p.K; k += nthr) sc[k] = sc[k] / s1;  // score / score.sum(0)  (tdmpc2.py:191)
-    const float s_ssum = block_sum_lds(sc, p.K, slots, tid, nthr) + 1e-9f;  // score.sum(0) + 1e-9 (tdmpc2.py:192-193)
-    RT_MARK(2)
-    const float *acts = p.actions + (size_t)e * p.H * p.N * p.A;
-    const int HA = p.H * p.A;
-    if (p.regen) {  // (always staged) elite actions re-derived from (old mean, old std, noise): see RefitParams
-        for (int idx = tid; idx < HA; idx += nthr) {
-            omean[idx] = p.mean[(size_t)e * HA + idx];
-            ostd[idx] = p.std[(size_t)e * HA + idx];
-        }
-        __syncthreads();
-        // one work item per PAIR of action columns (a, a + 1): one Philox call yields both normals, as in the rollout
-        const int hp = p.Apad / 2, hpa = (p.A + 1) / 2, per_k = p.H * hpa;
-        for (int idx = tid; idx < p.K * per_k; idx += nthr) {
-            const int k = idx / per_k, rem = idx - k * per_k;
-            const int t = rem / hpa, a0 = 2 * (rem - t * hpa);
-            const int n = ei[k];
-            float v[2] = {0.f, 0.f};
-            if (n < p.P) {  // policy-prior rows: written by ks_pitraj (an earlier launch) or, on the cluster path, by another
-                            // workgroup of THIS launch (agent-scope stores there, agent-scope loads here)
-                v[0] = __hip_atomic_load(acts + ((size_t)t * p.N + n) * p.A + a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a0 + 1 < p.A)
-                    v[1] = __hip_atomic_load(acts + ((size_t)t * p.N + n) * p.A + a0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                float r[2] = {0.f, 0.f};
-                if (p.sample_eps) {
-                    const float *ep = p.sample_eps + (size_t)e * p.sample_eps_estride + (unsigned)(((size_t)t * (p.N - p.P) + (n - p.P)) * p.A + a0);
-                    r[0] = ep[0];
-                    if (a0 + 1 < p.A) r[1] = ep[1];
-                } else {
-                    const unsigned pair = (unsigned)(((size_t)t * (p.N - p.P) + (n - p.P)) * hp + a0 / 2);
-                    rng_normal2(p.seed, p.call, SITE_SAMPLE, p.iter, e, pair, r[0], r[1]);
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (a0 + u < p.A) {
-                        v[u] = sample_action(omean[t * p.A + a0 + u], ostd[t * p.A + a0 + u], r[u]);
-                        if (p.act_mask) v[u] *= p.act_mask[(size_t)e * p.A + a0 + u];
-                    }
-                }
-            }
-            ea[k * HA + t * p.A + a0] = v[0];
-            if (a0 + 1 < p.A) ea[k * HA + t * p.A + a0 + 1] = v[1];
-        }
-        __syncthreads();
-    } else if (p.stage) {
-        // gather K x H x A elite actions: a wave takes every (nthr / 64)-th elite, its lanes the (t, a) columns -- one
-        // integer division per column instead of two per element, and the loads of a wave's elites are independent
-        const int wv = tid >> 6, ln = tid & 63, nwv = nthr >> 6;
-        for (int ha = ln; ha < HA; ha += 64) {
-            const int t = ha / p.A, a = ha - t * p.A;
-            const float *col = acts + (size_t)t * p.N * p.A + a;
-#pragma unroll 8
-            for (int k = wv; k < p.K; k += nwv) ea[k * HA + ha] = col[(size_t)ei[k] * p.A];
-        }
-        __syncthreads();
-    }
-    RT_MARK(3)
-    if (p.stage) {
-        // four lanes per (t, a) output, each over a quarter of the elites, combined with two quad shuffles
-        const int sub = tid & 3;
-        for (int idx = tid >> 2; idx < HA; idx += nthr >> 2) {  // the four lanes of a quad share idx: uniform trip count
-            float m = 0.f;
-#pragma unroll 4
-            for (int k = sub; k < p.K; k += 4) m += sc[k] * ea[k * HA + idx];
-            m += __shfl_xor(m, 1);
-            m += __shfl_xor(m, 2);
-            m = m / s_ssum;
-            float s2 = 0.f;
-#pragma unroll 4
-            for (int k = sub; k < p.K; k += 4) {
-                const float d = ea[k * HA + idx] - m;
-                s2 += sc[k] * (d * d);
-            }
-            s2 += __shfl_xor(s2, 1);
-            s2 += __shfl_xor(s2, 2);
-            if (sub != 0) continue;
-            float sd = sqrtf(s2 / s_ssum);
-            sd = fminf(fmaxf(sd, p.min_std), p.max_std);
-            if (p.act_mask) {
-                const float mk = p.act_mask[(size_t)e * p.A + idx % p.A];
-                m *= mk;
-                sd *= mk;
-            }
-            smean[idx] = m;
-            sstd[idx] = sd;
-            p.mean[(size_t)e * p.H * p.A + idx] = m;
-            p.std[(size_t)e * p.H * p.A + idx] = sd;
-            if (p.dbg_mean) p.dbg_mean[(size_t)e * p.dbg_mean_es + idx] = m;
-            if (p.dbg_std) p.dbg_std[(size_t)e * p.dbg_std_es + idx] = sd;
-        }
-    } else
-    for (int idx = tid; idx < HA; idx += nthr) {
-        const int t = idx / p.A, a = idx % p.A;
-        const float *at = acts + (size_t)t * p.N * p.A + a;
-        float m = 0.f;
-        for (int k = 0; k < p.K; ++k) m += sc[k] * at[(size_t)ei[k] * p.A];
-        m = m / s_ssum;
-        float s2 = 0.f;
-        for (int k = 0; k < p.K; ++k) {
-            const float d = at[(size_t)ei[k] * p.A] - m;
-            s2 += sc[k] * (d * d);
-        }
-        float sd = sqrtf(s2 / s_ssum);
-        sd = fminf(fmaxf(sd, p.min_std), p.max_std);
-        if (p.act_mask) {
-            const float mk = p.act_mask[(size_t)e * p.A + a];
-            m *= mk;
-            sd *= mk;
-        }
-        smean[idx] = m;
-        sstd[idx] = sd;
-        p.mean[(size_t)e * p.H * p.A + idx] = m;
-        p.std[(size_t)e * p.H * p.A + idx] = sd;
-        if (p.dbg_mean) p.dbg_mean[(size_t)e * p.dbg_mean_es + idx] = m;
-        if (p.dbg_std) p.dbg_std[(size_t)e * p.dbg_std_es + idx] = sd;
-    }
-    RT_MARK(4)
-#ifndef REFIT_TIMING
-    for (int k = tid; k < p.K; k += nthr) {
-        if (p.score) p.score[(size_t)e * p.K + k] = sc[k];
-        if (p.elite_idx) p.elite_idx[(size_t)e * p.K + k] = ei[k];
-        if (p.dbg_score) p.dbg_score[(size_t)e * p.dbg_score_es + k] = sc[k];
-        if (p.dbg_idx) p.dbg_idx[(size_t)e * p.dbg_idx_es + k] = ei[k];
-    }
-#endif
-    RT_MARK(5)
-    if (!p.last) return;
-    __syncthreads();
-    // gumbel_softmax_sample(score) (tdmpc2/common/math.py:86-94): argmax softmax(log p - log Exp(1)); first index on ties
-    for (int k = tid; k < p.K; k += nthr) {
-        const float ex = p.gumbel_exp ? p.gumbel_exp[(size_t)e * p.K + k]
-                                      : rng_exponential(p.seed, p.call, SITE_GUMBEL, 0, e, (unsigned)k);
-        ev[k] = logf(sc[k]) + (-logf(ex));
-    }
-    const float gmax = block_max_lds(ev, p.K, slots, tid, nthr);
-    for (int k = tid; k < p.K; k += nthr) ev[k] = expf(ev[k] - gmax);
-    const float gs = block_sum_lds(ev, p.K, slots, tid, nthr);
-    for (int k = tid; k < p.K; k += nthr) ev[k] = ev[k] / gs;
-    const float ymax = block_max_lds(ev, p.K, slots, tid, nthr);
-    if (tid == 0) *s_pick = p.K;
-    __syncthreads();
-    for (int k = tid; k < p.K; k += nthr)
-        if (ev[k] == ymax) atomicMin(s_pick, k);
-    __syncthreads();
-    const int pick = ei[*s_pick];
-    bool bad = false;
-    if (p.err || p.err2) {  // uniform: one system-scope load of the host-mapped word(s), broadcast through LDS
-        if (tid == 0) {
-            unsigned int w = 0;
-            if (p.err) w |= __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (p.err2) w |= __hip_atomic_load(p.err2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            s_pick[1] = w != 0;
-        }
-        __syncthreads();
-        bad = s_pick[1] != 0;
-    }
-    if (bad) {
-        for (int a = tid; a < p.A; a += nthr) p.action[(size_t)e * p.A + a] = __uint_as_float(0x7fc00000u);
-        return;
-    }
-    for (int a = tid; a < p.A; a += nthr) {
-        float x = p.stage ? ea[(size_t)*s_pick * HA + a] : acts[(size_t)pick * p.A + a];  // elite_actions[0, rand_idx]
-        if (!p.eval_mode) {
-            const float n = p.final_eps ? p.final_eps[(size_t)e * p.A + a]
-                                        : rng_normal(p.seed, p.call, SITE_FINAL, 0, e, (unsigned)a);
-            x = x + sstd[a] * n;  // a + std[0] * randn (tdmpc2.py:203-204)
-        }
-        p.action[(size_t)e * p.A + a] = fminf(fmaxf(x, -1.f), 1.f);
-    }
-    for (int idx = tid; idx < p.H * p.A; idx += nthr)
-        p.prev_mean[(size_t)e * p.H * p.A + idx] = smean[idx];  // _prev_mean.copy_(mean) (tdmpc2.py:205)
-    RT_MARK(6)
-}
-
-// threads of a k_refit workgroup: the sort width (one key per thread)
-inline int refit_threads(int N) {
-    int M = 64;
-    while (M < N) M <<= 1;
-    return M;
-}
 
 // one workgroup per plan (layered family; tdmpc2_plan_refit)
 __global__ void k_refit(RefitParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     refit_plan(p, blockIdx.x, smem, threadIdx.x, blockDim.x);
 }
+
+}  // namespace
+int tdk::launch_refit(const RefitParams &fp, int E, int N, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL(k_refit, dim3(E), dim3(refit_threads(N)), lds, st, fp);
+    LAUNCH_CHECK();
+    return 0;
+}
+namespace {
 
 // ================================================================ weight packing kernels
 // dst[ct][kb][lane][r] = W[row = ct*32 + (lane&31)][k = kb*8 + 4*(lane>>5) + r]; the packed k axis is
@@ -632,11 +78,7 @@ __global__ void k_copy_pad(const float *src, int n, int npad, float *dst) {
         dst[idx] = idx < n ? src[idx] : 0.f;
 }
 
-#include "fused_kernels.cuh"
-#include "cluster_kernels.cuh"
-#include "tile_order.h"
-#include "layered_kernels.cuh"
-#include "layered_split.cuh"
+#include "bind_kernels.cuh"
 #include "encoder_kernels.cuh"
 
 // ================================================================ the in-kernel generator as a noise tape (tdmpc2_plan_export_noise)
@@ -699,7 +141,8 @@ __global__ void k_export_noise(NoiseExportParams p) {
 
 // ================================================================ host side
 thread_local std::string g_err;
-int fail(int code, const char *fmt, ...) {
+}  // namespace
+int tdk::fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -708,11 +151,7 @@ int fail(int code, const char *fmt, ...) {
     g_err = buf;
     return code;
 }
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t _e = (expr);                                                                \
-        if (_e != hipSuccess) return fail(TDMPC2_ERR_HIP, "%s: %s", #expr, hipGetErrorString(_e)); \
-    } while (0)
+namespace {
 
 // Every entry point that allocates or launches runs on the handle's device and restores the caller's current device
 // (a C caller with several GPUs may have another one current).
@@ -734,52 +173,9 @@ struct DevGuard {
     DevGuard &operator=(const DevGuard &) = delete;
 };
 
-struct HostLayer {
-    float *wp = nullptr, *bias = nullptr, *g = nullptr, *b = nullptr, *wemb = nullptr;
-    // f16x2-split form (fused_kernels.cuh): hi/lo packed weights, per-matrix power-of-two scales (device scalars)
-    _Float16 *wps = nullptr;
-    LayerScal *scal = nullptr;   // split arithmetic: this layer's record inside the net's [heads][3] table
-    float *oscale = nullptr, *ascale = nullptr;  // -> scal->oscale / ascale (split) or the unit scalar (exact fp32)
-    int KB = 0, CT = 0, out = 0;  // KB: k-blocks of 8 (fp32 MFMA) or of 16 (split)
-    bool bound = false, alloc = false;
-    size_t wbytes = 0;            // bytes of this layer's packed weights (tdmpc2_plan_export_packed)
-};
-struct HostNet {
-    HostLayer l[3];
-    LayerScal *scal = nullptr;   // [heads][3] (heads of an ensemble share one allocation: stride 3 records)
-};
 
 }  // namespace
 
-// Workspace of the layer-at-a-time path (layered_kernels.cuh): activations of all E*N sample rows in HBM.
-struct Layered {
-    bool on = false;
-    int Kin = 0;    // row stride of X = first-layer K: round_up(L + A, 32)
-    int Mp = 0;     // mlp_dim (multiple of 32)
-    int ldl = 0;    // row stride of the head-logit buffer
-    int Ppad = 0;   // rows per plan in the policy-prior pass: round_up(P, 32)
-    float *X = nullptr, *HA = nullptr, *HB = nullptr, *LG = nullptr, *G = nullptr, *QT = nullptr, *TERM = nullptr;
-    int *qidx = nullptr;  // [E, 2] heads of the current iteration
-    // what the GEMM / row helpers of layered_host.cuh read besides their arguments (lay_value re-points them for a call)
-    const HostNet *qarr = nullptr;   // the Q ensemble in use: online (planning) or target (td_target)
-    const float *bias_tab = nullptr; // effective first-layer biases: per plan (h->beff) or per task (h->beff_tab)
-    const int *row_env = nullptr;    // per-row env of the bias / mask lookups, or null: row / rows_per_env
-    // LayerNorm + activation inside the GEMM epilogue (split arithmetic, g_gemm_s<.., EPI>): the exchange of per-row
-    // (mean, M2) partials between the column blocks of a row block, and the arrival counters of a stage's fused launches
-    // a second stream + buffer set for a second chain of GEMMs in flight (lay_estimate_value)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_side = nullptr, ev_xread = nullptr;
-    float *HA2 = nullptr, *HB2 = nullptr, *LG2 = nullptr, *stats2 = nullptr;
-    // t = 0 of every rollout: the z0 products of the reward / dynamics first layers, one vector per plan (lay_cvec)
-    float *Z0X = nullptr, *cvec = nullptr;
-    size_t cvec_rows = 0;
-    bool cvec_ready = false;
-    bool fuse_ln = false;
-    float *stats = nullptr;
-    size_t stats_cap = 0;            // floats
-    unsigned int *arrive = nullptr;
-    size_t arrive_cap = 0, arrive_off = 0;  // counters; the next free one (zeroed at the start of every stage)
-};
 
 // The layered path's second stream and its three events come from a process-wide pool and go back to it when a handle is
 // destroyed; they are never destroyed.  Measured on ROCm 7.0 / MI355X (profiles/README.md r03k): after hipStreamDestroy /
@@ -818,61 +214,6 @@ static void side_release(int dev, const SideRes &r) {
     g_side_pool.free_list[dev >= 0 && dev < 64 ? dev : 0].push_back(r);
 }
 
-struct tdmpc2_plan {
-    tdmpc2_plan_cfg cfg;
-    Layered lay;
-    std::atomic<int> busy{0};  // handles are not reentrant: a second concurrent call is refused (Busy), not raced
-    int fold_refit = 2;        // fused family: the last workgroup of a plan refits it inside the rollout launch (2 = auto)
-    unsigned int *ticket = nullptr;  // [max_envs] arrival counters of that hand-over
-    int *qidx_buf = nullptr;         // [max_envs, 2] the two Q heads of the current iteration (shard_values)
-    unsigned int shard_call = 0;     // call counter captured by shard_begin (Philox stream of the sharded plan)
-    bool in_shard = false;           // between shard_begin and the last shard_refit: a consumed fault marks the plan in flight (cl_err_host[4])
-    // per-task tables of policy_value / td_target on multitask batches (grown on demand)
-    float *beff_tab = nullptr, *mask_tab = nullptr, *disc_tab = nullptr;
-    int *task_rows = nullptr;  // [rows] copy of the row -> task map, padded to whole GEMM tiles (layered family)
-    int tab_tasks = 0;
-    size_t task_rows_cap = 0;
-    // cluster path of the fused family (cluster_kernels.cuh): single-plan latency
-    int cluster_mode = 2;            // TDMPC2_TUNE_CLUSTER: 0 never, 1 whenever the call fits, 2 auto (= 1 today)
-    int cl_max_clusters = 0;         // clusters the buffers below were sized for (0: path not available on this handle)
-    float *cl_xbuf = nullptr, *cl_zs = nullptr;
-    unsigned int *cl_flags = nullptr;
-    unsigned int *cl_err_host = nullptr, *cl_err_dev = nullptr;  // host-mapped error word of the bounded waits
-    size_t cl_lds = 0;
-    int cl_fault = 0;                // TDMPC2_CLUSTER_FAULT=1 at create: test hook of the bounded waits
-    int faults = 0;                  // cluster plans that gave up since the last tdmpc2_plan_take_fault
-    bool split = false;  // fused kernels on the f16 matrix pipe with hi/lo operand split (fused_kernels.cuh)
-    int force_rows = 0;  // TDMPC2_TUNE_ROWS_PER_WORKGROUP: 0 auto, 32, 64
-    size_t row_bytes = 0;  // bytes of one sample row of the fused kernels' LDS tile
-    float *one = nullptr;  // device scalar 1.0f: the output scale of the exact-fp32 arithmetic
-    int Apad = 0, stride = 0, tiles = 0, nnets = 0;
-    int num_cus = 0;  // compute units of cfg.device
-    size_t lds_bytes = 0;
-    HostNet dyn, rew, pi, term;
-    HostNet q[MAXQ];
-    HostNet tq[MAXQ];  // target ensemble (optional: tdmpc2_plan_td_target)
-    std::vector<void *> allocs;
-    uint64_t bytes = 0;
-    // workspace
-    float *bins = nullptr, *actions = nullptr, *value = nullptr, *mean = nullptr, *std = nullptr, *cvec = nullptr,
-          *beff = nullptr, *zscratch = nullptr;
-    // state-observation encoder (optional: bound with tdmpc2_plan_bind_encoder)
-    struct Enc {
-        float *wt = nullptr, *bias = nullptr, *g = nullptr, *b = nullptr;
-        int in = 0, out = 0;
-        bool bound = false;
-    } enc[6];
-    int enc_layers = 0;
-    float *zenc = nullptr;  // [max_envs, L]: latents of tdmpc2_plan_run_obs
-    float *enc_y = nullptr, *enc_x = nullptr;  // wide encoders: [max_envs, widest layer] pre-activations / activations
-    int enc_ws_width = 0;
-    unsigned int call = 0;
-    unsigned long long *timing = nullptr;  // TDMPC2_TIMING=1 with a -DSPLIT_TIMING build: in-kernel phase cycle counters
-    // profiling
-    bool profiling = false;
-    std::vector<hipEvent_t> ev;
-    int ev_used = 0;
-};
 
 namespace {
 
@@ -951,30 +292,41 @@ int check_ready(tdmpc2_plan *h) {
     return 0;
 }
 
-template <typename K>
-int set_lds(K kernel, size_t bytes) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)bytes));
-    return 0;
-}
 
 // The fused kernels are instantiated per action padding (compile-time LDS strides) and arithmetic (AR 0 = f16x2 split,
-// 1 = exact fp32 MFMA); ks_rollout / ks_pitraj also per workgroup geometry.
+// 1 = exact fp32 MFMA); ks_rollout / ks_pitraj also per workgroup geometry -- one translation unit per padding (k_fused.hip,
+// k_cluster.hip), reached through the tables of launch.h.
 #ifndef TDMPC2_DEFAULT_THROUGHPUT_ST
 #define TDMPC2_DEFAULT_THROUGHPUT_ST 2  // sample tiles per workgroup when a call has enough plans to fill the chip
 #endif
+const FusedOps &fused_ops(int apad) {
 #ifdef TDMPC2_ONLY_APAD  // experiment builds (tools/ablate.sh): one action padding only, a quarter of the compile time
-#define FUSED_DISPATCH(APAD_VALUE, AR_VALUE, CALL) \
-    if (AR_VALUE) { CALL(TDMPC2_ONLY_APAD, 1) } else { CALL(TDMPC2_ONLY_APAD, 0) }
+#define TDK_OPS_CAT_(a, b) a##b
+#define TDK_OPS_CAT(a, b) TDK_OPS_CAT_(a, b)
+    (void)apad;
+    return TDK_OPS_CAT(fused_ops_ap, TDMPC2_ONLY_APAD)();
 #else
-#define FUSED_DISPATCH(APAD_VALUE, AR_VALUE, CALL) \
-    switch (APAD_VALUE) {                          \
-        case 16: if (AR_VALUE) { CALL(16, 1) } else { CALL(16, 0) } break; \
-        case 32: if (AR_VALUE) { CALL(32, 1) } else { CALL(32, 0) } break; \
-        case 48: if (AR_VALUE) { CALL(48, 1) } else { CALL(48, 0) } break; \
-        default: if (AR_VALUE) { CALL(64, 1) } else { CALL(64, 0) } break; \
+    switch (apad) {
+        case 16: return fused_ops_ap16();
+        case 32: return fused_ops_ap32();
+        case 48: return fused_ops_ap48();
+        default: return fused_ops_ap64();
     }
 #endif
+}
+const ClusterOps &cluster_ops(int apad) {
+#ifdef TDMPC2_ONLY_APAD
+    (void)apad;
+    return TDK_OPS_CAT(cluster_ops_ap, TDMPC2_ONLY_APAD)();
+#else
+    switch (apad) {
+        case 16: return cluster_ops_ap16();
+        case 32: return cluster_ops_ap32();
+        case 48: return cluster_ops_ap48();
+        default: return cluster_ops_ap64();
+    }
+#endif
+}
 template <class NET> struct Kern;
 template <> struct Kern<NetS> {
     // 32- or 64-row workgroups.  A 64-row workgroup reuses every weight fragment for two row tiles and is the
@@ -995,53 +347,23 @@ template <> struct Kern<NetS> {
     // fragment loads and becomes L1-bound.
     static int waves(const tdmpc2_plan *, int, int) { return 8; }
     static void setup(const tdmpc2_plan *h, const SetupParamsT<NetS> &p, int E, hipStream_t st) {
-        const size_t lds = h->lds_bytes;
-        const int ar = h->split ? 0 : 1;
-#define CALL_SETUP(AP, AR) hipLaunchKernelGGL((ks_setup<AP, AR>), dim3(E), dim3(NTHREADS), lds, st, p);
-        FUSED_DISPATCH(h->Apad, ar, CALL_SETUP)
-#undef CALL_SETUP
+        fused_ops(h->Apad).setup(h->split ? 0 : 1, p, E, h->lds_bytes, st);
     }
     static void pitraj(const tdmpc2_plan *h, const PiTrajParamsT<NetS> &p, int E, hipStream_t st) {
-        const int ar = h->split ? 0 : 1;
-        if (p.P <= 32) {  // one 32-row tile holds the policy-prior trajectories (the reference uses 24)
-            const size_t lds = h->lds_bytes - (size_t)32 * h->row_bytes;
-#define CALL_PITRAJ1(AP, AR) hipLaunchKernelGGL((ks_pitraj<AP, 1, AR>), dim3(E), dim3(NTHREADS), lds, st, p);
-            FUSED_DISPATCH(h->Apad, ar, CALL_PITRAJ1)
-#undef CALL_PITRAJ1
-        } else {
-            const size_t lds = h->lds_bytes;
-#define CALL_PITRAJ2(AP, AR) hipLaunchKernelGGL((ks_pitraj<AP, 2, AR>), dim3(E), dim3(NTHREADS), lds, st, p);
-            FUSED_DISPATCH(h->Apad, ar, CALL_PITRAJ2)
-#undef CALL_PITRAJ2
-        }
+        // one 32-row tile holds the policy-prior trajectories when P <= 32 (the reference uses 24)
+        const int nst = p.P <= 32 ? 1 : 2;
+        const size_t lds = nst == 1 ? h->lds_bytes - (size_t)32 * h->row_bytes : h->lds_bytes;
+        fused_ops(h->Apad).pitraj(h->split ? 0 : 1, nst, p, E, lds, st);
     }
     static void rollout(const tdmpc2_plan *h, const RolloutParamsT<NetS> &p, int grid, hipStream_t st, int nst, int nw) {
         (void)nw;
-        const int ar = h->split ? 0 : 1;
-        const bool ep = h->cfg.episodic != 0;
         const bool tracing = p.trace_tiles || p.trace_scalars;  // (the host forces 64-row workgroups for a trace call)
         const size_t lds = nst == 2 ? h->lds_bytes : h->lds_bytes - (size_t)32 * h->row_bytes;
-#define CALL_ROLL(AP, AR)                                                                                                       \
-    if (nst == 2) {                                                                                                             \
-        if (ep) hipLaunchKernelGGL((ks_rollout<AP, 2, 8, AR, 1>), dim3(grid), dim3(NTHREADS), lds, st, p);                        \
-        else if (tracing) hipLaunchKernelGGL((ks_rollout<AP, 2, 8, AR, 0, 1>), dim3(grid), dim3(NTHREADS), lds, st, p);           \
-        else hipLaunchKernelGGL((ks_rollout<AP, 2, 8, AR, 0>), dim3(grid), dim3(NTHREADS), lds, st, p);                           \
-    } else {                                                                                                                    \
-        if (ep) hipLaunchKernelGGL((ks_rollout<AP, 1, 8, AR, 1>), dim3(grid), dim3(NTHREADS), lds, st, p);                        \
-        else hipLaunchKernelGGL((ks_rollout<AP, 1, 8, AR, 0>), dim3(grid), dim3(NTHREADS), lds, st, p);                           \
-    }
-        FUSED_DISPATCH(h->Apad, ar, CALL_ROLL)
-#undef CALL_ROLL
+        fused_ops(h->Apad).rollout(h->split ? 0 : 1, nst, h->cfg.episodic != 0, tracing, p, grid, lds, st);
     }
     // cluster path: `clusters` row tiles of 32 samples, 8 workgroups each, in groups of 8 clusters (one per XCD)
     static void rollout_cluster(const tdmpc2_plan *h, const RolloutParamsT<NetS> &p, int clusters, hipStream_t st) {
-        const int grid = (clusters + 7) / 8 * 64;
-        const bool ep = h->cfg.episodic != 0;
-#define CALL_ROLL_CL(AP, AR)                                                                              \
-    if (ep) hipLaunchKernelGGL((ks_rollout_cl<AP, 1>), dim3(grid), dim3(NTHREADS), h->cl_lds, st, p);    \
-    else hipLaunchKernelGGL((ks_rollout_cl<AP, 0>), dim3(grid), dim3(NTHREADS), h->cl_lds, st, p);
-        FUSED_DISPATCH(h->Apad, 0, CALL_ROLL_CL)
-#undef CALL_ROLL_CL
+        cluster_ops(h->Apad).rollout_cl(h->cfg.episodic != 0, p, (clusters + 7) / 8 * 64, h->cl_lds, st);
     }
 };
 
@@ -1109,7 +431,6 @@ int validate_envs(tdmpc2_plan *h, int E) {
     return check_ready(h);
 }
 
-#include "layered_host.cuh"
 
 // Everything of TDMPC2._plan after encode() (tdmpc2/tdmpc2.py:154-206) on the fused 512-wide path.
 template <class NET>
@@ -1461,14 +782,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
     }
     if (!h->lay.on) {
         const int ar = h->split ? 0 : 1;
-#define CALL_SETLDS(AP, AR)                                                                                          \
-    rc = set_lds(ks_setup<AP, AR>, h->lds_bytes) || set_lds(ks_pitraj<AP, 2, AR>, h->lds_bytes) ||                   \
-         set_lds(ks_pitraj<AP, 1, AR>, h->lds_bytes) || set_lds(ks_value<AP, AR>, h->lds_bytes) ||                    \
-         (c.episodic ? (set_lds(ks_rollout<AP, 2, 8, AR, 1>, h->lds_bytes) || set_lds(ks_rollout<AP, 1, 8, AR, 1>, h->lds_bytes)) \
-                     : (set_lds(ks_rollout<AP, 2, 8, AR, 0>, h->lds_bytes) || set_lds(ks_rollout<AP, 1, 8, AR, 0>, h->lds_bytes) || \
-                        set_lds(ks_rollout<AP, 2, 8, AR, 0, 1>, h->lds_bytes)));
-        FUSED_DISPATCH(h->Apad, ar, CALL_SETLDS)
-#undef CALL_SETLDS
+        rc = fused_ops(h->Apad).set_lds(ar, c.episodic, h->lds_bytes);
         if (rc) {
             tdmpc2_plan_destroy(h);
             return TDMPC2_ERR_HIP;
@@ -1500,9 +814,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
                 return fail(TDMPC2_ERR_HIP, "hipHostGetDevicePointer failed");
             }
             int rcl = 0;
-#define CALL_SETLDS_CL(AP, AR) rcl = c.episodic ? set_lds(ks_rollout_cl<AP, 1>, h->cl_lds) : set_lds(ks_rollout_cl<AP, 0>, h->cl_lds);
-            FUSED_DISPATCH(h->Apad, 0, CALL_SETLDS_CL)
-#undef CALL_SETLDS_CL
+            rcl = cluster_ops(h->Apad).set_lds(c.episodic, h->cl_lds);
             if (rcl) {
                 tdmpc2_plan_destroy(h);
                 return TDMPC2_ERR_HIP;
@@ -1874,9 +1186,7 @@ int launch_value(tdmpc2_plan *h, int rows, const float *z, bool target, bool red
             HIP_TRY(hipMemcpyAsync(h->task_rows, tk->task_ids, (size_t)rows * 4, hipMemcpyDeviceToDevice, st));
         }
         // the two heads: given, or randperm(num_q)[:2] once per call (world_model.py:212)
-        if (qidx) hipLaunchKernelGGL(l_copy_qidx, dim3(1), dim3(64), 0, st, 1, qidx, 2L, h->lay.qidx);
-        else hipLaunchKernelGGL(l_qidx, dim3(1), dim3(64), 0, st, 1, c.num_q, 0, (unsigned long long)seed, call, h->lay.qidx);
-        HIP_TRY(hipGetLastError());
+        if ((rc = lay_set_qidx(h, st, 1, qidx, 2L, c.num_q, 0, seed, call, h->lay.qidx))) return rc;
         return lay_value(h, st, rows, z, target, reduce_min, pi_eps, h->lay.qidx, seed, call, reward, terminated, discount,
                          c.multitask ? h->task_rows : nullptr, action, out);
     }
@@ -1896,9 +1206,7 @@ int launch_value(tdmpc2_plan *h, int rows, const float *z, bool target, bool red
     const int grid = (rows + ROWS - 1) / ROWS;
     const size_t lds = h->lds_bytes;
     const int ar = h->split ? 0 : 1;
-#define CALL_VALUE(AP, AR) hipLaunchKernelGGL((ks_value<AP, AR>), dim3(grid), dim3(NTHREADS), lds, st, p);
-    FUSED_DISPATCH(h->Apad, ar, CALL_VALUE)
-#undef CALL_VALUE
+    fused_ops(h->Apad).value(ar, p, grid, lds, st);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -2012,7 +1320,7 @@ int tdmpc2_plan_shard_values(tdmpc2_plan_t *h, int n_envs, int iter, int row_beg
     if (rc) return rc;
     if (!z0 || !disc_pow || !value) return fail(TDMPC2_ERR_INVALID, "null argument");
     const tdmpc2_plan_cfg &c = h->cfg;
-    const int E = n_envs, H = c.horizon, N = c.num_samples, A = c.action_dim, P = c.num_pi_trajs, I = c.iterations;
+    const int E = n_envs, N = c.num_samples, A = c.action_dim, I = c.iterations;
     if (iter < 0 || iter >= I) return fail(TDMPC2_ERR_INVALID, "iteration %d outside [0, %d)", iter, I);
     const int gran = h->lay.on ? GBM : ROWS;
     if (row_begin < 0 || row_end > N || row_begin >= row_end || row_begin % gran || row_end % gran)
@@ -2023,16 +1331,8 @@ int tdmpc2_plan_shard_values(tdmpc2_plan_t *h, int n_envs, int iter, int row_beg
     hipStream_t st = (hipStream_t)stream;
     const unsigned call = h->shard_call;
     // (1) the actions of ALL rows of this iteration (replicated: the refit needs every elite's actions)
-    SampleParams sp{};
-    sp.E = E; sp.H = H; sp.N = N; sp.A = A; sp.P = P; sp.iter = iter; sp.mean = h->mean; sp.std = h->std; sp.mask = act_mask;
-    sp.eps = tape ? tape->sample_eps + (size_t)iter * H * (N - P) * A : nullptr;
-    sp.eps_estride = (long)I * H * (N - P) * A;
-    sp.seed = seed; sp.call = call; sp.actions = h->actions;
-    hipLaunchKernelGGL(l_sample, dim3(1024), dim3(256), 0, st, sp);
     int *qbuf = h->lay.on ? h->lay.qidx : h->qidx_buf;
-    if (tape) hipLaunchKernelGGL(l_copy_qidx, dim3((E + 255) / 256), dim3(256), 0, st, E, tape->qidx + (size_t)iter * 2, (long)I * 2, qbuf);
-    else hipLaunchKernelGGL(l_qidx, dim3((E + 255) / 256), dim3(256), 0, st, E, c.num_q, iter, (unsigned long long)seed, call, qbuf);
-    HIP_TRY(hipGetLastError());
+    if ((rc = lay_sample_iteration(h, st, E, iter, act_mask, tape, seed, call, qbuf))) return rc;
     const float *pi_eps = tape ? tape->pi_eps + (size_t)iter * N * A : nullptr;
     // (2) this rank's rows
     if (h->lay.on)
@@ -2405,8 +1705,7 @@ int tdmpc2_plan_estimate_value_trace(tdmpc2_plan_t *h, int n_envs, const float *
         if (trace_tiles) return fail(TDMPC2_ERR_UNSUPPORTED, "the layered path dumps trace_scalars only");
         if ((rc = lay_setup(h, st, E, task_emb, nullptr, nullptr, false))) return rc;
         if ((rc = lay_cvec(h, st, E, z0))) return rc;
-        hipLaunchKernelGGL(l_copy_qidx, dim3((E + 255) / 256), dim3(256), 0, st, E, qidx, 2L, h->lay.qidx);
-        HIP_TRY(hipGetLastError());
+        if ((rc = lay_set_qidx(h, st, E, qidx, 2L, c.num_q, 0, 0, 0, h->lay.qidx))) return rc;
         return lay_estimate_value(h, st, E, z0, act_mask, disc_pow, actions, pi_eps, (long)N * A, h->lay.qidx, 0, 0, 0, value,
                                   trace_scalars);
     }
