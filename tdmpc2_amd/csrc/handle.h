@@ -61,6 +61,9 @@ struct Layered {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_side = nullptr, ev_xread = nullptr;
     float *HA2 = nullptr, *HB2 = nullptr, *LG2 = nullptr, *stats2 = nullptr;
+    // split arithmetic: fp32 pre-activations of a NormedLinear whose epilogue is not fused ([rows, ldpre], one per chain)
+    float *PRE = nullptr, *PRE2 = nullptr;
+    int ldpre = 0;
     // t = 0 of every rollout: the z0 products of the reward / dynamics first layers, one vector per plan (lay_cvec)
     float *Z0X = nullptr, *cvec = nullptr;
     size_t cvec_rows = 0;
@@ -70,6 +73,7 @@ struct Layered {
     size_t stats_cap = 0;            // floats
     unsigned int *arrive = nullptr;
     size_t arrive_cap = 0, arrive_off = 0;  // counters; the next free one (zeroed at the start of every stage)
+    size_t arrive_high = 0;                 // most counters any stage of this handle has used (the extent of that memset)
 };
 
 struct tdmpc2_plan {

@@ -8,6 +8,7 @@ namespace {
 #include "tile_order.h"
 #include "layered_kernels.cuh"
 #include "layered_split.cuh"
+#include "layered_wide.cuh"
 }  // namespace
 
 namespace tdk {

@@ -14,20 +14,27 @@ struct LnFuse {
 // Hidden-activation / logit buffers a chain of GEMMs runs through, and the exchange buffer of its fused epilogues: the
 // handle holds two sets so that two independent chains (reward || dynamics of one step, the two Q heads) can be in flight on
 // two streams at once -- the second chain's workgroups fill the slots the first one's last, partly filled round leaves idle
-// (c3: 840 workgroups on 512 slots) and the launch gaps of one chain hide behind the other's kernels.
+// and the launch gaps of one chain hide behind the other's kernels.  PRE: fp32 pre-activations of a NormedLinear whose
+// epilogue is NOT fused (split arithmetic: the operand buffers are fragment-packed, so the LayerNorm kernel cannot work in place).
 struct LayBufs {
-    float *HA, *HB, *LG, *stats;
+    float *HA, *HB, *LG, *stats, *PRE;
 };
 inline LayBufs lay_bufs(const tdmpc2_plan *h, int set) {
     const Layered &L = h->lay;
-    return set == 0 ? LayBufs{L.HA, L.HB, L.LG, L.stats} : LayBufs{L.HA2, L.HB2, L.LG2, L.stats2};
+    return set == 0 ? LayBufs{L.HA, L.HB, L.LG, L.stats, L.PRE} : LayBufs{L.HA2, L.HB2, L.LG2, L.stats2, L.PRE2};
 }
 
-// the arrival counters of the fused launches of one stage: zeroed once per stage (stream-ordered), a fresh slice per launch
+// The arrival counters of the fused launches of one stage: a fresh slice per launch, ALL counters handed out so far zeroed at
+// the start of every stage.  The memset covers [0, high-water mark of the handle) -- not "what the previous call used": under
+// hipGraph capture the extent is frozen into the graph while replays do not update the host's bookkeeping, so an extent that
+// depends on the call history can leave a counter of an earlier, larger eager call at its old value (a workgroup would then
+// skip its wait and read stale statistics).  The high-water mark only grows; a graph captured after any warm-up of the same
+// shape covers every slice its launches use.
 int lay_arrive_reset(tdmpc2_plan *h, hipStream_t st) {
     Layered &L = h->lay;
     if (!L.arrive) return 0;
-    if (L.arrive_off) HIP_TRY(hipMemsetAsync(L.arrive, 0, L.arrive_off * sizeof(unsigned int), st));
+    if (L.arrive_off > L.arrive_high) L.arrive_high = L.arrive_off;
+    if (L.arrive_high) HIP_TRY(hipMemsetAsync(L.arrive, 0, L.arrive_high * sizeof(unsigned int), st));
     L.arrive_off = 0;
     return 0;
 }
@@ -46,36 +53,36 @@ struct GemmRange {
     int kb0, kblocks;        // first k16-block, number of blocks (a multiple of 2)
     const float *bias_env;   // [env, Mp]
     long bias_env_stride;
-    int col_off;             // A's first column (halfs into the hi plane)
+    int col_off;             // A's first column (a multiple of 16)
 };
 
+int lay_ln(tdmpc2_plan *h, hipStream_t st, int act, float *x, int ld, int width, size_t rows, int rows_per_env,
+           const HostLayer &ly, long gb_sel_stride, const int *sel, float *out_packed = nullptr, int ld_out = 0);
+
 // One nn.Linear over `rows_p` (padded) rows.  `slot` = index of the net in beff (multitask first layers), -1 otherwise.
-// `ln` != null asks for the NormedLinear epilogue inside the GEMM; *fused tells the caller whether that happened (if not,
-// `out` holds fp32 pre-activations and the row kernel has to follow).
+// A / out: split arithmetic -- fragment-packed operand buffers of lda / ldo columns (out: only with `ln`; head logits and
+// pre-activations are fp32 [rows, ldo]); exact fp32 -- fp32 [rows, ld].
+// `ln` != null: the whole NormedLinear (layers.py:94-118) -- out <- ACT(LayerNorm(A W^T + b)) -- inside the GEMM's epilogue when the
+// handle's fused path is on and fits, else by the LayerNorm row kernel behind the GEMM (split: through bufs->PRE).
 int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t rows_p, int rows_per_env,
              const HostLayer &ly, long w_sel_stride, long bias_sel_stride, int slot, const int *sel, float *out, int ldo,
-             const LnFuse *ln = nullptr, bool *fused = nullptr, float *stats = nullptr, const GemmRange *range = nullptr) {
-    if (fused) *fused = false;
+             const LnFuse *ln = nullptr, const LayBufs *bufs = nullptr, const GemmRange *range = nullptr, size_t rows = 0) {
+    Layered &L = h->lay;
+    const LayBufs b0 = lay_bufs(h, 0);
+    if (!bufs) bufs = &b0;
     if (h->split) {
         GemmSParams q{};
-        q.A = reinterpret_cast<const _Float16 *>(A); q.lda = lda; q.K = ly.KB * 16; q.wp = ly.wps;
+        q.A = reinterpret_cast<const _Float16 *>(A); q.KBa = lda / 16; q.K = ly.KB * 16; q.wp = ly.wps;
         if (range) {
-            q.A += range->col_off; q.K = range->kblocks * 16; q.kb0 = range->kb0; q.kbs = ly.KB;
+            q.a_kb0 = range->col_off / 16; q.K = range->kblocks * 16; q.kb0 = range->kb0; q.kbs = ly.KB;
         }
         q.w_sel_stride = sel ? w_sel_stride : 0; q.oscale = ly.oscale;
         q.osc_sel_stride = sel ? (long)(3 * sizeof(LayerScal) / sizeof(float)) : 0;  // the net's [heads][3] scalar table
-        q.row_env = h->lay.row_env;
-        // wide outputs (>= 256 columns) take the 128 x 256 tile ...
-        // ... from 128 such workgroups on: with a second chain in flight (lay_estimate_value) a partly filled round is not idle,
-        // and the 128 x 256 tile does 1.7 x the MFMAs per operand byte (A/B r3n: threshold 512 -> 256: c3 +2.0 %, c4 +2.3 %;
-        // 128: single plans of the 317M model 20.8 -> 18.7 ms; below that single plans of the 48M model lose)
-        static const size_t wide_min = getenv("TDMPC2_GEMM_NCT1") ? (size_t)1 << 30 : getenv("TDMPC2_GEMM_WIDE_MIN") ? (size_t)atoi(getenv("TDMPC2_GEMM_WIDE_MIN")) : 128;
-        const bool wide = ly.CT >= 8 && (rows_p / GBM) * ((ly.CT + 7) / 8) >= wide_min;
-        q.CT = ly.CT; q.ncolblk = wide ? (ly.CT + 7) / 8 : (ly.CT + 3) / 4;
+        q.row_env = L.row_env;
         if (slot >= 0 && h->cfg.multitask) {
-            q.bias = h->lay.bias_tab + (size_t)slot * h->lay.Mp;
-            q.bias_env_stride = (long)h->nnets * h->lay.Mp;
-            q.bias_sel_stride = sel ? h->lay.Mp : 0;
+            q.bias = L.bias_tab + (size_t)slot * L.Mp;
+            q.bias_env_stride = (long)h->nnets * L.Mp;
+            q.bias_sel_stride = sel ? L.Mp : 0;
         } else {
             q.bias = ly.bias;
             q.bias_env_stride = 0;
@@ -84,10 +91,44 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         if (range && range->bias_env) {
             q.bias = range->bias_env; q.bias_env_stride = range->bias_env_stride; q.bias_sel_stride = 0;
         }
-        q.sel = sel; q.sel_stride = 2; q.rows_per_env = rows_per_env; q.out = out; q.ldo = ldo;
+        q.sel = sel; q.sel_stride = 2; q.rows_per_env = rows_per_env; q.CT = ly.CT;
+        const long cus = h->num_cus > 0 ? h->num_cus : 256;
+        // Can the NormedLinear epilogue run inside the GEMM?  (always decided the same way whatever the tile: the statistics'
+        // combination order is tile-independent, so a plan's bits do not depend on the size of the call it is part of)
+        const bool can_fuse = ln && L.fuse_ln && L.arrive && bufs->stats && rows_p * ((ly.CT + 3) / 4) * 2 <= L.stats_cap;
+        // ---- the 256 x 256 tile (g_gemm_w): fused NormedLinear layers of calls that fill the chip with one workgroup per CU
+        static const long w256_min = getenv("TDMPC2_GEMM_W256_MIN") ? atol(getenv("TDMPC2_GEMM_W256_MIN")) : 192;
+        const int ncb256 = (ly.CT + 7) / 8;
+        if (can_fuse && ly.CT >= 8 && rows_p % 256 == 0 && rows_per_env % 256 == 0 && ncb256 <= 32 &&
+            (long)(rows_p / 256) * ncb256 >= w256_min && w256_min >= 0) {
+            const int nrowblk = (int)(rows_p / 256);
+            if (L.arrive_off + (size_t)nrowblk > L.arrive_cap) return fail(TDMPC2_ERR_STATE, "arrival counters exhausted (%zu + %d > %zu)", L.arrive_off, nrowblk, L.arrive_cap);
+            q.ncolblk = ncb256;
+            q.ln_g = ly.g; q.ln_b = ly.b; q.gb_sel_stride = sel ? ln->gb_sel_stride : 0;
+            q.ascale = ly.ascale; q.asc_sel_stride = sel ? (long)(3 * sizeof(LayerScal) / sizeof(float)) : 0;
+            q.width = ln->width; q.stats = bufs->stats; q.arrive = L.arrive + L.arrive_off; q.err = h->cl_err_dev; q.fault = h->cl_fault;
+            L.arrive_off += (size_t)nrowblk;
+            q.out = out; q.KBo = ldo / 16;
+            // tile order: XCD-local row blocks keep the column blocks of a row block -- which wait for each other -- on consecutive
+            // slots of ONE XCD (with one workgroup per CU and <= 16 column blocks two launches in flight cannot starve each other:
+            // 2 x 15 waiting workgroups < 32 CUs), and read every A row through one L2
+            static const int xr_env = getenv("TDMPC2_GEMM_W_XCD_ROWS") ? atoi(getenv("TDMPC2_GEMM_W_XCD_ROWS")) : -1;
+            const GemmSOrder ord = gemm_s_order(nrowblk, q.ncolblk, xr_env >= 0 ? xr_env : (nrowblk >= 16 ? 1 : 0), 1);
+            q.xcd_rows = ord.xcd_rows; q.ncol_grid = ord.ncol_grid; q.nrowblk = nrowblk;
+            if (ln->act == 0) hipLaunchKernelGGL((g_gemm_w<1>), dim3(ord.nblk), dim3(512), 0, st, q);
+            else hipLaunchKernelGGL((g_gemm_w<2>), dim3(ord.nblk), dim3(512), 0, st, q);
+            LAUNCH_CHECK();
+            return 0;
+        }
+        // wide outputs (>= 256 columns) take the 128 x 256 tile from 128 such workgroups on: with a second chain in flight
+        // (lay_estimate_value) a partly filled round is not idle (A/B r3n: threshold 512 -> 256: c3 +2.0 %, c4 +2.3 %; 128: single
+        // plans of the 317M model 20.8 -> 18.7 ms; below that single plans of the 48M model lose)
+        static const size_t wide_min = getenv("TDMPC2_GEMM_NCT1") ? (size_t)1 << 30 : getenv("TDMPC2_GEMM_WIDE_MIN") ? (size_t)atoi(getenv("TDMPC2_GEMM_WIDE_MIN")) : 128;
+        const bool wide = ly.CT >= 8 && (rows_p / GBM) * ((ly.CT + 7) / 8) >= wide_min;
+        q.ncolblk = wide ? (ly.CT + 7) / 8 : (ly.CT + 3) / 4;
         // rows per workgroup tile: 128 when that fills the chip (two workgroups per CU), else 64 or 32 -- few rows mean
         // single-plan latency, where occupancy beats operand reuse (TDMPC2_GEMM_RT=4 forces the 128-row tile)
-        const long slots = 2L * (h->num_cus > 0 ? h->num_cus : 256);
+        const long slots = 2L * cus;
         int rt = 4;
         if (!wide && !getenv("TDMPC2_GEMM_RT4")) {
             static const double fill = getenv("TDMPC2_GEMM_FILL") ? atof(getenv("TDMPC2_GEMM_FILL")) : 0.75;
@@ -100,21 +141,14 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         // few workgroups per CU: row operand staged four chunks deep, weight ring of 8 / 16 blocks (g_gemm_s<.., .., 4>)
         const bool deep = !wide && (long)nblk < 2 * slots && !getenv("TDMPC2_GEMM_SD1");
         int epi = 0;
-        Layered &L = h->lay;
-        if (!stats) stats = L.stats;
-        // (always, whatever the tile: the statistics' combination order is tile-independent, so a plan's bits do not depend
-        // on the size of the call it is part of)
-        if (ln && L.fuse_ln && L.arrive && stats && (size_t)nrowblk * 32 * rt * ((ly.CT + 3) / 4) * 2 <= L.stats_cap) {
-            if (L.arrive_off + (size_t)nrowblk > L.arrive_cap) {  // (more fused launches in one stage than sized for)
-                HIP_TRY(hipMemsetAsync(L.arrive, 0, L.arrive_cap * sizeof(unsigned int), st));
-                L.arrive_off = 0;
-            }
+        const bool fuse = can_fuse && L.arrive_off + (size_t)nrowblk <= L.arrive_cap;
+        if (fuse) {
             epi = 1 + ln->act;
             q.ln_g = ly.g; q.ln_b = ly.b; q.gb_sel_stride = sel ? ln->gb_sel_stride : 0;
             q.ascale = ly.ascale; q.asc_sel_stride = sel ? (long)(3 * sizeof(LayerScal) / sizeof(float)) : 0;
-            q.width = ln->width; q.stats = stats; q.arrive = L.arrive + L.arrive_off; q.err = h->cl_err_dev; q.fault = h->cl_fault;
+            q.width = ln->width; q.stats = bufs->stats; q.arrive = L.arrive + L.arrive_off; q.err = h->cl_err_dev; q.fault = h->cl_fault;
             L.arrive_off += (size_t)nrowblk;
-            if (fused) *fused = true;
+            q.out = out; q.KBo = ldo / 16;
             // tile order (tile_order.h); TDMPC2_GEMM_XCD_ROWS = 0 / 1: never / always XCD-local row blocks, TDMPC2_GEMM_COL_PAD = 0:
             // no padding of the row-major order
             static const int xcd_rows_env = getenv("TDMPC2_GEMM_XCD_ROWS") ? atoi(getenv("TDMPC2_GEMM_XCD_ROWS")) : -1;
@@ -122,11 +156,14 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             const GemmSOrder ord = gemm_s_order(nrowblk, q.ncolblk, xcd_rows_env, col_pad_env);
             q.xcd_rows = ord.xcd_rows; q.ncol_grid = ord.ncol_grid; q.nrowblk = nrowblk;
             nblk = ord.nblk;
+        } else if (ln) {  // pre-activations -> PRE, the LayerNorm kernel writes the packed operand
+            if (!bufs->PRE) return fail(TDMPC2_ERR_STATE, "no pre-activation buffer on this handle");
+            q.out = bufs->PRE; q.ldo = L.ldpre;
+        } else {
+            q.out = out; q.ldo = ldo;
         }
-        // The throughput tile stages its row operand TWO chunks ahead (g_gemm_s<2, 4, 2, ..>: same sums; 242 VGPRs in the main loop
-        // instead of 226, the epilogue's 255 are the kernel's maximum either way): c3 +0.4 ... 0.7 %, c4 +0.5 % over one chunk ahead
-        // in three same-call A/Bs; a weight ring three k16-blocks deep instead (template parameter PF = 3) bought +0.3 ... 0.5 %, and
-        // both together do not fit the register file (profiles/README.md r3z / r3y / r3x).  Only the adopted variant is instantiated.
+        // The throughput tile stages its row operand TWO chunks ahead (g_gemm_s<2, 4, 2, ..>: same sums; c3 +0.4 ... 0.7 %,
+        // c4 +0.5 % over one chunk ahead in three same-call A/Bs, profiles/README.md r3z / r3y / r3x).
         if (wide) GEMM_S_LAUNCH(2, 4, 2);
         else if (deep && rt == 4) GEMM_S_LAUNCH(1, 4, 4);
         else if (deep && rt == 2) GEMM_S_LAUNCH(1, 2, 4);
@@ -135,6 +172,8 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         else if (rt == 2) GEMM_S_LAUNCH(1, 2, 1);
         else GEMM_S_LAUNCH(1, 1, 1);
         LAUNCH_CHECK();
+        if (ln && !fuse)
+            return lay_ln(h, st, ln->act, bufs->PRE, L.ldpre, ln->width, rows ? rows : rows_p, rows_per_env, ly, ln->gb_sel_stride, sel, out, ldo);
         return 0;
     }
     GemmParams p{};
@@ -154,15 +193,18 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
     const int nblocks = (int)(rows_p / GBM) * p.ncolblk;
     hipLaunchKernelGGL(g_gemm, dim3(nblocks), dim3(GTHREADS), 0, st, p);
     LAUNCH_CHECK();
+    if (ln) return lay_ln(h, st, ln->act, out, ldo, ln->width, rows ? rows : rows_p, rows_per_env, ly, ln->gb_sel_stride, sel);
     return 0;
 }
 
+// x <- ACT(LayerNorm(x)) row by row: exact fp32 -- in place on fp32 rows; split arithmetic -- fp32 rows `x` (a PRE buffer) ->
+// the fragment-packed operand buffer `out_packed` of `ld_out` columns.
 int lay_ln(tdmpc2_plan *h, hipStream_t st, int act, float *x, int ld, int width, size_t rows, int rows_per_env,
-           const HostLayer &ly, long gb_sel_stride, const int *sel) {
+           const HostLayer &ly, long gb_sel_stride, const int *sel, float *out_packed, int ld_out) {
     LnActParams p{};
     p.x = x; p.ld = ld; p.width = width; p.rows = (int)rows; p.rows_per_env = rows_per_env;
     p.g = ly.g; p.b = ly.b; p.gb_sel_stride = sel ? gb_sel_stride : 0; p.sel = sel; p.sel_stride = 2;
-    p.pad_to = ld;  // whole row: only X has columns beyond `width`
+    p.out = reinterpret_cast<char *>(out_packed); p.KBo = ld_out / 16;
     p.ascale = ly.ascale; p.asc_sel_stride = sel ? (long)(3 * sizeof(LayerScal) / sizeof(float)) : 0;
     const int grid = (int)((rows + RW_THREADS / 64 - 1) / (RW_THREADS / 64));
     if (h->split) {
@@ -194,16 +236,12 @@ int lay_hidden(tdmpc2_plan *h, hipStream_t st, const HostNet &net, int slot, siz
     const Layered &L = h->lay;
     const LayBufs b = bufs ? *bufs : lay_bufs(h, 0);
     int rc;
-    bool fused = false;
     const LnFuse f0{0, is_q ? q_gstride(h, 0) : 0, h->cfg.mlp_dim}, f1{0, is_q ? q_gstride(h, 1) : 0, h->cfg.mlp_dim};
     if ((rc = lay_gemm(h, st, L.X, L.Kin, rows_p, rpe, net.l[0], is_q ? q_wstride(h, 0) : 0, is_q ? q_bstride(h, 0) : 0, slot,
-                       sel, b.HA, L.Mp, &f0, &fused, b.stats, l0_range))) return rc;
+                       sel, b.HA, L.Mp, &f0, &b, l0_range, rows))) return rc;
     if (after_l0) HIP_TRY(hipEventRecord(after_l0, st));
-    if (!fused && (rc = lay_ln(h, st, 0, b.HA, L.Mp, h->cfg.mlp_dim, rows, rpe, net.l[0], is_q ? q_gstride(h, 0) : 0, sel))) return rc;
-    if ((rc = lay_gemm(h, st, b.HA, L.Mp, rows_p, rpe, net.l[1], is_q ? q_wstride(h, 1) : 0, is_q ? q_bstride(h, 1) : 0, -1,
-                       sel, b.HB, L.Mp, &f1, &fused, b.stats))) return rc;
-    if (fused) return 0;
-    return lay_ln(h, st, 0, b.HB, L.Mp, h->cfg.mlp_dim, rows, rpe, net.l[1], is_q ? q_gstride(h, 1) : 0, sel);
+    return lay_gemm(h, st, b.HA, L.Mp, rows_p, rpe, net.l[1], is_q ? q_wstride(h, 1) : 0, is_q ? q_bstride(h, 1) : 0, -1,
+                    sel, b.HB, L.Mp, &f1, &b, nullptr, rows);
 }
 
 // z <- next(z, a): dynamics MLP with SimNorm output written back into X[:, 0:L)  (world_model.py:114-121)
@@ -214,12 +252,9 @@ int lay_dynamics(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int
     int rc;
     if ((rc = lay_hidden(h, st, h->dyn, BE_DYN, rows, rows_p, rpe, nullptr, false, nullptr, nullptr, l0_range))) return rc;
     if (x_free) HIP_TRY(hipStreamWaitEvent(st, x_free, 0));
-    bool fused = false;
     const LnFuse f2{1, 0, h->cfg.latent_dim};
-    // fused: the SimNorm latent goes straight into X's z columns in operand form (action / padding columns untouched)
-    if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, rpe, h->dyn.l[2], 0, 0, -1, nullptr, L.X, L.Kin, &f2, &fused))) return rc;
-    if (fused) return 0;
-    return lay_ln(h, st, 1, L.X, L.Kin, h->cfg.latent_dim, rows, rpe, h->dyn.l[2], 0, nullptr);
+    // the SimNorm latent goes straight into X's z columns in operand form (action / padding columns untouched)
+    return lay_gemm(h, st, L.HB, L.Mp, rows_p, rpe, h->dyn.l[2], 0, 0, -1, nullptr, L.X, L.Kin, &f2, nullptr, nullptr, rows);
 }
 
 // a <- pi(z) into X[:, L:L+A) (+ actions[e, t, n < P] for the policy-prior trajectories)  (world_model.py:144-184)
@@ -288,7 +323,7 @@ int lay_cvec(tdmpc2_plan *h, hipStream_t st, int E, const float *z0) {
     if (!h->split || !L.Z0X || getenv("TDMPC2_Z0_SHARED_OFF")) return 0;
     const tdmpc2_plan_cfg &c = h->cfg;
     const size_t rows_p = round_up((size_t)E, GBM);
-    hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)E), dim3(256), 0, st, L.Z0X, L.Kin, c.latent_dim, 1, z0, (float *)nullptr, (float *)nullptr);
+    hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)((E + 31) / 32)), dim3(256), 0, st, L.Z0X, L.Kin, c.latent_dim, 1, z0, (float *)nullptr, (float *)nullptr, E);
     LAUNCH_CHECK();
     const HostNet *nets[2] = {&h->rew, &h->dyn};
     const int slots[2] = {BE_REW, BE_DYN};
@@ -296,7 +331,7 @@ int lay_cvec(tdmpc2_plan *h, hipStream_t st, int E, const float *z0) {
     for (int i = 0; i < 2; ++i) {
         GemmRange r{0, c.latent_dim / 16, nullptr, 0, 0};
         if ((rc = lay_gemm(h, st, L.Z0X, L.Kin, rows_p, 1, nets[i]->l[0], 0, 0, slots[i], nullptr, L.cvec + (size_t)i * L.cvec_rows * L.Mp, L.Mp,
-                           nullptr, nullptr, nullptr, &r))) return rc;
+                           nullptr, nullptr, &r))) return rc;
     }
     L.cvec_ready = true;
     return 0;
@@ -316,7 +351,7 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
     const size_t rows = (size_t)E * N, rows_p = round_up(rows, GBM);
     int rc;
     if ((rc = lay_arrive_reset(h, st))) return rc;
-    if (h->split) hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM);
+    if (h->split) hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM, (int)rows);
     else hipLaunchKernelGGL(l_init_x, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM);
     LAUNCH_CHECK();
     // Two chains at a time (h->lay.side: a second stream + a second buffer set): the reward chain of step t runs beside the
@@ -329,7 +364,7 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
     for (int t = 0; t < H; ++t) {
         const int total = (int)rows * A;
         if (h->split)
-            hipLaunchKernelGGL(l_set_action_s, dim3((total + 255) / 256), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, A, NF, H, t,
+            hipLaunchKernelGGL(l_set_action_s, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, A, NF, H, t,
                                (int)rows, actions, N, n_off);
         else
             hipLaunchKernelGGL(l_set_action, dim3((total + 255) / 256), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, A, NF, H, t,
@@ -391,8 +426,8 @@ int lay_pitraj(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const flo
     int rc;
     if ((rc = lay_arrive_reset(h, st))) return rc;
     if (h->split)
-        hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, rpe, z0, (float *)nullptr,
-                           (float *)nullptr);
+        hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, rpe, z0, (float *)nullptr,
+                           (float *)nullptr, (int)rows);
     else
         hipLaunchKernelGGL(l_init_x, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, rpe, z0, (float *)nullptr,
                            (float *)nullptr);
@@ -490,7 +525,7 @@ int lay_value(tdmpc2_plan *h, hipStream_t st, int rows, const float *z, bool tar
         int rc0 = lay_arrive_reset(h, st);
         if (rc0) return rc0;
     }
-    if (h->split) hipLaunchKernelGGL(l_init_rows_s, dim3((unsigned)rows_p), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, z, rows);
+    if (h->split) hipLaunchKernelGGL(l_init_rows_s, dim3((unsigned)(rows_p / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, z, rows);
     else hipLaunchKernelGGL(l_init_rows, dim3((unsigned)rows_p), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, z, rows);
     LAUNCH_CHECK();
     struct Restore {  // the helpers read these from the handle

@@ -160,7 +160,8 @@ struct LnActParams {
     long gb_sel_stride;
     const int *sel;
     long sel_stride;
-    int pad_to;  // operand-form rows (split arithmetic): columns [width, pad_to) are zeroed in both planes
+    char *out;   // split arithmetic: the fragment-packed operand buffer the activated row goes to (x is then read-only) ...
+    int KBo;     // ... and its k16-blocks per row
     const float *ascale;   // split arithmetic: operand scale of this layer's output (LayerScal::ascale), + sel * asc_sel_stride
     long asc_sel_stride;
 };

@@ -1,21 +1,28 @@
 // f16x2-split arithmetic (see fused_kernels.cuh) for the layer-at-a-time family: the 19M / 48M / 317M world models.
 //
-// Activations that feed a GEMM are stored in HBM in OPERAND FORM: a row of `ld` columns occupies the same ld * 4
-// bytes as an fp32 row, laid out [hi: ld halfs | lo: ld halfs] with hi = f16(32 x), lo = f16(32 x - hi).  The row
-// kernels that produce an activation (l_ln_act_s, l_init_x_s, l_set_action_s, l_pi_head_s) write that form once, so the
-// GEMM stages plain copies; GEMM outputs (pre-activations, head logits) stay fp32 and are converted in place, one
-// wavefront per row, by the LayerNorm kernel.
+// Activations that feed a GEMM are stored in HBM in OPERAND FORM, FRAGMENT-PACKED exactly like the weights: a buffer of
+// `KB` k16-blocks per row holds, for every 32-row tile r32 and k16-block kb, 2 KiB at ((r32 * KB + kb) * 2048): the hi plane
+// (1 KiB) then the lo plane, each [64 lanes][8 halfs] with lane = 32 (k >> 3 & 1) + (row & 31) -- the register image of a
+// v_mfma_f32_32x32x16_f16 operand (hi = f16(s x), lo = f16(s x - hi), s the layer's power-of-two operand scale).  One
+// wavefront-wide 16-byte load / LDS-DMA fetches a whole fragment plane as 1 KiB of contiguous bytes, its LDS image is read
+// back with conflict-free ds_read_b128 at lane * 16, and a GEMM epilogue writes 512 (or 1024) contiguous bytes per store
+// instruction.  Same bytes per row as fp32 (KB * 64).  opnd_off() below is the one definition of the layout; the row
+// kernels that produce an activation (l_ln_act_s, l_init_x_s, l_set_action_s, l_pi_head_s) and the GEMM epilogues use it.
+// GEMM outputs that are not operands (head logits, unfused pre-activations) stay fp32 row-major.
 // g_gemm_s<NCT>: 128 x (128 NCT) output tile per 256-thread workgroup; wave w owns 32 NCT output columns for all 128 rows
 // (4 row tiles x NCT column tiles): every weight fragment (2 KB per k16-block, from L2) feeds 12 MFMAs and the row
 // fragments come from LDS (8 ds_read_b128 per block, shared by the NCT column tiles).
 // Included by tdmpc2_plan.hip inside its anonymous namespace, after fused_kernels.cuh and layered_kernels.cuh.
 #pragma once
 
-constexpr int GS_LDH = GBK + 8;  // LDS row stride of one plane in halfs: 80 B = 20 dwords = 4 x odd -> conflict-free b128
+// byte offset of the hi half of element (row, col) in a fragment-packed operand buffer with KB k16-blocks per row (lo: + 1024)
+__host__ __device__ __forceinline__ size_t opnd_off(size_t row, int col, int KB) {
+    return ((row >> 5) * (size_t)KB + (size_t)(col >> 4)) * 2048 + (size_t)((((col >> 3) & 1) << 5) + (int)(row & 31)) * 16 + (size_t)(col & 7) * 2;
+}
 
 struct GemmSParams {
-    const _Float16 *A;  // operand form [Rp, lda]: row r at (char*)A + r * lda * 4: [hi lda halfs | lo lda halfs]
-    int lda;
+    const _Float16 *A;  // fragment-packed operand buffer (see above) with KBa k16-blocks per row
+    int KBa, a_kb0;     // blocks per row of A; the first block contracted (a k-range: the action columns of X)
     int K;              // contraction length, multiple of GBK
     int kb0, kbs;       // a k-range of the packed matrix: first k16-block and blocks per column tile (0: K / 16 = the whole matrix)
     const _Float16 *wp; // split-packed [CT][K/16][2][64][8] (k_pack_split), + sel * w_sel_stride (in halfs)
@@ -29,8 +36,8 @@ struct GemmSParams {
     long sel_stride;
     int rows_per_env;
     const int *row_env; // optional per-row env of the bias lookup (see GemmParams)
-    float *out;         // fp32 [Rp, ldo]  (EPI != 0: operand form, the same ldo * 4 bytes per row)
-    int ldo;
+    float *out;         // fp32 [Rp, ldo]  (EPI != 0: fragment-packed operand buffer with KBo k16-blocks per row)
+    int ldo, KBo;
     // ---- EPI != 0: LayerNorm + activation + hi / lo split in the epilogue (no fp32 round trip, no row kernel)
     const float *ln_g, *ln_b;  // LayerNorm weight / bias [width], + sel * gb_sel_stride
     long gb_sel_stride;
@@ -74,13 +81,8 @@ constexpr int GLN_MAXSPIN = 1 << 20;  // polls (an agent-scope load + s_sleep(2)
 template <int NCT, int RT = 4, int SD = 1, int EPI = 0, int PF = 0>
 __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     constexpr int TM = 32 * RT;  // rows of this workgroup's tile
-    __shared__ __attribute__((aligned(16))) _Float16 As[2][2][TM * GS_LDH];  // [buffer][plane][row][k]
-    // EPI != 0: the epilogue's output stage (one 32-row tile in operand form) -- the idle staging buffers when they are large
-    // enough (128-row tiles), memory of its own otherwise
-    constexpr int EPI_STAGE_BYTES = EPI ? 2 * 32 * (128 * NCT + 4) * 2 : 0;
-    constexpr bool EPI_ALIAS = EPI_STAGE_BYTES <= (int)sizeof(As);
-    __shared__ __attribute__((aligned(16))) char epi_own[EPI_ALIAS ? 16 : EPI_STAGE_BYTES];
-    char *epi_lds = EPI_ALIAS ? reinterpret_cast<char *>(&As[0][0][0]) : epi_own;
+    // LDS image of a 32-wide chunk: the chunk's RT x 2 (k16-blocks) x 2 (planes) fragment planes, 1 KiB each, as they lie in HBM
+    __shared__ __attribute__((aligned(16))) _Float16 As[2][RT * 4][512];  // [buffer][(row tile, k16-block, plane)][lane * 8]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rb, cb;
@@ -104,23 +106,14 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     unsigned voff = (unsigned)lane * 16u;
     asm volatile("" : "+v"(voff));
 
-    // A staging: TM rows x 2 planes x 4 sixteen-byte pieces per 32-wide chunk = 8 TM pieces, RT per thread
-    const char *ab = reinterpret_cast<const char *>(p.A) + (size_t)row0 * p.lda * 4;
+    // A staging: wave w copies plane (w & 1) of k16-block (w >> 1) of the chunk for each of the RT row tiles: 1 KiB contiguous
+    // per wave and instruction, LDS image = HBM image
+    const char *ab = reinterpret_cast<const char *>(p.A) + ((size_t)(row0 >> 5) * p.KBa + p.a_kb0) * 2048;
     int g_off[RT], l_off[RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
-        const int idx = tid + 256 * i;
-        // a quad of lanes copies 64 contiguous bytes of one row; the two quads of an 8-lane LDS write phase take rows 4 apart:
-        // with the 80-byte row stride rows r and r + 1 overlap in 4 banks, rows r and r + 4 do not (r01k PMC: 25 % of the LDS
-        // cycles of g_gemm_s<2> were bank conflicts; the b128 fragment READS are conflict-free with this stride)
-        const int plane = idx / (4 * TM), q = (idx >> 2) % TM, c16 = idx & 3;
-#ifdef GEMM_LINEAR_STAGING
-        const int r = q;
-#else
-        const int r = (q & ~7) | ((q & 1) << 2) | ((q >> 1) & 3);
-#endif
-        g_off[i] = r * p.lda * 4 + plane * p.lda * 2 + c16 * 16;
-        l_off[i] = (plane * TM * GS_LDH + r * GS_LDH) * 2 + c16 * 16;
+        g_off[i] = (i * p.KBa + (wave >> 1)) * 2048 + (wave & 1) * 1024 + lane * 16;
+        l_off[i] = (4 * i + wave) * 1024 + lane * 16;
     }
     const int nchunks = p.K / GBK;
     f32x4 stage[SD][RT];
@@ -128,10 +121,10 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     for (int d = 0; d < SD; ++d)
         if (d < nchunks) {
 #pragma unroll
-            for (int i = 0; i < RT; ++i) stage[d][i] = *reinterpret_cast<const f32x4 *>(ab + g_off[i] + (size_t)d * GBK * 2);
+            for (int i = 0; i < RT; ++i) stage[d][i] = *reinterpret_cast<const f32x4 *>(ab + g_off[i] + (size_t)d * 4096);
         }
     char *lds = reinterpret_cast<char *>(&As[0][0][0]);
-    constexpr int BUF_BYTES = 2 * TM * GS_LDH * 2;
+    constexpr int BUF_BYTES = RT * 4 * 1024;
 #pragma unroll
     for (int i = 0; i < RT; ++i) *reinterpret_cast<f32x4 *>(lds + l_off[i]) = stage[0][i];
     __syncthreads();
@@ -169,18 +162,17 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
         if (steady || ch + SD < nchunks) {  // chunk ch's slot is free (its rows went to LDS one chunk ago): request chunk ch + SD
 #pragma unroll
             for (int i = 0; i < RT; ++i)
-                stage[cc % SD][i] = *reinterpret_cast<const f32x4 *>(ab + g_off[i] + (size_t)(ch + SD) * GBK * 2);
+                stage[cc % SD][i] = *reinterpret_cast<const f32x4 *>(ab + g_off[i] + (size_t)(ch + SD) * 4096);
         }
-        const _Float16 *ah = &As[ch & 1][0][0] + i32 * GS_LDH + 8 * hh;
-        const _Float16 *al = &As[ch & 1][1][0] + i32 * GS_LDH + 8 * hh;
+        const _Float16 *af = &As[ch & 1][0][0] + lane * 8;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const int d = (cc * 2 + kb) % PFB;
             f16x8 fh[RT], fl[RT];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                fh[rt] = *reinterpret_cast<const f16x8 *>(ah + rt * 32 * GS_LDH + kb * 16);
-                fl[rt] = *reinterpret_cast<const f16x8 *>(al + rt * 32 * GS_LDH + kb * 16);
+                fh[rt] = *reinterpret_cast<const f16x8 *>(af + ((rt * 2 + kb) * 2 + 0) * 512);
+                fl[rt] = *reinterpret_cast<const f16x8 *>(af + ((rt * 2 + kb) * 2 + 1) * 512);
             }
             // EPI != 0: weight fragment as the A operand -> C[feature][row] (same sums, transposed accumulator tile)
 #pragma unroll
@@ -237,6 +229,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
         // plans in the call: per 32-column tile (mean, M2); tiles folded left to right inside groups of 128 columns; groups
         // folded left to right over the row.  A plan therefore computes the same bits alone, inside a batch and when its
         // rows are split over ranks, whichever g_gemm_s variant the call size selects.
+        static_assert((8 * NCT + 2) * TM * 4 <= (int)sizeof(As), "the epilogue's tables fit the idle staging buffers");
         float *red = reinterpret_cast<float *>(&As[0][0][0]);         // [4 NCT tiles of the column block][TM][2]
         float *rs = red + 4 * NCT * TM * 2;                            // [TM][2]
         // (1) v = acc * oscale + bias, in place
@@ -341,26 +334,20 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
             rs[2 * tid + 1] = 1.0f / sqrtf(q_acc / n_acc + LN_EPS);
         }
         __syncthreads();
-        // (6) normalise, activate, split -> operand form.  A lane holds 4 consecutive features of 32 different rows: stored
-        // directly that is 16 bytes per row per instruction (8 192 partial-line writes per 128 x 256 tile -- measured: + 31 us
-        // on a 242 us GEMM).  So each 32-row tile goes through LDS ([plane][row][features], row stride + 4 halfs: the b64
-        // writes of a wave spread over all banks) and leaves as 16-byte pieces, 512 contiguous bytes per row and plane.
+        // (6) normalise, activate, split -> the fragment-packed output.  A lane holds features 8 j + 4 hh + (0..3) of row i32 of
+        // column tile ct: k16-block 2 ct + (j >> 1), k-half j & 1 -> 8 bytes at lane' = 32 (j & 1) + i32, + 8 hh: one store
+        // instruction of the wave covers 512 contiguous bytes of a fragment plane.
         const float *gsel = p.ln_g + (size_t)sel * p.gb_sel_stride, *besel = p.ln_b + (size_t)sel * p.gb_sel_stride;
         const float oscl = EPI == 1 ? p.ascale[(size_t)sel * p.asc_sel_stride] : ACT_SCALE;
-        constexpr int WF = 128 * NCT;          // features of the workgroup's column block
-        constexpr int SROW = WF + 4;           // halfs
-        constexpr int PIECES = WF / 8;         // 16-byte pieces per row and plane
         float rmean[RT], rrstd[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             rmean[rt] = rs[2 * (rt * 32 + i32)];
             rrstd[rt] = rs[2 * (rt * 32 + i32) + 1];
         }
-        __syncthreads();  // rs is consumed: the stage may overwrite it
-        _Float16 *stg = reinterpret_cast<_Float16 *>(epi_lds);
-        const int nvalid_pieces = (p.CT * 32 - cb * WF < WF ? p.CT * 32 - cb * WF : WF) / 8;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
+            char *otile = reinterpret_cast<char *>(p.out) + (size_t)((row0 >> 5) + rt) * p.KBo * 2048 + i32 * 16 + hh * 8;
 #pragma unroll
             for (int n = 0; n < NCT; ++n) {
                 if (ct0 + n >= p.CT) continue;
@@ -390,22 +377,11 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
                     }
                     f16x4 hi, lo;
                     split4(y, hi, lo, oscl);
-                    const int fl = (wave * NCT + n) * 32 + 8 * j + 4 * hh;  // feature inside the column block
-                    *reinterpret_cast<f16x4 *>(stg + (0 * 32 + i32) * SROW + fl) = hi;
-                    *reinterpret_cast<f16x4 *>(stg + (1 * 32 + i32) * SROW + fl) = lo;
+                    char *o = otile + (size_t)((ct0 + n) * 2 + (j >> 1)) * 2048 + (j & 1) * 512;
+                    *reinterpret_cast<f16x4 *>(o) = hi;
+                    *reinterpret_cast<f16x4 *>(o + 1024) = lo;
                 }
             }
-            __syncthreads();
-            char *obase = reinterpret_cast<char *>(p.out) + (size_t)(row0 + rt * 32) * p.ldo * 4 + (size_t)cb * WF * 2;
-#pragma unroll
-            for (int c = tid; c < 2 * 32 * PIECES; c += GTHREADS) {
-                const int piece = c % PIECES, row = (c / PIECES) % 32, plane = c / (PIECES * 32);
-                if (piece < nvalid_pieces) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(stg + (plane * 32 + row) * SROW + piece * 8);
-                    *reinterpret_cast<f32x4 *>(obase + (size_t)row * p.ldo * 4 + (size_t)plane * p.ldo * 2 + piece * 16) = v;
-                }
-            }
-            if (rt + 1 < RT) __syncthreads();
         }
         return;
     }
@@ -428,24 +404,25 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     }
 }
 
-// ---------------------------------------------------------------- row kernels writing operand form
-__device__ __forceinline__ void put_split(_Float16 *rowp, int ld, int col, float v) {  // bounded operands: latents, actions
+// ---------------------------------------------------------------- row kernels writing operand form (fragment-packed)
+__device__ __forceinline__ void put_split(char *buf, int KB, size_t row, int col, float v) {  // bounded operands: latents, actions
     const float vs = v * ACT_SCALE;
     const _Float16 h = (_Float16)vs;
-    rowp[col] = h;
-    rowp[ld + col] = (_Float16)(vs - (float)h);
+    _Float16 *o = reinterpret_cast<_Float16 *>(buf + opnd_off(row, col, KB));
+    o[0] = h;
+    o[512] = (_Float16)(vs - (float)h);
 }
 
-// In place, one wavefront per row: fp32 pre-activation row (width <= 4096 columns at the start of the row's ld * 4
-// bytes) -> ACT(LayerNorm(.)) -> operand form [hi | lo] of the same row.  The whole row is held in registers between
-// the read and the write (the two forms alias).
+// One wavefront per row: fp32 pre-activation row pre[row * ldpre + (0 .. width)] (an unfused GEMM's output, width <= 4096)
+// -> ACT(LayerNorm(.)) -> columns [0, width) of row `row` of the fragment-packed operand buffer `out` (KBo k16-blocks per
+// row); the buffer's other columns are left alone (X: action and padding columns).
 template <int ACT>
 __global__ __launch_bounds__(RW_THREADS) void l_ln_act_s(LnActParams p) {
     const int row = blockIdx.x * (RW_THREADS / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= p.rows) return;
     const int sel = p.sel ? p.sel[(size_t)(row / p.rows_per_env) * p.sel_stride] : 0;
     const float *g = p.g + (size_t)sel * p.gb_sel_stride, *bb = p.b + (size_t)sel * p.gb_sel_stride;
-    float *xr = p.x + (size_t)row * p.ld;
+    const float *xr = p.x + (size_t)row * p.ld;
     const int n4 = p.width / 4;
     f32x4 v[16];
     float s = 0.f;
@@ -473,7 +450,6 @@ __global__ __launch_bounds__(RW_THREADS) void l_ln_act_s(LnActParams p) {
     const float rstd = 1.0f / sqrtf(var + LN_EPS);
     // operand scale of this layer's output: chosen at bind time for Mish layers (k_ascale), fixed for SimNorm outputs
     const float oscl = ACT == 0 ? p.ascale[(size_t)sel * p.asc_sel_stride] : ACT_SCALE;
-    _Float16 *hp = reinterpret_cast<_Float16 *>(xr);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int c4 = lane + 64 * q;
@@ -510,36 +486,58 @@ __global__ __launch_bounds__(RW_THREADS) void l_ln_act_s(LnActParams p) {
         if (ok) {
             f16x4 hi, lo;
             split4(y, hi, lo, oscl);
-            *reinterpret_cast<f16x4 *>(hp + 4 * c4) = hi;
-            *reinterpret_cast<f16x4 *>(hp + p.ld + 4 * c4) = lo;
+            char *o = p.out + opnd_off((size_t)row, 4 * c4, p.KBo);  // 4 consecutive columns never straddle an 8-column k-half
+            *reinterpret_cast<f16x4 *>(o) = hi;
+            *reinterpret_cast<f16x4 *>(o + 1024) = lo;
         }
     }
-    // The fp32 pre-activation row aliased the hi / lo planes beyond `width` too (X: action and padding columns): leave
-    // zeros there, not fp32 bit patterns that read as f16 Inf / NaN (the action columns are set afterwards).
-    for (int c = p.width + lane; c < p.pad_to; c += 64) {
-        hp[c] = (_Float16)0.f;
-        hp[p.ld + c] = (_Float16)0.f;
+}
+
+// Columns [c0, c1) (multiples of 8) of every row of the packed buffer X (KB k16-blocks per row) <- split(src(row, col)).
+// One workgroup per 32-row tile; a thread writes the 8 halfs (16 bytes per plane) of one (row, 8-column group): a wavefront's
+// store covers two runs of 512 contiguous bytes.
+template <class SRC>
+__device__ __forceinline__ void fill_packed_tile(char *X, int KB, int c0, int c1, SRC src) {
+    const int ng = (c1 - c0) >> 3;  // 8-column groups
+    for (int idx = threadIdx.x; idx < ng * 32; idx += blockDim.x) {
+        const int r = idx & 31, gq = idx >> 5, col = c0 + 8 * gq;
+        const size_t row = (size_t)blockIdx.x * 32 + r;
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float vs = src(row, col + e) * ACT_SCALE;
+            const _Float16 h = (_Float16)vs;
+            hi[e] = h;
+            lo[e] = (_Float16)(vs - (float)h);
+        }
+        char *o = X + opnd_off(row, col, KB);
+        *reinterpret_cast<f16x8 *>(o) = hi;
+        *reinterpret_cast<f16x8 *>(o + 1024) = lo;
     }
 }
 
-// X[row] <- operand form of [z0[env] | zeros]; G, term <- 0.  One workgroup per row.
-__global__ void l_init_x_s(float *X, int ldx, int L, int rows_per_env, const float *z0, float *G, float *term) {
-    const int row = blockIdx.x;
-    const float *z = z0 + (size_t)(row / rows_per_env) * L;
-    _Float16 *xr = reinterpret_cast<_Float16 *>(X + (size_t)row * ldx);
-    for (int c = threadIdx.x; c < ldx; c += blockDim.x) put_split(xr, ldx, c, c < L ? z[c] : 0.f);
-    if (threadIdx.x == 0) {
-        if (G) G[row] = 0.f;
-        if (term) term[row] = 0.f;
+// X[row] <- operand form of [z0[env] | zeros]; G, term <- 0.  One workgroup per 32-row tile (rows past `rows`: zeros).
+__global__ void l_init_x_s(float *X, int ldx, int L, int rows_per_env, const float *z0, float *G, float *term, int rows) {
+    fill_packed_tile(reinterpret_cast<char *>(X), ldx / 16, 0, ldx, [&](size_t row, int c) {
+        return (c < L && row < (size_t)rows) ? z0[(row / rows_per_env) * L + c] : 0.f;
+    });
+    if (threadIdx.x < 32) {
+        const size_t row = (size_t)blockIdx.x * 32 + threadIdx.x;
+        if (row < (size_t)rows) {
+            if (G) G[row] = 0.f;
+            if (term) term[row] = 0.f;
+        }
     }
 }
 
+// the action columns [L, ldx) of X <- split(actions[e, t, n, :]) (zeros past A).  One workgroup per 32-row tile; L % 8 == 0.
 __global__ void l_set_action_s(float *X, int ldx, int L, int A, int N, int H, int t, int rows, const float *actions, int nsub, int n_off) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= rows * A) return;
-    const int row = idx / A, a = idx % A;
-    const int e = row / nsub, n = n_off + row % nsub;
-    put_split(reinterpret_cast<_Float16 *>(X + (size_t)row * ldx), ldx, L + a, actions[(((size_t)e * H + t) * N + n) * A + a]);
+    fill_packed_tile(reinterpret_cast<char *>(X), ldx / 16, L, ldx, [&](size_t row, int c) {
+        const int a = c - L;
+        if (a >= A || row >= (size_t)rows) return 0.f;
+        const size_t e = row / nsub, n = n_off + row % nsub;
+        return actions[((e * H + t) * N + n) * A + a];
+    });
 }
 
 __global__ void l_pi_head_s(PiHeadParams p) {
@@ -562,14 +560,14 @@ __global__ void l_pi_head_s(PiHeadParams p) {
         eps *= mk;
     }
     const float act = tanhf(mu + eps * expf(ls));
-    put_split(reinterpret_cast<_Float16 *>(p.X + (size_t)row * p.ldx), p.ldx, p.L + a, act);
+    put_split(reinterpret_cast<char *>(p.X), p.ldx / 16, (size_t)row, p.L + a, act);
     if (p.actions && n < p.nvalid) p.actions[(((size_t)e * p.H + p.t) * p.N + n) * p.A + a] = act;
     if (p.trace) p.trace[(size_t)row * (p.H + 2 + p.A) + p.H + 2 + a] = act;
 }
 
-// X[row] <- operand form of [z[row] | zeros] (rows >= nvalid: zeros).  One workgroup per row.
+// X[row] <- operand form of [z[row] | zeros] (rows >= nvalid: zeros).  One workgroup per 32-row tile.
 __global__ void l_init_rows_s(float *X, int ldx, int L, const float *z, int nvalid) {
-    const int row = blockIdx.x;
-    _Float16 *xr = reinterpret_cast<_Float16 *>(X + (size_t)row * ldx);
-    for (int c = threadIdx.x; c < ldx; c += blockDim.x) put_split(xr, ldx, c, (c < L && row < nvalid) ? z[(size_t)row * L + c] : 0.f);
+    fill_packed_tile(reinterpret_cast<char *>(X), ldx / 16, 0, ldx, [&](size_t row, int c) {
+        return (c < L && row < (size_t)nvalid) ? z[row * L + c] : 0.f;
+    });
 }

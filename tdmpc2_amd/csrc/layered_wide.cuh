@@ -1,0 +1,392 @@
+// g_gemm_w: the throughput GEMM of the layer-at-a-time family (hidden NormedLinear layers of the 48M / 317M world models when a
+// call fills the chip: c3 / c4 / c5; reference: NormedLinear, tdmpc2/common/layers.py:94-118, inside the mlp() of
+// layers.py:121-133 that WorldModel.next / reward / pi / Q run, world_model.py:114-216).
+//
+// One 512-thread workgroup (8 waves, one per CU: 128 KiB of LDS) computes a 256-row x 256-column output tile of
+//     out = ACT(LayerNorm(A W^T * oscale + bias))            (f16x2-split products, fp32 accumulate: fused_kernels.cuh)
+// Both operands are fragment-packed in HBM (layered_split.cuh): a k16-slab of the tile is 8 row tiles x 2 KiB of A and
+// 8 column tiles x 2 KiB of W -- 32 planes of 1 KiB, each ONE wavefront-wide LDS-DMA (global_load_lds_dwordx4: 1 KiB of
+// contiguous HBM bytes -> 1 KiB of contiguous LDS, no VGPRs, no address arithmetic), 4 per wave and slab.  The LDS holds a ring
+// of NS = 4 slabs (32 KiB each).  Per slab a wave reads its 12 fragment planes (4 row tiles x {hi, lo} of A, 2 column tiles x
+// {hi, lo} of W; ds_read_b128 at lane * 16: conflict-free by construction) and issues 24 MFMAs (8 accumulator tiles x 3 products):
+// 21 operand bytes per MFMA against 32 for the 128 x 256 tile of g_gemm_s, and nothing but the slab's 4 DMA requests goes through
+// the vector memory path.
+//
+// Pipeline (phase s = slab s; fragments double-buffered in registers, 2 x 48 VGPRs):
+//     top of phase s      s_waitcnt lgkmcnt(0)        my fragments of slab s (read during phase s - 1) are in registers
+//                         s_waitcnt vmcnt(4 (NS - 2)) my DMA requests of slab s + 1 have landed (two newer slabs stay in flight)
+//                         s_barrier                   ... and everybody else's; everybody has slab s in registers
+//                         4 x LDS-DMA                 slab s + NS -> the ring slot of slab s (free: see the barrier)
+//                         24 MFMAs on slab s, the 12 ds_read_b128 of slab s + 1 issued between the first of them
+// One barrier per 24 MFMAs; a slab has NS - 1 = 3 phases (2-3 us) to arrive; no instruction of the loop waits for anything
+// issued in the same phase.  Every LDS read, MFMA and wait is an `asm volatile` (source order = issue order; hipcc neither
+// counts nor moves them), the DMA requests are compiler builtins fenced by sched_barrier.
+// The accumulation order per output element is that of g_gemm_s (slab by slab: w_hi a_hi, w_lo a_hi, w_hi a_lo), so the sums --
+// and with the canonical LayerNorm combination order the whole layer -- are bit-identical to the other tiles': a plan computes
+// the same bits alone (small tiles) and inside a batch that takes this one.
+// Epilogue: g_gemm_s's NormedLinear epilogue (statistics exchange between the column blocks of a row block, bounded wait),
+// writing the fragment-packed output with one 16-byte store per lane: v_permlane32_swap pairs the two k-halves of a row so
+// that a wavefront's store covers one whole 1 KiB fragment plane.
+// Included by k_layered.hip after layered_split.cuh.
+#pragma once
+
+template <int OFF>
+__device__ __forceinline__ void gw_dsrd(f16x8 &dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+__device__ __forceinline__ void gw_glds(const char *g, char *l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+#define GW_MFMA(ACC, WF, AF) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(WF), "v"(AF))
+
+struct GwFrags {
+    f16x8 ah[4], al[4], wh[2], wl[2];
+};
+
+constexpr int GW_SLOT = 32768;  // bytes of one k16-slab in the ring: [A: 8 row tiles x (hi, lo)][W: 8 column tiles x (hi, lo)]
+
+// Fragment planes of the slab in ring slot SLOT (la / lw: this wave's A / W read addresses for slots 0-1, + 65536 for 2-3),
+// two per step so that the phase can issue them between its first MFMAs.
+template <int SLOT, int STEP>
+__device__ __forceinline__ void gw_read2(GwFrags &f, const unsigned (&la)[2], const unsigned (&lw)[2]) {
+    constexpr int O = (SLOT & 1) * GW_SLOT;
+    const unsigned a = la[SLOT >> 1], w = lw[SLOT >> 1];
+    if constexpr (STEP == 0) {
+        gw_dsrd<O + 0>(f.wh[0], w);
+        gw_dsrd<O + 0 * 2048>(f.ah[0], a);
+    } else if constexpr (STEP == 1) {
+        gw_dsrd<O + 2048>(f.wh[1], w);
+        gw_dsrd<O + 1 * 2048>(f.ah[1], a);
+    } else if constexpr (STEP == 2) {
+        gw_dsrd<O + 2 * 2048>(f.ah[2], a);
+        gw_dsrd<O + 3 * 2048>(f.ah[3], a);
+    } else if constexpr (STEP == 3) {
+        gw_dsrd<O + 1024>(f.wl[0], w);
+        gw_dsrd<O + 2048 + 1024>(f.wl[1], w);
+    } else if constexpr (STEP == 4) {
+        gw_dsrd<O + 0 * 2048 + 1024>(f.al[0], a);
+        gw_dsrd<O + 1 * 2048 + 1024>(f.al[1], a);
+    } else {
+        gw_dsrd<O + 2 * 2048 + 1024>(f.al[2], a);
+        gw_dsrd<O + 3 * 2048 + 1024>(f.al[3], a);
+    }
+}
+template <int SLOT>
+__device__ __forceinline__ void gw_read(GwFrags &f, const unsigned (&la)[2], const unsigned (&lw)[2]) {
+    gw_read2<SLOT, 0>(f, la, lw);
+    gw_read2<SLOT, 1>(f, la, lw);
+    gw_read2<SLOT, 2>(f, la, lw);
+    gw_read2<SLOT, 3>(f, la, lw);
+    gw_read2<SLOT, 4>(f, la, lw);
+    gw_read2<SLOT, 5>(f, la, lw);
+}
+
+// One phase.  PH = s mod 4 (ring slot of slab s = PH, of slab s + 1 = (PH + 1) % 4; register set of slab s = PH & 1).
+// STEADY: slab s + 4 exists (its DMA is issued here) and so does slab s + 1; otherwise the flags say.
+template <int PH, bool STEADY>
+__device__ __forceinline__ void gw_phase(f32x16 (&acc)[2][4], GwFrags (&fr)[2], const unsigned (&la)[2], const unsigned (&lw)[2],
+                                         char *ring_w, const char *&pa, const char *&pw, unsigned voff, bool issue, bool next, int vmc) {
+    GwFrags &c = fr[PH & 1], &n = fr[(PH + 1) & 1];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (STEADY || vmc == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (vmc == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (STEADY || issue) {  // slab s + 4 -> the slot slab s has just left
+        char *slot = ring_w + PH * GW_SLOT;
+        gw_glds(pa + voff, slot);
+        gw_glds(pa + voff + 1024, slot + 1024);
+        gw_glds(pw + voff, slot + 16384);
+        gw_glds(pw + voff + 1024, slot + 16384 + 1024);
+        pa += 2048;
+        pw += 2048;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // product 1 of 3: w_hi a_hi, the reads of the next slab (two per MFMA) between the first six
+    const bool rd = STEADY || next;
+    GW_MFMA(acc[0][0], c.wh[0], c.ah[0]);
+    if (rd) gw_read2<(PH + 1) % 4, 0>(n, la, lw);
+    GW_MFMA(acc[1][0], c.wh[1], c.ah[0]);
+    if (rd) gw_read2<(PH + 1) % 4, 1>(n, la, lw);
+    GW_MFMA(acc[0][1], c.wh[0], c.ah[1]);
+    if (rd) gw_read2<(PH + 1) % 4, 2>(n, la, lw);
+    GW_MFMA(acc[1][1], c.wh[1], c.ah[1]);
+    if (rd) gw_read2<(PH + 1) % 4, 3>(n, la, lw);
+    GW_MFMA(acc[0][2], c.wh[0], c.ah[2]);
+    if (rd) gw_read2<(PH + 1) % 4, 4>(n, la, lw);
+    GW_MFMA(acc[1][2], c.wh[1], c.ah[2]);
+    if (rd) gw_read2<(PH + 1) % 4, 5>(n, la, lw);
+    GW_MFMA(acc[0][3], c.wh[0], c.ah[3]);
+    GW_MFMA(acc[1][3], c.wh[1], c.ah[3]);
+    // product 2: w_lo a_hi
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        GW_MFMA(acc[0][rt], c.wl[0], c.ah[rt]);
+        GW_MFMA(acc[1][rt], c.wl[1], c.ah[rt]);
+    }
+    // product 3: w_hi a_lo
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        GW_MFMA(acc[0][rt], c.wh[0], c.al[rt]);
+        GW_MFMA(acc[1][rt], c.wh[1], c.al[rt]);
+    }
+}
+
+// EPI = 1: LayerNorm + Mish, 2: LayerNorm + SimNorm(8).  Grid / tile order: tile_order.h with 256-row blocks.
+template <int EPI>
+__global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
+    static_assert(EPI == 1 || EPI == 2, "the wide tile exists for the NormedLinear layers");
+    constexpr int NS = 4, TM = 256;
+    __shared__ __attribute__((aligned(1024))) char ring[NS * GW_SLOT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;  // this wave's accumulators: row tiles 4 wr .. + 3, column tiles 2 wc, 2 wc + 1
+    int rb, cb;
+    if (!gemm_s_tile(blockIdx.x, p.nrowblk, p.ncolblk, p.xcd_rows, p.ncol_grid, rb, cb)) return;
+    const int row0 = rb * TM;
+    const int sel = p.sel ? p.sel[(size_t)(row0 / p.rows_per_env) * p.sel_stride] : 0;
+    const int nk = p.K / 16;
+    // DMA role of this wave: row tile `wave` of A and column tile `wave` of W (a column tile past the matrix re-reads the last one)
+    const int ctl = cb * 8 + wave < p.CT ? cb * 8 + wave : p.CT - 1;
+    const char *pa = reinterpret_cast<const char *>(p.A) + ((size_t)((row0 >> 5) + wave) * p.KBa + p.a_kb0) * 2048;
+    const char *pw = reinterpret_cast<const char *>(p.wp + (size_t)sel * p.w_sel_stride) + ((size_t)ctl * (p.kbs ? p.kbs : nk) + p.kb0) * 2048;
+    unsigned voff = (unsigned)lane * 16u;
+    asm volatile("" : "+v"(voff));
+    char *ring_w = ring + wave * 2048;
+    const unsigned lbase = lds_addr_of(ring) + (unsigned)lane * 16u;
+    const unsigned la[2] = {lbase + (unsigned)wr * 8192u, lbase + (unsigned)wr * 8192u + 65536u};
+    const unsigned lw[2] = {lbase + 16384u + (unsigned)wc * 4096u, lbase + 16384u + (unsigned)wc * 4096u + 65536u};
+
+    f32x16 acc[2][4];  // [column tile][row tile]: C = [feature][row] (weight fragment = the MFMA's A operand, as in g_gemm_s<EPI>)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[n][rt][e] = 0.f;
+    GwFrags fr[2];
+
+    // prologue: slabs 0 .. NS - 1 requested; slab 0 into registers
+    const int npro = nk < NS ? nk : NS;
+#pragma unroll
+    for (int d = 0; d < NS; ++d)
+        if (d < npro) {
+            char *slot = ring_w + d * GW_SLOT;
+            gw_glds(pa + voff, slot);
+            gw_glds(pa + voff + 1024, slot + 1024);
+            gw_glds(pw + voff, slot + 16384);
+            gw_glds(pw + voff + 1024, slot + 16384 + 1024);
+            pa += 2048;
+            pw += 2048;
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    if (npro >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (npro == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (npro == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    gw_read<0>(fr[0], la, lw);
+
+    int s = 0;
+#pragma unroll 1
+    for (; s + 7 < nk; s += 4) {  // steady state: phases s .. s + 3 each have a slab s' + 4 <= nk - 1 to request
+        gw_phase<0, true>(acc, fr, la, lw, ring_w, pa, pw, voff, true, true, 8);
+        gw_phase<1, true>(acc, fr, la, lw, ring_w, pa, pw, voff, true, true, 8);
+        gw_phase<2, true>(acc, fr, la, lw, ring_w, pa, pw, voff, true, true, 8);
+        gw_phase<3, true>(acc, fr, la, lw, ring_w, pa, pw, voff, true, true, 8);
+    }
+#pragma unroll 1
+    for (; s < nk; s += 4) {  // the last phases (and short contractions): wave-uniform flags
+#define GW_TAIL(PH)                                                                                         \
+    if (s + PH < nk) {                                                                                      \
+        const int ss = s + PH, last_req = ss + 3 < nk - 1 ? ss + 3 : nk - 1; /* newest slab requested so far */ \
+        const int inflight = last_req - (ss + 1);                             /* slabs allowed to stay in flight */ \
+        gw_phase<PH, false>(acc, fr, la, lw, ring_w, pa, pw, voff, ss + 4 < nk, ss + 1 < nk, inflight >= 2 ? 8 : inflight == 1 ? 4 : 0); \
+    }
+        GW_TAIL(0)
+        GW_TAIL(1)
+        GW_TAIL(2)
+        GW_TAIL(3)
+#undef GW_TAIL
+    }
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // XDL write -> VALU read of the accumulators
+
+    // ---------------------------------------------------------------- NormedLinear epilogue (the protocol of g_gemm_s<.., EPI>)
+    const int i32 = lane & 31, hh = lane >> 5;
+    const int ct0 = cb * 8 + wc * 2;  // this wave's column tiles
+    const float osc = p.oscale[(size_t)sel * p.osc_sel_stride];
+    const float *bsel = p.bias + (size_t)sel * p.bias_sel_stride;
+    __syncthreads();  // every wave is done with the ring
+    float *red = reinterpret_cast<float *>(ring);  // [8 column tiles of the block][TM][2]
+    float *rs = red + 8 * TM * 2;                   // [TM][2]
+    // (1) v = acc * oscale + bias, in place
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        const int row = row0 + wr * 128 + rt * 32 + i32;
+        const float *bp = bsel;
+        if (p.bias_env_stride != 0) bp += (size_t)(p.row_env ? p.row_env[row] : row / p.rows_per_env) * p.bias_env_stride;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int ct = ct0 + n < p.CT ? ct0 + n : p.CT - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bp + ct * 32 + 8 * j + 4 * hh);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[n][rt][4 * j + r] = fmaf(acc[n][rt][4 * j + r], osc, b4[r]);
+            }
+        }
+    }
+    // (2) (mean, M2) of every row over each 32-column tile: 16 thread-local values + the lane ^ 32 half
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s1 += acc[n][rt][e];
+            s1 += __shfl_xor(s1, 32);
+            const float mw = s1 * (1.f / 32.f);
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float d = acc[n][rt][e] - mw;
+                q = fmaf(d, d, q);
+            }
+            q += __shfl_xor(q, 32);
+            if (hh == 0) {
+                red[((wc * 2 + n) * TM + wr * 128 + rt * 32 + i32) * 2 + 0] = mw;
+                red[((wc * 2 + n) * TM + wr * 128 + rt * 32 + i32) * 2 + 1] = q;
+            }
+        }
+    __syncthreads();
+    // (3) fold the tiles of each 128-column group left to right -> stats[row block][group][row]: 2 groups x 256 rows = one per thread
+    const int NG = (p.CT + 3) / 4;  // groups of the whole row
+    {
+        const int g = tid >> 8, r = tid & 255, G = cb * 2 + g;
+        if (G < NG) {
+            float n_acc = 0.f, m_acc = 0.f, q_acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (G * 4 + t >= p.CT) break;
+                const float mb = red[((g * 4 + t) * TM + r) * 2], qb = red[((g * 4 + t) * TM + r) * 2 + 1];
+                const float nt = n_acc + 32.f, dl = mb - m_acc;
+                m_acc += dl * (32.f / nt);
+                q_acc += qb + dl * dl * (n_acc * 32.f / nt);
+                n_acc = nt;
+            }
+            float *slot = p.stats + (((size_t)rb * NG + G) * TM + r) * 2;
+            __hip_atomic_store(slot, m_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + 1, q_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // (4) arrive (stores acknowledged first), wait for the row block's other column blocks -- bounded
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        if (!(p.fault && rb == 0 && cb == 0)) __hip_atomic_fetch_add(p.arrive + rb, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int spin = 0;
+        while (__hip_atomic_load(p.arrive + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.ncolblk) {
+            if (++spin > GLN_MAXSPIN) {
+                if (p.err) __hip_atomic_store(p.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    // (5) the row's statistics: the groups folded left to right (loads eight at a time, the fold in order)
+    if (tid < TM) {
+        float n_acc = 0.f, m_acc = 0.f, q_acc = 0.f;
+        const float *all = p.stats + ((size_t)rb * NG * TM + tid) * 2;
+        for (int g0 = 0; g0 < NG; g0 += 8) {
+            float mb[8], qb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int G = g0 + u < NG ? g0 + u : NG - 1;
+                mb[u] = __hip_atomic_load(all + (size_t)G * TM * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                qb[u] = __hip_atomic_load(all + (size_t)G * TM * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (g0 + u >= NG) break;
+                int nt4 = p.CT - (g0 + u) * 4;
+                nt4 = nt4 > 4 ? 4 : nt4;
+                const float nb = 32.f * (float)nt4;
+                const float nt = n_acc + nb, dl = mb[u] - m_acc;
+                m_acc += dl * (nb / nt);
+                q_acc += qb[u] + dl * dl * (n_acc * nb / nt);
+                n_acc = nt;
+            }
+        }
+        rs[2 * tid] = m_acc;
+        rs[2 * tid + 1] = 1.0f / sqrtf(q_acc / n_acc + LN_EPS);
+    }
+    __syncthreads();
+    // (6) normalise, activate, split -> the fragment-packed output.  A lane holds features 8 j + 4 hh + (0..3) of row i32 of a
+    // column tile.  For the pair (j, j + 1) = the two k-halves of k16-block 2 ct + (j >> 1), v_permlane32_swap hands the lower
+    // half-wave the upper one's 4 features of k-half 0 and the upper half-wave the lower one's of k-half 1: every lane then
+    // holds 8 consecutive features (16 bytes per plane) of ITS k-half, lane' = 32 hh + i32 = lane: one store = one 1 KiB plane.
+    const float *gsel = p.ln_g + (size_t)sel * p.gb_sel_stride, *besel = p.ln_b + (size_t)sel * p.gb_sel_stride;
+    const float oscl = EPI == 1 ? p.ascale[(size_t)sel * p.asc_sel_stride] : ACT_SCALE;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        const float rmean = rs[2 * (wr * 128 + rt * 32 + i32)], rrstd = rs[2 * (wr * 128 + rt * 32 + i32) + 1];
+        char *otile = reinterpret_cast<char *>(p.out) + (size_t)((row0 >> 5) + wr * 4 + rt) * p.KBo * 2048 + lane * 16;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            if (ct0 + n >= p.CT) continue;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                unsigned hw[2][2], lw2[2][2];  // [j - 2 jp][dword]: hi / lo planes of this lane's 4 features
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * jp + jj;
+                    const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gsel + (ct0 + n) * 32 + 8 * j + 4 * hh);
+                    const f32x4 be4 = *reinterpret_cast<const f32x4 *>(besel + (ct0 + n) * 32 + 8 * j + 4 * hh);
+                    f32x4 y;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = fmaf((acc[n][rt][4 * j + r] - rmean) * rrstd, g4[r], be4[r]);
+                    if (EPI == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = mish_fast(y[r]);
+                    } else {  // SimNorm: groups of 8 consecutive features = this lane's 4 + lane ^ 32's 4
+                        float m = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
+                        m = fmaxf(m, __shfl_xor(m, 32));
+                        float es = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            y[r] = __expf(y[r] - m);
+                            es += y[r];
+                        }
+                        es += __shfl_xor(es, 32);
+                        const float inv = 1.0f / es;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] *= inv;
+                    }
+                    f16x4 hi, lo;
+                    split4(y, hi, lo, oscl);
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 hb = __builtin_bit_cast(u32x2, hi), lb = __builtin_bit_cast(u32x2, lo);
+                    hw[jj][0] = hb[0]; hw[jj][1] = hb[1];
+                    lw2[jj][0] = lb[0]; lw2[jj][1] = lb[1];
+                }
+                // swap: lower half-wave <- upper's k-half-0 features, upper half-wave <- lower's k-half-1 features
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 ho, lo4;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const auto sh = __builtin_amdgcn_permlane32_swap(hw[0][d], hw[1][d], false, false);
+                    const auto sl = __builtin_amdgcn_permlane32_swap(lw2[0][d], lw2[1][d], false, false);
+                    // after the swap: element 0 = features 0..3 of this lane's k-half, element 1 = features 4..7
+                    ho[d] = sh[0]; ho[2 + d] = sh[1];
+                    lo4[d] = sl[0]; lo4[2 + d] = sl[1];
+                }
+                char *o = otile + (size_t)((ct0 + n) * 2 + jp) * 2048;
+                *reinterpret_cast<u32x4 *>(o) = ho;
+                *reinterpret_cast<u32x4 *>(o + 1024) = lo4;
+            }
+        }
+    }
+}

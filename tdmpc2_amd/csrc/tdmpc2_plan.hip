@@ -768,6 +768,13 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             }
             L.fuse_ln = true;
             if (const char *fl = getenv("TDMPC2_FUSE_LN")) L.fuse_ln = atoi(fl) != 0;
+            // fp32 pre-activations of the NormedLinear layers whose epilogue is not fused (the fallback after a reported wait,
+            // TDMPC2_TUNE_FUSE_LN = 0, tiles the fused path does not take): one buffer per chain
+            L.ldpre = std::max(L.Mp, (int)round_up((size_t)c.latent_dim, 32));
+            if ((rc = dev_alloc(h, (void **)&L.PRE, Rp * L.ldpre * 4)) || (L.side && (rc = dev_alloc(h, (void **)&L.PRE2, Rp * L.ldpre * 4)))) {
+                tdmpc2_plan_destroy(h);
+                return rc;
+            }
         }
         // stale rows of padded tiles are computed but never read back; start them finite
         if (hipMemset(L.X, 0, Rp * L.Kin * 4) != hipSuccess || hipMemset(L.HA, 0, Rp * L.Mp * 4) != hipSuccess ||

@@ -14,7 +14,8 @@ from tests.test_gpu_planner import _compare_stages, _oracle_stage_inputs, _run_n
 pytestmark = pytest.mark.gpu
 
 PATH_FUSED, PATH_LAYERED = 1, 2
-LAYERED_CASES = ["small", "small_ep", "small_ep_fire", "small_mt", "c1_ep", "c3", "c4", "c4_l1024"]
+# c3_x4 / c4_x2: the fat pins of the large models (four 48M plans; two 317M plans x the full six iterations: VERDICT r3 #4)
+LAYERED_CASES = ["small", "small_ep", "small_ep_fire", "small_mt", "c1_ep", "c3", "c4", "c4_l1024", "c3_x4", "c4_x2"]
 _PN = {1: "fp32", 2: "split"}
 # both arithmetic modes of the layered family: exact-fp32 MFMA GEMMs (1) and the f16x2 split (2)
 PRECS = pytest.mark.parametrize("prec", [1, 2], ids=["fp32", "split"])
@@ -278,13 +279,14 @@ def test_sharded_plan_reports_a_wait_that_gave_up_in_an_earlier_iteration(monkey
     planner.close()
 
 
-@pytest.mark.parametrize("E", [6, 16])
+@pytest.mark.parametrize("E", [6, 16, 30])
 def test_a_plan_computes_the_same_bits_alone_and_in_a_batch_that_switches_tiles(E):
     """Six plans of the 48M model in one call run on the 128 x 256 GEMM tile with the NormedLinear epilogue exchanging over 7
     column blocks; one plan alone runs on 32-row x 128-column tiles with 14 (in a row of blocks padded to 16).  The LayerNorm
     statistics are combined in an order that depends on the layer only (32-column tiles -> 128-column groups -> the row, left
     to right), so the values agree BIT FOR BIT (and so do the rows of a plan split over ranks, test_gpu_dist.py).  Sixteen
-    plans are 64 row blocks: the fused launches then take the XCD-local tile order -- same bits again."""
+    plans (224 workgroups of 256 x 256) and thirty (the benched c3 leg: 60 row blocks x 7, XCD-local tile order) run the
+    hidden layers on g_gemm_w -- the 8-wave LDS-DMA tile -- same bits again."""
     from oracle import cases
     from oracle import planner_oracle as po
     from tdmpc2_amd import synth
@@ -310,7 +312,7 @@ def test_a_plan_computes_the_same_bits_alone_and_in_a_batch_that_switches_tiles(
     g = torch.Generator().manual_seed(5)
     actions = ((torch.rand(E, H, N, A, generator=g) * 2 - 1) * sd["_action_masks"][torch.tensor(tasks)].view(E, 1, 1, A)).to(dev()).contiguous()
     eps = torch.randn(E, N, A, generator=g).to(dev())
-    qidx = torch.tensor(([[0, 4], [3, 1], [2, 0], [1, 2], [4, 3], [0, 1]] * 3)[:E], dtype=torch.int32, device=dev())
+    qidx = torch.tensor(([[0, 4], [3, 1], [2, 0], [1, 2], [4, 3], [0, 1]] * 5)[:E], dtype=torch.int32, device=dev())
     v = planner.estimate_value(z0, disc, actions, eps, qidx, task_emb=emb, act_mask=mask)
     assert torch.isfinite(v).all() and v.std() > 0
     for e in (0, 3, E - 1):
@@ -318,4 +320,45 @@ def test_a_plan_computes_the_same_bits_alone_and_in_a_batch_that_switches_tiles(
                                     eps[e:e + 1].contiguous(), qidx[e:e + 1].contiguous(), task_emb=emb[e:e + 1].contiguous(),
                                     act_mask=mask[e:e + 1].contiguous())
         assert torch.equal(ve[0], v[e]), e
+    planner.close()
+
+
+def test_a_317m_plan_computes_the_same_bits_alone_and_on_the_wide_tile():
+    """Four plans of the 317M model (H5 N1024: 16 row blocks x 16 column blocks = 256 workgroups of g_gemm_w; latent 1376 = 43
+    column tiles: the last column block of the dynamics' output layer is partly empty) against each of them alone (128-row
+    tiles, the epilogue exchanging over 32 column blocks or the row kernel): bit for bit."""
+    from oracle import cases
+    from tdmpc2_amd import synth
+    from tdmpc2_amd.native import NativePlanner
+    from tests.gpu_common import dev, disc_pow
+
+    E = 4
+    c = cases.build_case("c4")
+    cfg = c["cfg"]
+    sd = {k: torch.as_tensor(v) for k, v in c["sd"].items()}
+    H, N, A = cfg.horizon, cfg.num_samples, cfg.action_dim
+    planner = NativePlanner(cfg, c["iterations"], dev(), max_envs=E, path=PATH_LAYERED, precision=2)
+    planner.bind_state_dict(sd)
+    z0 = torch.as_tensor(synth.make_latents(cfg, E, seed=12)).to(dev())
+    tasks = [(9 * e + 2) % len(cfg.tasks) for e in range(E)]
+    embs = []
+    for t in tasks:
+        v = sd["_task_emb.weight"][t]
+        n = v.norm(2)
+        embs.append(v * (1.0 / (n + 1e-7)) if n > 1.0 else v)
+    emb = torch.stack(embs).to(dev()).contiguous()
+    mask = sd["_action_masks"][torch.tensor(tasks)].to(dev()).contiguous()
+    disc = disc_pow(cfg, [0.99] * E).to(dev())
+    g = torch.Generator().manual_seed(6)
+    actions = ((torch.rand(E, H, N, A, generator=g) * 2 - 1) * sd["_action_masks"][torch.tensor(tasks)].view(E, 1, 1, A)).to(dev()).contiguous()
+    eps = torch.randn(E, N, A, generator=g).to(dev())
+    qidx = torch.tensor([[0, 7], [3, 1], [6, 2], [5, 4]], dtype=torch.int32, device=dev())
+    v = planner.estimate_value(z0, disc, actions, eps, qidx, task_emb=emb, act_mask=mask)
+    assert torch.isfinite(v).all() and v.std() > 0
+    for e in (0, E - 1):
+        ve = planner.estimate_value(z0[e:e + 1].contiguous(), disc[e:e + 1].contiguous(), actions[e:e + 1].contiguous(),
+                                    eps[e:e + 1].contiguous(), qidx[e:e + 1].contiguous(), task_emb=emb[e:e + 1].contiguous(),
+                                    act_mask=mask[e:e + 1].contiguous())
+        assert torch.equal(ve[0], v[e]), e
+    assert planner.take_fault() == 0
     planner.close()

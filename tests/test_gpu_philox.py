@@ -165,6 +165,56 @@ def test_benched_geometry_matches_the_oracle_on_its_own_draws():
     planner.close()
 
 
+@pytest.mark.parametrize("name,E,envs", [("c3", 30, (0, 13, 29)), ("c4", 8, (0, 7))], ids=["c3-E30", "c4-E8"])
+def test_benched_layered_geometry_matches_the_oracle_on_its_own_draws(name, E, envs):
+    """The layered legs of the bench line at THEIR geometry: c3 (mt30 48M) with E = 30 plans per call and c4 (mt80 317M, H5 N1024)
+    with E = 8, I = 6, tape = NULL -- hidden layers on g_gemm_w (256 x 256 tiles, XCD-local / row-major order), two chains in
+    flight, in-kernel Philox.  The draws of two or three of the plans replay through the oracle's plan() (a 317M plan is about
+    a minute of CPU): values of every iteration, elite sets, mean / std, action, new _prev_mean."""
+    from oracle import cases
+    from oracle import planner_oracle as po
+    from tdmpc2_amd.native import NativePlanner
+    from tests.gpu_common import dev
+
+    c = cases.build_case("c3_x4" if name == "c3" else "c4_x2")  # (the 6-iteration cases of those models)
+    cfg, I = c["cfg"], c["iterations"]
+    assert I == 6
+    model = po.OracleModel(cfg, {k: torch.as_tensor(v) for k, v in c["sd"].items()})
+    planner = NativePlanner(cfg, I, dev(), max_envs=E, path=2)
+    planner.bind_state_dict(model.sd)
+    inp = _many_env_inputs(c, model, E, seed=41)
+    seed = 20260925
+    call = planner.call_counter()
+    a, prev, st = _plan(planner, inp, None, seed)
+    assert planner.take_fault() == 0
+    worst = dict(value=0.0, mean=0.0, action=0.0, prev_mean=0.0)
+    swaps = 0
+    for e in envs:
+        tp = planner.export_noise(seed, call, 1, env_first=e)
+        tp = {k: v[0].cpu() for k, v in tp.items()}
+        wa, wpm, wst = po.plan(model, z0=torch.as_tensor(inp["z0_np"][e:e + 1]), tape=tp, prev_mean=torch.as_tensor(inp["prev_np"][e]),
+                               t0=bool(inp["t0_np"][e]), eval_mode=False, task=inp["tasks"][e], discount=inp["discounts"][e], iterations=I)
+        P = cfg.num_pi_trajs
+        np.testing.assert_array_equal(st["actions"][e, 0, :, P:].cpu().numpy(), wst["actions"][0][:, P:].numpy())
+        worst["value"] = max(worst["value"], value_err(st["value"][e, 0].cpu().numpy(), wst["value"][0].numpy()))
+        same = all(set(st["elite_idx"][e, it].cpu().tolist()) == set(wst["elite_idx"][it].tolist()) for it in range(I))
+        if not same:  # top-k is discontinuous: count, and require that the reference's own boundary is that close
+            swaps += 1
+            continue
+        for it in range(I):
+            worst["value"] = max(worst["value"], value_err(st["value"][e, it].cpu().numpy(), wst["value"][it].numpy()))
+        worst["mean"] = max(worst["mean"], (st["mean"][e].cpu() - wst["mean"]).abs().max().item())
+        worst["action"] = max(worst["action"], (a[e].cpu() - wa).abs().max().item())
+        worst["prev_mean"] = max(worst["prev_mean"], (prev[e].cpu() - wpm).abs().max().item())
+    print(f"[{name} E={E} philox, layered] worst {worst}, elite-boundary swaps {swaps}")
+    record_parity(f"{name}/layered/split/philox_E{E}_benched_geometry", value_rel=worst["value"], mean_abs=worst["mean"],
+                  action_abs=worst["action"], prev_mean_abs=worst["prev_mean"], elite_swaps=int(swaps), plans=len(envs))
+    assert worst["value"] < 1e-4
+    assert swaps <= 1
+    assert worst["action"] < ACT_ATOL and worst["prev_mean"] < ACT_ATOL and worst["mean"] < ACT_ATOL
+    planner.close()
+
+
 def _normal_checks(x, what):
     """x: 1-D float64 sample that should be N(0, 1)."""
     from scipy import stats
