@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define TDMPC2_PLAN_ABI_VERSION 6
+#define TDMPC2_PLAN_ABI_VERSION 7
 
 typedef struct tdmpc2_plan tdmpc2_plan_t;
 
@@ -318,16 +318,40 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
  * key TDMPC2_TUNE_FUSE_LN (layered family, f16x2-split arithmetic): 1 (default) = the LayerNorm + Mish / SimNorm + operand split
  * of every NormedLinear (tdmpc2/common/layers.py:94-118) runs in the epilogue of its GEMM -- the column blocks of a row block
  * exchange per-row (mean, M2) partials through L2, a bounded wait like the cluster path's (tdmpc2_plan_take_fault) --;
- * 0 = fp32 pre-activations to HBM and a row kernel per layer. */
-enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0, TDMPC2_TUNE_FOLD_REFIT = 1, TDMPC2_TUNE_CLUSTER = 2, TDMPC2_TUNE_FUSE_LN = 3 };
+ * 0 = fp32 pre-activations to HBM and a row kernel per layer.
+ * key TDMPC2_TUNE_REARM_AFTER: consecutive clean calls after which a handle that was downgraded by a reported wait goes back to
+ * the CLUSTER / FUSE_LN paths (default 64; 0 = never: the downgrade is for good, as in ABI <= 6).  See tdmpc2_plan_take_fault. */
+enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0, TDMPC2_TUNE_FOLD_REFIT = 1, TDMPC2_TUNE_CLUSTER = 2, TDMPC2_TUNE_FUSE_LN = 3,
+                     TDMPC2_TUNE_REARM_AFTER = 4 };
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
 
-/* Fault report of the cluster path (TDMPC2_TUNE_CLUSTER).  Its hand-overs between workgroups wait a bounded time (about
- * 0.13 s); when a wait gives up -- another process or a foreign kernel held the compute units -- the plan in flight is
- * invalid: its action[E, A] comes back as NaN and its prev_mean is left as it was, so the step can simply be planned again.
- * Call this after synchronising the stream of a tdmpc2_plan_run / run_obs: *faults = number of such plans since the last
- * call (0 = none); the handle has then switched to one workgroup per tile (the path that cannot time out) for good. */
+/* Fault report of the paths whose workgroups wait for each other: the cluster path (TDMPC2_TUNE_CLUSTER) and the NormedLinear
+ * epilogue inside the layered family's GEMMs (TDMPC2_TUNE_FUSE_LN).  Those waits are bounded (2^18 polls, about a third of a
+ * second; a healthy wait is microseconds to one tile's run time); when one gives up -- another process or a foreign kernel held
+ * the compute units -- the call in flight is invalid AND SAYS SO: a plan's action[E, A] comes back as NaN with prev_mean left as
+ * it was (the step can simply be planned again); tdmpc2_plan_td_target / policy_value (LAYERED family) return NaN in every
+ * element of out[] (and action[]).  The reference has no analogue (its only guard is the nan_to_num of tdmpc2.py:184).
+ * Call this after synchronising the stream of such a call: *faults = number of invalid calls since the last take_fault (0 = none).
+ * After a fault the handle runs the paths without inter-workgroup waits; it switches back to the fast ones after
+ * TDMPC2_TUNE_REARM_AFTER (default 64) consecutive clean calls, doubling that number (up to 4096) every time a fault follows a
+ * re-arm and forgetting the back-off after a long clean run; an explicit tdmpc2_plan_set_tuning(CLUSTER / FUSE_LN) re-arms at
+ * once.  Calls enqueued back to back without a synchronisation in between: a fault is attributed when the host next looks at
+ * the error word (the next API call or take_fault); a caller that pipelines calls on one handle must treat a reported fault as
+ * covering every call enqueued since its last synchronisation. */
 int tdmpc2_plan_take_fault(tdmpc2_plan_t *h, int *faults);
+
+/* The fault history of a handle (no synchronisation, nothing consumed): how often a bounded wait has given up, how long ago the
+ * last one was, whether the handle is currently on the downgraded paths and how far the re-arm counter has got. */
+typedef struct tdmpc2_fault_info {
+    int32_t faults_total;        /* bounded waits that gave up since tdmpc2_plan_create */
+    int32_t rearms;              /* times the fast paths were switched back on */
+    int32_t degraded;            /* 1: running the paths without inter-workgroup waits right now */
+    int32_t clean_calls;         /* consecutive clean calls since the downgrade (re-arm at rearm_after) */
+    int32_t rearm_after;         /* current threshold (doubles after a re-arm, TDMPC2_TUNE_REARM_AFTER resets it; 0: never) */
+    int32_t reserved;
+    double seconds_since_fault;  /* wall-clock seconds since the last fault was noted; -1: never */
+} tdmpc2_fault_info;
+int tdmpc2_plan_fault_info(tdmpc2_plan_t *h, tdmpc2_fault_info *info);
 
 /* Live timing of the dominant (rollout) stage: after set_profiling(h, n > 0) every rollout launch
  * (FUSED: one ks_rollout kernel; LAYERED: the GEMM / row-kernel sequence of one CEM iteration's

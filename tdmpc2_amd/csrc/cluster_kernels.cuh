@@ -42,7 +42,7 @@
 //             phase 4H+5  q1.l1 -> S1;  head.
 #pragma once
 
-constexpr int CL_MAXSPIN = 1 << 20;    // polls before a member gives up (a few 100 ms: longer than any kernel that could hold a CU back; a healthy wait is microseconds)
+constexpr int CL_MAXSPIN = 1 << 18;    // polls before a member gives up (about a third of a second: longer than any kernel that could hold a CU back; a healthy wait is microseconds)
 __host__ __device__ constexpr int cl_phases(int H) { return 8 * H + 7; }  // hand-overs per launch (upper bound: policy prior + termination)
 __host__ __device__ constexpr int cl_heads(int H) { return 3 * H + 4; }  // narrow heads per launch (upper bound): H reward, H policy prior, H + 1 termination, policy, two Q
 

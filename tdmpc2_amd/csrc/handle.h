@@ -3,6 +3,7 @@
 // instantiated in other translation units (k_fused.hip / k_cluster.hip per action padding, k_layered.hip).
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -99,6 +100,16 @@ struct tdmpc2_plan {
     size_t cl_lds = 0;
     int cl_fault = 0;                // TDMPC2_CLUSTER_FAULT=1 at create: test hook of the bounded waits
     int faults = 0;                  // cluster plans that gave up since the last tdmpc2_plan_take_fault
+    // Recovery from a reported wait (fault_note / fault_clean, tdmpc2_plan.hip): the paths with inter-workgroup waits are switched
+    // off when a wait gives up and switched back on after `rearm_after` consecutive clean calls (doubling, up to 4096, every time
+    // a fault follows a re-arm: a box that keeps faulting -- co-tenancy -- settles on the paths without waits)
+    bool degraded = false;
+    int user_cluster_mode = 2;       // what the caller / environment asked for (restored by a re-arm)
+    bool user_fuse_ln = false;
+    int rearm_after = 64, rearm_base = 64;   // 0: never re-arm (the round-3 behaviour)
+    int clean_calls = 0;             // consecutive calls without a fault since the downgrade
+    int faults_total = 0, rearms = 0;
+    std::chrono::steady_clock::time_point last_fault{};
     bool split = false;  // fused kernels on the f16 matrix pipe with hi/lo operand split (fused_kernels.cuh)
     int force_rows = 0;  // TDMPC2_TUNE_ROWS_PER_WORKGROUP: 0 auto, 32, 64
     size_t row_bytes = 0;  // bytes of one sample row of the fused kernels' LDS tile

@@ -546,6 +546,7 @@ int lay_value(tdmpc2_plan *h, hipStream_t st, int rows, const float *z, bool tar
         p.lg = L.LG; p.ld = L.ldl; p.rows = rows; p.num_bins = c.num_bins; p.mode = j; p.reduce_min = reduce_min ? 1 : 0;
         p.bins = h->bins; p.qtmp = L.QT; p.out = out; p.reward = reward; p.terminated = terminated; p.discount = discount;
         p.disc_tab = (c.multitask && reward) ? h->disc_tab : nullptr; p.row_env = row_task;
+        p.err = (h->split && L.fuse_ln) ? h->cl_err_dev : nullptr; p.action = action; p.A = c.action_dim;
         hipLaunchKernelGGL(l_value_head, dim3((unsigned)((rows + RW_THREADS / 64 - 1) / (RW_THREADS / 64))), dim3(RW_THREADS), 0, st, p);
         LAUNCH_CHECK();
     }

@@ -474,6 +474,11 @@ struct ValueHeadParams {
     float discount;
     const float *disc_tab;             // [n_tasks] or null
     const int *row_env;                // [rows] task of each row (with disc_tab)
+    // the handle's host-mapped error word: a bounded inter-workgroup wait (fused NormedLinear epilogue) gave up somewhere in this
+    // call -> the outputs are NaN, never finite garbage (tdmpc2_plan_take_fault; null: no such wait on this path)
+    const unsigned int *err;
+    float *action;                     // [rows, A] (policy_value's second output) or null: NaN-filled with `out` on a fault
+    int A;
 };
 __global__ __launch_bounds__(RW_THREADS) void l_value_head(ValueHeadParams p) {
     const int row = blockIdx.x * (RW_THREADS / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -488,6 +493,11 @@ __global__ __launch_bounds__(RW_THREADS) void l_value_head(ValueHeadParams p) {
     if (p.reward) {
         const float disc = p.disc_tab ? p.disc_tab[p.row_env[row]] : p.discount;
         v = p.reward[row] + disc * (1.f - p.terminated[row]) * v;
+    }
+    if (p.err && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) {
+        v = __builtin_nanf("");
+        if (p.action)
+            for (int a = 0; a < p.A; ++a) p.action[(size_t)row * p.A + a] = __builtin_nanf("");
     }
     p.out[row] = v;
 }

@@ -52,7 +52,7 @@ struct GemmSParams {
     int xcd_rows, nrowblk, ncol_grid;
 };
 
-constexpr int GLN_MAXSPIN = 1 << 20;  // polls (an agent-scope load + s_sleep(2) each: about a second in all); a healthy wait is microseconds -- peers of a row block are dispatched back to back
+constexpr int GLN_MAXSPIN = 1 << 18;  // polls (an agent-scope load + s_sleep(2) each: about a third of a second in all); a healthy wait is microseconds -- peers of a row block are dispatched back to back -- or, when a row block straddles the residency limit of its XCD, one tile's run time (< 1 ms)
 
 // NCT = 32-wide output column tiles per wave: 1 -> 128 x 128 workgroup tile (narrow outputs: heads, small models),
 // 2 -> 128 x 256 (a wave owns 64 columns x 128 rows = 8 accumulators: per k16-block 4 KB of weight fragments and 8 KB of

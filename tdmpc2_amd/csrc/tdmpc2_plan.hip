@@ -416,18 +416,51 @@ void fill_rollout(tdmpc2_plan *h, RolloutParamsT<NET> &p, int E) {
     p.timing = h->timing;
 }
 
+// A bounded inter-workgroup wait gave up (the handle's error word is set): the plan / call in flight returned NaN.  Switch to
+// the paths without such waits, remember when, and let fault_clean() switch back after `rearm_after` clean calls.
+void fault_note(tdmpc2_plan *h) {
+    *(volatile unsigned int *)h->cl_err_host = 0;
+    if (h->in_shard) ((volatile unsigned int *)h->cl_err_host)[4] = 1;  // the sharded plan in flight is invalid: its final pick says so
+    if (!h->degraded) {
+        h->user_cluster_mode = h->cluster_mode;
+        h->user_fuse_ln = h->lay.fuse_ln;
+    } else if (h->rearm_after > 0 && h->rearm_after < 4096) {
+        h->rearm_after *= 2;  // (a fault on the downgraded paths cannot happen; this branch is a fault right after a re-arm raced in)
+    }
+    h->degraded = true;
+    h->cluster_mode = 0;
+    h->lay.fuse_ln = false;
+    h->clean_calls = 0;
+    h->faults++;
+    h->faults_total++;
+    h->last_fault = std::chrono::steady_clock::now();
+}
+void fault_clean(tdmpc2_plan *h) {  // a call is about to be enqueued and no fault is pending
+    if (!h->degraded) {  // a long clean run on the fast paths forgets the back-off
+        if (h->rearm_after > h->rearm_base && ++h->clean_calls >= 16 * h->rearm_after) {
+            h->rearm_after = h->rearm_base;
+            h->clean_calls = 0;
+        }
+        return;
+    }
+    if (h->rearm_after <= 0 || h->in_shard) return;
+    if (++h->clean_calls < h->rearm_after) return;
+    h->cluster_mode = h->user_cluster_mode;
+    h->lay.fuse_ln = h->user_fuse_ln;
+    h->degraded = false;
+    h->clean_calls = 0;
+    h->rearms++;
+    if (h->rearm_after < 4096) h->rearm_after *= 2;  // the next downgrade lasts twice as long; a long clean run resets it (above)
+}
+
 int validate_envs(tdmpc2_plan *h, int E) {
     if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
     if (E < 1 || E > h->cfg.max_envs) return fail(TDMPC2_ERR_INVALID, "n_envs=%d outside [1, max_envs=%d]", E, h->cfg.max_envs);
-    // a cluster hand-over of an EARLIER plan gave up (bounded wait): that plan returned NaN actions and kept its prev_mean
-    // (refit_plan); from here on the handle plans with one workgroup per tile.  tdmpc2_plan_take_fault reports it.
-    if (h->cl_err_host && *(volatile unsigned int *)h->cl_err_host) {
-        *(volatile unsigned int *)h->cl_err_host = 0;
-        if (h->in_shard) ((volatile unsigned int *)h->cl_err_host)[4] = 1;  // the sharded plan in flight is invalid: its final pick says so
-        h->cluster_mode = 0;
-        h->lay.fuse_ln = false;
-        h->faults++;
-    }
+    // a cluster hand-over / fused-epilogue wait of an EARLIER call gave up (bounded wait): that plan returned NaN actions and kept
+    // its prev_mean (refit_plan), that td_target / policy_value returned NaN; the handle now runs the paths without waits
+    // until fault_clean() re-arms the fast ones.  tdmpc2_plan_take_fault / tdmpc2_plan_fault_info report it.
+    if (h->cl_err_host && *(volatile unsigned int *)h->cl_err_host) fault_note(h);
+    else fault_clean(h);
     return check_ready(h);
 }
 
@@ -1591,15 +1624,22 @@ int tdmpc2_plan_set_call_counter(tdmpc2_plan_t *h, uint32_t next_call) {
 int tdmpc2_plan_take_fault(tdmpc2_plan_t *h, int *faults) {
     if (!h || !faults) return fail(TDMPC2_ERR_INVALID, "null argument");
     ENTER(h);
-    if (h->cl_err_host && *(volatile unsigned int *)h->cl_err_host) {
-        *(volatile unsigned int *)h->cl_err_host = 0;
-        if (h->in_shard) ((volatile unsigned int *)h->cl_err_host)[4] = 1;  // (asked in the middle of a sharded plan: its final pick still says so)
-        h->cluster_mode = 0;
-        h->lay.fuse_ln = false;
-        h->faults++;
-    }
+    if (h->cl_err_host && *(volatile unsigned int *)h->cl_err_host) fault_note(h);
     *faults = h->faults;
     h->faults = 0;
+    return TDMPC2_OK;
+}
+
+int tdmpc2_plan_fault_info(tdmpc2_plan_t *h, tdmpc2_fault_info *info) {
+    if (!h || !info) return fail(TDMPC2_ERR_INVALID, "null argument");
+    ENTER(h);
+    info->faults_total = h->faults_total;
+    info->rearms = h->rearms;
+    info->degraded = h->degraded ? 1 : 0;
+    info->clean_calls = h->clean_calls;
+    info->rearm_after = h->rearm_after;
+    info->seconds_since_fault = h->faults_total
+        ? std::chrono::duration<double>(std::chrono::steady_clock::now() - h->last_fault).count() : -1.0;
     return TDMPC2_OK;
 }
 
@@ -1612,12 +1652,19 @@ int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value) {
     }
     if (key == TDMPC2_TUNE_CLUSTER) {
         if (value < 0 || value > 2) return fail(TDMPC2_ERR_INVALID, "cluster must be 0 (never), 1 (whenever the call fits) or 2 (auto)");
-        h->cluster_mode = value;
+        h->cluster_mode = h->user_cluster_mode = value;  // an explicit setting also re-arms (or keeps off) the path at once
+        if (h->degraded && h->lay.fuse_ln == h->user_fuse_ln) h->degraded = false;
         return TDMPC2_OK;
     }
     if (key == TDMPC2_TUNE_FUSE_LN) {
         if (value < 0 || value > 1) return fail(TDMPC2_ERR_INVALID, "fuse_ln must be 0 or 1");
-        h->lay.fuse_ln = value != 0 && h->lay.stats != nullptr;
+        h->lay.fuse_ln = h->user_fuse_ln = value != 0 && h->lay.stats != nullptr;
+        if (h->degraded && h->cluster_mode == h->user_cluster_mode) h->degraded = false;
+        return TDMPC2_OK;
+    }
+    if (key == TDMPC2_TUNE_REARM_AFTER) {
+        if (value < 0) return fail(TDMPC2_ERR_INVALID, "rearm_after must be >= 0 (0: never)");
+        h->rearm_after = h->rearm_base = value;
         return TDMPC2_OK;
     }
     if (key == TDMPC2_TUNE_FOLD_REFIT) {

@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("TDMPC2_PLAN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtdmpc2_plan.so")
 _lib = None
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol include/tdmpc2_plan.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
@@ -29,11 +29,17 @@ ABI_SYMBOLS = [
     "tdmpc2_plan_packed_size", "tdmpc2_plan_export_packed", "tdmpc2_plan_import_packed",
     "tdmpc2_plan_shard_begin", "tdmpc2_plan_shard_values", "tdmpc2_plan_shard_refit",
     "tdmpc2_plan_export_noise", "tdmpc2_plan_call_counter", "tdmpc2_plan_set_call_counter", "tdmpc2_plan_take_fault",
+    "tdmpc2_plan_fault_info",
 ]
 
 NET_DYNAMICS, NET_REWARD, NET_PI, NET_Q, NET_TERMINATION, NET_TARGET_Q = range(6)
 PATH_AUTO, PATH_FUSED, PATH_LAYERED = range(3)  # enum tdmpc2_path
 PREC_AUTO, PREC_FP32, PREC_SPLIT_F16 = range(3)  # enum tdmpc2_precision
+
+
+class FaultInfo(C.Structure):  # struct tdmpc2_fault_info
+    _fields_ = [("faults_total", C.c_int32), ("rearms", C.c_int32), ("degraded", C.c_int32), ("clean_calls", C.c_int32),
+                ("rearm_after", C.c_int32), ("reserved", C.c_int32), ("seconds_since_fault", C.c_double)]
 
 
 class PlanCfg(C.Structure):
@@ -136,6 +142,8 @@ def load_library():
     lib.tdmpc2_plan_set_call_counter.restype = i32
     lib.tdmpc2_plan_take_fault.argtypes = [vp, C.POINTER(i32)]
     lib.tdmpc2_plan_take_fault.restype = i32
+    lib.tdmpc2_plan_fault_info.argtypes = [vp, C.POINTER(FaultInfo)]
+    lib.tdmpc2_plan_fault_info.restype = i32
     lib.tdmpc2_plan_set_tuning.argtypes = [vp, i32, i32]
     lib.tdmpc2_plan_set_tuning.restype = i32
     lib.tdmpc2_plan_set_profiling.argtypes = [vp, i32]
@@ -361,11 +369,23 @@ class NativePlanner:
         return out
 
     def take_fault(self) -> int:
-        """Number of cluster-path plans that gave up (bounded hand-over wait) since the last call; such a plan returned NaN
-        actions and kept its prev_mean, and the handle now plans with one workgroup per tile.  Call after a sync."""
+        """Number of calls invalidated by a bounded inter-workgroup wait that gave up (cluster path, fused NormedLinear epilogue)
+        since the last take_fault; such a plan returned NaN actions and kept its prev_mean, such a td_target / policy_value
+        returned NaN.  The handle runs the paths without waits until it re-arms (fault_info, set_rearm_after).  Call after a sync."""
         n = C.c_int()
         self._check(self.lib.tdmpc2_plan_take_fault(self._h, C.byref(n)))
         return int(n.value)
+
+    def fault_info(self) -> dict:
+        """The handle's fault history (tdmpc2_plan_fault_info): faults_total, rearms, degraded, clean_calls, rearm_after,
+        seconds_since_fault (-1: never).  Nothing is consumed."""
+        fi = FaultInfo()
+        self._check(self.lib.tdmpc2_plan_fault_info(self._h, C.byref(fi)))
+        return {k: getattr(fi, k) for k, _ in FaultInfo._fields_ if k != "reserved"}
+
+    def set_rearm_after(self, clean_calls: int):
+        """TDMPC2_TUNE_REARM_AFTER: clean calls after which a handle downgraded by a reported wait returns to the fast paths (0: never)."""
+        self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 4, int(clean_calls)))
 
     # ------------------------------------------------------------------ training-side forward pieces
     def _task_tables(self, R, task_ids, task_emb_table, act_mask_table, discount_table=None):
