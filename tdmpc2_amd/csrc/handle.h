@@ -74,6 +74,7 @@ struct Layered {
     size_t stats_cap = 0;            // floats
     unsigned int *arrive = nullptr;
     size_t arrive_cap = 0, arrive_off = 0;  // counters; the next free one (zeroed at the start of every stage)
+    unsigned long long *gw_timing = nullptr;  // TDMPC2_GW_TIMING=1 with a -DGW_TIMING build: phase clocks of g_gemm_w, 4 classes x 8 words
     size_t arrive_high = 0;                 // most counters any stage of this handle has used (the extent of that memset)
 };
 

@@ -99,7 +99,7 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         // ---- the 256 x 256 tile (g_gemm_w): fused NormedLinear layers of calls that fill the chip with one workgroup per CU
         static const long w256_min = getenv("TDMPC2_GEMM_W256_MIN") ? atol(getenv("TDMPC2_GEMM_W256_MIN")) : 192;
         const int ncb256 = (ly.CT + 7) / 8;
-        if (can_fuse && ly.CT >= 8 && rows_p % 256 == 0 && rows_per_env % 256 == 0 && ncb256 <= 32 &&
+        if (can_fuse && ly.CT >= 8 && rows_p % 256 == 0 && rows_per_env % 256 == 0 && ncb256 <= 32 && !L.row_env &&
             (long)(rows_p / 256) * ncb256 >= w256_min && w256_min >= 0) {
             const int nrowblk = (int)(rows_p / 256);
             if (L.arrive_off + (size_t)nrowblk > L.arrive_cap) return fail(TDMPC2_ERR_STATE, "arrival counters exhausted (%zu + %d > %zu)", L.arrive_off, nrowblk, L.arrive_cap);
@@ -115,6 +115,7 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             static const int xr_env = getenv("TDMPC2_GEMM_W_XCD_ROWS") ? atoi(getenv("TDMPC2_GEMM_W_XCD_ROWS")) : -1;
             const GemmSOrder ord = gemm_s_order(nrowblk, q.ncolblk, xr_env >= 0 ? xr_env : (nrowblk >= 16 ? 1 : 0), 1);
             q.xcd_rows = ord.xcd_rows; q.ncol_grid = ord.ncol_grid; q.nrowblk = nrowblk;
+            q.timing = L.gw_timing ? L.gw_timing + (q.K >= 1024 ? 8 : 0) + (ln->act ? 16 : 0) : nullptr;  // [Mish K < 1024 | Mish K >= 1024 | SimNorm ...]
             if (ln->act == 0) hipLaunchKernelGGL((g_gemm_w<1>), dim3(ord.nblk), dim3(512), 0, st, q);
             else hipLaunchKernelGGL((g_gemm_w<2>), dim3(ord.nblk), dim3(512), 0, st, q);
             LAUNCH_CHECK();

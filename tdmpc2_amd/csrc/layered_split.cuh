@@ -50,6 +50,7 @@ struct GemmSParams {
     int fault;                 // test hook (TDMPC2_CLUSTER_FAULT at create): column block 0 of row block 0 never arrives
     // EPI != 0: the tile order (tile_order.h: gemm_s_order / gemm_s_tile)
     int xcd_rows, nrowblk, ncol_grid;
+    unsigned long long *timing;  // g_gemm_w profiling builds (-DGW_TIMING), else null
 };
 
 constexpr int GLN_MAXSPIN = 1 << 18;  // polls (an agent-scope load + s_sleep(2) each: about a third of a second in all); a healthy wait is microseconds -- peers of a row block are dispatched back to back -- or, when a row block straddles the residency limit of its XCD, one tile's run time (< 1 ms)

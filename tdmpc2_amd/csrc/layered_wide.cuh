@@ -39,16 +39,35 @@ __device__ __forceinline__ void gw_glds(const char *g, char *l) {
 }
 #define GW_MFMA(ACC, WF, AF) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(WF), "v"(AF))
 
+// In-kernel phase clocks of wave 0 (profiling builds only: -DGW_TIMING; TDMPC2_GW_TIMING=1 makes the host allocate and print
+// them): cycles from kernel start to [1] end of the main loop, [2] statistics stored, [3] peers arrived, [4] row statistics,
+// [5] end; [6] counts workgroups.
+#ifdef GW_TIMING
+#define GW_T0 unsigned long long gw_t[6]; gw_t[0] = __builtin_amdgcn_s_memtime();
+#define GW_T(i) { __builtin_amdgcn_sched_barrier(0); gw_t[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define GW_TFLUSH if (p.timing && tid == 0) { for (int i_ = 1; i_ < 6; ++i_) atomicAdd(p.timing + i_, gw_t[i_] - gw_t[0]); atomicAdd(p.timing + 6, 1ull); }
+#else
+#define GW_T0
+#define GW_T(i)
+#define GW_TFLUSH
+#endif
+
 struct GwFrags {
     f16x8 ah[4], al[4], wh[2], wl[2];
 };
 
 constexpr int GW_SLOT = 32768;  // bytes of one k16-slab in the ring: [A: 8 row tiles x (hi, lo)][W: 8 column tiles x (hi, lo)]
+#ifndef GW_NS
+#define GW_NS 4                 // ring slots (4: 128 KiB; 5: all 160 KiB of the CU, one more slab in flight -- experiment builds)
+#endif
+constexpr int GW_NSLOT = GW_NS;
+constexpr int GW_U = GW_NSLOT % 2 ? 2 * GW_NSLOT : GW_NSLOT;  // phases per unrolled trip: whole turns of the ring and of the register sets
+constexpr int GW_NB = (GW_NSLOT + 1) / 2;                      // read-address registers per operand (16-bit ds_read offsets: two slots each)
 
 // Fragment planes of the slab in ring slot SLOT (la / lw: this wave's A / W read addresses for slots 0-1, + 65536 for 2-3),
 // two per step so that the phase can issue them between its first MFMAs.
 template <int SLOT, int STEP>
-__device__ __forceinline__ void gw_read2(GwFrags &f, const unsigned (&la)[2], const unsigned (&lw)[2]) {
+__device__ __forceinline__ void gw_read2(GwFrags &f, const unsigned (&la)[GW_NB], const unsigned (&lw)[GW_NB]) {
     constexpr int O = (SLOT & 1) * GW_SLOT;
     const unsigned a = la[SLOT >> 1], w = lw[SLOT >> 1];
     if constexpr (STEP == 0) {
@@ -72,7 +91,7 @@ __device__ __forceinline__ void gw_read2(GwFrags &f, const unsigned (&la)[2], co
     }
 }
 template <int SLOT>
-__device__ __forceinline__ void gw_read(GwFrags &f, const unsigned (&la)[2], const unsigned (&lw)[2]) {
+__device__ __forceinline__ void gw_read(GwFrags &f, const unsigned (&la)[GW_NB], const unsigned (&lw)[GW_NB]) {
     gw_read2<SLOT, 0>(f, la, lw);
     gw_read2<SLOT, 1>(f, la, lw);
     gw_read2<SLOT, 2>(f, la, lw);
@@ -81,20 +100,28 @@ __device__ __forceinline__ void gw_read(GwFrags &f, const unsigned (&la)[2], con
     gw_read2<SLOT, 5>(f, la, lw);
 }
 
-// One phase.  PH = s mod 4 (ring slot of slab s = PH, of slab s + 1 = (PH + 1) % 4; register set of slab s = PH & 1).
-// STEADY: slab s + 4 exists (its DMA is issued here) and so does slab s + 1; otherwise the flags say.
+// One phase.  PH = s mod GW_U (ring slot of slab s = PH % NS, of slab s + 1 = (PH + 1) % NS; register set of slab s = PH & 1).
+// STEADY: slab s + NS exists (its DMA is issued here) and so does slab s + 1; otherwise the flags say (vmc: requests that may
+// stay in flight at the top of the phase).
 template <int PH, bool STEADY>
-__device__ __forceinline__ void gw_phase(f32x16 (&acc)[2][4], GwFrags (&fr)[2], const unsigned (&la)[2], const unsigned (&lw)[2],
+__device__ __forceinline__ void gw_phase(f32x16 (&acc)[2][4], GwFrags (&fr)[2], const unsigned (&la)[GW_NB], const unsigned (&lw)[GW_NB],
                                          char *ring_w, const char *&pa, const char *&pw, unsigned voff, bool issue, bool next, int vmc) {
+    constexpr int NS = GW_NSLOT, SL = PH % NS, SN = (PH + 1) % NS;
     GwFrags &c = fr[PH & 1], &n = fr[(PH + 1) & 1];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (STEADY || vmc == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (STEADY || vmc >= 4 * (NS - 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
+    else if (vmc == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (vmc == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (STEADY || issue) {  // slab s + 4 -> the slot slab s has just left
-        char *slot = ring_w + PH * GW_SLOT;
+#ifdef GW_GLDS_LATE
+    GW_MFMA(acc[0][0], c.wh[0], c.ah[0]);
+    GW_MFMA(acc[1][0], c.wh[1], c.ah[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    if (STEADY || issue) {  // slab s + NS -> the slot slab s has just left
+        char *slot = ring_w + SL * GW_SLOT;
         gw_glds(pa + voff, slot);
         gw_glds(pa + voff + 1024, slot + 1024);
         gw_glds(pw + voff, slot + 16384);
@@ -105,18 +132,22 @@ __device__ __forceinline__ void gw_phase(f32x16 (&acc)[2][4], GwFrags (&fr)[2], 
     __builtin_amdgcn_sched_barrier(0);
     // product 1 of 3: w_hi a_hi, the reads of the next slab (two per MFMA) between the first six
     const bool rd = STEADY || next;
+#ifndef GW_GLDS_LATE
     GW_MFMA(acc[0][0], c.wh[0], c.ah[0]);
-    if (rd) gw_read2<(PH + 1) % 4, 0>(n, la, lw);
+#endif
+    if (rd) gw_read2<SN, 0>(n, la, lw);
+#ifndef GW_GLDS_LATE
     GW_MFMA(acc[1][0], c.wh[1], c.ah[0]);
-    if (rd) gw_read2<(PH + 1) % 4, 1>(n, la, lw);
+#endif
+    if (rd) gw_read2<SN, 1>(n, la, lw);
     GW_MFMA(acc[0][1], c.wh[0], c.ah[1]);
-    if (rd) gw_read2<(PH + 1) % 4, 2>(n, la, lw);
+    if (rd) gw_read2<SN, 2>(n, la, lw);
     GW_MFMA(acc[1][1], c.wh[1], c.ah[1]);
-    if (rd) gw_read2<(PH + 1) % 4, 3>(n, la, lw);
+    if (rd) gw_read2<SN, 3>(n, la, lw);
     GW_MFMA(acc[0][2], c.wh[0], c.ah[2]);
-    if (rd) gw_read2<(PH + 1) % 4, 4>(n, la, lw);
+    if (rd) gw_read2<SN, 4>(n, la, lw);
     GW_MFMA(acc[1][2], c.wh[1], c.ah[2]);
-    if (rd) gw_read2<(PH + 1) % 4, 5>(n, la, lw);
+    if (rd) gw_read2<SN, 5>(n, la, lw);
     GW_MFMA(acc[0][3], c.wh[0], c.ah[3]);
     GW_MFMA(acc[1][3], c.wh[1], c.ah[3]);
     // product 2: w_lo a_hi
@@ -137,8 +168,9 @@ __device__ __forceinline__ void gw_phase(f32x16 (&acc)[2][4], GwFrags (&fr)[2], 
 template <int EPI>
 __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
     static_assert(EPI == 1 || EPI == 2, "the wide tile exists for the NormedLinear layers");
-    constexpr int NS = 4, TM = 256;
+    constexpr int NS = GW_NSLOT, TM = 256;
     __shared__ __attribute__((aligned(1024))) char ring[NS * GW_SLOT];
+    GW_T0
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;  // this wave's accumulators: row tiles 4 wr .. + 3, column tiles 2 wc, 2 wc + 1
@@ -147,6 +179,18 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
     const int row0 = rb * TM;
     const int sel = p.sel ? p.sel[(size_t)(row0 / p.rows_per_env) * p.sel_stride] : 0;
     const int nk = p.K / 16;
+    // the epilogue's vectors: in flight behind the prologue's DMA requests (one env per 256-row block: rows_per_env % 256 == 0)
+    float vb = 0.f, vg = 0.f, vbe = 0.f;
+    if (tid < 256) {
+        const int col = cb * 256 + tid;
+        if (col < p.CT * 32) {
+            const float *bp = p.bias + (size_t)sel * p.bias_sel_stride;
+            if (p.bias_env_stride != 0) bp += (size_t)(row0 / p.rows_per_env) * p.bias_env_stride;
+            vb = bp[col];
+            vg = p.ln_g[(size_t)sel * p.gb_sel_stride + col];
+            vbe = p.ln_b[(size_t)sel * p.gb_sel_stride + col];
+        }
+    }
     // DMA role of this wave: row tile `wave` of A and column tile `wave` of W (a column tile past the matrix re-reads the last one)
     const int ctl = cb * 8 + wave < p.CT ? cb * 8 + wave : p.CT - 1;
     const char *pa = reinterpret_cast<const char *>(p.A) + ((size_t)((row0 >> 5) + wave) * p.KBa + p.a_kb0) * 2048;
@@ -155,8 +199,15 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
     asm volatile("" : "+v"(voff));
     char *ring_w = ring + wave * 2048;
     const unsigned lbase = lds_addr_of(ring) + (unsigned)lane * 16u;
-    const unsigned la[2] = {lbase + (unsigned)wr * 8192u, lbase + (unsigned)wr * 8192u + 65536u};
-    const unsigned lw[2] = {lbase + 16384u + (unsigned)wc * 4096u, lbase + 16384u + (unsigned)wc * 4096u + 65536u};
+    unsigned la[GW_NB], lw[GW_NB];
+#pragma unroll
+    for (int b = 0; b < GW_NB; ++b) {
+        la[b] = lbase + (unsigned)wr * 8192u + 65536u * b;
+        lw[b] = lbase + 16384u + (unsigned)wc * 4096u + 65536u * b;
+    }
+#ifdef GW_PRIO  // static priority for the younger half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
     f32x16 acc[2][4];  // [column tile][row tile]: C = [feature][row] (weight fragment = the MFMA's A operand, as in g_gemm_s<EPI>)
 #pragma unroll
@@ -181,7 +232,8 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
             pw += 2048;
         }
     __builtin_amdgcn_sched_barrier(0);
-    if (npro >= 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (npro >= 5) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (npro == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if (npro == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (npro == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -190,54 +242,60 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
     gw_read<0>(fr[0], la, lw);
 
     int s = 0;
-#pragma unroll 1
-    for (; s + 7 < nk; s += 4) {  // steady state: phases s .. s + 3 each have a slab s' + 4 <= nk - 1 to request
-        gw_phase<0, true>(acc, fr, la, lw, ring_w, pa, pw, voff, true, true, 8);
-        gw_phase<1, true>(acc, fr, la, lw, ring_w, pa, pw, voff, true, true, 8);
-        gw_phase<2, true>(acc, fr, la, lw, ring_w, pa, pw, voff, true, true, 8);
-        gw_phase<3, true>(acc, fr, la, lw, ring_w, pa, pw, voff, true, true, 8);
-    }
-#pragma unroll 1
-    for (; s < nk; s += 4) {  // the last phases (and short contractions): wave-uniform flags
+#define GW_STEADY(PH) gw_phase<PH, true>(acc, fr, la, lw, ring_w, pa, pw, voff, true, true, 4 * (NS - 2));
+    // a phase with wave-uniform flags: the newest slab requested so far is min(nk - 1, ss + NS - 1); slab ss + 1 must have landed
 #define GW_TAIL(PH)                                                                                         \
     if (s + PH < nk) {                                                                                      \
-        const int ss = s + PH, last_req = ss + 3 < nk - 1 ? ss + 3 : nk - 1; /* newest slab requested so far */ \
-        const int inflight = last_req - (ss + 1);                             /* slabs allowed to stay in flight */ \
-        gw_phase<PH, false>(acc, fr, la, lw, ring_w, pa, pw, voff, ss + 4 < nk, ss + 1 < nk, inflight >= 2 ? 8 : inflight == 1 ? 4 : 0); \
+        const int ss = s + PH, last_req = ss + NS - 1 < nk - 1 ? ss + NS - 1 : nk - 1;                        \
+        const int inflight = last_req - (ss + 1);                                                           \
+        gw_phase<PH, false>(acc, fr, la, lw, ring_w, pa, pw, voff, ss + NS < nk, ss + 1 < nk, inflight > 0 ? 4 * inflight : 0); \
     }
-        GW_TAIL(0)
-        GW_TAIL(1)
-        GW_TAIL(2)
-        GW_TAIL(3)
+#pragma unroll 1
+    for (; s + GW_U - 1 + NS < nk; s += GW_U) {  // steady state: every phase of the trip has a slab s' + NS <= nk - 1 to request
+        GW_STEADY(0) GW_STEADY(1) GW_STEADY(2) GW_STEADY(3)
+#if GW_NS == 5
+        GW_STEADY(4) GW_STEADY(5) GW_STEADY(6) GW_STEADY(7) GW_STEADY(8) GW_STEADY(9)
+#endif
+    }
+#pragma unroll 1
+    for (; s < nk; s += GW_U) {  // the last phases (and short contractions)
+        GW_TAIL(0) GW_TAIL(1) GW_TAIL(2) GW_TAIL(3)
+#if GW_NS == 5
+        GW_TAIL(4) GW_TAIL(5) GW_TAIL(6) GW_TAIL(7) GW_TAIL(8) GW_TAIL(9)
+#endif
+    }
 #undef GW_TAIL
-    }
+#undef GW_STEADY
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // XDL write -> VALU read of the accumulators
+    GW_T(1)
 
     // ---------------------------------------------------------------- NormedLinear epilogue (the protocol of g_gemm_s<.., EPI>)
     const int i32 = lane & 31, hh = lane >> 5;
     const int ct0 = cb * 8 + wc * 2;  // this wave's column tiles
     const float osc = p.oscale[(size_t)sel * p.osc_sel_stride];
-    const float *bsel = p.bias + (size_t)sel * p.bias_sel_stride;
     __syncthreads();  // every wave is done with the ring
     float *red = reinterpret_cast<float *>(ring);  // [8 column tiles of the block][TM][2]
     float *rs = red + 8 * TM * 2;                   // [TM][2]
+    // the block's 256 columns of bias / LayerNorm weight / LayerNorm bias: requested before the main loop (three registers ride
+    // through it), read by the epilogue from LDS instead of 96 dependent 16-byte global loads per lane
+    float *vecs = rs + TM * 2;                      // [bias | g | b][256]
+    if (tid < 256) {
+        vecs[tid] = vb;
+        vecs[256 + tid] = vg;
+        vecs[512 + tid] = vbe;
+    }
+    __syncthreads();
     // (1) v = acc * oscale + bias, in place
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-        const int row = row0 + wr * 128 + rt * 32 + i32;
-        const float *bp = bsel;
-        if (p.bias_env_stride != 0) bp += (size_t)(p.row_env ? p.row_env[row] : row / p.rows_per_env) * p.bias_env_stride;
+    for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int ct = ct0 + n < p.CT ? ct0 + n : p.CT - 1;
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(vecs + (wc * 2 + n) * 32 + 8 * j + 4 * hh);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bp + ct * 32 + 8 * j + 4 * hh);
+            for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[n][rt][4 * j + r] = fmaf(acc[n][rt][4 * j + r], osc, b4[r]);
-            }
         }
-    }
     // (2) (mean, M2) of every row over each 32-column tile: 16 thread-local values + the lane ^ 32 half
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
@@ -281,6 +339,7 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
             __hip_atomic_store(slot + 1, q_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    GW_T(2)
     // (4) arrive (stores acknowledged first), wait for the row block's other column blocks -- bounded
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -296,6 +355,7 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
         }
     }
     __syncthreads();
+    GW_T(3)
     // (5) the row's statistics: the groups folded left to right (loads eight at a time, the fold in order)
     if (tid < TM) {
         float n_acc = 0.f, m_acc = 0.f, q_acc = 0.f;
@@ -324,11 +384,11 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
         rs[2 * tid + 1] = 1.0f / sqrtf(q_acc / n_acc + LN_EPS);
     }
     __syncthreads();
+    GW_T(4)
     // (6) normalise, activate, split -> the fragment-packed output.  A lane holds features 8 j + 4 hh + (0..3) of row i32 of a
     // column tile.  For the pair (j, j + 1) = the two k-halves of k16-block 2 ct + (j >> 1), v_permlane32_swap hands the lower
     // half-wave the upper one's 4 features of k-half 0 and the upper half-wave the lower one's of k-half 1: every lane then
     // holds 8 consecutive features (16 bytes per plane) of ITS k-half, lane' = 32 hh + i32 = lane: one store = one 1 KiB plane.
-    const float *gsel = p.ln_g + (size_t)sel * p.gb_sel_stride, *besel = p.ln_b + (size_t)sel * p.gb_sel_stride;
     const float oscl = EPI == 1 ? p.ascale[(size_t)sel * p.asc_sel_stride] : ACT_SCALE;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
@@ -343,8 +403,8 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     const int j = 2 * jp + jj;
-                    const f32x4 g4 = *reinterpret_cast<const f32x4 *>(gsel + (ct0 + n) * 32 + 8 * j + 4 * hh);
-                    const f32x4 be4 = *reinterpret_cast<const f32x4 *>(besel + (ct0 + n) * 32 + 8 * j + 4 * hh);
+                    const f32x4 g4 = *reinterpret_cast<const f32x4 *>(vecs + 256 + (wc * 2 + n) * 32 + 8 * j + 4 * hh);
+                    const f32x4 be4 = *reinterpret_cast<const f32x4 *>(vecs + 512 + (wc * 2 + n) * 32 + 8 * j + 4 * hh);
                     f32x4 y;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) y[r] = fmaf((acc[n][rt][4 * j + r] - rmean) * rrstd, g4[r], be4[r]);
@@ -389,4 +449,6 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
             }
         }
     }
+    GW_T(5)
+    GW_TFLUSH
 }

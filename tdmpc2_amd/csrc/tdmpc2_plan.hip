@@ -803,6 +803,12 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             if (const char *fl = getenv("TDMPC2_FUSE_LN")) L.fuse_ln = atoi(fl) != 0;
             // fp32 pre-activations of the NormedLinear layers whose epilogue is not fused (the fallback after a reported wait,
             // TDMPC2_TUNE_FUSE_LN = 0, tiles the fused path does not take): one buffer per chain
+            if (getenv("TDMPC2_GW_TIMING")) {
+                if ((rc = dev_alloc(h, (void **)&L.gw_timing, 32 * 8)) || hipMemset(L.gw_timing, 0, 32 * 8) != hipSuccess) {
+                    tdmpc2_plan_destroy(h);
+                    return rc ? rc : fail(TDMPC2_ERR_HIP, "hipMemset failed");
+                }
+            }
             L.ldpre = std::max(L.Mp, (int)round_up((size_t)c.latent_dim, 32));
             if ((rc = dev_alloc(h, (void **)&L.PRE, Rp * L.ldpre * 4)) || (L.side && (rc = dev_alloc(h, (void **)&L.PRE2, Rp * L.ldpre * 4)))) {
                 tdmpc2_plan_destroy(h);
@@ -883,6 +889,19 @@ void tdmpc2_plan_destroy(tdmpc2_plan_t *h) {
             for (int i = 0; i < 15; ++i)
                 if (names[i][0]) fprintf(stderr, " %s=%.0f", names[i], (double)t[i] / (double)t[15]);
             fprintf(stderr, "\n");
+        }
+    }
+    if (h->lay.gw_timing) {  // phase clocks of g_gemm_w (-DGW_TIMING build + TDMPC2_GW_TIMING=1)
+        unsigned long long t[32];
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(t, h->lay.gw_timing, sizeof t, hipMemcpyDeviceToHost) == hipSuccess) {
+            static const char *cls[4] = {"mish K<1024", "mish K>=1024", "simnorm K<1024", "simnorm K>=1024"};
+            for (int c = 0; c < 4; ++c) {
+                const unsigned long long *q = t + 8 * c;
+                if (!q[6]) continue;
+                const double n = (double)q[6];
+                fprintf(stderr, "[g_gemm_w timing max_envs=%d, %s] workgroups=%llu mean cycles of wave 0: loop_end=%.0f stats_stored=%.0f "
+                        "peers_arrived=%.0f row_stats=%.0f end=%.0f\n", h->cfg.max_envs, cls[c], q[6], q[1] / n, q[2] / n, q[3] / n, q[4] / n, q[5] / n);
+            }
         }
     }
     if (h->lay.side) {  // back to the pool, never destroyed (see SidePool)

@@ -14,7 +14,7 @@ for rep in $(seq 1 ${AB_REPS:-2}); do
     for spec in "${SP[@]}"; do
       set -- $spec
       echo "== [$envset] $1 E=$2" >> $out
-      env $envset timeout 300 python bench.py --config $1 --envs $2 --steps $3 --warmup 2 --skip-cpu-baseline --skip-extra-configs --skip-traffic 2>/dev/null \
+      env TDMPC2_BENCH_EXACT_STEPS=1 $envset timeout 300 python bench.py --config $1 --envs $2 --steps $3 --warmup 2 --skip-cpu-baseline --skip-extra-configs --skip-traffic 2>/dev/null \
         | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('plans/s', d['value'], 'stage_ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'lat1_ms', d['extra'].get('latency_ms_single_env'), 'sha', d['extra'].get('action_sha1'))" >> $out 2>&1
     done
   done
