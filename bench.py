@@ -62,6 +62,25 @@ def flops_plan(cfg, iterations):
     return 2 * pitraj + iterations * flops_rollout_launch(cfg, 1)
 
 
+# TDMPC2_BENCH_STUB=1: CPU dry run of the JOB logic (argument contract, rank-0-only line, max-over-ranks timing, the c5 leg's
+# collective) with 2 real ranks over gloo and a planner stand-in (tests/bench_stub.py); never a measurement
+# (tests/test_bench_contract.py).  Everything that needs kernels is skipped in that mode.
+STUB = os.environ.get("TDMPC2_BENCH_STUB") == "1"
+
+
+def _planner_cls():
+    if STUB:
+        from tests.bench_stub import StubPlanner
+        return StubPlanner
+    from tdmpc2_amd.native import NativePlanner
+    return NativePlanner
+
+
+def _sync(device):
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
 def disc_pow_rows(cfg, n_envs, device):
     g = get_discount(cfg, cfg.episode_length)
     d, vals = 1, []
@@ -109,7 +128,7 @@ def traffic_child(name, E, I, steps):
         qidx = torch.tensor([[0, 1]] * E, dtype=torch.int32, device=device)
         for i in range(steps):
             planner.estimate_value(x["z0"], x["disc"], acts, eps, qidx, task_emb=x["emb"], act_mask=x["mask"])
-    torch.cuda.synchronize(device)
+    _sync(device)
     planner.close()
 
 
@@ -213,12 +232,12 @@ def torch_eager_gpu_baseline(cfg, iterations, sd_np, device, n_plans=5):
         for _ in range(2):
             a, prev, _ = po.plan(model, z0=z0, tape=tape, prev_mean=prev, t0=False, eval_mode=False, task=task, discount=disc,
                                  iterations=iterations)
-        torch.cuda.synchronize(device)
+        _sync(device)
         t0 = time.perf_counter()
         for _ in range(n_plans):
             a, prev, _ = po.plan(model, z0=z0, tape=tape, prev_mean=prev, t0=False, eval_mode=False, task=task, discount=disc,
                                  iterations=iterations)
-        torch.cuda.synchronize(device)
+        _sync(device)
         el = time.perf_counter() - t0
     return {"value": round(n_plans / el, 2), "unit": "plans/s", "ms_per_plan": round(1e3 * el / n_plans, 2),
             "what": f"oracle restatement of the reference planner as PyTorch-ROCm {torch.__version__} eager ops on this GPU, "
@@ -252,14 +271,14 @@ def torch_compile_child(name, iterations, n_plans=20):
             torch.compiler.cudagraph_mark_step_begin()
             a, pm = fn(z0, prev)
             prev = pm.clone()
-        torch.cuda.synchronize(device)
+        _sync(device)
         compile_s = time.perf_counter() - t_c
         t0 = time.perf_counter()
         for _ in range(n_plans):
             torch.compiler.cudagraph_mark_step_begin()
             a, pm = fn(z0, prev)
             prev = pm.clone()
-        torch.cuda.synchronize(device)
+        _sync(device)
         el = time.perf_counter() - t0
     print(json.dumps({"value": round(n_plans / el, 2), "unit": "plans/s", "ms_per_plan": round(1e3 * el / n_plans, 3),
                       "compile_s": round(compile_s, 1), "finite": bool(torch.isfinite(a).all()),
@@ -334,21 +353,25 @@ def c5_leg(device, rank, world, fence, steps=2, envs_per_gpu=64):
     ranks of this job (512 envs at 8 GPUs) -- run by EVERY rank after the main measurement when the job has more than one
     GPU; same timing protocol (barrier + synchronize on both sides, max over ranks)."""
     import torch.distributed as dist
-    from tdmpc2_amd.native import NativePlanner
+    NativePlanner = _planner_cls()
 
     cfg = named_config("c4")
     I = cfg.iterations + 2 * int(cfg.action_dim >= 20)
     E = envs_per_gpu
-    sd_np = synth.make_state_dict(cfg, seed=0)  # identical on every rank (seeded): no broadcast needed for the leg
-    sd = {k: torch.as_tensor(v).to(device) for k, v in sd_np.items() if not k.startswith("_encoder.")}
-    planner = NativePlanner(cfg, I, device, max_envs=E)
-    planner.bind_state_dict(sd)
     tasks = (torch.arange(E) + rank * E) % len(cfg.tasks)
-    w = torch.as_tensor(sd_np["_task_emb.weight"])[tasks]
-    n = w.norm(dim=1, keepdim=True)
-    emb = torch.where(n > 1.0, w / (n + 1e-7), w).to(device).contiguous()
-    mask = torch.as_tensor(sd_np["_action_masks"])[tasks].to(device).contiguous()
-    del sd_np
+    planner = NativePlanner(cfg, I, device, max_envs=E)
+    if STUB:  # (no 317M of synthetic weights for a dry run of the job logic)
+        emb = torch.zeros(E, cfg.task_dim)
+        mask = torch.ones(E, cfg.action_dim)
+    else:
+        sd_np = synth.make_state_dict(cfg, seed=0)  # identical on every rank (seeded): no broadcast needed for the leg
+        sd = {k: torch.as_tensor(v).to(device) for k, v in sd_np.items() if not k.startswith("_encoder.")}
+        planner.bind_state_dict(sd)
+        w = torch.as_tensor(sd_np["_task_emb.weight"])[tasks]
+        n = w.norm(dim=1, keepdim=True)
+        emb = torch.where(n > 1.0, w / (n + 1e-7), w).to(device).contiguous()
+        mask = torch.as_tensor(sd_np["_action_masks"])[tasks].to(device).contiguous()
+        del sd_np
     z0 = torch.as_tensor(synth.make_latents(cfg, E, seed=3000 + rank)).to(device)
     disc = disc_pow_rows(cfg, E, device)
     prev = torch.zeros(E, cfg.horizon, cfg.action_dim, device=device)
@@ -412,11 +435,11 @@ def config_leg(name, E, steps, device, rank=0):
     planner.plan(z0, disc, prev, cold, task_emb=emb, act_mask=mask, seed=1, out=out)
     planner.plan(z0, disc, prev, warm, task_emb=emb, act_mask=mask, seed=2, out=out)
     planner.set_profiling(steps * I)
-    torch.cuda.synchronize(device)
+    _sync(device)
     t1 = time.perf_counter()
     for i in range(steps):
         planner.plan(z0, disc, prev, warm, task_emb=emb, act_mask=mask, seed=10 + i, out=out)
-    torch.cuda.synchronize(device)
+    _sync(device)
     el = time.perf_counter() - t1
     ms, n = planner.profile_read()
     finite = bool(torch.isfinite(out).all())
@@ -432,11 +455,11 @@ def config_leg(name, E, steps, device, rank=0):
     o1 = torch.empty(1, cfg.action_dim, device=device)
     for i in range(2):
         one.plan(z1, d1, p1, warm[:1], seed=i, out=o1, task_emb=e1, act_mask=m1)
-    torch.cuda.synchronize(device)
+    _sync(device)
     t1 = time.perf_counter()
     for i in range(3):
         one.plan(z1, d1, p1, warm[:1], seed=10 + i, out=o1, task_emb=e1, act_mask=m1)
-    torch.cuda.synchronize(device)
+    _sync(device)
     lat1 = (time.perf_counter() - t1) / 3 * 1e3
     one.close()
     launch_s = (ms / 1e3) / max(n, 1)
@@ -497,10 +520,13 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the planner has no CPU path")
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    if STUB:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the planner has no CPU path")
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
     import torch.distributed as dist
     # under torch.distributed.run (RANK set) the RCCL group is always initialised, also for one rank, so that the same
     # collective calls run at every N
@@ -508,10 +534,13 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if STUB:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from tdmpc2_amd.dist import broadcast_state_dict
-    from tdmpc2_amd.native import NativePlanner
+    NativePlanner = _planner_cls()
 
     cfg = named_config(args.config)
     I, E, K, W = args.iterations, args.envs, args.steps, args.warmup
@@ -552,10 +581,10 @@ def main():
                      seed=(rank << 32) + i, out=out)
 
     def fence():
-        torch.cuda.synchronize(device)
+        _sync(device)
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize(device)
+            _sync(device)
 
     def log(msg):
         if rank == 0:
@@ -563,7 +592,7 @@ def main():
 
     log(f"planner ready: {planner.device_bytes / 2**20:.0f} MiB on device, E={E} I={I}")
     step(0, cold)
-    torch.cuda.synchronize(device)
+    _sync(device)
     log("first (cold) step done")
     fence()
     t_w = time.perf_counter()
@@ -603,7 +632,7 @@ def main():
     # (digest of the last timed step's actions: same seed, same inputs -> A/B variants that claim identical sums can be compared)
     import hashlib
     extra = {"bounded_wait_faults": faults, "action_sha1": hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:16]}
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not STUB:
         # What box is this?  The fused kernels are power-managed (profiles/README.md): boxes of the same pool differ by up to 15 %
         # in EVERY figure of this line.  Outside the timed region: queue half a second of the same steps and read the
         # clocks / socket power the driver reports while they run.
@@ -612,7 +641,7 @@ def main():
             for i in range(15):
                 step(500 + i, warm)
             smi = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower"], capture_output=True, text=True, timeout=20)
-            torch.cuda.synchronize(device)
+            _sync(device)
             keep = {}
             for line in smi.stdout.splitlines():
                 low = line.lower()
@@ -628,7 +657,7 @@ def main():
             extra["box_under_load"] = keep or {"raw": smi.stdout[:300]}
         except Exception as ex:  # no rocm-smi, no permission: the line is still valid
             extra["box_under_load"] = {"error": repr(ex)[:120]}
-    if rank == 0:
+    if rank == 0 and not STUB:
         # single-environment latency (the reference's E = 1 semantics), reported beside the throughput
         one = NativePlanner(cfg, I, device, max_envs=1, path=path, precision=prec)
         one.bind_state_dict(sd)
@@ -639,22 +668,22 @@ def main():
         o1 = torch.empty(1, cfg.action_dim, device=device)
         for i in range(2):
             one.plan(z1, d1, p1, warm[:1], seed=i, out=o1, task_emb=e1, act_mask=m1)
-        torch.cuda.synchronize(device)
+        _sync(device)
         t1 = time.perf_counter()
         for i in range(5):
             one.plan(z1, d1, p1, warm[:1], seed=10 + i, out=o1, task_emb=e1, act_mask=m1)
-        torch.cuda.synchronize(device)
+        _sync(device)
         extra["latency_ms_single_env"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
         if family == "fused" and one.precision == 2:
             # the same plan with one workgroup per 32-row tile (TDMPC2_TUNE_CLUSTER 0): what the cluster path buys
             one.set_cluster(0)
             for i in range(2):
                 one.plan(z1, d1, p1, warm[:1], seed=i, out=o1, task_emb=e1, act_mask=m1)
-            torch.cuda.synchronize(device)
+            _sync(device)
             t1 = time.perf_counter()
             for i in range(5):
                 one.plan(z1, d1, p1, warm[:1], seed=10 + i, out=o1, task_emb=e1, act_mask=m1)
-            torch.cuda.synchronize(device)
+            _sync(device)
             extra["latency_ms_single_env_no_cluster"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
             one.set_cluster(2)
         # the same from the observation on (WorldModel.encode in the library, tdmpc2_plan_run_obs): what one
@@ -664,18 +693,18 @@ def main():
             ob = torch.as_tensor(synth.make_obs(cfg, 1, seed=3)).to(device)
             for i in range(2):
                 one.plan_obs(ob, d1, p1, warm[:1], seed=i, out=o1, task_emb=e1, act_mask=m1)
-            torch.cuda.synchronize(device)
+            _sync(device)
             t1 = time.perf_counter()
             for i in range(5):
                 one.plan_obs(ob, d1, p1, warm[:1], seed=20 + i, out=o1, task_emb=e1, act_mask=m1)
-            torch.cuda.synchronize(device)
+            _sync(device)
             extra["latency_ms_single_env_from_obs"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
             zb = torch.empty(1, cfg.latent_dim, device=device)
-            torch.cuda.synchronize(device)
+            _sync(device)
             t1 = time.perf_counter()
             for i in range(20):
                 one.encode(ob, e1, out=zb)
-            torch.cuda.synchronize(device)
+            _sync(device)
             extra["encode_us_single_env"] = round((time.perf_counter() - t1) / 20 * 1e6, 1)
         except Exception as ex:
             extra["latency_ms_single_env_from_obs"] = {"error": repr(ex)}
@@ -689,11 +718,11 @@ def main():
                 rw, tm = torch.randn(R, device=device), torch.zeros(R, device=device)
                 for i in range(3):
                     planner.td_target(nz, rw, tm, 0.99, seed=i)
-                torch.cuda.synchronize(device)
+                _sync(device)
                 t1 = time.perf_counter()
                 for i in range(20):
                     planner.td_target(nz, rw, tm, 0.99, seed=10 + i)
-                torch.cuda.synchronize(device)
+                _sync(device)
                 extra["td_target_us_768_rows"] = round((time.perf_counter() - t1) / 20 * 1e6, 1)
             except Exception as ex:
                 extra["td_target_us_768_rows"] = {"error": repr(ex)}
@@ -711,11 +740,11 @@ def main():
             for i in range(2):
                 ex.plan(z0, disc, pe, warm, task_emb=emb, act_mask=mask, seed=900 + i, out=out)
             ex.set_profiling(3 * I)
-            torch.cuda.synchronize(device)
+            _sync(device)
             t1 = time.perf_counter()
             for i in range(3):
                 ex.plan(z0, disc, pe, warm, task_emb=emb, act_mask=mask, seed=910 + i, out=out)
-            torch.cuda.synchronize(device)
+            _sync(device)
             el = time.perf_counter() - t1
             ms, n = ex.profile_read()
             ach = flops_rollout_launch(cfg, E) / (ms / 1e3 / max(n, 1)) / 1e12
@@ -815,7 +844,7 @@ def main():
                                           "vs_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 3)}} if split else {}),
         "extra": extra,
     }
-    if world == 1 and not args.skip_cpu_baseline:
+    if world == 1 and not args.skip_cpu_baseline and not STUB:
         try:
             line["extra"]["torch_rocm_eager_same_gpu"] = torch_eager_gpu_baseline(cfg, I, sd_np, device)
         except Exception as ex:
@@ -828,7 +857,7 @@ def main():
         except Exception as ex:  # the baseline is a reported number, never a reason to lose the measurement
             line["cpu_baseline"] = {"value": None, "error": repr(ex)}
     # last (a counter pass that times out cannot cost the baselines above): roofline.traffic from rocprofv3 --pmc children
-    if world == 1 and not args.skip_traffic and args.path == "auto" and args.precision == "auto":
+    if world == 1 and not args.skip_traffic and args.path == "auto" and args.precision == "auto" and not STUB:
         log("measuring roofline.traffic (rocprofv3 --pmc children)")
         traffic, traffic_info = measured_traffic(args.config, E, I, family == "fused", E * cfg.num_samples // 64)
         for nm, leg in extra.get("configs", {}).items():

@@ -1,55 +1,57 @@
-"""CPU: the bench line contract (one JSON object with the driver's keys plus `roofline` and `cpu_baseline`), checked on the
-line committed from the last MI355X run, and that bench.py refuses to run without a GPU instead of falling back."""
+"""bench.py's job contract with 2 REAL ranks on CPU (gloo) and a planner stand-in (TDMPC2_BENCH_STUB=1, tests/bench_stub.py):
+the launch line the driver uses for N > 1, rank 0 alone prints ONE JSON line, `n_gpus` / `parallelism` / `value` follow
+the world size, every rank takes part in the c5 leg and its all_reduce(MAX), the timed region is extended to >= 2 s.
+No kernel runs here: the numbers are the stand-in's; the logic around them is bench.py's own."""
 import json
 import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _latest_bench_line():
-    prof = os.path.join(ROOT, "profiles")
-    names = sorted(n for n in os.listdir(prof) if n.endswith("_bench.json"))
-    assert names, "no committed bench line under profiles/"
-    with open(os.path.join(prof, names[-1])) as f:
-        return names[-1], json.loads(f.read())
+def _run(nproc, args, extra_env=None, port=29641):
+    env = dict(os.environ, TDMPC2_BENCH_STUB="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")], p.stderr
 
 
-def test_committed_bench_line_has_the_contract_keys():
-    name, d = _latest_bench_line()
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in d, (name, k)
-    assert d["unit"] == "plans/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
-    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
-    r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert k in r, k
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s"
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    # value and per-step time agree: plans/s = envs * steps / elapsed
-    envs = d["config"]["envs_per_gpu"] * d["n_gpus"]
-    assert abs(d["value"] - envs / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
-    # the as-written FLOP figure is the one DESIGN.md section 1 states
-    sys.path.insert(0, ROOT)
-    import bench
-    from tdmpc2_amd.config import named_config
-
-    cfg = named_config("c2")
-    assert abs(bench.flops_plan(cfg, 6) / 1e9 - 47.74) < 0.01
-    assert abs(bench.flops_rollout_launch(cfg, 1) / 1e9 - 7.93) < 0.01
-    c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
-        assert k in c, k
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+def test_two_ranks_print_one_line_with_whole_job_throughput_and_run_the_c5_leg():
+    lines, err = _run(2, ["--gpus", "2", "--steps", "5", "--warmup", "2", "--envs", "16"], {"TDMPC2_BENCH_EXACT_STEPS": "1"})
+    assert len(lines) == 1, (lines, err[-1500:])  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["steps_requested"] == 5 and d["warmup"] == 2
+    assert d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["unit"] == "plans/s" and d["metric"].startswith("plan() calls/sec")
+    assert d["config"]["parallelism"] == "env-sharded x2" and d["config"]["envs_per_gpu"] == 16
+    # whole-job aggregate: plans of BOTH ranks over the max-over-ranks time
+    assert d["value"] == pytest.approx(2 * 16 * 5 / (d["ms_per_step"] * 5 / 1e3), rel=1e-3)
+    assert d["ms_per_step"] >= 4.0  # the stand-in sleeps 4 ms per step
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    c5 = d["extra"]["configs"]["c5"]
+    assert "error" not in c5, c5
+    assert c5["n_gpus"] == 2 and c5["config"]["envs_per_gpu"] == 64 and "128 envs" in c5["config"]["workload"]
+    assert c5["value"] == pytest.approx(2 * 64 * c5["steps"] / (c5["ms_per_step"] * c5["steps"] / 1e3), rel=1e-2)
 
 
-def test_bench_refuses_to_run_without_a_gpu():
-    import torch
+def test_timed_region_is_extended_to_two_seconds_and_says_so():
+    lines, _ = _run(1, ["--gpus", "1", "--steps", "10", "--warmup", "2", "--envs", "8", "--skip-extra-configs"], port=29643)
+    d = json.loads(lines[0])
+    assert d["steps_requested"] == 10 and d["steps"] > 10
+    assert d["steps"] * d["ms_per_step"] / 1e3 >= 1.9
+    assert d["n_gpus"] == 1 and d["config"]["parallelism"] == "env-sharded x1"
 
-    if torch.cuda.is_available():
-        return
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True,
-                       text=True, timeout=300)
-    assert p.returncode != 0 and "no CPU path" in (p.stderr + p.stdout)
+
+def test_world_size_must_match_gpus():
+    env = dict(os.environ, TDMPC2_BENCH_STUB="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
