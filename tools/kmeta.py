@@ -11,11 +11,18 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 def kernels(so):
+    """The library holds one gfx950 code object per translation unit (tdmpc2_amd/csrc/build.sh): every ELF of the fat binary."""
+    out = ""
     with tempfile.TemporaryDirectory() as d:
         subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={d}/fatbin", so], check=True)
         data = open(f"{d}/fatbin", "rb").read()
-        open(f"{d}/dev.co", "wb").write(data[data.find(b"\x7fELF"):])
-        out = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", f"{d}/dev.co"], capture_output=True, text=True).stdout
+        pos, n = data.find(b"\x7fELF"), 0
+        while pos >= 0:
+            nxt = data.find(b"\x7fELF", pos + 4)
+            open(f"{d}/dev{n}.co", "wb").write(data[pos:nxt if nxt >= 0 else len(data)])
+            r = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", f"{d}/dev{n}.co"], capture_output=True, text=True)
+            out += r.stdout
+            pos, n = nxt, n + 1
     cur, res = {}, []
     keys = (".vgpr_count", ".agpr_count", ".sgpr_count", ".vgpr_spill_count", ".sgpr_spill_count", ".private_segment_fixed_size",
             ".group_segment_fixed_size")
