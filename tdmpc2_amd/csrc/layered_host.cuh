@@ -98,8 +98,13 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         const bool can_fuse = ln && L.fuse_ln && L.arrive && bufs->stats && rows_p * ((ly.CT + 3) / 4) * 2 <= L.stats_cap;
         // ---- the 256 x 256 tile (g_gemm_w): fused NormedLinear layers of calls that fill the chip with one workgroup per CU
         static const long w256_min = getenv("TDMPC2_GEMM_W256_MIN") ? atol(getenv("TDMPC2_GEMM_W256_MIN")) : 192;
-        const int ncb256 = (ly.CT + 7) / 8;
-        if (can_fuse && ly.CT >= 8 && rows_p % 256 == 0 && rows_per_env % 256 == 0 && ncb256 <= 32 && !L.row_env &&
+        // (Measured and rejected, profiles/README.md r4f: 256 x 224 / 192 tiles -- 8 x 1 wave layout, one W fragment set -- for widths
+        // like the 48M model's 1792 = 8 x 224, which would fill 1.875 rounds of the chip instead of 1.64: the layout reads every W
+        // fragment eight times from LDS (128 KiB per slab) and lost 4.5 % in spite of the better fill.)
+        constexpr int NT = 8;
+        const int ncb256 = (ly.CT + NT - 1) / NT;
+        const size_t stats_need = rows_p * ((ly.CT + 3) / 4) * 2;
+        if (can_fuse && ly.CT >= 8 && rows_p % 256 == 0 && rows_per_env % 256 == 0 && ncb256 <= 32 && !L.row_env && stats_need <= L.stats_cap &&
             (long)(rows_p / 256) * ncb256 >= w256_min && w256_min >= 0) {
             const int nrowblk = (int)(rows_p / 256);
             if (L.arrive_off + (size_t)nrowblk > L.arrive_cap) return fail(TDMPC2_ERR_STATE, "arrival counters exhausted (%zu + %d > %zu)", L.arrive_off, nrowblk, L.arrive_cap);
@@ -116,8 +121,11 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             const GemmSOrder ord = gemm_s_order(nrowblk, q.ncolblk, xr_env >= 0 ? xr_env : (nrowblk >= 16 ? 1 : 0), 1);
             q.xcd_rows = ord.xcd_rows; q.ncol_grid = ord.ncol_grid; q.nrowblk = nrowblk;
             q.timing = L.gw_timing ? L.gw_timing + (q.K >= 1024 ? 8 : 0) + (ln->act ? 16 : 0) : nullptr;  // [Mish K < 1024 | Mish K >= 1024 | SimNorm ...]
-            if (ln->act == 0) hipLaunchKernelGGL((g_gemm_w<1>), dim3(ord.nblk), dim3(512), 0, st, q);
-            else hipLaunchKernelGGL((g_gemm_w<2>), dim3(ord.nblk), dim3(512), 0, st, q);
+            const int epi = 1 + ln->act;
+#define GEMM_W_LAUNCH(K) hipLaunchKernelGGL(K, dim3(ord.nblk), dim3(512), 0, st, q)
+            if (epi == 1) GEMM_W_LAUNCH((g_gemm_w<1>));
+            else GEMM_W_LAUNCH((g_gemm_w<2>));
+#undef GEMM_W_LAUNCH
             LAUNCH_CHECK();
             return 0;
         }

@@ -53,6 +53,17 @@ struct GemmSParams {
     unsigned long long *timing;  // g_gemm_w profiling builds (-DGW_TIMING), else null
 };
 
+// One step of Chan's parallel (mean, M2) combination: (n_acc, m_acc, q_acc) <- combined with a block of nb values of mean mb and
+// M2 qb.  Every kernel that folds LayerNorm partials uses THIS function, with explicitly rounded operations (no fused
+// multiply-add contraction the compiler could apply in one kernel and not in another): the row statistics -- and with them a
+// plan's bits -- do not depend on which GEMM tile computed them.
+__device__ __forceinline__ void chan_fold(float &n_acc, float &m_acc, float &q_acc, float nb, float mb, float qb) {
+    const float nt = __fadd_rn(n_acc, nb), dl = __fsub_rn(mb, m_acc);
+    m_acc = __fadd_rn(m_acc, __fmul_rn(dl, __fdiv_rn(nb, nt)));
+    q_acc = __fadd_rn(q_acc, __fadd_rn(qb, __fmul_rn(__fmul_rn(dl, dl), __fdiv_rn(__fmul_rn(n_acc, nb), nt))));
+    n_acc = nt;
+}
+
 constexpr int GLN_MAXSPIN = 1 << 18;  // polls (an agent-scope load + s_sleep(2) each: about a third of a second in all); a healthy wait is microseconds -- peers of a row block are dispatched back to back -- or, when a row block straddles the residency limit of its XCD, one tile's run time (< 1 ms)
 
 // NCT = 32-wide output column tiles per wave: 1 -> 128 x 128 workgroup tile (narrow outputs: heads, small models),
@@ -282,11 +293,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (G * 4 + t >= p.CT) break;
-                const float mb = red[((g * 4 + t) * TM + r) * 2], qb = red[((g * 4 + t) * TM + r) * 2 + 1];
-                const float nt = n_acc + 32.f, dl = mb - m_acc;
-                m_acc += dl * (32.f / nt);
-                q_acc += qb + dl * dl * (n_acc * 32.f / nt);
-                n_acc = nt;
+                chan_fold(n_acc, m_acc, q_acc, 32.f, red[((g * 4 + t) * TM + r) * 2], red[((g * 4 + t) * TM + r) * 2 + 1]);
             }
             float *slot = p.stats + (((size_t)rb * NG + G) * TM + r) * 2;
             __hip_atomic_store(slot, m_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -324,11 +331,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
                     if (g0 + u >= NG) break;
                     int nt4 = p.CT - (g0 + u) * 4;
                     nt4 = nt4 > 4 ? 4 : nt4;
-                    const float nb = 32.f * (float)nt4;
-                    const float nt = n_acc + nb, dl = mb[u] - m_acc;
-                    m_acc += dl * (nb / nt);
-                    q_acc += qb[u] + dl * dl * (n_acc * nb / nt);
-                    n_acc = nt;
+                    chan_fold(n_acc, m_acc, q_acc, 32.f * (float)nt4, mb[u], qb[u]);
                 }
             }
             rs[2 * tid] = m_acc;

@@ -328,11 +328,7 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (G * 4 + t >= p.CT) break;
-                const float mb = red[((g * 4 + t) * TM + r) * 2], qb = red[((g * 4 + t) * TM + r) * 2 + 1];
-                const float nt = n_acc + 32.f, dl = mb - m_acc;
-                m_acc += dl * (32.f / nt);
-                q_acc += qb + dl * dl * (n_acc * 32.f / nt);
-                n_acc = nt;
+                chan_fold(n_acc, m_acc, q_acc, 32.f, red[((g * 4 + t) * TM + r) * 2], red[((g * 4 + t) * TM + r) * 2 + 1]);
             }
             float *slot = p.stats + (((size_t)rb * NG + G) * TM + r) * 2;
             __hip_atomic_store(slot, m_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -373,11 +369,7 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
                 if (g0 + u >= NG) break;
                 int nt4 = p.CT - (g0 + u) * 4;
                 nt4 = nt4 > 4 ? 4 : nt4;
-                const float nb = 32.f * (float)nt4;
-                const float nt = n_acc + nb, dl = mb[u] - m_acc;
-                m_acc += dl * (nb / nt);
-                q_acc += qb[u] + dl * dl * (n_acc * nb / nt);
-                n_acc = nt;
+                chan_fold(n_acc, m_acc, q_acc, 32.f * (float)nt4, mb[u], qb[u]);
             }
         }
         rs[2 * tid] = m_acc;
@@ -452,3 +444,4 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
     GW_T(5)
     GW_TFLUSH
 }
+
