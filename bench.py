@@ -594,19 +594,22 @@ def main():
     step(0, cold)
     _sync(device)
     log("first (cold) step done")
-    fence()
-    t_w = time.perf_counter()
     for i in range(W):
         step(1 + i, warm)
-    fence()
     # The timed region covers at least MIN_TIMED_S whatever --steps says (the driver's --steps 20 were half a second:
     # too short for an outside GPU-activity sampler): EXACTLY K steps are timed, where K is --steps
-    # raised to what the warm-up's step time needs for that; `steps` in the line is the number actually timed,
+    # raised to what a short fenced pilot's step time needs for that; `steps` in the line is the number actually timed,
     # `steps_requested` what was asked for.  All ranks agree on K (max over ranks of the estimate).
     K_req = K
-    if W > 0 and not os.environ.get("TDMPC2_BENCH_EXACT_STEPS"):
-        est = (time.perf_counter() - t_w) / W
-        need = int(np.ceil(MIN_TIMED_S / max(est, 1e-6)))
+    if not os.environ.get("TDMPC2_BENCH_EXACT_STEPS"):
+        n_pilot = max(2, min(K_req, 8))
+        fence()
+        t_w = time.perf_counter()
+        for i in range(n_pilot):
+            step(50 + i, warm)
+        fence()
+        est = (time.perf_counter() - t_w) / n_pilot
+        need = int(np.ceil(1.1 * MIN_TIMED_S / max(est, 1e-6)))
         if use_dist:
             tn = torch.tensor([need], dtype=torch.int64, device=device)
             dist.all_reduce(tn, op=dist.ReduceOp.MAX)
