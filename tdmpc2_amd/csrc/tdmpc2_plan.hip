@@ -444,7 +444,10 @@ void fault_clean(tdmpc2_plan *h) {  // a call is about to be enqueued and no fau
         return;
     }
     if (h->rearm_after <= 0 || h->in_shard) return;
-    if (++h->clean_calls < h->rearm_after) return;
+    if (h->clean_calls < h->rearm_after) {  // this call still runs on the downgraded paths: rearm_after of them in all
+        ++h->clean_calls;
+        return;
+    }
     h->cluster_mode = h->user_cluster_mode;
     h->lay.fuse_ln = h->user_fuse_ln;
     h->degraded = false;

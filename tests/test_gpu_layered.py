@@ -362,3 +362,176 @@ def test_a_317m_plan_computes_the_same_bits_alone_and_on_the_wide_tile():
         assert torch.equal(ve[0], v[e]), e
     assert planner.take_fault() == 0
     planner.close()
+
+
+def test_a_reported_wait_downgrades_the_handle_and_clean_calls_rearm_it(monkeypatch):
+    """Recovery from the fault fallback (ABI 7): a fused-epilogue wait that gives up switches the handle to the row-kernel
+    path; after TDMPC2_TUNE_REARM_AFTER clean calls it goes back to the fused epilogue, the back-off doubles, and
+    tdmpc2_plan_fault_info tells the story.  The test hook mutes one workgroup for the handle's whole life, so the first
+    plan after every re-arm faults again -- which is exactly the ping-pong the doubling bounds."""
+    import torch
+
+    from tdmpc2_amd.native import NativePlanner
+    from tests.gpu_common import case_on_gpu, dev, plan_inputs
+
+    c, model, _ = case_on_gpu("small", PATH_LAYERED, 2)
+    monkeypatch.setenv("TDMPC2_CLUSTER_FAULT", "1")
+    planner = NativePlanner(c["cfg"], c["iterations"], dev(), max_envs=c["n_envs"], path=PATH_LAYERED, precision=2)
+    monkeypatch.delenv("TDMPC2_CLUSTER_FAULT")
+    planner.bind_state_dict(model.sd)
+    planner.set_rearm_after(3)
+    inp = plan_inputs(c, model)
+    kw = dict(eval_mode=c["eval_mode"], task_emb=inp["task_emb"], act_mask=inp["act_mask"], tape=inp["tape"])
+
+    def plan():
+        pm = inp["prev_mean"].clone()
+        a = planner.plan(inp["z0"], inp["disc_pow"], pm, inp["t0"], **kw)
+        torch.cuda.synchronize()
+        return a
+
+    fi = planner.fault_info()
+    assert fi["faults_total"] == 0 and fi["degraded"] == 0 and fi["seconds_since_fault"] < 0
+    assert torch.isnan(plan()).all()                       # plan 0: the muted workgroup never arrives
+    assert planner.take_fault() == 1
+    fi = planner.fault_info()
+    assert fi["faults_total"] == 1 and fi["degraded"] == 1 and fi["rearms"] == 0 and 0 <= fi["seconds_since_fault"] < 60
+    good = [plan() for _ in range(3)]                      # three clean plans on the row-kernel path ...
+    assert all(torch.isfinite(g).all() for g in good) and planner.take_fault() == 0
+    fi = planner.fault_info()
+    assert fi["degraded"] == 1 and fi["clean_calls"] == 3 and fi["rearms"] == 0
+    bad = plan()                                           # ... the fourth call re-arms the fused epilogue before it enqueues:
+    fi = planner.fault_info()                              # it runs fused, and the muted workgroup makes it fault again
+    assert fi["rearms"] == 1 and fi["rearm_after"] == 6
+    assert torch.isnan(bad).all() and planner.take_fault() == 1
+    fi = planner.fault_info()
+    assert fi["faults_total"] == 2 and fi["degraded"] == 1 and fi["rearm_after"] == 6 and fi["clean_calls"] == 0
+    planner.set_fuse_ln(0)                                 # an explicit setting ends the story: no fused epilogue, nothing to fault
+    for _ in range(8):                                     # (past the next re-arm point: it restores what the caller asked for -- off)
+        assert torch.isfinite(plan()).all()
+    assert planner.take_fault() == 0 and planner.fault_info()["faults_total"] == 2
+    planner.close()
+
+
+def test_td_target_says_nan_when_a_wait_gave_up(monkeypatch):
+    """ADVICE r3 (medium): `td_target` / `policy_value` of the layered family run through the bounded-wait fused epilogues too;
+    a wait that gives up must not hand the learner finite garbage -- every output element is NaN and take_fault() reports it."""
+    import torch
+
+    from tdmpc2_amd import synth
+    from tdmpc2_amd.native import NativePlanner
+    from tests.gpu_common import case_on_gpu, dev
+
+    c, model, ref = case_on_gpu("small", PATH_LAYERED, 2)
+    cfg = c["cfg"]
+    monkeypatch.setenv("TDMPC2_CLUSTER_FAULT", "1")
+    planner = NativePlanner(cfg, c["iterations"], dev(), max_envs=c["n_envs"], path=PATH_LAYERED, precision=2)
+    monkeypatch.delenv("TDMPC2_CLUSTER_FAULT")
+    planner.bind_state_dict(model.sd)
+    R = 256
+    z = torch.as_tensor(synth.make_latents(cfg, R, seed=9)).to(dev())
+    rw, tm = torch.randn(R, device=dev()), torch.zeros(R, device=dev())
+    td = planner.td_target(z, rw, tm, 0.99, seed=1)
+    torch.cuda.synchronize()
+    assert torch.isnan(td).all()
+    assert planner.take_fault() == 1
+    td2 = planner.td_target(z, rw, tm, 0.99, seed=1)  # the downgraded path: finite, equal to a handle without the fused epilogue
+    torch.cuda.synchronize()
+    assert torch.isfinite(td2).all() and planner.take_fault() == 0
+    planner.close()
+
+
+def test_graph_replay_after_a_smaller_eager_call_resets_every_arrival_counter():
+    """the arrival counters of the fused epilogues are zeroed at the start of every stage over the handle's
+    high-water mark, not over 'what the previous call used': a hipGraph captured at E plans keeps working after an eager call
+    with fewer plans moved the host's bookkeeping (the frozen memset extent still covers every slice the replay uses)."""
+    import torch
+
+    from tests.gpu_common import case_on_gpu, plan_inputs
+
+    c, model, planner = case_on_gpu("small", PATH_LAYERED, 2)
+    inp = plan_inputs(c, model)
+    kw = dict(task_emb=inp["task_emb"], act_mask=inp["act_mask"], tape=inp["tape"], eval_mode=c["eval_mode"])
+    pm0 = inp["prev_mean"].clone()
+    want = planner.plan(inp["z0"], inp["disc_pow"], pm0, inp["t0"], **kw).clone()
+    pm_static, out = inp["prev_mean"].clone(), torch.empty_like(want)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        planner.plan(inp["z0"], inp["disc_pow"], pm_static.clone(), inp["t0"], out=out, **kw)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        planner.plan(inp["z0"], inp["disc_pow"], pm_static, inp["t0"], out=out, **kw)
+    # an eager call with ONE plan in between (fewer counters handed out), then the replay of the full-size graph
+    one = {k: (v[:1].contiguous() if torch.is_tensor(v) and v.shape[0] == c["n_envs"] else v) for k, v in inp.items()}
+    tape1 = {k: v[:1].contiguous() for k, v in inp["tape"].items()} if isinstance(inp["tape"], dict) else inp["tape"]
+    if isinstance(tape1, dict):
+        planner.plan(one["z0"], one["disc_pow"], one["prev_mean"].clone(), one["t0"], eval_mode=c["eval_mode"],
+                     task_emb=None if inp["task_emb"] is None else inp["task_emb"][:1].contiguous(),
+                     act_mask=None if inp["act_mask"] is None else inp["act_mask"][:1].contiguous(), tape=tape1)
+    torch.cuda.synchronize()
+    for i in range(2):
+        pm_static.copy_(inp["prev_mean"])
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, want) and torch.equal(pm_static, pm0) and planner.take_fault() == 0, i
+
+
+def test_two_chains_in_flight_never_starve_each_other():
+    """The two chains of a layered stage run fused-epilogue GEMMs -- workgroups that wait for their row block's peers -- on two
+    hardware queues at once.  Many stages back to back, with random host-side skew between the launches of the two
+    streams and a foreign kernel stream in the background: no bounded wait may give up (the XCD-local tile order keeps a row
+    block's peers on consecutive slots of one XCD; 2 x (column blocks - 1) waiting workgroups never fill an XCD's 32 CUs)."""
+    import os
+    import random
+    import time
+
+    import torch
+
+    from oracle import cases
+    from tdmpc2_amd import synth
+    from tdmpc2_amd.native import NativePlanner
+    from tests.gpu_common import dev, disc_pow
+
+    stages = int(os.environ.get("TDMPC2_STRESS_STAGES", "1500"))
+    E = 16
+    c = cases.build_case("c3")
+    cfg = c["cfg"]
+    sd = {k: torch.as_tensor(v) for k, v in c["sd"].items()}
+    H, N, A = cfg.horizon, cfg.num_samples, cfg.action_dim
+    planner = NativePlanner(cfg, c["iterations"], dev(), max_envs=E, path=PATH_LAYERED, precision=2)
+    planner.bind_state_dict(sd)
+    z0 = torch.as_tensor(synth.make_latents(cfg, E, seed=11)).to(dev())
+    tasks = [(4 * e + 1) % len(cfg.tasks) for e in range(E)]
+    embs = []
+    for t in tasks:
+        v = sd["_task_emb.weight"][t]
+        n = v.norm(2)
+        embs.append(v * (1.0 / (n + 1e-7)) if n > 1.0 else v)
+    emb = torch.stack(embs).to(dev()).contiguous()
+    mask = sd["_action_masks"][torch.tensor(tasks)].to(dev()).contiguous()
+    disc = disc_pow(cfg, [0.99] * E).to(dev())
+    g = torch.Generator().manual_seed(5)
+    actions = ((torch.rand(E, H, N, A, generator=g) * 2 - 1) * sd["_action_masks"][torch.tensor(tasks)].view(E, 1, 1, A)).to(dev()).contiguous()
+    eps = torch.randn(E, N, A, generator=g).to(dev())
+    qidx = torch.tensor(([[0, 4], [3, 1], [2, 0], [1, 2], [4, 3], [0, 1]] * 3)[:E], dtype=torch.int32, device=dev())
+    want = planner.estimate_value(z0, disc, actions, eps, qidx, task_emb=emb, act_mask=mask).clone()
+    rng = random.Random(3)
+    noise_stream = torch.cuda.Stream()
+    junk = torch.randn(2048, 2048, device=dev())
+    t0 = time.perf_counter()
+    for i in range(stages):
+        if i % 7 == 0:  # a foreign kernel now and then (another tenant of the chip)
+            with torch.cuda.stream(noise_stream):
+                junk = junk @ junk * 1e-3
+        if rng.random() < 0.3:
+            time.sleep(rng.random() * 2e-4)  # host-side skew: the next stage's launches trickle in
+        v = planner.estimate_value(z0, disc, actions, eps, qidx, task_emb=emb, act_mask=mask)
+        if i % 250 == 249:
+            torch.cuda.synchronize()
+            assert torch.equal(v, want), i
+    torch.cuda.synchronize()
+    fi = planner.fault_info()
+    print(f"[stress] {stages} stages of c3 E={E} in {time.perf_counter() - t0:.1f} s, faults {fi['faults_total']}")
+    assert planner.take_fault() == 0 and fi["faults_total"] == 0 and fi["degraded"] == 0
+    planner.close()
