@@ -46,6 +46,12 @@ int lay_arrive_reset(tdmpc2_plan *h, hipStream_t st) {
         else hipLaunchKernelGGL((g_gemm_s<NCTV, RTV, SDV, 2, PFV>), dim3(nblk), dim3(GTHREADS), 0, st, q);     \
     } while (0)
 #define GEMM_S_LAUNCH(NCTV, RTV, SDV) GEMM_S_LAUNCH_PF(NCTV, RTV, SDV, 0)
+// the narrow tiles that can run the two-hot epilogue (epi == 3)
+#define GEMM_S_LAUNCH_TH(RTV, SDV)                                                                              \
+    do {                                                                                                      \
+        if (epi == 3) hipLaunchKernelGGL((g_gemm_s<1, RTV, SDV, 3, 0>), dim3(nblk), dim3(GTHREADS), 0, st, q);  \
+        else GEMM_S_LAUNCH(1, RTV, SDV);                                                                      \
+    } while (0)
 
 // A k-range of a layer with a per-environment bias of the caller's: the action columns of a first layer at t = 0, where the
 // z columns' product is one vector per plan (lay_cvec).
@@ -66,7 +72,9 @@ int lay_ln(tdmpc2_plan *h, hipStream_t st, int act, float *x, int ld, int width,
 // handle's fused path is on and fits, else by the LayerNorm row kernel behind the GEMM (split: through bufs->PRE).
 int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t rows_p, int rows_per_env,
              const HostLayer &ly, long w_sel_stride, long bias_sel_stride, int slot, const int *sel, float *out, int ldo,
-             const LnFuse *ln = nullptr, const LayBufs *bufs = nullptr, const GemmRange *range = nullptr, size_t rows = 0) {
+             const LnFuse *ln = nullptr, const LayBufs *bufs = nullptr, const GemmRange *range = nullptr, size_t rows = 0,
+             const TwoHotParams *th = nullptr, bool *th_done = nullptr) {
+    if (th_done) *th_done = false;
     Layered &L = h->lay;
     const LayBufs b0 = lay_bufs(h, 0);
     if (!bufs) bufs = &b0;
@@ -168,6 +176,12 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         } else if (ln) {  // pre-activations -> PRE, the LayerNorm kernel writes the packed operand
             if (!bufs->PRE) return fail(TDMPC2_ERR_STATE, "no pre-activation buffer on this handle");
             q.out = bufs->PRE; q.ldo = L.ldpre;
+        } else if (th && !wide && rt <= 2 && ly.CT <= 4 && (long)nblk >= cus && !getenv("TDMPC2_TWOHOT_UNFUSED")) {
+            // two-hot head: the row routine in the epilogue -- from one workgroup per CU on (c3 E = 30: +1.4 %; a single plan's 16-32
+            // workgroups are better served by l_twohot's one wavefront per row across the chip: 3.33 vs 3.44 ms, profiles r4i)
+            epi = 3;
+            q.th = *th;
+            if (th_done) *th_done = true;
         } else {
             q.out = out; q.ldo = ldo;
         }
@@ -175,11 +189,11 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         // c4 +0.5 % over one chunk ahead in three same-call A/Bs, profiles/README.md r3z / r3y / r3x).
         if (wide) GEMM_S_LAUNCH(2, 4, 2);
         else if (deep && rt == 4) GEMM_S_LAUNCH(1, 4, 4);
-        else if (deep && rt == 2) GEMM_S_LAUNCH(1, 2, 4);
-        else if (deep) GEMM_S_LAUNCH(1, 1, 4);
+        else if (deep && rt == 2) GEMM_S_LAUNCH_TH(2, 4);
+        else if (deep) GEMM_S_LAUNCH_TH(1, 4);
         else if (rt == 4) GEMM_S_LAUNCH(1, 4, 1);
-        else if (rt == 2) GEMM_S_LAUNCH(1, 2, 1);
-        else GEMM_S_LAUNCH(1, 1, 1);
+        else if (rt == 2) GEMM_S_LAUNCH_TH(2, 1);
+        else GEMM_S_LAUNCH_TH(1, 1);
         LAUNCH_CHECK();
         if (ln && !fuse)
             return lay_ln(h, st, ln->act, bufs->PRE, L.ldpre, ln->width, rows ? rows : rows_p, rows_per_env, ly, ln->gb_sel_stride, sel, out, ldo);
@@ -289,18 +303,39 @@ int lay_policy(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int r
     return 0;
 }
 
-int lay_twohot(tdmpc2_plan *h, hipStream_t st, size_t rows, int rpe, int mode, int t, const float *disc_pow, float *value,
-               float *trace, int n_full = 0, int n_off = 0, const float *lg = nullptr) {
+TwoHotParams lay_twohot_params(tdmpc2_plan *h, size_t rows, int rpe, int mode, int t, const float *disc_pow, float *value,
+                               float *trace, int n_full, int n_off, const float *lg) {
     const Layered &L = h->lay;
     TwoHotParams p{};
     p.lg = lg ? lg : L.LG; p.ld = L.ldl; p.rows = (int)rows; p.rows_per_env = rpe; p.num_bins = h->cfg.num_bins; p.mode = mode;
     p.t = t; p.H = h->cfg.horizon; p.bins = h->bins; p.disc_pow = disc_pow; p.G = L.G; p.qtmp = L.QT; p.value = value;
     p.term = h->cfg.episodic ? L.TERM : nullptr; p.trace = trace; p.trace_ld = h->cfg.horizon + 2 + h->cfg.action_dim;
     p.n_full = n_full; p.n_off = n_off;
+    return p;
+}
+
+int lay_twohot(tdmpc2_plan *h, hipStream_t st, size_t rows, int rpe, int mode, int t, const float *disc_pow, float *value,
+               float *trace, int n_full = 0, int n_off = 0, const float *lg = nullptr) {
+    const TwoHotParams p = lay_twohot_params(h, rows, rpe, mode, t, disc_pow, value, trace, n_full, n_off, lg);
     const int grid = (int)((rows + RW_THREADS / 64 - 1) / (RW_THREADS / 64));
     hipLaunchKernelGGL(l_twohot, dim3(grid), dim3(RW_THREADS), 0, st, p);
     LAUNCH_CHECK();
     return 0;
+}
+
+// A two-hot head (reward / Q: world_model.py:123-130,186-216 -> math.two_hot_inv): the output nn.Linear over the hidden
+// activations `A` and the row routine -- inside the GEMM's epilogue on the narrow tiles (split arithmetic), else GEMM + l_twohot.
+int lay_head_twohot(tdmpc2_plan *h, hipStream_t st, const float *A, size_t rows, size_t rows_p, int rpe, const HostLayer &ly,
+                    long w_sel_stride, long bias_sel_stride, const int *sel, float *lg, int mode, int t, const float *disc_pow,
+                    float *value, float *trace, int n_full = 0, int n_off = 0) {
+    const Layered &L = h->lay;
+    const TwoHotParams th = lay_twohot_params(h, rows, rpe, mode, t, disc_pow, value, trace, n_full, n_off, lg);
+    bool done = false;
+    int rc;
+    if ((rc = lay_gemm(h, st, A, L.Mp, rows_p, rpe, ly, w_sel_stride, bias_sel_stride, -1, sel, lg, L.ldl, nullptr, nullptr, nullptr, 0,
+                       &th, &done))) return rc;
+    if (done) return 0;
+    return lay_twohot(h, st, rows, rpe, mode, t, disc_pow, value, trace, n_full, n_off, lg);
 }
 
 int lay_setup(tdmpc2_plan *h, hipStream_t st, int E, const float *task_emb, const float *prev_mean, const unsigned char *t0,
@@ -360,9 +395,16 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
     const size_t rows = (size_t)E * N, rows_p = round_up(rows, GBM);
     int rc;
     if ((rc = lay_arrive_reset(h, st))) return rc;
-    if (h->split) hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM, (int)rows);
-    else hipLaunchKernelGGL(l_init_x, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM);
-    LAUNCH_CHECK();
+    // X <- [z0 | .] for every sample row, G <- 0, TERM <- 0.  With the shared z0 products (lay_cvec) nothing reads the z columns
+    // before the first dynamics step has written z_1 there (the t = 0 GEMMs contract the action columns only), G is
+    // overwritten at t = 0 and the action / padding columns are set by every step: only TERM is left to clear.
+    if (h->split && L.cvec_ready) {
+        if (c.episodic) HIP_TRY(hipMemsetAsync(L.TERM, 0, rows * sizeof(float), st));
+    } else {
+        if (h->split) hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM, (int)rows);
+        else hipLaunchKernelGGL(l_init_x, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM);
+        LAUNCH_CHECK();
+    }
     // Two chains at a time (h->lay.side: a second stream + a second buffer set): the reward chain of step t runs beside the
     // dynamics chain, the second Q head beside the first.  Hazards: reward.l0 is the side chain's only reader of X -- the
     // dynamics' last layer (the writer of z_{t+1}) waits for it; the termination update waits for the reward's two-hot (which
@@ -391,8 +433,7 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
         // reward(z, a_t) -> two_hot_inv -> G += disc * (1 - term) * r
         if ((rc = lay_hidden(h, sd, h->rew, BE_REW, rows, rows_p, N, nullptr, false, &b2, two ? L.ev_xread : nullptr,
                              shortk ? &r_rew : nullptr))) return rc;
-        if ((rc = lay_gemm(h, sd, b2.HB, L.Mp, rows_p, N, h->rew.l[2], 0, 0, -1, nullptr, b2.LG, L.ldl))) return rc;
-        if ((rc = lay_twohot(h, sd, rows, N, 0, t, disc_pow, value, trace, 0, 0, b2.LG))) return rc;
+        if ((rc = lay_head_twohot(h, sd, b2.HB, rows, rows_p, N, h->rew.l[2], 0, 0, nullptr, b2.LG, 0, t, disc_pow, value, trace))) return rc;
         if (two) HIP_TRY(hipEventRecord(L.ev_side, sd));
         // z = next(z, a_t)
         if ((rc = lay_dynamics(h, st, rows, rows_p, N, two ? L.ev_xread : nullptr, shortk ? &r_dyn : nullptr))) return rc;
@@ -413,8 +454,8 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
     }
     // head 0 on the main stream, head 1 beside it
     if ((rc = lay_hidden(h, st, h->q[0], BE_Q0, rows, rows_p, N, qidx, true))) return rc;
-    if ((rc = lay_gemm(h, st, L.HB, L.Mp, rows_p, N, h->q[0].l[2], q_wstride(h, 2), q_bstride(h, 2), -1, qidx, L.LG, L.ldl))) return rc;
-    if ((rc = lay_twohot(h, st, rows, N, 1, 0, disc_pow, value, trace, ranged ? NF : 0, n_off))) return rc;
+    if ((rc = lay_head_twohot(h, st, L.HB, rows, rows_p, N, h->q[0].l[2], q_wstride(h, 2), q_bstride(h, 2), qidx, L.LG, 1, 0, disc_pow, value,
+                              trace, ranged ? NF : 0, n_off))) return rc;
     if ((rc = lay_hidden(h, sd, h->q[0], BE_Q0, rows, rows_p, N, qidx + 1, true, &b2))) return rc;
     if ((rc = lay_gemm(h, sd, b2.HB, L.Mp, rows_p, N, h->q[0].l[2], q_wstride(h, 2), q_bstride(h, 2), -1, qidx + 1, b2.LG,
                        L.ldl))) return rc;

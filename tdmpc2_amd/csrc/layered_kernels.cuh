@@ -255,11 +255,9 @@ struct TwoHotParams {
     int n_full, n_off;             // value[env * n_full + n_off + row % rows_per_env]: a row range of every plan (n_full = 0: value[row])
 };
 
-__global__ __launch_bounds__(RW_THREADS) void l_twohot(TwoHotParams p) {
-    const int row = blockIdx.x * (RW_THREADS / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= p.rows) return;
-    const float r = twohot_wave(p.lg + (size_t)row * p.ld, p.bins, p.num_bins, lane);
-    if (lane != 0) return;
+// what a two-hot head's value of one row goes into (lane 0 of the row's wavefront): shared by l_twohot and the head GEMM's
+// two-hot epilogue (g_gemm_s<.., EPI = 3>)
+__device__ __forceinline__ void twohot_apply(const TwoHotParams &p, int row, float r) {
     const float *disc = p.disc_pow + (size_t)(row / p.rows_per_env) * (p.H + 1);
     const float live = p.term ? 1.f - p.term[row] : 1.f;
     if (p.mode == 0) {
@@ -274,6 +272,14 @@ __global__ __launch_bounds__(RW_THREADS) void l_twohot(TwoHotParams p) {
         p.value[vi] = p.G[row] + disc[p.H] * live * ((p.qtmp[row] + r) / 2.f);
         if (p.trace) p.trace[(size_t)row * p.trace_ld + p.H + 1] = r;
     }
+}
+
+__global__ __launch_bounds__(RW_THREADS) void l_twohot(TwoHotParams p) {
+    const int row = blockIdx.x * (RW_THREADS / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= p.rows) return;
+    const float r = twohot_wave(p.lg + (size_t)row * p.ld, p.bins, p.num_bins, lane);
+    if (lane != 0) return;
+    twohot_apply(p, row, r);
 }
 
 // Termination head (tdmpc2/common/world_model.py:132-141, tdmpc2/tdmpc2.py:133-134):

@@ -51,6 +51,7 @@ struct GemmSParams {
     // EPI != 0: the tile order (tile_order.h: gemm_s_order / gemm_s_tile)
     int xcd_rows, nrowblk, ncol_grid;
     unsigned long long *timing;  // g_gemm_w profiling builds (-DGW_TIMING), else null
+    TwoHotParams th;             // EPI = 3: what the two-hot value of a row goes into (lg / ld unused: the logits stay in LDS)
 };
 
 // One step of Chan's parallel (mean, M2) combination: (n_acc, m_acc, q_acc) <- combined with a block of nb values of mean mb and
@@ -88,6 +89,10 @@ constexpr int GLN_MAXSPIN = 1 << 18;  // polls (an agent-scope load + s_sleep(2)
 // row sums, one lane ^ 32 exchange) and writes 4 consecutive features per store.  The workgroups of a row block must be
 // dispatched together: row-major tile order (never the strip order of gemm_tile_of_block), in-order dispatch per XCD; a wait
 // that gives up raises the handle's error word (the plan then returns NaN, tdmpc2_plan_take_fault).
+// EPI = 3 (NCT = 1, RT <= 2: the narrow two-hot heads -- reward, Q): two_hot_inv (math.py:74-83) in the epilogue.  The workgroup
+// holds all 128 logit columns of its rows: they are staged in LDS as the fp32 values EPI = 0 would have written, and each
+// wavefront runs l_twohot's own row routine (twohot_wave + twohot_apply) on its rows -- the same bits as GEMM + l_twohot,
+// without the logits' round trip through HBM and the extra launch.
 // PF = k16-blocks of the weight ring (0: the rule below).  PF = 3 on the throughput tile: three chunks per trip, weight
 // fragments requested 1.5 chunks ahead instead of 1 (16 more VGPRs).
 template <int NCT, int RT = 4, int SD = 1, int EPI = 0, int PF = 0>
@@ -95,10 +100,14 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
     constexpr int TM = 32 * RT;  // rows of this workgroup's tile
     // LDS image of a 32-wide chunk: the chunk's RT x 2 (k16-blocks) x 2 (planes) fragment planes, 1 KiB each, as they lie in HBM
     __shared__ __attribute__((aligned(16))) _Float16 As[2][RT * 4][512];  // [buffer][(row tile, k16-block, plane)][lane * 8]
+    constexpr int LGS_LD = 132;  // floats per staged logit row (EPI = 3)
+    __shared__ __attribute__((aligned(16))) float lgs[EPI == 3 ? TM * LGS_LD : 4];
+    static_assert(EPI != 3 || (NCT == 1 && RT <= 2), "two-hot epilogue: one 128-column block, at most 64 rows of logits in LDS");
+    constexpr bool LN = EPI == 1 || EPI == 2;  // NormedLinear epilogue: transposed accumulator tile, tile order of tile_order.h
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int rb, cb;
-    if (EPI == 0) {
+    if (!LN) {
         gemm_tile_of_block(blockIdx.x, gridDim.x, p.ncolblk, rb, cb);
     } else {  // tile_order.h: XCD-local row blocks, or (padded) row-major
         if (!gemm_s_tile(blockIdx.x, p.nrowblk, p.ncolblk, p.xcd_rows, p.ncol_grid, rb, cb)) return;
@@ -191,17 +200,17 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
             for (int n = 0; n < NCT; ++n)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
-                    acc[n][rt] = EPI ? SPLIT_MFMA(rh[d][n], fh[rt], acc[n][rt]) : SPLIT_MFMA(fh[rt], rh[d][n], acc[n][rt]);
+                    acc[n][rt] = LN ? SPLIT_MFMA(rh[d][n], fh[rt], acc[n][rt]) : SPLIT_MFMA(fh[rt], rh[d][n], acc[n][rt]);
 #pragma unroll
             for (int n = 0; n < NCT; ++n)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
-                    acc[n][rt] = EPI ? SPLIT_MFMA(rl[d][n], fh[rt], acc[n][rt]) : SPLIT_MFMA(fh[rt], rl[d][n], acc[n][rt]);
+                    acc[n][rt] = LN ? SPLIT_MFMA(rl[d][n], fh[rt], acc[n][rt]) : SPLIT_MFMA(fh[rt], rl[d][n], acc[n][rt]);
 #pragma unroll
             for (int n = 0; n < NCT; ++n)
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt)
-                    acc[n][rt] = EPI ? SPLIT_MFMA(rh[d][n], fl[rt], acc[n][rt]) : SPLIT_MFMA(fl[rt], rh[d][n], acc[n][rt]);
+                    acc[n][rt] = LN ? SPLIT_MFMA(rh[d][n], fl[rt], acc[n][rt]) : SPLIT_MFMA(fl[rt], rh[d][n], acc[n][rt]);
             const int kn = ch * 2 + kb + PFB;
             const int knc = kn < KB ? kn : KB - 1;
 #pragma unroll
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
 
     const float osc = p.oscale[(size_t)sel * p.osc_sel_stride];
     const float *bsel = p.bias + (size_t)sel * p.bias_sel_stride;
-    if constexpr (EPI != 0) {
+    if constexpr (LN) {
         // transposed C fragment: lane holds row (l & 31) of row tile rt and features (reg & 3) + 8 (reg >> 2) + 4 (l >> 5) of
         // column tile ct0 + n.  LDS (the staging buffers are idle now): per-wave partials, then the rows' (mean, rstd).
         __syncthreads();  // every wave is done with the last chunk's fragments
@@ -386,6 +395,26 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
                     *reinterpret_cast<f16x4 *>(o + 1024) = lo;
                 }
             }
+        }
+        return;
+    }
+    if constexpr (EPI == 3) {
+        // logits -> LDS (C fragment: lane holds column (l & 31) of this wave's tile, rows (reg & 3) + 8 (reg >> 2) + 4 (l >> 5))
+        const int colv = ct0 < p.CT ? ct0 * 32 + i32 : 0;
+        const float bv = ct0 < p.CT ? bsel[colv] : 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                lgs[r * LGS_LD + wave * 32 + i32] = fmaf(acc[0][rt][reg], osc, bv);
+            }
+        __syncthreads();
+        for (int r = wave; r < TM; r += 4) {  // one wavefront per row, as l_twohot
+            const int row = row0 + r;
+            if (row >= p.th.rows) continue;
+            const float v = twohot_wave(lgs + r * LGS_LD, p.th.bins, p.th.num_bins, lane);
+            if (lane == 0) twohot_apply(p.th, row, v);
         }
         return;
     }
