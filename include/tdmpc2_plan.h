@@ -314,7 +314,9 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
  * key TDMPC2_TUNE_CLUSTER (fused family, f16x2-split arithmetic): single-plan latency path -- every 512-wide
  * layer of a 32-row sample tile is split over a cluster of 8 workgroups on 8 CUs that exchange the layer's raw sums through
  * L2 (tdmpc2_amd/csrc/cluster_kernels.cuh); used when all of a call's clusters fit the chip at once (one or two plans of
- * 512 samples on 256 CUs).  0 = never, 1 / 2 (default) = whenever the call fits.
+ * 512 samples on 256 CUs).  0 = never, 1 = whenever the call fits, 2 (default) = 1, and for a SINGLE non-episodic plan every
+ * launch after the first gives each tile a second cluster that runs the reward chain (and the second Q head) beside the
+ * dynamics chain (cluster2_kernels.cuh: all 256 CUs, 16 instead of 23 hand-overs on the critical path; identical values).
  * key TDMPC2_TUNE_FUSE_LN (layered family, f16x2-split arithmetic): 1 (default) = the LayerNorm + Mish / SimNorm + operand split
  * of every NormedLinear (tdmpc2/common/layers.py:94-118) runs in the epilogue of its GEMM -- the column blocks of a row block
  * exchange per-row (mean, M2) partials through L2, a bounded wait like the cluster path's (tdmpc2_plan_take_fault) --;

@@ -59,6 +59,7 @@ struct ClState {
     unsigned hphase;   // narrow heads so far (arrival words 8..15 of the cluster)
     bool learned;      // the launch's first hand-over is behind us (x.fast is valid)
     bool mute;         // test hook (TDMPC2_CLUSTER_FAULT): this member never signals -- the others must time out, not hang
+    int pub = 0;       // the next exchange / head tile is also read by ANOTHER cluster (cluster2_kernels.cuh): write-through stores
 };
 
 __device__ __forceinline__ void cl_st16(float *p, f32x4 v, int fast) {
@@ -222,7 +223,7 @@ __device__ __forceinline__ void cl_gemm(const CT &c, ClState &x, const WRef la, 
     // order would park it: idx4 = (rank * 2 + ft') * 4 + m
     const int rft = c.tid >> 8, rm = (c.tid >> 6) & 3, rl = c.tid & 63;
     const int nl = lb.wp ? 2 : 1;
-    const int fast = learn ? 0 : *x.fast;
+    const int fast = (learn || x.pub) ? 0 : *x.fast;
     for (int layer = 0; layer < nl; ++layer) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -323,13 +324,13 @@ __device__ __forceinline__ void cl_layer(const CT &c, ClState &x, const WRef ly,
 // was slower still (r02v).  Members that are neither producer nor consumer walk through.
 // Reuse of the head tile: two heads are always separated by a cluster barrier, which a consumer reaches after its reads.
 template <class CT>
-__device__ __forceinline__ void cl_head_logits(const CT &c, ClState &x, const LayerS &ly, bool consume) {
+__device__ __forceinline__ void cl_head_logits(const CT &c, ClState &x, const LayerS &ly, bool consume, int slot = 4) {
     static_assert(CT::ZKB == 32, "8 waves x 4 k-blocks");
 #ifdef CL_ABL_NO_HEAD  // timing experiment: results are wrong
     return;
 #endif
     x.hphase += 1;
-    float *hbuf = x.xbuf + (size_t)4 * CL_TILE;
+    float *hbuf = x.xbuf + (size_t)slot * CL_TILE;
     unsigned *hflags = x.flags + 8;
     const bool produce = x.rank < ly.CT;
     if (produce) {
@@ -343,7 +344,7 @@ __device__ __forceinline__ void cl_head_logits(const CT &c, ClState &x, const La
         const float osc = *ly.oscale;
         const int lane = c.tid & 63, col = lane & 31;
         const float bv = ly.bias[x.rank * 32 + col];
-        const int fast = *x.fast;
+        const int fast = x.pub ? 0 : *x.fast;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int reg = (c.tid >> 6) + 8 * u;

@@ -148,6 +148,11 @@ struct RolloutParamsT {
     int cl_fault;              // test hook: member 7 of cluster 0 never signals (the bounded waits must report it)
     int pi_fold;               // the policy-prior trajectories (tdmpc2.py:154-160) are computed by cluster 0 of each plan in launch 0
     const float *pi_traj_eps;  // [E,H,P,A] or null (Philox)
+    // two clusters per tile (cluster2_kernels.cuh, ks_rollout_cl2): their exchange tiles, arrival words, z_H scratch, (G, Qb) mailbox
+    float *cl2_xbuf;
+    unsigned int *cl2_flags;
+    float *cl2_zs;
+    float *cl2_mail;
 };
 
 // pi + two Q heads on a batch of latent rows (fused_kernels.cuh: ks_value)
@@ -269,6 +274,8 @@ struct SetupParamsT {
     float *beff, *cvec, *mean, *std;
     unsigned int *cl_flags;  // cluster path: arrival words, zeroed at the start of every plan ([E][cl_flag_words]) or null
     int cl_flag_words;
+    unsigned int *cl2_flags; // ks_rollout_cl2's arrival words (single plans), zeroed by plan 0's workgroup, or null
+    int cl2_flag_words;
     int skip_cvec;           // cluster path: no z0 products (cvec unused)
 };
 

@@ -1076,6 +1076,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
          __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63};
     if (p.cl_flags)  // cluster path (cluster_kernels.cuh): this plan's arrival words start at phase 0
         for (int idx = tid; idx < p.cl_flag_words; idx += NTHREADS) p.cl_flags[(size_t)e * p.cl_flag_words + idx] = 0u;
+    if (p.cl2_flags && e == 0)
+        for (int idx = tid; idx < p.cl2_flag_words; idx += NTHREADS) p.cl2_flags[idx] = 0u;
     if (p.multitask) {
         const float *emb = p.task_emb + (size_t)e * p.T;
         for (int net = 0; net < p.nnets; ++net) {

@@ -99,6 +99,10 @@ struct tdmpc2_plan {
     unsigned int *cl_flags = nullptr;
     unsigned int *cl_err_host = nullptr, *cl_err_dev = nullptr;  // host-mapped error word of the bounded waits
     size_t cl_lds = 0;
+    // ks_rollout_cl2 (cluster2_kernels.cuh): two clusters per tile for ONE plan -- buffers for 2 x tiles-of-32 clusters, or null
+    float *cl2_xbuf = nullptr, *cl2_zs = nullptr, *cl2_mail = nullptr;
+    unsigned int *cl2_flags = nullptr;
+    int cl2_mode = 1;                // TDMPC2_CLUSTER2=0: off
     int cl_fault = 0;                // TDMPC2_CLUSTER_FAULT=1 at create: test hook of the bounded waits
     int faults = 0;                  // cluster plans that gave up since the last tdmpc2_plan_take_fault
     // Recovery from a reported wait (fault_note / fault_clean, tdmpc2_plan.hip): the paths with inter-workgroup waits are switched

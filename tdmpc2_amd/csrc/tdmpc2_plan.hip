@@ -314,6 +314,7 @@ const FusedOps &fused_ops(int apad) {
     }
 #endif
 }
+constexpr int CL2_SLOTS_HOST = 6 + MAXH;  // = CL2_SLOTS of cluster2_kernels.cuh (exchange tiles per cluster of ks_rollout_cl2)
 const ClusterOps &cluster_ops(int apad) {
 #ifdef TDMPC2_ONLY_APAD
     (void)apad;
@@ -394,6 +395,8 @@ int launch_setup(tdmpc2_plan *h, int E, const float *z0, const float *task_emb, 
     // cluster path: the arrival words of this call's clusters start every plan at zero (phase numbers grow through its launches)
     p.cl_flags = (h->cl_max_clusters && (long)E * h->tiles * 2 <= h->cl_max_clusters) ? h->cl_flags : nullptr;
     p.cl_flag_words = h->tiles * 2 * CL_FLAG_STRIDE;
+    p.cl2_flags = (p.cl_flags && E == 1 && h->cl2_flags && h->cl2_mode && h->cluster_mode == 2) ? h->cl2_flags : nullptr;
+    p.cl2_flag_words = h->tiles * 4 * CL_FLAG_STRIDE;
     p.skip_cvec = skip_cvec ? 1 : 0;
     Kern<NET>::setup(h, p, E, st);
     HIP_TRY(hipGetLastError());
@@ -504,6 +507,10 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
     rp.tiles = h->tiles * (2 / nst);
     rp.cl_xbuf = h->cl_xbuf; rp.cl_flags = h->cl_flags; rp.cl_err = h->cl_err_dev; rp.cl_zs = h->cl_zs;
     rp.cl_fault = h->cl_fault;
+    rp.cl2_xbuf = h->cl2_xbuf; rp.cl2_flags = h->cl2_flags; rp.cl2_zs = h->cl2_zs; rp.cl2_mail = h->cl2_mail;
+    // a single non-episodic plan: from the second launch on the reward chain runs beside the dynamics chain on a second cluster
+    // per tile (ks_rollout_cl2: all 256 CUs; launch 0 also computes the policy-prior trajectories and stays on ks_rollout_cl)
+    const bool cluster2 = cluster && h->cluster_mode == 2 && E == 1 && h->cl2_xbuf && h->cl2_mode && !c.episodic && !h->cl_fault;
     std::unique_lock<std::mutex> gate;
     bool gate_record = false;
     const int gdev = c.device >= 0 && c.device < 64 ? c.device : 0;
@@ -565,7 +572,8 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
             fp.sample_eps = rp.sample_eps; fp.sample_eps_estride = rp.sample_eps_estride;
         }
         if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
-        if (cluster) Kern<NET>::rollout_cluster(h, rp, (int)clusters, st);
+        if (cluster2 && it > 0) cluster_ops(h->Apad).rollout_cl2(rp, (int)((2 * clusters + 7) / 8 * 64), h->cl_lds, st);
+        else if (cluster) Kern<NET>::rollout_cluster(h, rp, (int)clusters, st);
         else Kern<NET>::rollout(h, rp, E * rp.tiles, st, nst, nw);
         HIP_TRY(hipGetLastError());
         if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) {
@@ -869,6 +877,22 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
                 return TDMPC2_ERR_HIP;
             }
             h->cl_max_clusters = (int)ncl;
+            // two clusters per tile for ONE plan (ks_rollout_cl2): needs every CU of the chip
+            if (!c.episodic && 2 * per_env * CL <= cus && c.horizon <= MAXH) {
+                const size_t n2 = (size_t)(2 * per_env);
+                if ((rc = dev_alloc(h, (void **)&h->cl2_xbuf, n2 * CL2_SLOTS_HOST * CL_TILE * 4)) ||
+                    (rc = dev_alloc(h, (void **)&h->cl2_zs, n2 * CL * 32 * WIDTH * 4)) ||
+                    (rc = dev_alloc(h, (void **)&h->cl2_flags, n2 * CL_FLAG_STRIDE * 4)) ||
+                    (rc = dev_alloc(h, (void **)&h->cl2_mail, (size_t)per_env * 32 * 2 * 4))) {
+                    tdmpc2_plan_destroy(h);
+                    return rc;
+                }
+                if (hipMemset(h->cl2_flags, 0, n2 * CL_FLAG_STRIDE * 4) != hipSuccess) {
+                    tdmpc2_plan_destroy(h);
+                    return fail(TDMPC2_ERR_HIP, "hipMemset(cl2 flags) failed");
+                }
+                if (const char *c2 = getenv("TDMPC2_CLUSTER2")) h->cl2_mode = atoi(c2);
+            }
         }
     }
     if (const char *cm = getenv("TDMPC2_CLUSTER")) h->cluster_mode = atoi(cm);

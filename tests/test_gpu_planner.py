@@ -520,3 +520,28 @@ def test_cluster_hand_over_that_never_arrives_is_reported_not_hung(monkeypatch):
     assert torch.equal(a, b) and torch.equal(pm_a, pm_b)
     assert planner.take_fault() == 0
     planner.close()
+
+
+@pytest.mark.parametrize("name", ["c1_wide"])
+def test_second_cluster_per_tile_computes_the_same_bits(name):
+    """Single plans (evaluate.py:80): from the second CEM launch on every 32-row tile gets a second cluster of 8 workgroups that
+    runs the reward chain and the second Q head beside the dynamics chain (cluster2_kernels.cuh, TDMPC2_TUNE_CLUSTER = 2).  Same
+    operations in the same order per row: every stage of the plan is bit-identical to the one-cluster path (= 1), and both
+    match the reference golden."""
+    from tests.gpu_common import case_on_gpu
+
+    c, model, planner = case_on_gpu(name)
+    assert c["n_envs"] == 1
+    g = load_golden(name)
+    planner.set_cluster(2)
+    two = _run_native(c, model, planner)
+    planner.set_cluster(1)
+    try:
+        one = _run_native(c, model, planner)
+    finally:
+        planner.set_cluster(2)
+    assert planner.take_fault() == 0
+    for k in ("value", "elite_idx", "mean", "std", "action", "prev_mean"):
+        if k in two and k in one:
+            assert np.array_equal(np.asarray(two[k]), np.asarray(one[k])), k
+    _compare_stages(name, c, two, g, g["action"], g["prev_mean_out"], tag="/fused/split/golden/two_clusters")
