@@ -15,11 +15,14 @@
 // Cross-cluster reads use D's arrival words (R polls them exactly as D's own members do; phase numbers are a function of
 // (launch, step) alone) and agent-scope loads; D writes Z[t] and the policy-head tile with write-through stores whatever the
 // placement.  Every wait is bounded and raises the handle's error word like the cluster path's.
-// Used for launches 1 .. I - 1 of a single non-episodic plan (launch 0 also computes the policy-prior trajectories: ks_rollout_cl).
+// Launch 0 also computes the policy-prior trajectories (tdmpc2.py:154-160: rows < P of tile 0, a_t = pi(z_t)): tile 0's D cluster
+// runs pi.l0, pi.l1 and the policy head in front of every step's dynamics (as ks_rollout_cl's cluster 0 does) and leaves each
+// step's head logits in a tile of its own; tile 0's R cluster turns them into the same actions with the same noise.
+// Used for single non-episodic plans.
 // Included by k_cluster.hip after cluster_kernels.cuh.
 #pragma once
 
-constexpr int CL2_SLOTS = 6 + MAXH;  // exchange tiles per cluster: 0 / 1 layers, 4 head, 5 policy head, 6 + t: Z[t]
+constexpr int CL2_SLOTS = 6 + 2 * MAXH;  // exchange tiles per cluster: 0 / 1 layers, 4 head, 5 policy head, 6 + t: Z[t], 6 + MAXH + t: prior policy head of step t
 constexpr int CL2_MAIL = 15;         // arrival word of R's cluster that carries the mailbox's launch tag
 
 // poll the 8 arrival words of a PEER cluster until all have reached `phase` (bounded)
@@ -100,10 +103,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl2(RolloutParamsT<Net
     const float *b_pi = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_PI) * WIDTH : p.pi.l[0].bias;
     const float *b_q0 = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_Q0 + q0) * WIDTH : p.q[q0].l[0].bias;
     const float *b_q1 = p.multitask ? p.beff + ((size_t)e * p.nnets + BE_Q0 + q1) * WIDTH : p.q[q1].l[0].bias;
-    if (role == 0) gb_prefetch(c, p.dyn.l[0].g, p.dyn.l[0].b);
-    else gb_prefetch(c, p.rew.l[0].g, p.rew.l[0].b);
+    // the policy-prior trajectories of this plan: tile 0's first P rows, first launch (host: P <= 32)
+    const bool pifold = p.pi_fold && p.iter == 0 && tile == 0;
+    const unsigned pf = pifold ? 5u : 3u;  // D's layer hand-overs per step
+    if (role == 0) {
+        if (pifold) gb_prefetch(c, p.pi.l[0].g, p.pi.l[0].b);
+        else gb_prefetch(c, p.dyn.l[0].g, p.dyn.l[0].b);
+    } else {
+        gb_prefetch(c, p.rew.l[0].g, p.rew.l[0].b);
+    }
     tile_broadcast_row_s(c, p.z0 + (size_t)e * WIDTH);  // z_0 in every row (tdmpc2.py:163)
     epi_barrier(c);
+    if (pifold) {  // zs <- z_0 in register order (later steps: the SimNorm epilogue's copy): the policy head's staging view clobbers z
+        f32x16 y[1][2];
+        const int hh = c.lane >> 5;
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 z = *reinterpret_cast<const f32x4 *>(p.z0 + (size_t)e * WIDTH + 64 * c.wave + 32 * ft + 8 * m + 4 * hh);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[0][ft][4 * m + r] = z[r];
+            }
+        park(c, y, zs);
+    }
 
     // the sampled actions of step t into this member's tile (tdmpc2.py:176-181); D's member 0 also writes them out
     auto fill_actions = [&](int t) {
@@ -124,7 +147,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl2(RolloutParamsT<Net
                 const int a = a0 + u;
                 if (a < p.A) {
                     if (!sampled) {
-                        v[u] = ag[(size_t)n * p.A + a];  // policy-prior rows: written by launch 0
+                        v[u] = pifold ? 0.f : ag[(size_t)n * p.A + a];  // policy-prior rows: written by launch 0 (there: the policy head below)
                     } else {
                         float r = z[u];
                         if (p.sample_eps)
@@ -148,15 +171,63 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl2(RolloutParamsT<Net
         return rng_normal(p.seed, p.call, SITE_PI, p.iter, e, ridx);
     };
 
+    // D's policy-head logits (exchange tile `slot`, complete when its head arrival words reach `hphase`) -> this member's staging view
+    auto peer_head_to_staging = [&](int slot, unsigned hphase) {
+        const unsigned *hflags = peer_flags + 8;
+        const int nct = p.pi.l[2].CT;
+        if (tid < nct && !*x.dead) {
+            int spin = 0;
+            while (__hip_atomic_load(hflags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < hphase) {
+                if (++spin > CL_MAXSPIN) {
+                    __hip_atomic_store(x.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    *x.dead = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        const float *hbuf = peer_xbuf + (size_t)slot * CL_TILE;
+        const int row = tid >> 4, c4 = (tid & 15) * 4;
+        f32x4 v0, v1;
+        cl_ld16(v0, hbuf + row * 128 + c4);
+        cl_ld16(v1, hbuf + row * 128 + 64 + c4);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
+        float *f = c.f32() + row * CT::RSF();  // (the staging view aliases the z columns' hi plane: z comes back from zs afterwards)
+        *reinterpret_cast<f32x4 *>(f + c4) = v0;
+        *reinterpret_cast<f32x4 *>(f + 64 + c4) = v1;
+        __syncthreads();
+    };
+    // a_t of the policy-prior rows from the step's policy-head logits in the staging view (tdmpc2.py:156-160), then z_t back
+    auto prior_actions = [&](int t, float *gdst) {
+        const float *tape = p.pi_traj_eps ? p.pi_traj_eps + ((size_t)e * p.H + t) * p.P * p.A : nullptr;
+        auto eps = [&](int row, int a) -> float {
+            if (row >= p.P) return 0.f;
+            if (tape) return tape[row * p.A + a];
+            return rng_normal(p.seed, p.call, SITE_PITRAJ, t, e, (unsigned)(row * p.A + a));
+        };
+        head_pi_rows_s(c, p.A, p.Apad, p.log_std_min, p.log_std_dif, mask, eps, gdst, p.P, nullptr, nullptr, nullptr, p.P, true);
+        tile_from_global_s(c, zs);
+        __syncthreads();
+    };
+
     if (role == 0) {
         // ================================================================ D: dynamics, policy, first Q head, the value
         for (int t = 0; t < p.H; ++t) {
             fill_actions(t);
+            if (pifold) {
+                cl_layer<0>(c, x, CL_L(p.pi.l[0]), b_pi, 0, ZKB16, 0, gb_of(p.pi.l[1]));
+                cl_layer<0>(c, x, CL_L(p.pi.l[1]), p.pi.l[1].bias, 0, ZKB16, 1, gb_of(p.dyn.l[0]));
+                x.pub = 1;
+                cl_head_logits(c, x, p.pi.l[2], true, 6 + MAXH + t);
+                x.pub = 0;
+                prior_actions(t, rank == 0 ? p.actions + ((size_t)e * p.H + t) * p.N * p.A : nullptr);
+            }
             cl_layer<0>(c, x, CL_L(p.dyn.l[0]), b_dyn, 0, KBA, 0, gb_of(p.dyn.l[1]));
             cl_layer<0>(c, x, CL_L(p.dyn.l[1]), p.dyn.l[1].bias, 0, ZKB16, 1, gb_of(p.dyn.l[2]));
             x.pub = 1;  // Z[t] is read by the other cluster: write-through whatever the placement
-            cl_layer<1>(c, x, CL_L(p.dyn.l[2]), p.dyn.l[2].bias, 0, ZKB16, 6 + t, t == p.H - 1 ? gb_of(p.pi.l[0]) : gb_of(p.dyn.l[0]),
-                        t == p.H - 1 ? zs : nullptr);
+            cl_layer<1>(c, x, CL_L(p.dyn.l[2]), p.dyn.l[2].bias, 0, ZKB16, 6 + t, (t == p.H - 1 || pifold) ? gb_of(p.pi.l[0]) : gb_of(p.dyn.l[0]),
+                        (t == p.H - 1 || pifold) ? zs : nullptr);
             x.pub = 0;
         }
         // a_H = pi(z_H) (tdmpc2.py:135); z_H was also saved to zs
@@ -218,46 +289,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl2(RolloutParamsT<Net
     float G = 0.f;
     for (int t = 0; t < p.H; ++t) {
         if (t > 0) {  // z_t: D's Z[t - 1] through the SimNorm epilogue (c.gb holds dyn.l2's parameters: named by rew.l1 below)
-            cl2_wait_peer(c, x, peer_flags, base_ph + 3u * (unsigned)t);
-            cl_epi<1>(c, xp, 6 + t - 1, CL_E(p.dyn.l[2]), p.dyn.l[2].bias, gb_of(p.rew.l[0]));
+            cl2_wait_peer(c, x, peer_flags, base_ph + pf * (unsigned)t);
+            cl_epi<1>(c, xp, 6 + t - 1, CL_E(p.dyn.l[2]), p.dyn.l[2].bias, gb_of(p.rew.l[0]), pifold ? zs : nullptr);
         }
         fill_actions(t);
+        if (pifold) {  // the prior rows' a_t: D's policy-head logits of this step, the same noise
+            peer_head_to_staging(6 + MAXH + t, base_hp + (unsigned)t + 1u);
+            prior_actions(t, nullptr);
+        }
         cl_layer<0>(c, x, CL_L(p.rew.l[0]), b_rew, 0, KBA, 0, gb_of(p.rew.l[1]));
         cl_layer<0>(c, x, CL_L(p.rew.l[1]), p.rew.l[1].bias, 0, ZKB16, 1, gb_of(p.dyn.l[2]));
         const float r = cl_head_twohot(c, x, p.rew.l[2], p.bins, p.num_bins);
         G += disc[t] * r;
     }
     // z_H, then a_H from D's policy-head logits and the same noise
-    cl2_wait_peer(c, x, peer_flags, base_ph + 3u * (unsigned)p.H);
+    cl2_wait_peer(c, x, peer_flags, base_ph + pf * (unsigned)p.H);
     cl_epi<1>(c, xp, 6 + p.H - 1, CL_E(p.dyn.l[2]), p.dyn.l[2].bias, gb_of(p.q[q1].l[0]), zs);
-    {
-        const unsigned *hflags = peer_flags + 8;
-        const int nct = p.pi.l[2].CT;
-        if (tid < nct && !*x.dead) {
-            int spin = 0;
-            while (__hip_atomic_load(hflags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < base_hp + 1u) {
-                if (++spin > CL_MAXSPIN) {
-                    __hip_atomic_store(x.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    *x.dead = 1;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        __syncthreads();
-        const float *hbuf = peer_xbuf + (size_t)5 * CL_TILE;
-        const int row = tid >> 4, c4 = (tid & 15) * 4;
-        f32x4 v0, v1;
-        cl_ld16(v0, hbuf + row * 128 + c4);
-        cl_ld16(v1, hbuf + row * 128 + 64 + c4);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
-        float *f = c.f32() + row * CT::RSF();
-        // (the staging view aliases the z columns' hi plane: z_H comes back from zs below)
-        *reinterpret_cast<f32x4 *>(f + c4) = v0;
-        *reinterpret_cast<f32x4 *>(f + 64 + c4) = v1;
-        __syncthreads();
-        head_pi_rows_s(c, p.A, p.Apad, p.log_std_min, p.log_std_dif, mask, eps_pi, nullptr, 0, nullptr);
-    }
+    peer_head_to_staging(5, base_hp + (pifold ? (unsigned)p.H : 0u) + 1u);
+    head_pi_rows_s(c, p.A, p.Apad, p.log_std_min, p.log_std_dif, mask, eps_pi, nullptr, 0, nullptr);
     tile_from_global_s(c, zs);
     __syncthreads();
     // Qb(z_H, a_H)

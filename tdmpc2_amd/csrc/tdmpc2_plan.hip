@@ -314,7 +314,7 @@ const FusedOps &fused_ops(int apad) {
     }
 #endif
 }
-constexpr int CL2_SLOTS_HOST = 6 + MAXH;  // = CL2_SLOTS of cluster2_kernels.cuh (exchange tiles per cluster of ks_rollout_cl2)
+constexpr int CL2_SLOTS_HOST = 6 + 2 * MAXH;  // = CL2_SLOTS of cluster2_kernels.cuh (exchange tiles per cluster of ks_rollout_cl2)
 const ClusterOps &cluster_ops(int apad) {
 #ifdef TDMPC2_ONLY_APAD
     (void)apad;
@@ -509,7 +509,7 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
     rp.cl_fault = h->cl_fault;
     rp.cl2_xbuf = h->cl2_xbuf; rp.cl2_flags = h->cl2_flags; rp.cl2_zs = h->cl2_zs; rp.cl2_mail = h->cl2_mail;
     // a single non-episodic plan: from the second launch on the reward chain runs beside the dynamics chain on a second cluster
-    // per tile (ks_rollout_cl2: all 256 CUs; launch 0 also computes the policy-prior trajectories and stays on ks_rollout_cl)
+    // per tile (ks_rollout_cl2: all 256 CUs)
     const bool cluster2 = cluster && h->cluster_mode == 2 && E == 1 && h->cl2_xbuf && h->cl2_mode && !c.episodic && !h->cl_fault;
     std::unique_lock<std::mutex> gate;
     bool gate_record = false;
@@ -572,7 +572,7 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
             fp.sample_eps = rp.sample_eps; fp.sample_eps_estride = rp.sample_eps_estride;
         }
         if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
-        if (cluster2 && it > 0) cluster_ops(h->Apad).rollout_cl2(rp, (int)((2 * clusters + 7) / 8 * 64), h->cl_lds, st);
+        if (cluster2) cluster_ops(h->Apad).rollout_cl2(rp, (int)((2 * clusters + 7) / 8 * 64), h->cl_lds, st);
         else if (cluster) Kern<NET>::rollout_cluster(h, rp, (int)clusters, st);
         else Kern<NET>::rollout(h, rp, E * rp.tiles, st, nst, nw);
         HIP_TRY(hipGetLastError());

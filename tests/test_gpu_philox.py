@@ -66,6 +66,8 @@ GEOMETRIES = [
     ("c2_i6", 1, 256, dict(rows=64, fold=0)),   # THE benched launch geometry
     ("c1", 1, 3, dict(rows=32, fold=1, cluster=0)),
     ("c1", 1, 1, dict(cluster=1)),
+    ("c1", 1, 1, dict(cluster=2)),              # two clusters per tile (ks_rollout_cl2): the E = 1 latency path
+    ("c2_i6", 1, 1, dict(cluster=2)),
     ("c2_ep", 1, 1, dict(cluster=1)),
     ("mt5", 1, 5, dict()),
     ("small_mt", 2, 3, dict()),
@@ -74,7 +76,7 @@ GEOMETRIES = [
 ]
 
 
-@pytest.mark.parametrize("name,path,E,tune", GEOMETRIES, ids=[f"{g[0]}-p{g[1]}-E{g[2]}" for g in GEOMETRIES])
+@pytest.mark.parametrize("name,path,E,tune", GEOMETRIES, ids=[f"{g[0]}-p{g[1]}-E{g[2]}" + "".join(f"-{k}{v}" for k, v in g[3].items()) for g in GEOMETRIES])
 def test_exported_tape_reproduces_the_philox_plan_bit_for_bit(name, path, E, tune):
     from oracle import cases
     from oracle import planner_oracle as po
