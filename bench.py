@@ -673,10 +673,10 @@ def main():
             one.plan(z1, d1, p1, warm[:1], seed=i, out=o1, task_emb=e1, act_mask=m1)
         _sync(device)
         t1 = time.perf_counter()
-        for i in range(5):
+        for i in range(20):
             one.plan(z1, d1, p1, warm[:1], seed=10 + i, out=o1, task_emb=e1, act_mask=m1)
         _sync(device)
-        extra["latency_ms_single_env"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+        extra["latency_ms_single_env"] = round((time.perf_counter() - t1) / 20 * 1e3, 3)
         if family == "fused" and one.precision == 2:
             # the same plan with one workgroup per 32-row tile (TDMPC2_TUNE_CLUSTER 0): what the cluster path buys
             one.set_cluster(0)
@@ -688,6 +688,17 @@ def main():
                 one.plan(z1, d1, p1, warm[:1], seed=10 + i, out=o1, task_emb=e1, act_mask=m1)
             _sync(device)
             extra["latency_ms_single_env_no_cluster"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
+            # ... and with ONE cluster of 8 workgroups per tile (TDMPC2_TUNE_CLUSTER 1, round 3's path): what the second cluster
+            # per tile (reward chain beside the dynamics chain, cluster2_kernels.cuh) buys
+            one.set_cluster(1)
+            for i in range(2):
+                one.plan(z1, d1, p1, warm[:1], seed=i, out=o1, task_emb=e1, act_mask=m1)
+            _sync(device)
+            t1 = time.perf_counter()
+            for i in range(5):
+                one.plan(z1, d1, p1, warm[:1], seed=10 + i, out=o1, task_emb=e1, act_mask=m1)
+            _sync(device)
+            extra["latency_ms_single_env_one_cluster_per_tile"] = round((time.perf_counter() - t1) / 5 * 1e3, 3)
             one.set_cluster(2)
         # the same from the observation on (WorldModel.encode in the library, tdmpc2_plan_run_obs): what one
         # TDMPC2.act() costs on the device

@@ -152,3 +152,88 @@ def test_restatement_matches_the_kernel_source():
             ("gemm", "5", "0"), ("layer", "0"), ("layer", "1"), ("epi", "5"), ("layer", "0"),  # value: termination, policy
             ("gemm", "2", "3"), ("epi", "3"), ("layer", "0"), ("epi", "2"), ("layer", "1")]
     assert slots == want, slots
+
+
+# ---------------------------------------------------------------------------------------------------- two clusters per tile
+MAXH = 8
+
+
+def launch_program_cl2(H, pifold, role):
+    """ks_rollout_cl2 (tdmpc2_amd/csrc/cluster2_kernels.cuh): the program order of one cluster -- role 0 = D (dynamics, policy,
+    first Q head), role 1 = R (rewards, second Q head).  Own exchange tiles: 0 / 1 layers, 4 head, 5 policy head, 6 + t: Z[t],
+    6 + MAXH + t: the prior policy head of step t.  ("peer_read", slot): a tile of the OTHER cluster."""
+    ev = []
+
+    def layer(slot):
+        ev.append(("write", slot))
+        ev.append(("handover",))
+        ev.append(("read", slot))
+
+    if role == 0:
+        for t in range(H):
+            if pifold:
+                layer(0)  # pi.l0
+                layer(1)  # pi.l1
+                ev.append(("head", 6 + MAXH + t))
+            layer(0)  # dyn.l0
+            layer(1)  # dyn.l1
+            layer(6 + t)  # dyn.l2 -> Z[t]
+        layer(0)  # pi.l0
+        layer(1)  # pi.l1
+        ev.append(("head", 5))
+        layer(0)  # q0.l0
+        layer(1)  # q0.l1
+        ev.append(("head", 4))
+    else:
+        for t in range(H):
+            if t > 0:
+                ev.append(("peer_read", 6 + t - 1))
+            if pifold:
+                ev.append(("peer_read", 6 + MAXH + t))
+            layer(0)  # rew.l0
+            layer(1)  # rew.l1
+            ev.append(("head", 4))
+        ev.append(("peer_read", 6 + H - 1))
+        ev.append(("peer_read", 5))
+        layer(0)  # q1.l0
+        layer(1)  # q1.l1
+        ev.append(("head", 4))
+    return ev
+
+
+@pytest.mark.parametrize("H,pifold", list(itertools.product([1, 2, 3, 5, 8], [False, True])))
+def test_two_cluster_schedule(H, pifold):
+    """Each cluster's own tiles follow the reuse rule; every tile the OTHER cluster reads is written exactly once per launch (so a
+    reader that lags by any number of hand-overs still finds it), and the reader only names tiles its peer really writes."""
+    progs = [launch_program_cl2(H, pifold, r) for r in (0, 1)]
+    for prog in progs:
+        own = [(e[0], e[1]) if e[0] in ("write", "read") else (("head",) if e[0] == "head" else e) for e in prog if e[0] != "peer_read"]
+        n = check(own)
+        assert n <= 8 * H + 7
+        assert sum(1 for e in prog if e[0] == "head") <= 3 * H + 4
+    d_writes = [e[1] for e in progs[0] if e[0] == "write"] + [e[1] for e in progs[0] if e[0] == "head"]
+    for slot in {e[1] for e in progs[1] if e[0] == "peer_read"}:
+        assert d_writes.count(slot) == 1, (slot, d_writes)
+    assert max(d_writes) < 6 + 2 * MAXH
+    # R's own head tile: two heads are separated by a hand-over (the checker's rule), and D's head tiles 4 / 5 / prior are distinct
+    d_heads = [e[1] for e in progs[0] if e[0] == "head"]
+    assert len(set(d_heads)) == len(d_heads)
+
+
+def test_two_cluster_restatement_matches_the_kernel_source():
+    """The slot expressions of cluster2_kernels.cuh in program order (D then R), against the restatement above."""
+    import os
+    import re
+
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tdmpc2_amd", "csrc", "cluster2_kernels.cuh")).read()
+    body = src[src.index("void ks_rollout_cl2("):]
+    d_body, r_body = body[:body.index("R: rewards, second Q head")], body[body.index("R: rewards, second Q head"):]
+    d_slots = re.findall(r"cl_layer<\d>\(c, x, CL_L\(p\.(\w+(?:\[q\d\])?)\.l\[(\d)\]\), [^;]*?, (?:KBA|ZKB16), ([^,;]+),", d_body)
+    assert [(n, l, s.strip()) for n, l, s in d_slots] == [
+        ("pi", "0", "0"), ("pi", "1", "1"), ("dyn", "0", "0"), ("dyn", "1", "1"), ("dyn", "2", "6 + t"),
+        ("pi", "0", "0"), ("pi", "1", "1"), ("q[q0]", "0", "0"), ("q[q0]", "1", "1")]
+    r_slots = re.findall(r"cl_layer<\d>\(c, x, CL_L\(p\.(\w+(?:\[q\d\])?)\.l\[(\d)\]\), [^;]*?, (?:KBA|ZKB16), ([^,;]+),", r_body)
+    assert [(n, l, s.strip()) for n, l, s in r_slots] == [("rew", "0", "0"), ("rew", "1", "1"), ("q[q1]", "0", "0"), ("q[q1]", "1", "1")]
+    assert re.findall(r"cl_epi<1>\(c, xp, ([^,]+),", r_body) == ["6 + t - 1", "6 + p.H - 1"]
+    assert "cl_head_logits(c, x, p.pi.l[2], true, 6 + MAXH + t)" in d_body and "cl_head_logits(c, x, p.pi.l[2], true, 5)" in d_body
+    assert "peer_head_to_staging(6 + MAXH + t" in r_body and "peer_head_to_staging(5," in r_body
