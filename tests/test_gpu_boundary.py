@@ -87,13 +87,15 @@ def test_plan_batch_vectorised_envs():
     assert not torch.equal(a, b)
 
 
-def test_plan_is_hip_graph_capturable():
+@pytest.mark.parametrize("name", ["c1", "c1_wide"])
+def test_plan_is_hip_graph_capturable(name):
     """`run` allocates nothing and launches only on the caller's stream: a whole plan (setup, policy prior, I x (rollout, refit))
     captures into a hipGraph (what the reference obtains with torch.compile's reduce-overhead mode, tdmpc2.py:52) and the
-    replay reproduces the eager result bit for bit on the same noise tape."""
+    replay reproduces the eager result bit for bit on the same noise tape.  c1: two plans (one cluster per tile); c1_wide: ONE
+    plan -- the two-clusters-per-tile kernel (ks_rollout_cl2), whose arrival words ks_setup zeroes inside the graph."""
     from tests.gpu_common import case_on_gpu, plan_inputs
 
-    c, model, planner = case_on_gpu("c1")
+    c, model, planner = case_on_gpu(name)
     inp = plan_inputs(c, model)
     kw = dict(task_emb=inp["task_emb"], act_mask=inp["act_mask"], tape=inp["tape"])
     pm_eager = inp["prev_mean"].clone()
@@ -108,7 +110,7 @@ def test_plan_is_hip_graph_capturable():
         planner.plan(inp["z0"], inp["disc_pow"], pm_static, inp["t0"], out=out, **kw)
     from tests.helpers import load_golden
 
-    want = torch.as_tensor(load_golden("c1")["action"]).to(a_eager.device)
+    want = torch.as_tensor(load_golden(name)["action"]).to(a_eager.device)
     assert (a_eager - want).abs().max() < ACT_ATOL
     for i in range(2):
         pm_static.copy_(inp["prev_mean"])
