@@ -60,9 +60,9 @@ if has pmc; then
   rm -rf gpurun_out/pmc_${TAG}/*/ 2>/dev/null
 fi
 if has torchrun; then
-  HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 5 --warmup 2 --skip-cpu-baseline --skip-extra-configs > gpurun_out/${TAG}_torchrun_n1.log 2>&1
+  HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 5 --warmup 2 --skip-cpu-baseline --skip-extra-configs --skip-traffic > gpurun_out/${TAG}_torchrun_n1.log 2>&1
   tail -c 600 gpurun_out/${TAG}_torchrun_n1.log; echo
-  TDMPC2_BENCH_FORCE_C5=1 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 2 --warmup 1 --skip-cpu-baseline > gpurun_out/${TAG}_torchrun_c5_leg.log 2>&1
+  TDMPC2_BENCH_FORCE_C5=1 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 2 --warmup 1 --skip-cpu-baseline --skip-traffic > gpurun_out/${TAG}_torchrun_c5_leg.log 2>&1
   tail -c 400 gpurun_out/${TAG}_torchrun_c5_leg.log; echo
 fi
 du -sh gpurun_out | tail -1
