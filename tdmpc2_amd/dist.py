@@ -132,6 +132,11 @@ def sharded_plan(backend, z0, disc_pow, prev_mean, t0, eval_mode: bool = False, 
     prev_in = prev_mean.clone() if can_fault else None
     backend.last_shard_retries = 0
     call0 = None
+    if can_fault:
+        backend.take_fault()  # a fault left over from an EARLIER call (its caller had its chance) must not cost this plan a re-plan
+    # what the caller had asked for (NativePlanner tracks explicit settings; defaults: both paths on) -- restored after a re-plan,
+    # so that the retry's "no inter-workgroup waits" is a property of the retry, not of the rest of the process
+    asked = (getattr(backend, "tuned_cluster", 2), getattr(backend, "tuned_fuse_ln", 1))
     for attempt in range(2):
         if world > 1 and tape is None:
             _agree_on_stream(backend, seed, z0.device, group)
@@ -161,6 +166,9 @@ def sharded_plan(backend, z0, disc_pow, prev_mean, t0, eval_mode: bool = False, 
         if world > 1:
             dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
         if not int(bad.item()) or attempt == 1:
+            if attempt == 1 and hasattr(backend, "set_cluster"):  # back to the caller's settings (the library's own re-arm logic
+                backend.set_cluster(asked[0])                       # keeps a rank that really faulted on the safe paths for a while)
+                backend.set_fuse_ln(asked[1])
             break
         backend.last_shard_retries += 1
         backend.set_fuse_ln(0)

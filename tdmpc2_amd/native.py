@@ -627,13 +627,16 @@ class NativePlanner:
 
     def set_cluster(self, mode):
         """Fused family, split arithmetic: the single-plan latency path (8 workgroups per 32-row tile, cluster_kernels.cuh):
-        0 never, 1 / 2 (default) whenever all of a call's clusters fit the chip at once."""
+        0 never, 1 whenever all of a call's clusters fit the chip at once, 2 (default) = 1 plus, for a single non-episodic plan,
+        a second cluster per tile that runs the reward chain beside the dynamics chain (cluster2_kernels.cuh)."""
         self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 2, int(mode)))
+        self.tuned_cluster = int(mode)
 
     def set_fuse_ln(self, on):
         """Layered family, split arithmetic: LayerNorm + Mish / SimNorm + operand split inside the GEMM epilogue (1, default)
         or as a row kernel over fp32 pre-activations (0)."""
         self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 3, int(bool(on))))
+        self.tuned_fuse_ln = int(bool(on))
 
     def set_profiling(self, max_launches: int):
         """Bracket up to `max_launches` rollout-kernel launches with HIP events (0 = off)."""

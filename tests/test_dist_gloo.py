@@ -256,8 +256,8 @@ def _fault_worker(rank, world, port, out_dir):
 
 def test_a_fault_on_one_rank_makes_every_rank_replan_once(tmp_path):
     """dist.sharded_plan: rank 1's slice of iteration 1 is garbage and only rank 1 knows.  The verdict is all-reduced, BOTH
-    ranks switch kernels, restore prev_mean and the Philox call counter and plan the step again; the result is the plan of a
-    run that never faulted."""
+    ranks switch kernels for the retry, restore prev_mean and the Philox call counter and plan the step again; the result is the
+    plan of a run that never faulted."""
     from oracle import cases
     from tdmpc2_amd.dist import sharded_plan
 
@@ -265,7 +265,9 @@ def test_a_fault_on_one_rank_makes_every_rank_replan_once(tmp_path):
     r0 = torch.load(tmp_path / "fault0.pt", weights_only=False)
     r1 = torch.load(tmp_path / "fault1.pt", weights_only=False)
     assert int(r0["retries"]) == 1 and int(r1["retries"]) == 1
-    assert not r0["fused"] and not r1["fused"]
+    # after the re-plan both ranks are back on what the caller had asked for (the retry's safe kernels are a property of the
+    # retry; a rank that really faulted stays downgraded inside the library until it re-arms: DESIGN 8)
+    assert r0["fused"] and r1["fused"]
     # two attempts on each rank, the second with the first one's call counter and the safe kernels
     for r in (r0, r1):
         assert [e[0] for e in r["log"]] == ["begin", "begin"]
