@@ -934,7 +934,16 @@ void tdmpc2_plan_destroy(tdmpc2_plan_t *h) {
     if (h->lay.side) {  // back to the pool, never destroyed (see SidePool)
         SideRes sr;
         sr.stream = h->lay.side; sr.ev[0] = h->lay.ev_fork; sr.ev[1] = h->lay.ev_side; sr.ev[2] = h->lay.ev_xread;
-        side_release(h->cfg.device, sr);
+        // TDMPC2_DEBUG_SIDE_DESTROY (tools/gpu_r4n.sh, the r03k hunt): 1 = destroy stream + events as round 3 did before the
+        // pool, 2 = hipStreamSynchronize first, 3 = hipDeviceSynchronize first.  Not a tuning knob.
+        static const int dbg = [] { const char *e = getenv("TDMPC2_DEBUG_SIDE_DESTROY"); return e ? atoi(e) : 0; }();
+        if (dbg) {
+            if (dbg == 2) (void)hipStreamSynchronize(sr.stream);
+            if (dbg == 3) (void)hipDeviceSynchronize();
+            for (hipEvent_t e : sr.ev) (void)hipEventDestroy(e);
+            (void)hipStreamDestroy(sr.stream);
+        } else
+            side_release(h->cfg.device, sr);
     }
     for (void *p : h->allocs) (void)hipFree(p);
     if (h->cl_err_host) (void)hipHostFree(h->cl_err_host);
