@@ -31,7 +31,14 @@
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*);
  *     a handle is not re-entrant: a call entered while another thread is inside
  *     the same handle returns TDMPC2_ERR_STATE (use one handle per thread; handles
- *     share nothing).  Every call runs on the handle's device (cfg.device) and
+ *     share nothing).  A handle is one workspace, so its calls must not overlap on
+ *     the device either: calls on ONE stream are ordered by the stream; when a handle
+ *     moves to another stream its first call there waits (hipStreamWaitEvent) for the
+ *     handle's last call on the previous stream -- the library does that itself.
+ *     The exception is stream capture: a captured call neither waits nor leaves an
+ *     event (the graph replays wherever it is launched); ordering a graph launch
+ *     against eager calls of the same handle on other streams is the caller's.
+ *     Every call runs on the handle's device (cfg.device) and
  *     restores the caller's current device.  Return value 0 = ok, otherwise an error code
  *     (no C++ exception crosses the ABI); `tdmpc2_last_error()` has the text.
  *   - E = number of independent environments planned in one call (the reference

@@ -115,6 +115,10 @@ struct tdmpc2_plan {
     int clean_calls = 0;             // consecutive calls without a fault since the downgrade
     int faults_total = 0, rearms = 0;
     std::chrono::steady_clock::time_point last_fault{};
+    // stream hand-over (StreamTurn, tdmpc2_plan.hip): the event every call leaves on its stream; a call on another stream waits for it
+    hipEvent_t turn_ev = nullptr;
+    hipStream_t turn_stream = nullptr;
+    bool turn_valid = false;
     bool split = false;  // fused kernels on the f16 matrix pipe with hi/lo operand split (fused_kernels.cuh)
     int force_rows = 0;  // TDMPC2_TUNE_ROWS_PER_WORKGROUP: 0 auto, 32, 64
     size_t row_bytes = 0;  // bytes of one sample row of the fused kernels' LDS tile

@@ -178,9 +178,10 @@ struct DevGuard {
 
 
 // The layered path's second stream and its three events come from a process-wide pool and go back to it when a handle is
-// destroyed; they are never destroyed.  Measured on ROCm 7.0 / MI355X (profiles/README.md r03k): after hipStreamDestroy /
-// hipEventDestroy of a stream the NULL stream had waited on, kernels launched back to back on the NULL stream by the NEXT
-// handle overlapped (garbage plans; gone with GPU_MAX_HW_QUEUES=1, AMD_SERIALIZE_KERNEL=3, or without the destroys).
+// destroyed (creating a stream costs a hardware-queue set-up; handles come and go in a training script's evaluation loop).
+// (Round 3 believed the pool also cured garbage plans seen after hipStreamDestroy -- profiles/README.md r03k.  It did not: the
+// cause was a test moving ONE handle between two streams without ordering them, see StreamTurn below; tools/gpu_r4n.sh
+// reproduced the failure with and without the destroys.)
 struct SideRes {
     hipStream_t stream = nullptr;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -237,6 +238,44 @@ struct Busy {
     if (!busy_.ok) return fail(TDMPC2_ERR_STATE, "the handle is in use by another call (handles are not reentrant)"); \
     DevGuard dev_((h)->cfg.device);                                                                                \
     if (!dev_.ok) return fail(TDMPC2_ERR_HIP, "hipSetDevice(%d) failed", (h)->cfg.device)
+
+// One workspace also means one stream at a time.  A caller that moves a handle to another stream owes the ordering between the
+// two (as with any stream-bound workspace); the handle nevertheless orders its own calls: every call on a stream leaves an event
+// behind, and the first call on a DIFFERENT stream waits for it.  (Found the hard way, profiles/README.md "r03k, root cause": a
+// test planned on the NULL stream and warmed up a graph capture on a non-blocking stream right behind it -- the second plan's
+// set-up kernels overwrote the first plan's workspace whenever a second hardware queue already existed.)  Not while the
+// stream is capturing: a captured call replays wherever its graph is launched, which the handle cannot see.
+struct StreamTurn {
+    tdmpc2_plan *h;
+    hipStream_t st;
+    bool live;
+    hipError_t err;
+    StreamTurn(tdmpc2_plan *hh, hipStream_t s) : h(hh), st(s), live(false), err(hipSuccess) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        static const bool off = getenv("TDMPC2_DEBUG_NO_TURN") != nullptr;  // negative control of the test that pins this (tools/gpu_r4r.sh)
+        if (!h->turn_ev || off) return;
+        if (hipStreamIsCapturing(st, &cap) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        if (cap != hipStreamCaptureStatusNone) return;
+        live = true;
+        if (h->turn_valid && h->turn_stream != st) err = hipStreamWaitEvent(st, h->turn_ev, 0);
+    }
+    ~StreamTurn() {
+        if (!live) return;
+        if (hipEventRecord(h->turn_ev, st) == hipSuccess) {
+            h->turn_stream = st;
+            h->turn_valid = true;
+        }
+    }
+    StreamTurn(const StreamTurn &) = delete;
+    StreamTurn &operator=(const StreamTurn &) = delete;
+};
+#define ENTER_ON(h, stream)                                \
+    ENTER(h);                                              \
+    StreamTurn turn_((h), (hipStream_t)(stream));          \
+    if (turn_.err != hipSuccess) return fail(TDMPC2_ERR_HIP, "hipStreamWaitEvent (stream hand-over of the handle) failed: %s", hipGetErrorString(turn_.err))
 
 int dev_alloc(tdmpc2_plan *h, void **p, size_t bytes) {
     HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
@@ -837,6 +876,11 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
         tdmpc2_plan_destroy(h);
         return fail(TDMPC2_ERR_HIP, "hipMemcpy(bins) failed");
     }
+    if (hipEventCreateWithFlags(&h->turn_ev, hipEventDisableTiming) != hipSuccess) {  // (StreamTurn)
+        h->turn_ev = nullptr;
+        tdmpc2_plan_destroy(h);
+        return fail(TDMPC2_ERR_HIP, "hipEventCreate failed");
+    }
     if (!h->lay.on) {
         const int ar = h->split ? 0 : 1;
         rc = fused_ops(h->Apad).set_lds(ar, c.episodic, h->lds_bytes);
@@ -934,20 +978,12 @@ void tdmpc2_plan_destroy(tdmpc2_plan_t *h) {
     if (h->lay.side) {  // back to the pool, never destroyed (see SidePool)
         SideRes sr;
         sr.stream = h->lay.side; sr.ev[0] = h->lay.ev_fork; sr.ev[1] = h->lay.ev_side; sr.ev[2] = h->lay.ev_xread;
-        // TDMPC2_DEBUG_SIDE_DESTROY (tools/gpu_r4n.sh, the r03k hunt): 1 = destroy stream + events as round 3 did before the
-        // pool, 2 = hipStreamSynchronize first, 3 = hipDeviceSynchronize first.  Not a tuning knob.
-        static const int dbg = [] { const char *e = getenv("TDMPC2_DEBUG_SIDE_DESTROY"); return e ? atoi(e) : 0; }();
-        if (dbg) {
-            if (dbg == 2) (void)hipStreamSynchronize(sr.stream);
-            if (dbg == 3) (void)hipDeviceSynchronize();
-            for (hipEvent_t e : sr.ev) (void)hipEventDestroy(e);
-            (void)hipStreamDestroy(sr.stream);
-        } else
-            side_release(h->cfg.device, sr);
+        side_release(h->cfg.device, sr);
     }
     for (void *p : h->allocs) (void)hipFree(p);
     if (h->cl_err_host) (void)hipHostFree(h->cl_err_host);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    if (h->turn_ev) (void)hipEventDestroy(h->turn_ev);
     delete h;
 }
 
@@ -1052,7 +1088,7 @@ int tdmpc2_plan_bind_weights(tdmpc2_plan_t *h, int net, int layer, const float *
     const tdmpc2_plan_cfg &c = h->cfg;
     if (net == TDMPC2_NET_TERMINATION && !c.episodic)
         return fail(TDMPC2_ERR_INVALID, "termination head bound on a non-episodic planner");
-    ENTER(h);
+    ENTER_ON(h, stream);
     hipStream_t st = (hipStream_t)stream;
     const LayerShape sh = layer_shape(h, net, layer);
     if (in_features != sh.in || out_features != sh.out)
@@ -1135,7 +1171,7 @@ int tdmpc2_plan_bind_encoder(tdmpc2_plan_t *h, int layer, int n_layers, const fl
     if (layer == n_layers - 1 && (c.latent_dim % c.simnorm_dim || (c.simnorm_dim & (c.simnorm_dim - 1)) || c.simnorm_dim > 64))
         return fail(TDMPC2_ERR_UNSUPPORTED, "SimNorm groups of %d over %d latents", c.simnorm_dim, c.latent_dim);
     if (h->enc_layers && h->enc_layers != n_layers) return fail(TDMPC2_ERR_STATE, "encoder depth changed from %d to %d", h->enc_layers, n_layers);
-    ENTER(h);
+    ENTER_ON(h, stream);
     int rc = ensure_enc_alloc(h, layer, in_features, out_features);
     if (rc) return rc;
     tdmpc2_plan::Enc &L = h->enc[layer];
@@ -1197,7 +1233,7 @@ int tdmpc2_plan_encode(tdmpc2_plan_t *h, int n_envs, const float *obs, int obs_d
                        void *stream) {
     if (!h || !obs || !z_out) return fail(TDMPC2_ERR_INVALID, "null argument");
     if (n_envs < 1) return fail(TDMPC2_ERR_INVALID, "n_envs %d < 1", n_envs);
-    ENTER(h);
+    ENTER_ON(h, stream);
     return launch_encode(h, n_envs, obs, obs_dim, task_emb, z_out, (hipStream_t)stream);
 }
 
@@ -1206,7 +1242,7 @@ int tdmpc2_plan_run_obs(tdmpc2_plan_t *h, int n_envs, const float *obs, int obs_
                         const tdmpc2_noise *tape, uint64_t seed, float *action, void *stream) {
     if (!h || !obs) return fail(TDMPC2_ERR_INVALID, "null argument");
     if (n_envs < 1 || n_envs > h->cfg.max_envs) return fail(TDMPC2_ERR_INVALID, "n_envs %d outside [1, %d]", n_envs, h->cfg.max_envs);
-    ENTER(h);
+    ENTER_ON(h, stream);
     int rc = launch_encode(h, n_envs, obs, obs_dim, task_emb, h->zenc, (hipStream_t)stream);
     if (rc) return rc;
     return run_impl(h, n_envs, h->zenc, task_emb, act_mask, discount_pow, prev_mean, t0, eval_mode, tape, seed, action, nullptr,
@@ -1312,7 +1348,7 @@ int tdmpc2_plan_policy_value_mt(tdmpc2_plan_t *h, int n_rows, const float *z, co
                                 void *stream) {
     if (!h || !z || !q) return fail(TDMPC2_ERR_INVALID, "null argument");
     if (n_rows < 1) return fail(TDMPC2_ERR_INVALID, "n_rows %d < 1", n_rows);
-    ENTER(h);
+    ENTER_ON(h, stream);
     return launch_value(h, n_rows, z, use_target != 0, reduce_min != 0, pi_eps, qidx, seed, nullptr, nullptr, 0.f, tasks, action, q,
                         (hipStream_t)stream);
 }
@@ -1327,7 +1363,7 @@ int tdmpc2_plan_td_target_mt(tdmpc2_plan_t *h, int n_rows, const float *next_z, 
                              uint64_t seed, float *td, void *stream) {
     if (!h || !next_z || !reward || !terminated || !td) return fail(TDMPC2_ERR_INVALID, "null argument");
     if (n_rows < 1) return fail(TDMPC2_ERR_INVALID, "n_rows %d < 1", n_rows);
-    ENTER(h);
+    ENTER_ON(h, stream);
     return launch_value(h, n_rows, next_z, true, true, pi_eps, qidx, seed, reward, terminated, discount, tasks, nullptr, td,
                         (hipStream_t)stream);
 }
@@ -1371,7 +1407,7 @@ void fill_refit(tdmpc2_plan *h, RefitParams &fp, int E, int it, int eval_mode, f
 int tdmpc2_plan_shard_begin(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *task_emb, const float *act_mask,
                             const float *prev_mean, const uint8_t *t0, const tdmpc2_noise *tape, uint64_t seed, void *stream) {
     if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
-    ENTER(h);
+    ENTER_ON(h, stream);
     int rc = validate_envs(h, n_envs);
     if (rc) return rc;
     if (!z0 || !prev_mean || !t0) return fail(TDMPC2_ERR_INVALID, "null argument");
@@ -1410,7 +1446,7 @@ int tdmpc2_plan_shard_values(tdmpc2_plan_t *h, int n_envs, int iter, int row_beg
                              const float *act_mask, const float *disc_pow, const tdmpc2_noise *tape, uint64_t seed,
                              float *value, void *stream) {
     if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
-    ENTER(h);
+    ENTER_ON(h, stream);
     int rc = validate_envs(h, n_envs);
     if (rc) return rc;
     if (!z0 || !disc_pow || !value) return fail(TDMPC2_ERR_INVALID, "null argument");
@@ -1449,7 +1485,7 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
                             int eval_mode, const tdmpc2_noise *tape, uint64_t seed, float *action, const tdmpc2_debug *dbg,
                             void *stream) {
     if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
-    ENTER(h);
+    ENTER_ON(h, stream);
     if (n_envs < 1 || n_envs > h->cfg.max_envs) return fail(TDMPC2_ERR_INVALID, "n_envs=%d outside [1, %d]", n_envs, h->cfg.max_envs);
     if (!value || !prev_mean || !action) return fail(TDMPC2_ERR_INVALID, "null argument");
     const tdmpc2_plan_cfg &c = h->cfg;
@@ -1554,7 +1590,7 @@ int tdmpc2_plan_packed_size(tdmpc2_plan_t *h, uint64_t *bytes) {
 
 int tdmpc2_plan_export_packed(tdmpc2_plan_t *h, void *host_buf, uint64_t bytes, void *stream) {
     if (!h || !host_buf) return fail(TDMPC2_ERR_INVALID, "null argument");
-    ENTER(h);
+    ENTER_ON(h, stream);
     int rc = check_ready(h);
     if (rc) return rc;
     for (int l = 0; l < h->enc_layers; ++l)
@@ -1586,7 +1622,7 @@ int tdmpc2_plan_export_packed(tdmpc2_plan_t *h, void *host_buf, uint64_t bytes, 
 
 int tdmpc2_plan_import_packed(tdmpc2_plan_t *h, const void *host_buf, uint64_t bytes, void *stream) {
     if (!h || !host_buf) return fail(TDMPC2_ERR_INVALID, "null argument");
-    ENTER(h);
+    ENTER_ON(h, stream);
     if (bytes < sizeof(PackHdr)) return fail(TDMPC2_ERR_INVALID, "packed weights: truncated header");
     PackHdr hdr;
     memcpy(&hdr, host_buf, sizeof hdr);
@@ -1652,7 +1688,7 @@ int tdmpc2_plan_export_noise(tdmpc2_plan_t *h, int env_first, int n_envs, uint64
                              const tdmpc2_noise_out *out, void *stream) {
     if (!h || !out) return fail(TDMPC2_ERR_INVALID, "null argument");
     if (env_first < 0 || n_envs < 1) return fail(TDMPC2_ERR_INVALID, "environment range [%d, +%d)", env_first, n_envs);
-    ENTER(h);
+    ENTER_ON(h, stream);
     const tdmpc2_plan_cfg &c = h->cfg;
     NoiseExportParams p{};
     p.e0 = env_first; p.n = n_envs; p.H = c.horizon; p.N = c.num_samples; p.P = c.num_pi_trajs; p.A = c.action_dim;
@@ -1763,7 +1799,7 @@ int tdmpc2_plan_run(tdmpc2_plan_t *h, int n_envs, const float *z0, const float *
                     const float *disc_pow, float *prev_mean, const uint8_t *t0, int eval_mode, const tdmpc2_noise *tape,
                     uint64_t seed, float *action, const tdmpc2_debug *dbg, void *stream) {
     if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
-    ENTER(h);
+    ENTER_ON(h, stream);
     return run_impl(h, n_envs, z0, task_emb, act_mask, disc_pow, prev_mean, t0, eval_mode, tape, seed, action, dbg, stream);
 }
 
@@ -1801,7 +1837,7 @@ int tdmpc2_plan_estimate_value_trace(tdmpc2_plan_t *h, int n_envs, const float *
                                      const float *pi_eps, const int32_t *qidx, float *value, float *trace_tiles,
                                      float *trace_scalars, void *stream) {
     if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
-    ENTER(h);
+    ENTER_ON(h, stream);
     int rc = validate_envs(h, n_envs);
     if (rc) return rc;
     if (!z0 || !disc_pow || !actions || !pi_eps || !qidx || !value) return fail(TDMPC2_ERR_INVALID, "null argument");
@@ -1827,7 +1863,7 @@ int tdmpc2_plan_refit(tdmpc2_plan_t *h, int n_envs, float *value, const float *a
     if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
     if (n_envs < 1 || n_envs > h->cfg.max_envs) return fail(TDMPC2_ERR_INVALID, "n_envs=%d outside [1, %d]", n_envs, h->cfg.max_envs);
     if (!value || !actions) return fail(TDMPC2_ERR_INVALID, "null argument");
-    ENTER(h);
+    ENTER_ON(h, stream);
     const tdmpc2_plan_cfg &c = h->cfg;
     hipStream_t st = (hipStream_t)stream;
     int refit_stage = 0;

@@ -111,7 +111,7 @@ def test_plan_is_hip_graph_capturable(name):
     from tests.helpers import load_golden
 
     want = torch.as_tensor(load_golden(name)["action"]).to(a_eager.device)
-    assert (a_eager - want).abs().max() < ACT_ATOL
+    assert (a_eager - want).abs().max() < ACT_ATOL, (a_eager.tolist(), planner.take_fault(), planner.fault_info())
     for i in range(2):
         pm_static.copy_(inp["prev_mean"])
         out.zero_()
@@ -119,6 +119,38 @@ def test_plan_is_hip_graph_capturable(name):
         torch.cuda.synchronize()
         assert torch.equal(out, a_eager) and torch.equal(pm_static, pm_eager), \
             (i, float((out - want).abs().max()), float((a_eager - want).abs().max()), planner.take_fault())
+
+
+def test_a_handle_moved_to_another_stream_orders_its_own_calls():
+    """One handle = one workspace: a plan on the NULL stream followed AT ONCE by a plan of the same handle on a non-blocking
+    stream (no wait_stream in between -- what test_plan_is_hip_graph_capturable did, and what made it fail whenever a second
+    hardware queue already existed: profiles/README.md 'r03k, root cause') must not overlap.  The handle leaves an event
+    behind every call and makes the first call on a different stream wait for it (StreamTurn, tdmpc2_plan.hip)."""
+    from tests.gpu_common import case_on_gpu, plan_inputs
+
+    c, model, planner = case_on_gpu("c1")
+    inp = plan_inputs(c, model)
+    kw = dict(task_emb=inp["task_emb"], act_mask=inp["act_mask"], tape=inp["tape"])
+    z_b = inp["z0"].roll(1, 0).contiguous()  # the second plan: other latents -> another answer
+    pm = inp["prev_mean"]
+    want_a = planner.plan(inp["z0"], inp["disc_pow"], pm.clone(), inp["t0"], **kw).clone()
+    want_b = planner.plan(z_b, inp["disc_pow"], pm.clone(), inp["t0"], **kw).clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(want_a, want_b)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):  # the stream's hardware queue exists before the race starts
+        torch.zeros(8, device=want_a.device).add_(1)
+    torch.cuda.synchronize()
+    for _ in range(20):
+        pm_a, pm_b = pm.clone(), pm.clone()
+        torch.cuda.synchronize()
+        a = planner.plan(inp["z0"], inp["disc_pow"], pm_a, inp["t0"], **kw).clone()  # NULL stream, still running when ...
+        with torch.cuda.stream(s):                                                   # ... the same handle plans on `s`
+            b = planner.plan(z_b, inp["disc_pow"], pm_b, inp["t0"], **kw).clone()
+        a2 = planner.plan(inp["z0"], inp["disc_pow"], pm.clone(), inp["t0"], **kw).clone()  # and back
+        torch.cuda.synchronize()
+        assert torch.equal(a, want_a) and torch.equal(b, want_b) and torch.equal(a2, want_a)
+    assert planner.take_fault() == 0
 
 
 def test_rebinding_weights_and_concurrent_handles():
