@@ -61,7 +61,7 @@ def tiles(lib, nrowblk, ncolblk, o):
 SHAPES = [(nr, nc) for nr in (1, 5, 8, 23, 24, 64, 120, 130, 512) for nc in (1, 3, 6, 7, 8, 14, 16, 32)]
 
 
-@pytest.mark.parametrize("force", [-1, 0, 1])
+@pytest.mark.parametrize("force", [-1, 0, 1, 2, 4])
 @pytest.mark.parametrize("nrowblk,ncolblk", SHAPES)
 def test_every_tile_exactly_once_and_peers_together(lib, nrowblk, ncolblk, force):
     o = order(lib, nrowblk, ncolblk, force)
@@ -71,11 +71,16 @@ def test_every_tile_exactly_once_and_peers_together(lib, nrowblk, ncolblk, force
     for b, rb, cb in t:
         by_rb.setdefault(rb, []).append((b, cb))
     if o["xcd_rows"]:
-        assert o["nblk"] == 8 * ((nrowblk + 7) // 8) * ncolblk
+        g = o["xcd_rows"]  # XCDs a row block is spread over (1: XCD-local row blocks; 2 / 4: XCD rectangles)
+        assert g in (1, 2, 4) and ncolblk % g == 0 and (g == 1 or force == g)
+        assert o["nblk"] == 8 * ((nrowblk + 8 // g - 1) // (8 // g)) * (ncolblk // g)
         for rb, peers in by_rb.items():
-            assert {b % 8 for b, _ in peers} == {rb % 8}                    # one XCD
-            local = sorted(b // 8 for b, _ in peers)                        # positions in that XCD's dispatch order
-            assert local == list(range(local[0], local[0] + ncolblk))       # consecutive there
+            xs = sorted({b % 8 for b, _ in peers})
+            assert xs == [g * (rb % (8 // g)) + i for i in range(g)]        # g neighbouring XCDs (g = 1: one)
+            for x in xs:
+                local = sorted(b // 8 for b, _ in peers if b % 8 == x)      # positions in that XCD's dispatch order
+                assert local == list(range(local[0], local[0] + ncolblk // g))  # consecutive there ...
+                assert local[0] == (rb // (8 // g)) * (ncolblk // g)        # ... and at the same position on each of the g XCDs
         # in an XCD's order row blocks follow each other whole: at most one of them is partly dispatched at any time
         for x in range(8):
             seq = [rb for b, rb, _ in t if b % 8 == x]
@@ -102,5 +107,8 @@ def test_the_rule_is_the_measured_one(lib):
     assert order(lib, 16, 14) == {"xcd_rows": 0, "ncol_grid": 16, "nblk": 256}
     # ... never padded when that would leave an XCD without work (7 -> 8), nor with the switch off
     assert order(lib, 24, 7)["ncol_grid"] == 7 and order(lib, 16, 14, col_pad=0)["ncol_grid"] == 14
+    # XCD rectangles are asked for by the caller (lay_gemm: the 256 x 256 tile at 16 column blocks, profiles/README.md r4s / r4t)
+    assert order(lib, 32, 16, force=2) == {"xcd_rows": 2, "ncol_grid": 0, "nblk": 512}
+    assert order(lib, 60, 7, force=2)["xcd_rows"] == 1  # 7 column blocks do not split over 2 XCDs
     # the switches
     assert order(lib, 120, 7, force=0)["xcd_rows"] == 0 and order(lib, 8, 16, force=1)["xcd_rows"] == 1
