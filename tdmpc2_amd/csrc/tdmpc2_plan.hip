@@ -202,7 +202,7 @@ static bool side_acquire(int dev, SideRes *out) {
         }
     }
     SideRes r;
-    if (hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess) return false;
+    if (hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking) != hipSuccess) return false;  // (a priority above / below the caller's stream loses 2-13 %: profiles/README.md r4u)
     for (int i = 0; i < 3; ++i)
         if (hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) != hipSuccess) return false;  // (a failed create leaks what it made)
     *out = r;

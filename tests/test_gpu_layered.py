@@ -477,11 +477,14 @@ def test_graph_replay_after_a_smaller_eager_call_resets_every_arrival_counter():
         assert torch.equal(out, want) and torch.equal(pm_static, pm0) and planner.take_fault() == 0, i
 
 
-def test_two_chains_in_flight_never_starve_each_other():
+@pytest.mark.parametrize("name,E,default_stages", [("c3", 16, 1500), ("c4", 8, 300)])
+def test_two_chains_in_flight_never_starve_each_other(name, E, default_stages):
     """The two chains of a layered stage run fused-epilogue GEMMs -- workgroups that wait for their row block's peers -- on two
     hardware queues at once.  Many stages back to back, with random host-side skew between the launches of the two
     streams and a foreign kernel stream in the background: no bounded wait may give up (the XCD-local tile order keeps a row
-    block's peers on consecutive slots of one XCD; 2 x (column blocks - 1) waiting workgroups never fill an XCD's 32 CUs)."""
+    block's peers on consecutive slots of one XCD; 2 x (column blocks - 1) waiting workgroups never fill an XCD's 32 CUs).
+    c4: the 317M model's hidden GEMMs spread a row block over TWO XCDs (XCD rectangles, tile_order.h) -- no such capacity
+    argument there, hence this run."""
     import os
     import random
     import time
@@ -493,9 +496,8 @@ def test_two_chains_in_flight_never_starve_each_other():
     from tdmpc2_amd.native import NativePlanner
     from tests.gpu_common import dev, disc_pow
 
-    stages = int(os.environ.get("TDMPC2_STRESS_STAGES", "1500"))
-    E = 16
-    c = cases.build_case("c3")
+    stages = int(os.environ.get("TDMPC2_STRESS_STAGES", str(default_stages)))
+    c = cases.build_case(name)
     cfg = c["cfg"]
     sd = {k: torch.as_tensor(v) for k, v in c["sd"].items()}
     H, N, A = cfg.horizon, cfg.num_samples, cfg.action_dim
@@ -514,7 +516,7 @@ def test_two_chains_in_flight_never_starve_each_other():
     g = torch.Generator().manual_seed(5)
     actions = ((torch.rand(E, H, N, A, generator=g) * 2 - 1) * sd["_action_masks"][torch.tensor(tasks)].view(E, 1, 1, A)).to(dev()).contiguous()
     eps = torch.randn(E, N, A, generator=g).to(dev())
-    qidx = torch.tensor(([[0, 4], [3, 1], [2, 0], [1, 2], [4, 3], [0, 1]] * 3)[:E], dtype=torch.int32, device=dev())
+    qidx = torch.tensor(([[0, 4], [3, 1], [2, 0], [1, 2], [4, 3], [0, 1]] * 3)[:E], dtype=torch.int32, device=dev()) % cfg.num_q
     want = planner.estimate_value(z0, disc, actions, eps, qidx, task_emb=emb, act_mask=mask).clone()
     rng = random.Random(3)
     noise_stream = torch.cuda.Stream()
@@ -532,6 +534,6 @@ def test_two_chains_in_flight_never_starve_each_other():
             assert torch.equal(v, want), i
     torch.cuda.synchronize()
     fi = planner.fault_info()
-    print(f"[stress] {stages} stages of c3 E={E} in {time.perf_counter() - t0:.1f} s, faults {fi['faults_total']}")
+    print(f"[stress] {stages} stages of {name} E={E} in {time.perf_counter() - t0:.1f} s, faults {fi['faults_total']}")
     assert planner.take_fault() == 0 and fi["faults_total"] == 0 and fi["degraded"] == 0
     planner.close()
