@@ -258,6 +258,9 @@ __device__ __forceinline__ void kloop_f32(const CT &c, const LayerS &ly, int kb0
 #ifndef SPLIT_NO_ASM_KLOOP
 #define SPLIT_ASM_KLOOP 1
 #endif
+#ifndef KLOOP_RING
+#define KLOOP_RING 2
+#endif
 #ifdef SPLIT_ASM_KLOOP
 #define A_MFMA(ACC, WF, AF) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(WF), "v"(AF))
 template <int OFF>
@@ -344,46 +347,58 @@ __device__ __forceinline__ void kloop_asm(const CT &c, const LayerS &ly, int kb0
     const size_t cts = (size_t)ly.KB * 2048;
     const unsigned voff = (unsigned)c.lane * 16u;
     const int nk = kb1 - kb0;
-    BFragT<2> ring[2];
+    // weight ring of RD k-blocks (KLOOP_RING, 16 VGPRs each): at step k blocks k + 1 .. k + RD - 1 are in flight behind the 12
+    // MFMAs of block k -- RD - 1 steps (768 cycles each with the partner wave's) to cover the L2's latency
+    constexpr int RD = KLOOP_RING;
+    static_assert(RD == 2 || RD == 4 || RD == 6, "ring depth: even (the activation fragments alternate with the step)");
+    BFragT<2> ring[RD];
     AFragT<CT::NST> a2[2];
-    a_load_w(ring[0], voff, u0, u0 + cts);
-    if (nk > 1) a_load_w(ring[1], voff, u0 + 2048, u0 + cts + 2048);
+#pragma unroll
+    for (int d = 0; d < RD; ++d)
+        if (d < nk) a_load_w(ring[d], voff, u0 + d * 2048, u0 + cts + d * 2048);
     a_load_act<CT>(a2[0], la0, la1);
     int k = 0;
-    const char *pn = u0 + 2 * 2048;  // block k + 2
-    // steady state, two steps per trip (ring slot / fragment set = step parity), no conditionals: while k + 3 < nk
+    const char *pn = u0 + RD * 2048;  // block k + RD
+    // steady state, RD steps per trip (ring slot = step % RD, fragment set = step parity), no conditionals
 #pragma unroll 1
-    for (; k + 3 < nk; k += 2) {
+    for (; k + 2 * RD - 1 < nk; k += RD) {
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
+        for (int d = 0; d < RD; ++d) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             la0 += 32;
             la1 += 32;
-            a_load_act<CT>(a2[d ^ 1], la0, la1);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            a_mfma12<CT>(acc, ring[d], a2[d]);
+            a_load_act<CT>(a2[(d & 1) ^ 1], la0, la1);
+            if constexpr (RD == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if constexpr (RD == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            a_mfma12<CT>(acc, ring[d], a2[d & 1]);
             a_load_w(ring[d], voff, pn, pn + cts);
             pn += 2048;
         }
     }
-    // the last two or three steps
+    // the last RD .. 2 RD - 1 steps
 #pragma unroll 1
-    for (; k < nk; k += 2) {
+    for (; k < nk; k += RD) {
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
+        for (int d = 0; d < RD; ++d) {
             const int kk = k + d;
             if (kk < nk) {  // wave-uniform
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (kk + 1 < nk) {
                     la0 += 32;
                     la1 += 32;
-                    a_load_act<CT>(a2[d ^ 1], la0, la1);
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    a_load_act<CT>(a2[(d & 1) ^ 1], la0, la1);
                 }
-                a_mfma12<CT>(acc, ring[d], a2[d]);
-                if (kk + 2 < nk) {
+                // blocks behind block kk that are still in flight: those issued and not yet consumed
+                const int behind = nk - 1 - kk < RD - 1 ? nk - 1 - kk : RD - 1;
+                if (behind >= 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                else if (behind == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (behind == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (behind == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                a_mfma12<CT>(acc, ring[d], a2[d & 1]);
+                if (kk + RD < nk) {
                     a_load_w(ring[d], voff, pn, pn + cts);
                     pn += 2048;
                 }
@@ -1283,8 +1298,15 @@ __device__ __forceinline__ void first_layers_s(const CT &c, const LayerS &la, co
 // instantiations (TR = 0) carry no trace code -- 66 fewer spilled SGPRs, 7 fewer VGPRs, +0.6 % (A/B r03h).  Episodic kernels
 // keep the dumps inside the one instantiation (TRACE = TR || EP).
 #define DUMP_TILE(...) do { if constexpr (TRACE) dump_tile_s(__VA_ARGS__); } while (0)
+// (The second launch-bounds argument is CUDA's "blocks per multiprocessor": 2 x 8 waves = 4 per SIMD = a 128-VGPR budget.  The
+// 64-row tile's 144 KB of LDS allow ONE workgroup per CU anyway; ROLLOUT_WIDE_REGS drops the argument: 2 waves per SIMD, 256 VGPRs.)
+#ifdef ROLLOUT_WIDE_REGS
+#define ROLLOUT_BOUNDS(NW) __launch_bounds__(64 * (NW))
+#else
+#define ROLLOUT_BOUNDS(NW) __launch_bounds__(64 * (NW), 2)
+#endif
 template <int APAD, int ST, int NW, int AR, int EP, int TR = 0>
-__global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p) {
+__global__ ROLLOUT_BOUNDS(NW) void ks_rollout(RolloutParamsT<NetS> p) {
     constexpr bool TRACE = TR || EP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int s_is_last;
