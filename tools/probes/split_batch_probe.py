@@ -1,5 +1,6 @@
 """Does a stage of the layered family lose to tile quantisation?  G planners of E / G plans each on G torch streams against one
 planner of E plans (c3: 420 tiles of 256 x 256 on 256 CUs = 1.64 rounds per GEMM).  usage: python tools/probes/split_batch_probe.py c3 30 2 3 5"""
+import os
 import sys
 import time
 
@@ -37,6 +38,8 @@ def run(G, steps=6):
     for g in range(G):
         p = NativePlanner(cfg, I, dev, max_envs=per)
         p.bind_state_dict(sd)
+        if os.environ.get("PROBE_UNFUSED"):  # GEMM + row kernel instead of the NormedLinear epilogue with its cross-workgroup wait
+            p.set_fuse_ln(0)
         ps.append(p)
         ins.append(inputs(g * per, per))
         streams.append(torch.cuda.Stream(device=dev))
