@@ -344,9 +344,10 @@ int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
  * After a fault the handle runs the paths without inter-workgroup waits; it switches back to the fast ones after
  * TDMPC2_TUNE_REARM_AFTER (default 64) consecutive clean calls, doubling that number (up to 4096) every time a fault follows a
  * re-arm and forgetting the back-off after a long clean run; an explicit tdmpc2_plan_set_tuning(CLUSTER / FUSE_LN) re-arms at
- * once.  Calls enqueued back to back without a synchronisation in between: a fault is attributed when the host next looks at
- * the error word (the next API call or take_fault); a caller that pipelines calls on one handle must treat a reported fault as
- * covering every call enqueued since its last synchronisation. */
+ * once.  Calls enqueued back to back without a synchronisation in between each carry their own verdict: the word a call's last
+ * kernel reads is raised on the device and cleared by the NEXT call in stream order, never by the host (which looks at a
+ * separate sticky word: the count reported here is "looks that found it set", at most one per API call).  The later calls of a
+ * sharded plan (shard_values / shard_refit) do not clear it: a wait that gave up in any iteration invalidates the final pick. */
 int tdmpc2_plan_take_fault(tdmpc2_plan_t *h, int *faults);
 
 /* The fault history of a handle (no synchronisation, nothing consumed): how often a bounded wait has given up, how long ago the

@@ -32,7 +32,7 @@ __device__ __forceinline__ void cl2_wait_peer(const CT &c, ClState &x, const uns
         int spin = 0;
         while ((__hip_atomic_load(pflags + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffffu) < phase) {
             if (++spin > CL_MAXSPIN) {
-                __hip_atomic_store(x.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                raise_fault(x.err, 1u);
                 *x.dead = 1;
                 break;
             }
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl2(RolloutParamsT<Net
             int spin = 0;
             while (__hip_atomic_load(hflags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < hphase) {
                 if (++spin > CL_MAXSPIN) {
-                    __hip_atomic_store(x.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    raise_fault(x.err, 1u);
                     *x.dead = 1;
                     break;
                 }
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl2(RolloutParamsT<Net
             int spin = 0;
             while (__hip_atomic_load(peer_flags + CL2_MAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(p.iter + 1)) {
                 if (++spin > CL_MAXSPIN) {
-                    __hip_atomic_store(x.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    raise_fault(x.err, 1u);
                     *x.dead = 1;
                     break;
                 }

@@ -184,7 +184,7 @@ __device__ __forceinline__ void cl_barrier(const CT &c, ClState &x, bool learn) 
         unsigned v;
         while (((v = __hip_atomic_load(x.flags + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffffu) < x.phase) {
             if (++spin > CL_MAXSPIN) {  // host-mapped word: a plain system-scope store
-                __hip_atomic_store(x.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                raise_fault(x.err, 1u);
                 *x.dead = 1;
                 v = 0xff000000u;
                 break;
@@ -366,7 +366,7 @@ __device__ __forceinline__ void cl_head_logits(const CT &c, ClState &x, const La
         int spin = 0;
         while (__hip_atomic_load(hflags + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < x.hphase) {
             if (++spin > CL_MAXSPIN) {
-                __hip_atomic_store(x.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                raise_fault(x.err, 1u);
                 *x.dead = 1;
                 break;
             }

@@ -65,6 +65,16 @@ struct NetS {
 
 // ---------------------------------------------------------------- kernel parameter blocks (NET = NetS, fused_kernels.cuh)
 // elite select + refit (tdmpc2/tdmpc2.py:184-206): refit_plan() below
+// A bounded inter-workgroup wait gave up.  The handle's host-mapped line: word 0 = "the call in flight is invalid" -- read by the
+// call's own last kernel (refit_plan's final pick, l_value_head), cleared IN STREAM ORDER at the start of the next call, never by
+// the host; word 8 = sticky "a wait gave up since the host last looked" -- read and cleared by the host (validate_envs,
+// take_fault).  (Round 3 had one word that the host cleared when it enqueued the next call: pipelined calls could lose the verdict
+// of the call still running -- ADVICE r3.)
+__device__ __forceinline__ void raise_fault(unsigned int *err, unsigned int code) {
+    __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(err + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 struct RefitParams {
     int E, N, H, A, K, iter, last, eval_mode;
     int stage;             // elite actions are staged in LDS ([K][H*A] floats after the other arrays): see refit_lds_bytes
@@ -277,6 +287,7 @@ struct SetupParamsT {
     unsigned int *cl2_flags; // ks_rollout_cl2's arrival words (single plans), zeroed by plan 0's workgroup, or null
     int cl2_flag_words;
     int skip_cvec;           // cluster path: no z0 products (cvec unused)
+    unsigned int *err_clear; // word 0 of the handle's error line: zeroed here, i.e. in stream order at the start of the plan (raise_fault)
 };
 
 // policy-prior trajectories (tdmpc2/tdmpc2.py:154-160): rows < P of one tile per plan

@@ -1093,6 +1093,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_setup(SetupParamsT<NetS> p) {
         for (int idx = tid; idx < p.cl_flag_words; idx += NTHREADS) p.cl_flags[(size_t)e * p.cl_flag_words + idx] = 0u;
     if (p.cl2_flags && e == 0)
         for (int idx = tid; idx < p.cl2_flag_words; idx += NTHREADS) p.cl2_flags[idx] = 0u;
+    if (p.err_clear && e == 0 && tid == 0) __hip_atomic_store(p.err_clear, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (p.multitask) {
         const float *emb = p.task_emb + (size_t)e * p.T;
         for (int net = 0; net < p.nnets; ++net) {

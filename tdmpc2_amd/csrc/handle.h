@@ -86,7 +86,7 @@ struct tdmpc2_plan {
     unsigned int *ticket = nullptr;  // [max_envs] arrival counters of that hand-over
     int *qidx_buf = nullptr;         // [max_envs, 2] the two Q heads of the current iteration (shard_values)
     unsigned int shard_call = 0;     // call counter captured by shard_begin (Philox stream of the sharded plan)
-    bool in_shard = false;           // between shard_begin and the last shard_refit: a consumed fault marks the plan in flight (cl_err_host[4])
+    bool in_shard = false;           // between shard_begin and the last shard_refit: no re-arm in between; word 0 of the error line is not cleared in between
     // per-task tables of policy_value / td_target on multitask batches (grown on demand)
     float *beff_tab = nullptr, *mask_tab = nullptr, *disc_tab = nullptr;
     int *task_rows = nullptr;  // [rows] copy of the row -> task map, padded to whole GEMM tiles (layered family)

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
             int spin = 0;
             while (__hip_atomic_load(p.arrive + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.ncolblk) {
                 if (++spin > GLN_MAXSPIN) {
-                    if (p.err) __hip_atomic_store(p.err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (p.err) raise_fault(p.err, 2u);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);

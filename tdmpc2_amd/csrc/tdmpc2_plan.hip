@@ -437,6 +437,7 @@ int launch_setup(tdmpc2_plan *h, int E, const float *z0, const float *task_emb, 
     p.cl2_flags = (p.cl_flags && E == 1 && h->cl2_flags && h->cl2_mode && h->cluster_mode == 2) ? h->cl2_flags : nullptr;
     p.cl2_flag_words = h->tiles * 4 * CL_FLAG_STRIDE;
     p.skip_cvec = skip_cvec ? 1 : 0;
+    p.err_clear = h->cl_err_dev;  // word 0 of the error line back to zero, in stream order (fault_fresh)
     Kern<NET>::setup(h, p, E, st);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -461,8 +462,6 @@ void fill_rollout(tdmpc2_plan *h, RolloutParamsT<NET> &p, int E) {
 // A bounded inter-workgroup wait gave up (the handle's error word is set): the plan / call in flight returned NaN.  Switch to
 // the paths without such waits, remember when, and let fault_clean() switch back after `rearm_after` clean calls.
 void fault_note(tdmpc2_plan *h) {
-    *(volatile unsigned int *)h->cl_err_host = 0;
-    if (h->in_shard) ((volatile unsigned int *)h->cl_err_host)[4] = 1;  // the sharded plan in flight is invalid: its final pick says so
     if (!h->degraded) {
         h->user_cluster_mode = h->cluster_mode;
         h->user_fuse_ln = h->lay.fuse_ln;
@@ -498,14 +497,31 @@ void fault_clean(tdmpc2_plan *h) {  // a call is about to be enqueued and no fau
     if (h->rearm_after < 4096) h->rearm_after *= 2;  // the next downgrade lasts twice as long; a long clean run resets it (above)
 }
 
+// The host's look at the sticky word (common.cuh: raise_fault).  It never touches word 0 -- the verdict of the call in flight,
+// which that call's own last kernel reads and the NEXT call clears in stream order (fault_fresh): calls of one handle may be
+// pipelined without a sync and each still gets its own verdict.
+bool fault_poll(tdmpc2_plan *h) {
+    volatile unsigned int *w = (volatile unsigned int *)h->cl_err_host;
+    if (!w || !w[8]) return false;
+    w[8] = 0;
+    fault_note(h);
+    return true;
+}
+// Start of a call that stands for itself (a plan, an estimate_value, a td_target ...; NOT the later calls of a sharded plan, whose
+// final pick must still see a wait that gave up in its first iteration): word 0 back to zero, in stream order.  The fused
+// family's ks_setup does it itself (SetupParamsT::err_clear).
+int fault_fresh(tdmpc2_plan *h, hipStream_t st) {
+    if (h->cl_err_dev) HIP_TRY(hipMemsetAsync(h->cl_err_dev, 0, 4, st));
+    return 0;
+}
+
 int validate_envs(tdmpc2_plan *h, int E) {
     if (!h) return fail(TDMPC2_ERR_INVALID, "null handle");
     if (E < 1 || E > h->cfg.max_envs) return fail(TDMPC2_ERR_INVALID, "n_envs=%d outside [1, max_envs=%d]", E, h->cfg.max_envs);
     // a cluster hand-over / fused-epilogue wait of an EARLIER call gave up (bounded wait): that plan returned NaN actions and kept
     // its prev_mean (refit_plan), that td_target / policy_value returned NaN; the handle now runs the paths without waits
     // until fault_clean() re-arms the fast ones.  tdmpc2_plan_take_fault / tdmpc2_plan_fault_info report it.
-    if (h->cl_err_host && *(volatile unsigned int *)h->cl_err_host) fault_note(h);
-    else fault_clean(h);
+    if (!fault_poll(h)) fault_clean(h);
     return check_ready(h);
 }
 
@@ -1301,6 +1317,8 @@ int launch_value(tdmpc2_plan *h, int rows, const float *z, bool target, bool red
     }
     int rc = check_ready(h);
     if (rc) return rc;
+    (void)fault_poll(h);  // (a wait that gave up in an earlier call: this one already runs on the paths without waits)
+    if ((rc = fault_fresh(h, st))) return rc;
     if (target)
         for (int i = 0; i < 3; ++i)
             for (int qh = 0; qh < c.num_q; ++qh)
@@ -1391,9 +1409,8 @@ void fill_refit(tdmpc2_plan *h, RefitParams &fp, int E, int it, int eval_mode, f
     fp.gumbel_exp = tape ? tape->gumbel_exp : nullptr; fp.final_eps = tape ? tape->final_eps : nullptr;
     fp.seed = seed; fp.call = call; fp.prev_mean = prev_mean; fp.action = action;
     // a bounded inter-workgroup wait (fused NormedLinear epilogue) that gave up in ANY iteration of this sharded plan: NaN
-    // action, prev_mean kept -- word 0: raised by this iteration's kernels; word 4: raised by validate_envs when it consumed
-    // word 0 between two iterations
-    fp.err = h->cl_err_dev; fp.err2 = h->cl_err_dev ? h->cl_err_dev + 4 : nullptr;
+    // action, prev_mean kept -- word 0 is cleared by shard_begin only (in stream order), not by the calls in between
+    fp.err = h->cl_err_dev; fp.err2 = nullptr;
     if (dbg) {
         if (dbg->value) { fp.dbg_value = dbg->value + (size_t)it * N; fp.dbg_value_es = (long)I * N; }
         if (dbg->elite_idx) { fp.dbg_idx = dbg->elite_idx + (size_t)it * K; fp.dbg_idx_es = (long)I * K; }
@@ -1418,10 +1435,10 @@ int tdmpc2_plan_shard_begin(tdmpc2_plan_t *h, int n_envs, const float *z0, const
     hipStream_t st = (hipStream_t)stream;
     const unsigned call = h->call++;
     h->shard_call = call;
-    h->in_shard = true;  // (after validate_envs: a fault it consumed belonged to an earlier plan)
-    if (h->cl_err_host) ((volatile unsigned int *)h->cl_err_host)[4] = 0;
+    h->in_shard = true;  // (no re-arm between the calls of this plan: fault_clean)
     const int E = n_envs, P = c.num_pi_trajs;
     if (h->lay.on) {
+        if ((rc = fault_fresh(h, st))) return rc;
         if ((rc = lay_setup(h, st, E, task_emb, prev_mean, t0, true))) return rc;
         if ((rc = lay_cvec(h, st, E, z0))) return rc;
         if (P > 0 && (rc = lay_pitraj(h, st, E, z0, act_mask, tape ? tape->pi_traj_eps : nullptr, seed, call))) return rc;
@@ -1715,7 +1732,7 @@ int tdmpc2_plan_set_call_counter(tdmpc2_plan_t *h, uint32_t next_call) {
 int tdmpc2_plan_take_fault(tdmpc2_plan_t *h, int *faults) {
     if (!h || !faults) return fail(TDMPC2_ERR_INVALID, "null argument");
     ENTER(h);
-    if (h->cl_err_host && *(volatile unsigned int *)h->cl_err_host) fault_note(h);
+    (void)fault_poll(h);
     *faults = h->faults;
     h->faults = 0;
     return TDMPC2_OK;
@@ -1818,8 +1835,10 @@ int run_impl(tdmpc2_plan *h, int n_envs, const float *z0, const float *task_emb,
                  (c.num_pi_trajs > 0 && !tape->pi_traj_eps) || (!eval_mode && !tape->final_eps)))
         return fail(TDMPC2_ERR_INVALID, "noise tape has null fields");
     hipStream_t st = (hipStream_t)stream;
-    if (h->lay.on)
+    if (h->lay.on) {
+        if ((rc = fault_fresh(h, st))) return rc;
         return lay_run(h, st, n_envs, z0, task_emb, act_mask, disc_pow, prev_mean, t0, eval_mode, tape, seed, action, dbg);
+    }
     return fused_run<NetS>(h, st, n_envs, z0, task_emb, act_mask, disc_pow, prev_mean, t0, eval_mode, tape, seed, action, dbg);
 }
 }  // namespace
@@ -1846,6 +1865,7 @@ int tdmpc2_plan_estimate_value_trace(tdmpc2_plan_t *h, int n_envs, const float *
     if (!c.multitask) { task_emb = nullptr; act_mask = nullptr; }
     hipStream_t st = (hipStream_t)stream;
     const int E = n_envs, N = c.num_samples, A = c.action_dim;
+    if ((rc = fault_fresh(h, st))) return rc;
     if (h->lay.on) {
         if (trace_tiles) return fail(TDMPC2_ERR_UNSUPPORTED, "the layered path dumps trace_scalars only");
         if ((rc = lay_setup(h, st, E, task_emb, nullptr, nullptr, false))) return rc;

@@ -522,6 +522,49 @@ def test_cluster_hand_over_that_never_arrives_is_reported_not_hung(monkeypatch):
     planner.close()
 
 
+def test_pipelined_plans_each_get_their_own_verdict(monkeypatch):
+    """calls of one handle may be enqueued back to back without a sync.  The verdict of the plan in flight
+    ("a wait gave up": word 0 of the handle's error line) is read by that plan's own final pick and cleared by the NEXT call in
+    stream order -- never by the host, which only looks at a separate sticky word.  Plan A faults; while A is still running
+    the host enqueues plan B on the same handle (and notices the fault there): A comes back as NaN with its prev_mean intact, B
+    -- already on the kernels without waits -- is the healthy plan of a handle with the cluster path switched off."""
+    import time
+
+    from tdmpc2_amd.native import NativePlanner
+    from tests.gpu_common import case_on_gpu, dev, plan_inputs
+
+    c, model, ref = case_on_gpu("c1", 1, 2)
+    monkeypatch.setenv("TDMPC2_CLUSTER_FAULT", "1")
+    planner = NativePlanner(c["cfg"], c["iterations"], dev(), max_envs=c["n_envs"], path=1, precision=2)
+    monkeypatch.delenv("TDMPC2_CLUSTER_FAULT")
+    planner.bind_state_dict(model.sd)
+    inp = plan_inputs(c, model)
+    kw = dict(eval_mode=c["eval_mode"], task_emb=inp["task_emb"], act_mask=inp["act_mask"], tape=inp["tape"])
+    t = time.perf_counter()
+    planner.plan(inp["z0"], inp["disc_pow"], inp["prev_mean"].clone(), inp["t0"], **kw)  # how long a plan with a muted member takes
+    torch.cuda.synchronize()
+    dur = time.perf_counter() - t
+    assert dur < 60 and planner.take_fault() == 1
+    planner.set_cluster(2)  # an explicit tuning call re-arms at once: the next plan takes the cluster path (and faults) again
+    pm_a, pm_b = inp["prev_mean"].clone(), inp["prev_mean"].clone()
+    torch.cuda.synchronize()
+    a = planner.plan(inp["z0"], inp["disc_pow"], pm_a, inp["t0"], **kw)
+    time.sleep(0.5 * dur)  # A's first wait has given up, A is still running
+    b = planner.plan(inp["z0"], inp["disc_pow"], pm_b, inp["t0"], **kw)
+    torch.cuda.synchronize()
+    assert torch.isnan(a).all() and torch.equal(pm_a, inp["prev_mean"])
+    pm_r = inp["prev_mean"].clone()
+    ref.set_cluster(0)
+    try:
+        want = ref.plan(inp["z0"], inp["disc_pow"], pm_r, inp["t0"], **kw).clone()
+    finally:
+        ref.set_cluster(2)
+    torch.cuda.synchronize()
+    assert torch.equal(b, want) and torch.equal(pm_b, pm_r)
+    assert planner.take_fault() == 1 and planner.take_fault() == 0
+    planner.close()
+
+
 @pytest.mark.parametrize("name", ["c1_wide"])
 def test_second_cluster_per_tile_computes_the_same_bits(name):
     """Single plans (evaluate.py:80): from the second CEM launch on every 32-row tile gets a second cluster of 8 workgroups that
