@@ -126,10 +126,12 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             // slots of ONE XCD (with one workgroup per CU and <= 16 column blocks two launches in flight cannot starve each other:
             // 2 x 15 waiting workgroups < 32 CUs), and read every A row through one L2
             static const int xr_env = getenv("TDMPC2_GEMM_W_XCD_ROWS") ? atoi(getenv("TDMPC2_GEMM_W_XCD_ROWS")) : -1;
-            // 16 column blocks (317M model): XCD rectangles, a row block on 2 XCDs -- per XCD and launch A/4 + W/2 instead of
-            // A/8 + W through the L2 (profiles/README.md r4s: c4 +0.5 %, fabric-side reads of the launch 881 -> 654 MB, of a stage 27.3 -> 20.6 GB: r4t; 4 XCDs: one
-            // run in two lost a wait)
-            const int xr_auto = nrowblk >= 16 ? (q.ncolblk % 16 == 0 ? 2 : 1) : 0;
+            // TDMPC2_GEMM_W_XCD_ROWS=2: XCD rectangles, a row block on 2 XCDs -- per XCD and launch A/4 + W/2 instead of A/8 + W
+            // through the L2.  At 16 column blocks (317M model): c4 +1 %, fabric-side reads of the launch 881 -> 654 MB, of a stage
+            // 27.3 -> 20.6 GB (profiles/README.md r4s, r4t) -- but NOT the default: with a row block on two XCDs two launches in
+            // flight can wait for each other in a circle (A's XCD full of launch 1 waiting for B's, B's full of launch 2 waiting
+            // for A's); the stress test lost 3 waits in 6 300 stages that way, the XCD-local order none (r4za).
+            const int xr_auto = nrowblk >= 16 ? 1 : 0;
             const GemmSOrder ord = gemm_s_order(nrowblk, q.ncolblk, xr_env >= 0 ? xr_env : xr_auto, 1);
             q.xcd_rows = ord.xcd_rows; q.ncol_grid = ord.ncol_grid; q.nrowblk = nrowblk;
             q.timing = L.gw_timing ? L.gw_timing + (q.K >= 1024 ? 8 : 0) + (ln->act ? 16 : 0) : nullptr;  // [Mish K < 1024 | Mish K >= 1024 | SimNorm ...]

@@ -483,8 +483,9 @@ def test_two_chains_in_flight_never_starve_each_other(name, E, default_stages):
     hardware queues at once.  Many stages back to back, with random host-side skew between the launches of the two
     streams and a foreign kernel stream in the background: no bounded wait may give up (the XCD-local tile order keeps a row
     block's peers on consecutive slots of one XCD; 2 x (column blocks - 1) waiting workgroups never fill an XCD's 32 CUs).
-    c4: the 317M model's hidden GEMMs spread a row block over TWO XCDs (XCD rectangles, tile_order.h) -- no such capacity
-    argument there, hence this run."""
+    c4: 16 column blocks, the limit of that argument (2 x 15 = 30 < 32).  (XCD rectangles -- a row block on TWO XCDs,
+    TDMPC2_GEMM_W_XCD_ROWS=2, 1 % faster on c4 -- lost 3 waits in 6 300 stages of this test and are therefore not the default:
+    profiles/README.md r4za.)"""
     import os
     import random
     import time
