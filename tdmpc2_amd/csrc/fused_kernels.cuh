@@ -1299,15 +1299,10 @@ __device__ __forceinline__ void first_layers_s(const CT &c, const LayerS &la, co
 // instantiations (TR = 0) carry no trace code -- 66 fewer spilled SGPRs, 7 fewer VGPRs, +0.6 % (A/B r03h).  Episodic kernels
 // keep the dumps inside the one instantiation (TRACE = TR || EP).
 #define DUMP_TILE(...) do { if constexpr (TRACE) dump_tile_s(__VA_ARGS__); } while (0)
-// (The second launch-bounds argument is CUDA's "blocks per multiprocessor": 2 x 8 waves = 4 per SIMD = a 128-VGPR budget.  The
-// 64-row tile's 144 KB of LDS allow ONE workgroup per CU anyway; ROLLOUT_WIDE_REGS drops the argument: 2 waves per SIMD, 256 VGPRs.)
-#ifdef ROLLOUT_WIDE_REGS
-#define ROLLOUT_BOUNDS(NW) __launch_bounds__(64 * (NW))
-#else
-#define ROLLOUT_BOUNDS(NW) __launch_bounds__(64 * (NW), 2)
-#endif
+// (Registers: the 8-wave instantiations fill the 256-VGPR budget of two waves per SIMD -- 65 spilled, none inside a k-loop or
+// an epilogue; dropping the second launch-bounds argument changes nothing: tools/kmeta.py, profiles/README.md r4w.)
 template <int APAD, int ST, int NW, int AR, int EP, int TR = 0>
-__global__ ROLLOUT_BOUNDS(NW) void ks_rollout(RolloutParamsT<NetS> p) {
+__global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p) {
     constexpr bool TRACE = TR || EP;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ int s_is_last;

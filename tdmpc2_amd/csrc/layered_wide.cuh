@@ -57,10 +57,7 @@ struct GwFrags {
 };
 
 constexpr int GW_SLOT = 32768;  // bytes of one k16-slab in the ring: [A: 8 row tiles x (hi, lo)][W: 8 column tiles x (hi, lo)]
-#ifndef GW_NS
-#define GW_NS 4                 // ring slots (4: 128 KiB; 5: all 160 KiB of the CU, one more slab in flight -- experiment builds)
-#endif
-constexpr int GW_NSLOT = GW_NS;
+constexpr int GW_NSLOT = 4;     // ring slots: 128 KiB (a fifth -- all 160 KiB of the CU, one more slab in flight -- bought nothing: profiles/README.md r4c)
 constexpr int GW_U = GW_NSLOT % 2 ? 2 * GW_NSLOT : GW_NSLOT;  // phases per unrolled trip: whole turns of the ring and of the register sets
 constexpr int GW_NB = (GW_NSLOT + 1) / 2;                      // read-address registers per operand (16-bit ds_read offsets: two slots each)
 
@@ -115,11 +112,6 @@ __device__ __forceinline__ void gw_phase(f32x16 (&acc)[2][4], GwFrags (&fr)[2], 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-#ifdef GW_GLDS_LATE
-    GW_MFMA(acc[0][0], c.wh[0], c.ah[0]);
-    GW_MFMA(acc[1][0], c.wh[1], c.ah[0]);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     if (STEADY || issue) {  // slab s + NS -> the slot slab s has just left
         char *slot = ring_w + SL * GW_SLOT;
         gw_glds(pa + voff, slot);
@@ -132,13 +124,9 @@ __device__ __forceinline__ void gw_phase(f32x16 (&acc)[2][4], GwFrags (&fr)[2], 
     __builtin_amdgcn_sched_barrier(0);
     // product 1 of 3: w_hi a_hi, the reads of the next slab (two per MFMA) between the first six
     const bool rd = STEADY || next;
-#ifndef GW_GLDS_LATE
     GW_MFMA(acc[0][0], c.wh[0], c.ah[0]);
-#endif
     if (rd) gw_read2<SN, 0>(n, la, lw);
-#ifndef GW_GLDS_LATE
     GW_MFMA(acc[1][0], c.wh[1], c.ah[0]);
-#endif
     if (rd) gw_read2<SN, 1>(n, la, lw);
     GW_MFMA(acc[0][1], c.wh[0], c.ah[1]);
     if (rd) gw_read2<SN, 2>(n, la, lw);
@@ -205,9 +193,6 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
         la[b] = lbase + (unsigned)wr * 8192u + 65536u * b;
         lw[b] = lbase + 16384u + (unsigned)wc * 4096u + 65536u * b;
     }
-#ifdef GW_PRIO  // static priority for the younger half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
 
     f32x16 acc[2][4];  // [column tile][row tile]: C = [feature][row] (weight fragment = the MFMA's A operand, as in g_gemm_s<EPI>)
 #pragma unroll
@@ -253,16 +238,10 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
 #pragma unroll 1
     for (; s + GW_U - 1 + NS < nk; s += GW_U) {  // steady state: every phase of the trip has a slab s' + NS <= nk - 1 to request
         GW_STEADY(0) GW_STEADY(1) GW_STEADY(2) GW_STEADY(3)
-#if GW_NS == 5
-        GW_STEADY(4) GW_STEADY(5) GW_STEADY(6) GW_STEADY(7) GW_STEADY(8) GW_STEADY(9)
-#endif
     }
 #pragma unroll 1
     for (; s < nk; s += GW_U) {  // the last phases (and short contractions)
         GW_TAIL(0) GW_TAIL(1) GW_TAIL(2) GW_TAIL(3)
-#if GW_NS == 5
-        GW_TAIL(4) GW_TAIL(5) GW_TAIL(6) GW_TAIL(7) GW_TAIL(8) GW_TAIL(9)
-#endif
     }
 #undef GW_TAIL
 #undef GW_STEADY

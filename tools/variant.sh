@@ -2,7 +2,7 @@
 # Build a VARIANT of the library for a same-call A/B (tools/gpu_ab.sh): the objects of the in-tree build are reused, only the
 # translation unit(s) whose flags differ are recompiled (seconds for the layered unit, about a minute for a fused one).
 # usage: tools/variant.sh <name> <unit>:"<flags>" [<unit>:"<flags>" ...]      units: main layered fused cluster
-#   e.g. tools/variant.sh ns5 layered:"-DGW_NS=5"      ->  build/ablate/lib_ns5.so
+#   e.g. tools/variant.sh wr4 fused:"-DKLOOP_RING=4"   ->  build/ablate/lib_wr4.so
 set -euo pipefail
 R="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 NAME="$1"; shift
