@@ -561,7 +561,8 @@ def test_pipelined_plans_each_get_their_own_verdict(monkeypatch):
         ref.set_cluster(2)
     torch.cuda.synchronize()
     assert torch.equal(b, want) and torch.equal(pm_b, pm_r)
-    assert planner.take_fault() == 1 and planner.take_fault() == 0
+    # the host looked twice while A was failing (at B's enqueue, and now): one or two looks found the sticky word set
+    assert planner.take_fault() in (1, 2) and planner.take_fault() == 0
     planner.close()
 
 
