@@ -25,7 +25,7 @@
 // In-kernel phase timers (profiling builds only: -DSPLIT_TIMING, see tools/ablate.sh): wave 0 of every workgroup sums
 // the shader-clock cycles it spends in each phase class into p.timing[class].
 #ifdef SPLIT_TIMING
-#define TIMER_FIELDS mutable unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; mutable unsigned long long t_last = 0, t_begin = 0;
+#define TIMER_FIELDS mutable unsigned long long t_acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; mutable unsigned long long t_last = 0, t_begin = 0;
 #define TIMER_START(c) { (c).t_last = (c).t_begin = __builtin_amdgcn_s_memtime(); }
 #define TIMER_MARK(c, cls) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_now = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); (c).t_acc[cls] += t_now - (c).t_last; (c).t_last = t_now; }
 // the wave whose clock is read: 0-3 are the first-dispatched (older) wave of their SIMD, 4-7 the younger one, which loses
@@ -33,7 +33,7 @@
 #ifndef SPLIT_TIMING_WAVE
 #define SPLIT_TIMING_WAVE 4
 #endif
-#define TIMER_FLUSH(c, ptr) if ((ptr) && threadIdx.x == 64 * SPLIT_TIMING_WAVE) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd((ptr) + i_, (c).t_acc[i_]); atomicAdd((ptr) + 14, (c).t_last - (c).t_begin); atomicAdd((ptr) + 15, 1ull); }
+#define TIMER_FLUSH(c, ptr) if ((ptr) && threadIdx.x == 64 * SPLIT_TIMING_WAVE) { for (int i_ = 0; i_ < 14; ++i_) atomicAdd((ptr) + i_, (c).t_acc[i_]); atomicAdd((ptr) + 14, (c).t_last - (c).t_begin); atomicAdd((ptr) + 15, 1ull); }
 #else
 #define TIMER_FIELDS
 #define TIMER_START(c)
@@ -41,7 +41,7 @@
 #define TIMER_FLUSH(c, ptr)
 #endif
 enum { T_KLOOP = 0, T_EPI = 1, T_HEAD = 2, T_ACT = 3, T_PARK = 4, T_TILE = 5, T_EPI_PRE = 6, T_EPI_SYNC = 7, T_EPI_BIAS = 8,
-       T_EPI_COMB = 9, T_EPI_MATH = 10, T_CL_WAIT = 11 };
+       T_EPI_COMB = 9, T_EPI_MATH = 10, T_CL_WAIT = 11, T_HEAD_K = 12, T_HEAD_ST = 13 };  // (head = what is left: the row routines)
 
 
 
@@ -934,11 +934,13 @@ __device__ __forceinline__ int head_logits_s(const CT &c, const LayerS &ly) {
         const int ct = c.wave;
         if (ct < ly.CT) kloop_tile_s(c, ly, ct, 0, CT::ZKB, acc);
         __syncthreads();
+        TIMER_MARK(c, T_HEAD_K)
         if (ct < ly.CT) {
 #pragma unroll
             for (int rt = 0; rt < CT::NST; ++rt) store_tile_s(c, acc[rt], osc, ly.bias, ct, rt);
         }
         __syncthreads();
+        TIMER_MARK(c, T_HEAD_ST)
         return 0;
     }
 }

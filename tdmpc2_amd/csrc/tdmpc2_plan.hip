@@ -971,7 +971,7 @@ void tdmpc2_plan_destroy(tdmpc2_plan_t *h) {
         unsigned long long t[16];
         if (hipMemcpy(t, h->timing, sizeof t, hipMemcpyDeviceToHost) == hipSuccess && t[15] > 0) {
             static const char *names[16] = {"kloop", "epi_post", "head", "actions", "park/unpark", "tile_from_global", "epi_stats", "epi_sync",
-                                            "epi_bias", "epi_combine", "epi_math_store", "cluster_wait", "", "", "total", "workgroups"};
+                                            "epi_bias", "epi_combine", "epi_math_store", "cluster_wait", "head_kloop", "head_stage", "total", "workgroups"};
             fprintf(stderr, "[tdmpc2_plan timing max_envs=%d] mean cycles per workgroup (one wave, SPLIT_TIMING_WAVE):", h->cfg.max_envs);
             for (int i = 0; i < 15; ++i)
                 if (names[i][0]) fprintf(stderr, " %s=%.0f", names[i], (double)t[i] / (double)t[15]);
