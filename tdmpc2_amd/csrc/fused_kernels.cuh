@@ -844,25 +844,23 @@ __device__ __forceinline__ void add_row_bias(const CT &c, f32x16 (&acc)[CT::NST]
 // Narrow output layers (two-hot / policy heads): acc * oscale + bias -> fp32 logits in the staging view of the tile.
 // C/D fragment of kloop_tile_s (activations as the A operand): lane holds column (l & 31), rows (reg&3) + 8 (reg>>2) + 4 (l>>5).
 template <class CT>
-__device__ __forceinline__ void store_tile_s(const CT &c, const f32x16 &acc, float osc, const float *bias, int ct, int rt, int coff = 0) {
-    // coff != 0: the second k-half of a head contracted by two waves (HEAD_SPLITK): its partial sums go to staging columns
-    // coff + col, without the bias; the row kernels add the two
+__device__ __forceinline__ void store_tile_s(const CT &c, const f32x16 &acc, float osc, const float *bias, int ct, int rt) {
     float *f = c.f32();
     constexpr int RSF = CT::RSF();
     const int j = c.lane & 31, hh = c.lane >> 5;
     const int col = ct * 32 + j;
-    const float bv = coff ? 0.f : bias[col];
+    const float bv = bias[col];
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int row = rt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-        f[row * RSF + coff + col] = fmaf(acc[reg], osc, bv);
+        f[row * RSF + col] = fmaf(acc[reg], osc, bv);
     }
 }
 
 // two_hot_inv (math.py:74-83) on fp32 logits in the staging view.
 // softmax(logits) . bins -> symexp; the softmax normalisation is applied once to the weighted sum.
 template <class CT>
-__device__ __forceinline__ float twohot_rows_s(const CT &c, const float *bins, int num_bins, int second = 0) {
+__device__ __forceinline__ float twohot_rows_s(const CT &c, const float *bins, int num_bins) {
     const int part = c.tid & 7;
     const bool live = (c.tid >> 3) < CT::TROWS;  // ST = 1: the upper half of the workgroup has no row
     const int row = live ? c.tid >> 3 : 0;
@@ -872,7 +870,7 @@ __device__ __forceinline__ float twohot_rows_s(const CT &c, const float *bins, i
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int jj = part + 8 * q;
-        v[q] = (jj < num_bins) ? (second ? rp[jj] + rp[second + jj] : rp[jj]) : -INFINITY;
+        v[q] = (jj < num_bins) ? rp[jj] : -INFINITY;
         m = fmaxf(m, v[q]);
     }
     m = group_max<8>(m);
@@ -904,51 +902,29 @@ __device__ __forceinline__ void layer_full_s(const CT &c, const LayerS &ly, cons
     TIMER_MARK(c, T_EPI)
 }
 
-// HEAD_SPLITK (split arithmetic, 8 waves, <= 4 column tiles): the contraction of a narrow head is split over the wave pairs
-// (w, w + 4) -- column tile w & 3, k-half w >> 2 -- so that all 8 waves (both waves of every SIMD) work on it instead of 4 or 3
-// (VERDICT r3 weak #2); the second half's partial sums go to staging columns 128 .., the row kernels add them: no extra barrier.
-#ifdef HEAD_SPLITK
+// logits of a narrow head (<= 4 column tiles: one wave per column tile, both row tiles) -> the staging view.  (The contraction
+// split over wave pairs -- all 8 waves, half of K each -- was built and measured: -0.2 %, profiles/README.md r4e: the head GEMM is
+// MFMA work on one wave per SIMD that two waves per SIMD do not finish sooner.)
 template <class CT>
-constexpr bool head_splitk_v = CT::ARITH == 0 && CT::NWAVES == 8;
-#else
-template <class CT>
-constexpr bool head_splitk_v = false;
-#endif
-
-// logits of a narrow head (<= 4 column tiles) -> the staging view; returns the offset of the second partial (0: none)
-template <class CT>
-__device__ __forceinline__ int head_logits_s(const CT &c, const LayerS &ly) {
+__device__ __forceinline__ void head_logits_s(const CT &c, const LayerS &ly) {
     f32x16 acc[CT::NST];
     const float osc = *ly.oscale;
-    if constexpr (head_splitk_v<CT>) {
-        const int ct = c.wave & 3, half = c.wave >> 2;
-        if (ct < ly.CT) kloop_tile_s(c, ly, ct, half * (CT::ZKB / 2), (half + 1) * (CT::ZKB / 2), acc);
-        __syncthreads();
-        if (ct < ly.CT) {
+    const int ct = c.wave;
+    if (ct < ly.CT) kloop_tile_s(c, ly, ct, 0, CT::ZKB, acc);
+    __syncthreads();
+    TIMER_MARK(c, T_HEAD_K)
+    if (ct < ly.CT) {
 #pragma unroll
-            for (int rt = 0; rt < CT::NST; ++rt) store_tile_s(c, acc[rt], osc, ly.bias, ct, rt, half * 128);
-        }
-        __syncthreads();
-        return 128;
-    } else {
-        const int ct = c.wave;
-        if (ct < ly.CT) kloop_tile_s(c, ly, ct, 0, CT::ZKB, acc);
-        __syncthreads();
-        TIMER_MARK(c, T_HEAD_K)
-        if (ct < ly.CT) {
-#pragma unroll
-            for (int rt = 0; rt < CT::NST; ++rt) store_tile_s(c, acc[rt], osc, ly.bias, ct, rt);
-        }
-        __syncthreads();
-        TIMER_MARK(c, T_HEAD_ST)
-        return 0;
+        for (int rt = 0; rt < CT::NST; ++rt) store_tile_s(c, acc[rt], osc, ly.bias, ct, rt);
     }
+    __syncthreads();
+    TIMER_MARK(c, T_HEAD_ST)
 }
 
 template <class CT>
 __device__ __forceinline__ float head_twohot_s(const CT &c, const LayerS &ly, const float *bins, int num_bins) {
-    const int second = head_logits_s(c, ly);
-    const float r = twohot_rows_s(c, bins, num_bins, second);
+    head_logits_s(c, ly);
+    const float r = twohot_rows_s(c, bins, num_bins);
     __syncthreads();
     return r;
 }
@@ -970,8 +946,7 @@ __device__ __forceinline__ void put_action(const CT &c, int row, int a, float v)
 template <class CT, typename EpsFn>
 __device__ __forceinline__ void head_pi_rows_s(const CT &c, int A, int Apad, float lsmin, float lsdif, const float *mask_wg, EpsFn eps,
                                                float *gdst, int nvalid, float *tsc, const float *mask_tab = nullptr,
-                                               const int *row_task = nullptr, int put_rows = CT::TROWS, bool agent_store = false,
-                                               int second = 0);
+                                               const int *row_task = nullptr, int put_rows = CT::TROWS, bool agent_store = false);
 
 // Policy prior output layer + squashed Gaussian sample (world_model.py:152-173); action -> operand-form action columns
 // (zero for padded columns) and optionally gdst[row * A + a] for rows < nvalid.
@@ -979,15 +954,15 @@ template <class CT, typename EpsFn>
 __device__ __forceinline__ void head_pi_s(const CT &c, const LayerS &ly, int A, int Apad, float lsmin, float lsdif,
                                           const float *mask_wg, EpsFn eps, float *gdst, int nvalid, float *tsc,
                                           const float *mask_tab = nullptr, const int *row_task = nullptr) {
-    const int second = head_logits_s(c, ly);
-    head_pi_rows_s(c, A, Apad, lsmin, lsdif, mask_wg, eps, gdst, nvalid, tsc, mask_tab, row_task, CT::TROWS, false, second);
+    head_logits_s(c, ly);
+    head_pi_rows_s(c, A, Apad, lsmin, lsdif, mask_wg, eps, gdst, nvalid, tsc, mask_tab, row_task, CT::TROWS, false);
 }
 
 // the policy head's logits (mean | log_std, staging view) -> squashed Gaussian sample -> operand-form action columns
 template <class CT, typename EpsFn>
 __device__ __forceinline__ void head_pi_rows_s(const CT &c, int A, int Apad, float lsmin, float lsdif, const float *mask_wg, EpsFn eps,
                                                float *gdst, int nvalid, float *tsc, const float *mask_tab, const int *row_task,
-                                               int put_rows, bool agent_store, int second) {
+                                               int put_rows, bool agent_store) {
     // put_rows: only rows < put_rows take the action into their operand columns (the cluster path's in-launch policy prior:
     // the other rows of the tile keep their sampled actions); agent_store: gdst is read by another workgroup of this launch
     const int row = c.tid >> 3, part = c.tid & 7;
@@ -1001,10 +976,6 @@ __device__ __forceinline__ void head_pi_rows_s(const CT &c, int A, int Apad, flo
         float out = 0.f;
         if (a < A) {
             float mu = rp[a], lsr = rp[A + a];
-            if (second) {  // the second k-half's partial sums (HEAD_SPLITK)
-                mu += rp[second + a];
-                lsr += rp[second + A + a];
-            }
             float ls = lsmin + 0.5f * lsdif * (tanhf(lsr) + 1.f);  // math.log_std, math.py:12-13
             float e = eps(row, a);
             if (mask) {
