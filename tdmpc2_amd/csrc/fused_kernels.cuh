@@ -265,28 +265,7 @@ __device__ __forceinline__ void kloop_f32(const CT &c, const LayerS &ly, int kb0
 #define A_MFMA(ACC, WF, AF) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(WF), "v"(AF))
 template <int OFF>
 __device__ __forceinline__ void a_dsrd(f16x8 &dst, unsigned addr) {
-#ifdef ASMK_NO_DS
-    dst = *reinterpret_cast<const __attribute__((address_space(3))) f16x8 *>((size_t)(addr + OFF));
-#else
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
-#endif
-}
-template <int OFF>
-__device__ __forceinline__ void a_gld(f16x8 &dst, unsigned voff, const char *sbase) {
-#ifdef ASMK_NO_GLD
-    dst = *reinterpret_cast<const f16x8 *>(sbase + voff + OFF);
-#elif defined(ASMK_VADDR)
-    const char *vp = sbase + voff;
-    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(vp), "n"(OFF));
-#elif defined(ASMK_RFL)
-    // force the base through v_readfirstlane: an "s" operand whose value the compiler only knows as per-lane
-    const unsigned long long b = (unsigned long long)sbase;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-    const char *ub = (const char *)(((unsigned long long)hi << 32) | lo);
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(ub), "n"(OFF));
-#else
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(sbase), "n"(OFF));
-#endif
 }
 __device__ __forceinline__ unsigned lds_addr_of(const void *p) {  // byte address inside the workgroup's LDS allocation
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)(p);
@@ -306,12 +285,6 @@ __device__ __forceinline__ void a_load_act(AFragT<CT::NST> &a, unsigned la0, uns
 // an SGPR) right in front of the loads, and a VMEM instruction that reads such an SGPR needs 5 wait states -- the
 // compiler's hazard recognizer does not look inside inline asm (found the hard way: memory faults, tools/probes/saddr_test.hip).
 __device__ __forceinline__ void a_load_w(BFragT<2> &b, unsigned voff, const char *s0, const char *s1) {
-#if defined(ASMK_NO_GLD)
-    a_gld<0>(b.h[0], voff, s0);
-    a_gld<1024>(b.l[0], voff, s0);
-    a_gld<0>(b.h[1], voff, s1);
-    a_gld<1024>(b.l[1], voff, s1);
-#else
     asm volatile("s_nop 4\n\t"
                  "global_load_dwordx4 %0, %4, %5\n\t"
                  "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
@@ -319,7 +292,6 @@ __device__ __forceinline__ void a_load_w(BFragT<2> &b, unsigned voff, const char
                  "global_load_dwordx4 %3, %4, %6 offset:1024"
                  : "=&v"(b.h[0]), "=&v"(b.l[0]), "=&v"(b.h[1]), "=&v"(b.l[1])
                  : "v"(voff), "s"(s0), "s"(s1));
-#endif
 }
 template <class CT>
 __device__ __forceinline__ void a_mfma12(f32x16 (&acc)[CT::NST][2], const BFragT<2> &w, const AFragT<CT::NST> &a) {
@@ -556,13 +528,11 @@ __device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int 
         __builtin_amdgcn_sched_barrier(0);
     };
     int k = 0;
-#ifndef HEAD_NO_STEADY_LOOP
 #pragma unroll 1
     for (; k + 2 * PFT <= nk; k += PFT) {  // every block has a successor and a block PFT ahead
 #pragma unroll
         for (int d = 0; d < PFT; ++d) step(k + d, d, true);
     }
-#endif
 #pragma unroll 1
     for (; k < nk; k += PFT) {
 #pragma unroll
@@ -721,10 +691,6 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][CT::FT
         }
     }
     TIMER_MARK(c, T_EPI_BIAS)
-#ifdef SPLIT_GB_IN_EPI
-    // the successor's g / b (this layer's own are in c.gb already); behind the bias loads, which are needed first
-    if (next.g) gb_prefetch(c, next.g, next.b);
-#endif
     // per-wave partial statistics of the sample rows this lane works on
 #pragma unroll
     for (int st = 0; st < CT::NST; ++st) {
@@ -892,9 +858,7 @@ __device__ __forceinline__ void layer_full_s(const CT &c, const LayerS &ly, cons
                                              GB next, float *zcopy = nullptr) {
     f32x16 acc[CT::NST][CT::FT];
     zero_acc(acc);
-#ifndef SPLIT_GB_IN_EPI
     if (next.g) gb_prefetch(c, next.g, next.b);  // in flight behind the whole contraction
-#endif
     kloop_s(c, ly, kb0, kb1, acc);
     TIMER_MARK(c, T_KLOOP)
     epi_t<ACT>(c, acc, *ly.oscale, *ly.ascale, bias, next, zcopy);
@@ -1182,83 +1146,14 @@ __device__ __forceinline__ float head_term_s(const CT &c, const LayerS &ly) {
     return pr > 0.5f ? 1.f : 0.f;
 }
 
-// Two first layers over the same [z | a] operand tile in ONE pass (dynamics + reward, or the two selected Q heads): the
-// activation fragments are read from LDS once per k-block and feed both nets' feature tiles (24 MFMAs per k-block per
-// wave instead of 2 x 12 with two reads of the same fragments): identical sums in identical order, so results do not change
-// by a bit; +1.5 ... 2.6 % on the launch (A/B in one gpurun call, profiles/README.md r02c).  Weight ring one k-block deep
-// per net.  -DSPLIT_NO_PAIR restores the two separate loops.
-#if !defined(SPLIT_NO_PAIR) && !defined(SPLIT_ASM_KLOOP)  // the hand-ordered loop (kloop_asm) beats the paired compiler loop
-#define SPLIT_PAIR 1
-#endif
-#ifdef SPLIT_PAIR
-template <class CT>
-__device__ __forceinline__ void kloop_pair_s(const CT &c, const LayerS &la, const LayerS &lb, int kb0, int kb1,
-                                             f32x16 (&acca)[CT::NST][CT::FT], f32x16 (&accb)[CT::NST][CT::FT]) {
-    static_assert(CT::ARITH == 0, "paired first layers exist for the split arithmetic");
-    constexpr int FT = CT::FT;
-    const int i = c.lane & 31, hh = c.lane >> 5;
-    const _Float16 *a0p = c.act + i * c.RSH + 8 * hh + kb0 * 16;
-    const char *ua = reinterpret_cast<const char *>(la.wp) + ((size_t)(FT * c.wave) * la.KB + kb0) * 2048;
-    const char *ub = reinterpret_cast<const char *>(lb.wp) + ((size_t)(FT * c.wave) * lb.KB + kb0) * 2048;
-    const size_t cts = (size_t)la.KB * 2048;  // both nets have the same first-layer shape
-    unsigned voff = (unsigned)c.lane * 16u;
-    asm volatile("" : "+v"(voff));
-    const int nk = kb1 - kb0;
-    BFragT<FT> ra, rb;
-    load_b(ra, ua, cts, voff);
-    load_b(rb, ub, cts, voff);
-    AFragT<CT::NST> an;
-    load_a<CT>(an, a0p, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-    for (int kk = 0; kk < nk; ++kk) {
-        const AFragT<CT::NST> a = an;
-        load_a<CT>(an, a0p, kk + 1 < nk ? kk + 1 : kk);
-        const int kn = kk + 1 < nk ? kk + 1 : nk - 1;
-#pragma unroll
-        for (int cc = 0; cc < FT; ++cc)
-#pragma unroll
-            for (int st = 0; st < CT::NST; ++st) acca[st][cc] = SPLIT_MFMA(ra.h[cc], a.h[st], acca[st][cc]);
-#pragma unroll
-        for (int cc = 0; cc < FT; ++cc)
-#pragma unroll
-            for (int st = 0; st < CT::NST; ++st) acca[st][cc] = SPLIT_MFMA(ra.l[cc], a.h[st], acca[st][cc]);
-#pragma unroll
-        for (int cc = 0; cc < FT; ++cc)
-#pragma unroll
-            for (int st = 0; st < CT::NST; ++st) acca[st][cc] = SPLIT_MFMA(ra.h[cc], a.l[st], acca[st][cc]);
-        load_b(ra, ua + (size_t)kn * 2048, cts, voff);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int cc = 0; cc < FT; ++cc)
-#pragma unroll
-            for (int st = 0; st < CT::NST; ++st) accb[st][cc] = SPLIT_MFMA(rb.h[cc], a.h[st], accb[st][cc]);
-#pragma unroll
-        for (int cc = 0; cc < FT; ++cc)
-#pragma unroll
-            for (int st = 0; st < CT::NST; ++st) accb[st][cc] = SPLIT_MFMA(rb.l[cc], a.h[st], accb[st][cc]);
-#pragma unroll
-        for (int cc = 0; cc < FT; ++cc)
-#pragma unroll
-            for (int st = 0; st < CT::NST; ++st) accb[st][cc] = SPLIT_MFMA(rb.h[cc], a.l[st], accb[st][cc]);
-        load_b(rb, ub + (size_t)kn * 2048, cts, voff);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-#endif
-
+// (Round 2 contracted the two first layers over the same [z | a] tile in ONE compiler-scheduled pass -- fragments read from LDS
+// once, +1.5 ... 2.6 % --; the hand-ordered loop (kloop_asm) run twice beats it: profiles/README.md r02c and "What was tried".)
 // first layers of two nets over the same tile: acca <- la, accb <- lb (raw sums)
 template <class CT>
 __device__ __forceinline__ void first_layers_s(const CT &c, const LayerS &la, const LayerS &lb, int kb0, int kb1,
                                                f32x16 (&acca)[CT::NST][CT::FT], f32x16 (&accb)[CT::NST][CT::FT]) {
     zero_acc(acca);
     zero_acc(accb);
-#ifdef SPLIT_PAIR
-    if constexpr (CT::ARITH == 0) {
-        kloop_pair_s(c, la, lb, kb0, kb1, acca, accb);
-        return;
-    }
-#endif
     kloop_s(c, la, kb0, kb1, acca);
     kloop_s(c, lb, kb0, kb1, accb);
 }
@@ -1476,10 +1371,6 @@ __global__ __launch_bounds__(64 * NW, 2) void ks_rollout(RolloutParamsT<NetS> p)
         tsc[p.H + 1] = qb;
     }
     const float val = G + disc[p.H] * (1.f - termv) * ((qa + qb) / 2.f);
-#ifdef TDMPC2_NO_FOLD  // experiment builds: the hand-over compiled out
-    if ((tid & 7) == 0 && live) p.value[(size_t)e * p.N + row0 + (tid >> 3)] = val;
-    return;
-#endif
     if (!p.fold_refit) {
         if ((tid & 7) == 0 && live) p.value[(size_t)e * p.N + row0 + (tid >> 3)] = val;
         return;
