@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define TDMPC2_PLAN_ABI_VERSION 7
+#define TDMPC2_PLAN_ABI_VERSION 8
 
 typedef struct tdmpc2_plan tdmpc2_plan_t;
 
@@ -322,31 +322,37 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
  * layer of a 32-row sample tile is split over a cluster of 8 workgroups on 8 CUs that exchange the layer's raw sums through
  * L2 (tdmpc2_amd/csrc/cluster_kernels.cuh); used when all of a call's clusters fit the chip at once (one or two plans of
  * 512 samples on 256 CUs).  0 = never, 1 = whenever the call fits, 2 (default) = 1, and for a SINGLE non-episodic plan every
- * launch after the first gives each tile a second cluster that runs the reward chain (and the second Q head) beside the
- * dynamics chain (cluster2_kernels.cuh: all 256 CUs, 16 instead of 23 hand-overs on the critical path; identical values).
+ * launch -- the first included, which also folds the policy-prior trajectories in -- gives each tile a second cluster that runs
+ * the reward chain (and the second Q head) beside the dynamics chain (cluster2_kernels.cuh: all 256 CUs, 16 instead of 23 hand-overs on the critical path; identical values).
  * key TDMPC2_TUNE_FUSE_LN (layered family, f16x2-split arithmetic): 1 (default) = the LayerNorm + Mish / SimNorm + operand split
  * of every NormedLinear (tdmpc2/common/layers.py:94-118) runs in the epilogue of its GEMM -- the column blocks of a row block
  * exchange per-row (mean, M2) partials through L2, a bounded wait like the cluster path's (tdmpc2_plan_take_fault) --;
  * 0 = fp32 pre-activations to HBM and a row kernel per layer.
  * key TDMPC2_TUNE_REARM_AFTER: consecutive clean calls after which a handle that was downgraded by a reported wait goes back to
- * the CLUSTER / FUSE_LN paths (default 64; 0 = never: the downgrade is for good, as in ABI <= 6).  See tdmpc2_plan_take_fault. */
+ * the CLUSTER / FUSE_LN paths (default 8 -- 64 before ABI 8; 0 = never: the downgrade is for good, as in ABI <= 6).  See
+ * tdmpc2_plan_take_fault.
+ * key TDMPC2_TUNE_SAFE_ONCE (ABI 8): 1 = the NEXT whole plan on this handle (tdmpc2_plan_run / run_obs, or shard_begin .. the last
+ * shard_refit) runs on the paths without inter-workgroup waits, whatever CLUSTER / FUSE_LN say; the caller's settings, the
+ * downgrade state and the re-arm counter are not touched and the flag clears itself when that plan has been enqueued (the
+ * re-plan of a sharded plan after a reported wait: dist.sharded_plan). */
 enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0, TDMPC2_TUNE_FOLD_REFIT = 1, TDMPC2_TUNE_CLUSTER = 2, TDMPC2_TUNE_FUSE_LN = 3,
-                     TDMPC2_TUNE_REARM_AFTER = 4 };
+                     TDMPC2_TUNE_REARM_AFTER = 4, TDMPC2_TUNE_SAFE_ONCE = 5 };
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
 
 /* Fault report of the paths whose workgroups wait for each other: the cluster path (TDMPC2_TUNE_CLUSTER) and the NormedLinear
- * epilogue inside the layered family's GEMMs (TDMPC2_TUNE_FUSE_LN).  Those waits are bounded (2^18 polls, about a third of a
- * second; a healthy wait is microseconds to one tile's run time); when one gives up -- another process or a foreign kernel held
+ * epilogue inside the layered family's GEMMs (TDMPC2_TUNE_FUSE_LN).  Those waits are bounded by the wall clock (5 ms of the constant
+ * 100 MHz clock -- a poll count worth a third of a second before ABI 8; a healthy wait is microseconds to one tile's run time); when one gives up -- another process or a foreign kernel held
  * the compute units -- the call in flight is invalid AND SAYS SO: a plan's action[E, A] comes back as NaN with prev_mean left as
  * it was (the step can simply be planned again); tdmpc2_plan_td_target / policy_value (LAYERED family) return NaN in every
  * element of out[] (and action[]).  The reference has no analogue (its only guard is the nan_to_num of tdmpc2.py:184).
  * Call this after synchronising the stream of such a call: *faults = number of invalid calls since the last take_fault (0 = none).
  * After a fault the handle runs the paths without inter-workgroup waits; it switches back to the fast ones after
- * TDMPC2_TUNE_REARM_AFTER (default 64) consecutive clean calls, doubling that number (up to 4096) every time a fault follows a
+ * TDMPC2_TUNE_REARM_AFTER (default 8) consecutive clean calls, doubling that number (up to 4096) every time a fault follows a
  * re-arm and forgetting the back-off after a long clean run; an explicit tdmpc2_plan_set_tuning(CLUSTER / FUSE_LN) re-arms at
  * once.  Calls enqueued back to back without a synchronisation in between each carry their own verdict: the word a call's last
  * kernel reads is raised on the device and cleared by the NEXT call in stream order, never by the host (which looks at a
- * separate sticky word: the count reported here is "looks that found it set", at most one per API call).  The later calls of a
+ * separate sticky word with one atomic exchange: the count reported here is "looks that found it set", at most one per API
+ * call -- a lower bound on the waits that gave up).  The later calls of a
  * sharded plan (shard_values / shard_refit) do not clear it: a wait that gave up in any iteration invalidates the final pick. */
 int tdmpc2_plan_take_fault(tdmpc2_plan_t *h, int *faults);
 

@@ -29,9 +29,9 @@ constexpr int CL2_MAIL = 15;         // arrival word of R's cluster that carries
 template <class CT>
 __device__ __forceinline__ void cl2_wait_peer(const CT &c, ClState &x, const unsigned *pflags, unsigned phase) {
     if (c.tid < CL && !*x.dead) {
-        int spin = 0;
+        WaitClock wc;
         while ((__hip_atomic_load(pflags + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffffu) < phase) {
-            if (++spin > CL_MAXSPIN) {
+            if (wc.expired()) {
                 raise_fault(x.err, 1u);
                 *x.dead = 1;
                 break;
@@ -176,9 +176,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl2(RolloutParamsT<Net
         const unsigned *hflags = peer_flags + 8;
         const int nct = p.pi.l[2].CT;
         if (tid < nct && !*x.dead) {
-            int spin = 0;
+            WaitClock wc;
             while (__hip_atomic_load(hflags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < hphase) {
-                if (++spin > CL_MAXSPIN) {
+                if (wc.expired()) {
                     raise_fault(x.err, 1u);
                     *x.dead = 1;
                     break;
@@ -246,9 +246,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl2(RolloutParamsT<Net
         if (rank != 0) return;  // member 0 owns the values
         // (G, Qb) of the tile's rows from R's member 0
         if (tid == 0 && !*x.dead) {
-            int spin = 0;
+            WaitClock wc;
             while (__hip_atomic_load(peer_flags + CL2_MAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(p.iter + 1)) {
-                if (++spin > CL_MAXSPIN) {
+                if (wc.expired()) {
                     raise_fault(x.err, 1u);
                     *x.dead = 1;
                     break;

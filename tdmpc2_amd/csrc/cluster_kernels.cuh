@@ -42,7 +42,7 @@
 //             phase 4H+5  q1.l1 -> S1;  head.
 #pragma once
 
-constexpr int CL_MAXSPIN = 1 << 18;    // polls before a member gives up (about a third of a second: longer than any kernel that could hold a CU back; a healthy wait is microseconds)
+// (bounded waits: WaitClock, common.cuh -- 5 ms by the wall clock)
 __host__ __device__ constexpr int cl_phases(int H) { return 8 * H + 7; }  // hand-overs per launch (upper bound: policy prior + termination)
 __host__ __device__ constexpr int cl_heads(int H) { return 3 * H + 4; }  // narrow heads per launch (upper bound): H reward, H policy prior, H + 1 termination, policy, two Q
 
@@ -180,10 +180,10 @@ __device__ __forceinline__ void cl_barrier(const CT &c, ClState &x, bool learn) 
     x.phase += 1;
     if (c.tid == 0 && !x.mute) __hip_atomic_store(x.flags + x.rank, x.phase | (x.xcc << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (c.tid < CL && !*x.dead) {
-        int spin = 0;
+        WaitClock wc;
         unsigned v;
         while (((v = __hip_atomic_load(x.flags + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffffu) < x.phase) {
-            if (++spin > CL_MAXSPIN) {  // host-mapped word: a plain system-scope store
+            if (wc.expired()) {  // host-mapped word: a plain system-scope store
                 raise_fault(x.err, 1u);
                 *x.dead = 1;
                 v = 0xff000000u;
@@ -363,9 +363,9 @@ __device__ __forceinline__ void cl_head_logits(const CT &c, ClState &x, const La
     }
     if (!consume) return;
     if (c.tid < ly.CT && !*x.dead) {
-        int spin = 0;
+        WaitClock wc;
         while (__hip_atomic_load(hflags + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < x.hphase) {
-            if (++spin > CL_MAXSPIN) {
+            if (wc.expired()) {
                 raise_fault(x.err, 1u);
                 *x.dead = 1;
                 break;

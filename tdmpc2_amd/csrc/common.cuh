@@ -70,6 +70,24 @@ struct NetS {
 // the host; word 8 = sticky "a wait gave up since the host last looked" -- read and cleared by the host (validate_envs,
 // take_fault).  (Round 3 had one word that the host cleared when it enqueued the next call: pipelined calls could lose the verdict
 // of the call still running -- ADVICE r3.)
+// The bound of those waits is wall-clock time (round 5; it was a poll count worth about a third of a second): 5 ms of the
+// constant 100 MHz clock (s_memrealtime).  A healthy wait is microseconds, or -- a row block that straddles its XCD's residency
+// limit, a tile whose last K-part is still queued -- one tile's run time (< 0.5 ms for the 317M model's K = 4096).  The clock is
+// only read from the 256th poll on (and then every 64th), so that a hand-over on the latency path never pays for it.
+constexpr unsigned long long WAIT_TICKS = 500000ull;
+struct WaitClock {
+    int spin = 0;
+    unsigned long long t0 = 0;
+    __device__ __forceinline__ bool expired() {
+        if (++spin < 256 || (spin & 63) != 0) return false;
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (t0 == 0) {
+            t0 = now;
+            return false;
+        }
+        return now - t0 > WAIT_TICKS;
+    }
+};
 __device__ __forceinline__ void raise_fault(unsigned int *err, unsigned int code) {
     __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(err + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -109,9 +109,10 @@ struct tdmpc2_plan {
     // off when a wait gives up and switched back on after `rearm_after` consecutive clean calls (doubling, up to 4096, every time
     // a fault follows a re-arm: a box that keeps faulting -- co-tenancy -- settles on the paths without waits)
     bool degraded = false;
-    int user_cluster_mode = 2;       // what the caller / environment asked for (restored by a re-arm)
+    bool safe_once = false;          // TDMPC2_TUNE_SAFE_ONCE: the next whole plan runs without inter-workgroup waits (apply_modes)
+    int user_cluster_mode = 2;       // what the caller / environment asked for (apply_modes derives cluster_mode / lay.fuse_ln from it)
     bool user_fuse_ln = false;
-    int rearm_after = 64, rearm_base = 64;   // 0: never re-arm (the round-3 behaviour)
+    int rearm_after = 8, rearm_base = 8;     // 0: never re-arm (the round-3 behaviour)
     int clean_calls = 0;             // consecutive calls without a fault since the downgrade
     int faults_total = 0, rearms = 0;
     std::chrono::steady_clock::time_point last_fault{};

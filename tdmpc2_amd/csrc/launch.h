@@ -18,7 +18,7 @@ struct FusedOps {
 struct ClusterOps {
     void (*rollout_cl)(int ep, const RolloutParamsT<NetS> &p, int grid, size_t lds, hipStream_t st);
     int (*set_lds)(int episodic, size_t lds_bytes);
-    // two clusters per 32-row tile (reward chain beside the dynamics chain): single non-episodic plans, launches 1 .. I - 1
+    // two clusters per 32-row tile (reward chain beside the dynamics chain): single non-episodic plans, every launch (launch 0 with the policy-prior fold)
     void (*rollout_cl2)(const RolloutParamsT<NetS> &p, int grid, size_t lds, hipStream_t st);
 };
 // (accessor functions, not global tables: hipcc would emit a constant-initialised table on the device side as well)

@@ -113,9 +113,9 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         const int ncb256 = (ly.CT + NT - 1) / NT;
         const size_t stats_need = rows_p * ((ly.CT + 3) / 4) * 2;
         if (can_fuse && ly.CT >= 8 && rows_p % 256 == 0 && rows_per_env % 256 == 0 && ncb256 <= 32 && !L.row_env && stats_need <= L.stats_cap &&
-            (long)(rows_p / 256) * ncb256 >= w256_min && w256_min >= 0) {
+            (long)(rows_p / 256) * ncb256 >= w256_min && w256_min >= 0 &&
+            L.arrive_off + rows_p / 256 <= L.arrive_cap /* out of arrival counters: the narrow tiles below degrade to the unfused LayerNorm */) {
             const int nrowblk = (int)(rows_p / 256);
-            if (L.arrive_off + (size_t)nrowblk > L.arrive_cap) return fail(TDMPC2_ERR_STATE, "arrival counters exhausted (%zu + %d > %zu)", L.arrive_off, nrowblk, L.arrive_cap);
             q.ncolblk = ncb256;
             q.ln_g = ly.g; q.ln_b = ly.b; q.gb_sel_stride = sel ? ln->gb_sel_stride : 0;
             q.ascale = ly.ascale; q.asc_sel_stride = sel ? (long)(3 * sizeof(LayerScal) / sizeof(float)) : 0;

@@ -65,7 +65,8 @@ __device__ __forceinline__ void chan_fold(float &n_acc, float &m_acc, float &q_a
     n_acc = nt;
 }
 
-constexpr int GLN_MAXSPIN = 1 << 18;  // polls (an agent-scope load + s_sleep(2) each: about a third of a second in all); a healthy wait is microseconds -- peers of a row block are dispatched back to back -- or, when a row block straddles the residency limit of its XCD, one tile's run time (< 1 ms)
+// (bounded waits: WaitClock, common.cuh -- 5 ms by the wall clock; a healthy wait is microseconds -- peers of a row block are
+// dispatched back to back -- or, when a row block straddles the residency limit of its XCD, one tile's run time)
 
 // NCT = 32-wide output column tiles per wave: 1 -> 128 x 128 workgroup tile (narrow outputs: heads, small models),
 // 2 -> 128 x 256 (a wave owns 64 columns x 128 rows = 8 accumulators: per k16-block 4 KB of weight fragments and 8 KB of
@@ -313,9 +314,9 @@ __global__ __launch_bounds__(GTHREADS, 2) void g_gemm_s(GemmSParams p) {
         __syncthreads();
         if (tid == 0) {
             if (!(p.fault && rb == 0 && cb == 0)) __hip_atomic_fetch_add(p.arrive + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int spin = 0;
+            WaitClock wc;
             while (__hip_atomic_load(p.arrive + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.ncolblk) {
-                if (++spin > GLN_MAXSPIN) {
+                if (wc.expired()) {
                     if (p.err) raise_fault(p.err, 2u);
                     break;
                 }

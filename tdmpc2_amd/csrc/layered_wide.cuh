@@ -320,9 +320,9 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
     __syncthreads();
     if (tid == 0) {
         if (!(p.fault && rb == 0 && cb == 0)) __hip_atomic_fetch_add(p.arrive + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spin = 0;
+        WaitClock wc;
         while (__hip_atomic_load(p.arrive + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.ncolblk) {
-            if (++spin > GLN_MAXSPIN) {
+            if (wc.expired()) {
                 if (p.err) raise_fault(p.err, 2u);
                 break;
             }

@@ -22,6 +22,7 @@
 // contiguous; one small workgroup per plan does nan_to_num + top-k + score + mean/std refit (+ the final Gumbel pick)
 // between rollout launches (k_refit below).  DESIGN.md has the full account.
 #include <cstdarg>
+#include <cstring>
 #include <new>
 
 #include "handle.h"
@@ -461,16 +462,19 @@ void fill_rollout(tdmpc2_plan *h, RolloutParamsT<NET> &p, int E) {
 
 // A bounded inter-workgroup wait gave up (the handle's error word is set): the plan / call in flight returned NaN.  Switch to
 // the paths without such waits, remember when, and let fault_clean() switch back after `rearm_after` clean calls.
+// What the kernels run = what the caller asked for (user_*: environment at create, tdmpc2_plan_set_tuning) unless the handle is
+// downgraded (a reported wait) or asked to plan once without inter-workgroup waits (TDMPC2_TUNE_SAFE_ONCE: the re-plan of a
+// sharded plan).  The one place that writes cluster_mode / lay.fuse_ln after create.
+void apply_modes(tdmpc2_plan *h) {
+    const bool safe = h->degraded || h->safe_once;
+    h->cluster_mode = safe ? 0 : h->user_cluster_mode;
+    h->lay.fuse_ln = safe ? false : h->user_fuse_ln;
+}
 void fault_note(tdmpc2_plan *h) {
-    if (!h->degraded) {
-        h->user_cluster_mode = h->cluster_mode;
-        h->user_fuse_ln = h->lay.fuse_ln;
-    } else if (h->rearm_after > 0 && h->rearm_after < 4096) {
+    if (h->degraded && h->rearm_after > 0 && h->rearm_after < 4096)
         h->rearm_after *= 2;  // (a fault on the downgraded paths cannot happen; this branch is a fault right after a re-arm raced in)
-    }
     h->degraded = true;
-    h->cluster_mode = 0;
-    h->lay.fuse_ln = false;
+    apply_modes(h);
     h->clean_calls = 0;
     h->faults++;
     h->faults_total++;
@@ -489,9 +493,8 @@ void fault_clean(tdmpc2_plan *h) {  // a call is about to be enqueued and no fau
         ++h->clean_calls;
         return;
     }
-    h->cluster_mode = h->user_cluster_mode;
-    h->lay.fuse_ln = h->user_fuse_ln;
     h->degraded = false;
+    apply_modes(h);
     h->clean_calls = 0;
     h->rearms++;
     if (h->rearm_after < 4096) h->rearm_after *= 2;  // the next downgrade lasts twice as long; a long clean run resets it (above)
@@ -501,9 +504,9 @@ void fault_clean(tdmpc2_plan *h) {  // a call is about to be enqueued and no fau
 // which that call's own last kernel reads and the NEXT call clears in stream order (fault_fresh): calls of one handle may be
 // pipelined without a sync and each still gets its own verdict.
 bool fault_poll(tdmpc2_plan *h) {
-    volatile unsigned int *w = (volatile unsigned int *)h->cl_err_host;
-    if (!w || !w[8]) return false;
-    w[8] = 0;
+    unsigned int *w = h->cl_err_host;
+    // read-and-clear in ONE step: a device store that lands between a separate read and clear would be lost
+    if (!w || !__atomic_exchange_n(w + 8, 0u, __ATOMIC_RELAXED)) return false;
     fault_note(h);
     return true;
 }
@@ -860,7 +863,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
                 tdmpc2_plan_destroy(h);
                 return fail(TDMPC2_ERR_HIP, "allocating the fused-epilogue counters / error word failed");
             }
-            *h->cl_err_host = 0;
+            memset(h->cl_err_host, 0, 64);  // hipHostMalloc does not zero: word 0 (verdict) AND word 8 (sticky, fault_poll)
             if (hipHostGetDevicePointer((void **)&h->cl_err_dev, h->cl_err_host, 0) != hipSuccess) {
                 tdmpc2_plan_destroy(h);
                 return fail(TDMPC2_ERR_HIP, "hipHostGetDevicePointer failed");
@@ -925,7 +928,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
                 tdmpc2_plan_destroy(h);
                 return fail(TDMPC2_ERR_HIP, "allocating the cluster path's arrival / error words failed");
             }
-            *h->cl_err_host = 0;
+            memset(h->cl_err_host, 0, 64);  // hipHostMalloc does not zero: word 0 (verdict) AND word 8 (sticky, fault_poll)
             if (hipHostGetDevicePointer((void **)&h->cl_err_dev, h->cl_err_host, 0) != hipSuccess) {
                 tdmpc2_plan_destroy(h);
                 return fail(TDMPC2_ERR_HIP, "hipHostGetDevicePointer failed");
@@ -956,6 +959,8 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
         }
     }
     if (const char *cm = getenv("TDMPC2_CLUSTER")) h->cluster_mode = atoi(cm);
+    h->user_cluster_mode = h->cluster_mode;  // what was asked for (environment or default); set_tuning / fault recovery go through apply_modes
+    h->user_fuse_ln = h->lay.fuse_ln;
     if (const char *cf = getenv("TDMPC2_CLUSTER_FAULT")) h->cl_fault = atoi(cf);
     if (getenv("TDMPC2_TIMING")) {
         if (dev_alloc(h, (void **)&h->timing, 16 * 8) == 0) (void)hipMemset(h->timing, 0, 16 * 8);
@@ -1318,7 +1323,8 @@ int launch_value(tdmpc2_plan *h, int rows, const float *z, bool target, bool red
     int rc = check_ready(h);
     if (rc) return rc;
     (void)fault_poll(h);  // (a wait that gave up in an earlier call: this one already runs on the paths without waits)
-    if ((rc = fault_fresh(h, st))) return rc;
+    // between the calls of a sharded plan word 0 is that plan's verdict (its final pick reads it): keep it
+    if (!h->in_shard && (rc = fault_fresh(h, st))) return rc;
     if (target)
         for (int i = 0; i < 3; ++i)
             for (int qh = 0; qh < c.num_q; ++qh)
@@ -1435,13 +1441,19 @@ int tdmpc2_plan_shard_begin(tdmpc2_plan_t *h, int n_envs, const float *z0, const
     hipStream_t st = (hipStream_t)stream;
     const unsigned call = h->call++;
     h->shard_call = call;
-    h->in_shard = true;  // (no re-arm between the calls of this plan: fault_clean)
+    // in_shard: no re-arm between the calls of this plan (fault_clean), word 0 of the error line kept until the final pick.  Set
+    // only when the whole prologue has been enqueued: a shard_begin that fails leaves the handle as an ordinary call would.
+    struct ShardGuard {
+        tdmpc2_plan *h; bool ok;
+        ~ShardGuard() { h->in_shard = ok; }
+    } guard{h, false};
     const int E = n_envs, P = c.num_pi_trajs;
     if (h->lay.on) {
         if ((rc = fault_fresh(h, st))) return rc;
         if ((rc = lay_setup(h, st, E, task_emb, prev_mean, t0, true))) return rc;
         if ((rc = lay_cvec(h, st, E, z0))) return rc;
         if (P > 0 && (rc = lay_pitraj(h, st, E, z0, act_mask, tape ? tape->pi_traj_eps : nullptr, seed, call))) return rc;
+        guard.ok = true;
         return TDMPC2_OK;
     }
     if ((rc = launch_setup<NetS>(h, E, z0, task_emb, prev_mean, t0, st))) return rc;
@@ -1456,6 +1468,7 @@ int tdmpc2_plan_shard_begin(tdmpc2_plan_t *h, int n_envs, const float *z0, const
         Kern<NetS>::pitraj(h, p, E, st);
         HIP_TRY(hipGetLastError());
     }
+    guard.ok = true;
     return TDMPC2_OK;
 }
 
@@ -1515,7 +1528,10 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
     fill_refit(h, fp, n_envs, iter, eval_mode, value, c.multitask ? act_mask : nullptr, tape, seed, h->shard_call, prev_mean, action, dbg, stage);
     hipLaunchKernelGGL(k_refit, dim3(n_envs), dim3(refit_threads(c.num_samples)), lds, st, fp);
     HIP_TRY(hipGetLastError());
-    if (fp.last) h->in_shard = false;
+    if (fp.last) {
+        h->in_shard = false;
+        if (h->safe_once) { h->safe_once = false; apply_modes(h); }
+    }
     if (dbg && dbg->actions)
         HIP_TRY(hipMemcpy2DAsync(dbg->actions + (size_t)iter * c.horizon * c.num_samples * c.action_dim,
                                  (size_t)c.iterations * c.horizon * c.num_samples * c.action_dim * 4, h->actions,
@@ -1760,19 +1776,29 @@ int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value) {
     }
     if (key == TDMPC2_TUNE_CLUSTER) {
         if (value < 0 || value > 2) return fail(TDMPC2_ERR_INVALID, "cluster must be 0 (never), 1 (whenever the call fits) or 2 (auto)");
-        h->cluster_mode = h->user_cluster_mode = value;  // an explicit setting also re-arms (or keeps off) the path at once
-        if (h->degraded && h->lay.fuse_ln == h->user_fuse_ln) h->degraded = false;
+        h->user_cluster_mode = value;  // an explicit setting also re-arms the handle at once
+        h->degraded = false;
+        apply_modes(h);
         return TDMPC2_OK;
     }
     if (key == TDMPC2_TUNE_FUSE_LN) {
         if (value < 0 || value > 1) return fail(TDMPC2_ERR_INVALID, "fuse_ln must be 0 or 1");
-        h->lay.fuse_ln = h->user_fuse_ln = value != 0 && h->lay.stats != nullptr;
-        if (h->degraded && h->cluster_mode == h->user_cluster_mode) h->degraded = false;
+        h->user_fuse_ln = value != 0 && h->lay.stats != nullptr;
+        h->degraded = false;
+        apply_modes(h);
         return TDMPC2_OK;
     }
     if (key == TDMPC2_TUNE_REARM_AFTER) {
         if (value < 0) return fail(TDMPC2_ERR_INVALID, "rearm_after must be >= 0 (0: never)");
         h->rearm_after = h->rearm_base = value;
+        return TDMPC2_OK;
+    }
+    if (key == TDMPC2_TUNE_SAFE_ONCE) {
+        // the next whole plan (tdmpc2_plan_run*, or shard_begin .. the last shard_refit) runs on the paths without inter-workgroup
+        // waits; the caller's settings, the downgrade state and the re-arm counter are not touched (dist.sharded_plan's re-plan)
+        if (value < 0 || value > 1) return fail(TDMPC2_ERR_INVALID, "safe_once must be 0 or 1");
+        h->safe_once = value != 0;
+        apply_modes(h);
         return TDMPC2_OK;
     }
     if (key == TDMPC2_TUNE_FOLD_REFIT) {
@@ -1825,6 +1851,7 @@ namespace {
 int run_impl(tdmpc2_plan *h, int n_envs, const float *z0, const float *task_emb, const float *act_mask, const float *disc_pow,
              float *prev_mean, const uint8_t *t0, int eval_mode, const tdmpc2_noise *tape, uint64_t seed, float *action,
              const tdmpc2_debug *dbg, void *stream) {
+    if (h) h->in_shard = false;  // a whole plan on this handle abandons whatever sharded plan was left open (an exception in the caller)
     int rc = validate_envs(h, n_envs);
     if (rc) return rc;
     if (!z0 || !disc_pow || !prev_mean || !t0 || !action) return fail(TDMPC2_ERR_INVALID, "null argument");
@@ -1835,6 +1862,10 @@ int run_impl(tdmpc2_plan *h, int n_envs, const float *z0, const float *task_emb,
                  (c.num_pi_trajs > 0 && !tape->pi_traj_eps) || (!eval_mode && !tape->final_eps)))
         return fail(TDMPC2_ERR_INVALID, "noise tape has null fields");
     hipStream_t st = (hipStream_t)stream;
+    struct SafeOnce {  // TDMPC2_TUNE_SAFE_ONCE covers exactly this plan
+        tdmpc2_plan *h;
+        ~SafeOnce() { if (h->safe_once) { h->safe_once = false; apply_modes(h); } }
+    } once{h};
     if (h->lay.on) {
         if ((rc = fault_fresh(h, st))) return rc;
         return lay_run(h, st, n_envs, z0, task_emb, act_mask, disc_pow, prev_mean, t0, eval_mode, tape, seed, action, dbg);

@@ -134,9 +134,6 @@ def sharded_plan(backend, z0, disc_pow, prev_mean, t0, eval_mode: bool = False, 
     call0 = None
     if can_fault:
         backend.take_fault()  # a fault left over from an EARLIER call (its caller had its chance) must not cost this plan a re-plan
-    # what the caller had asked for (NativePlanner tracks explicit settings; defaults: both paths on) -- restored after a re-plan,
-    # so that the retry's "no inter-workgroup waits" is a property of the retry, not of the rest of the process
-    asked = (getattr(backend, "tuned_cluster", 2), getattr(backend, "tuned_fuse_ln", 1))
     for attempt in range(2):
         if world > 1 and tape is None:
             _agree_on_stream(backend, seed, z0.device, group)
@@ -166,13 +163,14 @@ def sharded_plan(backend, z0, disc_pow, prev_mean, t0, eval_mode: bool = False, 
         if world > 1:
             dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
         if not int(bad.item()) or attempt == 1:
-            if attempt == 1 and hasattr(backend, "set_cluster"):  # back to the caller's settings (the library's own re-arm logic
-                backend.set_cluster(asked[0])                       # keeps a rank that really faulted on the safe paths for a while)
-                backend.set_fuse_ln(asked[1])
             break
+        # The retry is a property of the retry: TDMPC2_TUNE_SAFE_ONCE covers exactly the next shard_begin .. last shard_refit and
+        # touches neither the caller's CLUSTER / FUSE_LN settings (explicit or from the environment) nor the handle's own
+        # downgrade / re-arm bookkeeping -- a rank that really faulted stays on the safe paths for `rearm_after` calls, with the
+        # library's back-off, instead of running into the same wait on every step.
         backend.last_shard_retries += 1
-        backend.set_fuse_ln(0)
-        backend.set_cluster(0)
+        if hasattr(backend, "plan_safely_once"):
+            backend.plan_safely_once(True)
         prev_mean.copy_(prev_in)
         if call0 is not None:
             backend.set_call_counter(call0)

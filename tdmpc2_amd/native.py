@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("TDMPC2_PLAN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtdmpc2_plan.so")
 _lib = None
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # every symbol include/tdmpc2_plan.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
@@ -383,6 +383,11 @@ class NativePlanner:
         self._check(self.lib.tdmpc2_plan_fault_info(self._h, C.byref(fi)))
         return {k: getattr(fi, k) for k, _ in FaultInfo._fields_ if k != "reserved"}
 
+    def plan_safely_once(self, on: bool = True):
+        """TDMPC2_TUNE_SAFE_ONCE: the next whole plan (plan(), or shard_begin .. the last shard_refit) runs on the paths without
+        inter-workgroup waits; the settings asked for, the downgrade state and the re-arm counter stay as they are."""
+        self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 5, int(bool(on))))
+
     def set_rearm_after(self, clean_calls: int):
         """TDMPC2_TUNE_REARM_AFTER: clean calls after which a handle downgraded by a reported wait returns to the fast paths (0: never)."""
         self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 4, int(clean_calls)))
@@ -630,13 +635,11 @@ class NativePlanner:
         0 never, 1 whenever all of a call's clusters fit the chip at once, 2 (default) = 1 plus, for a single non-episodic plan,
         a second cluster per tile that runs the reward chain beside the dynamics chain (cluster2_kernels.cuh)."""
         self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 2, int(mode)))
-        self.tuned_cluster = int(mode)
 
     def set_fuse_ln(self, on):
         """Layered family, split arithmetic: LayerNorm + Mish / SimNorm + operand split inside the GEMM epilogue (1, default)
         or as a row kernel over fp32 pre-activations (0)."""
         self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 3, int(bool(on))))
-        self.tuned_fuse_ln = int(bool(on))
 
     def set_profiling(self, max_launches: int):
         """Bracket up to `max_launches` rollout-kernel launches with HIP events (0 = off)."""

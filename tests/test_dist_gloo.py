@@ -199,21 +199,32 @@ def test_plan_sharded_over_two_ranks_is_bit_identical_to_one_rank(tmp_path):
 
 class FaultyShardBackend(OracleShardBackend):
     """The stand-in with NativePlanner's fault interface: on `faulty_rank` the first attempt's value slice is garbage (what a
-    bounded inter-workgroup wait that gave up leaves behind) and take_fault() reports it once; set_fuse_ln(0) -- which
-    sharded_plan calls on EVERY rank before it re-plans -- switches to the kernels that cannot fault."""
+    bounded inter-workgroup wait that gave up leaves behind) and take_fault() reports it once; plan_safely_once() -- which
+    sharded_plan calls on EVERY rank before it re-plans (TDMPC2_TUNE_SAFE_ONCE) -- puts exactly the next plan on the kernels that
+    cannot fault and leaves the settings asked for (`fused`) alone."""
 
     def __init__(self, case, faulty):
         super().__init__(case)
         self.faulty, self.fused, self.pending, self.counter, self.log = faulty, True, 0, 7, []
+        self.safe_once, self.setter_calls = False, 0
 
     def shard_begin(self, *a, **kw):
-        self.log.append(("begin", self.counter, self.fused))
+        self.log.append(("begin", self.counter, self.fused and not self.safe_once))
         self.counter += 1
         return super().shard_begin(*a, **kw)
 
+    def shard_refit(self, it, *a, **kw):
+        out = super().shard_refit(it, *a, **kw)
+        if it == self.iterations - 1:
+            self.safe_once = False  # the library drops the flag when the plan it covered has been enqueued
+        return out
+
+    def plan_safely_once(self, on=True):
+        self.safe_once = bool(on)
+
     def shard_values(self, it, r0, r1, z0, disc_pow, value, **kw):
         super().shard_values(it, r0, r1, z0, disc_pow, value, **kw)
-        if self.faulty and self.fused and it == 1:
+        if self.faulty and self.fused and not self.safe_once and it == 1:
             value[0, r0:r1] = 123.0
             self.pending += 1
 
@@ -227,11 +238,12 @@ class FaultyShardBackend(OracleShardBackend):
     def set_call_counter(self, v):
         self.counter = int(v)
 
-    def set_fuse_ln(self, on):
+    def set_fuse_ln(self, on):  # the caller's settings: sharded_plan must not touch them
         self.fused = bool(on)
+        self.setter_calls += 1
 
     def set_cluster(self, mode):
-        pass
+        self.setter_calls += 1
 
 
 def _fault_worker(rank, world, port, out_dir):
@@ -248,7 +260,8 @@ def _fault_worker(rank, world, port, out_dir):
         tape = {k: v[:1] for k, v in c["tape"].items()}
         a = sharded_plan(be, torch.as_tensor(c["z0"][:1]), None, prev, torch.tensor([0], dtype=torch.uint8), tape=tape, seed=3)
         torch.save({"action": a, "prev_mean": prev, "retries": torch.tensor(be.last_shard_retries),
-                    "log": be.log, "fused": be.fused}, os.path.join(out_dir, f"fault{rank}.pt"))
+                    "log": be.log, "fused": be.fused, "setter_calls": be.setter_calls, "safe_once": be.safe_once},
+                   os.path.join(out_dir, f"fault{rank}.pt"))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -265,9 +278,10 @@ def test_a_fault_on_one_rank_makes_every_rank_replan_once(tmp_path):
     r0 = torch.load(tmp_path / "fault0.pt", weights_only=False)
     r1 = torch.load(tmp_path / "fault1.pt", weights_only=False)
     assert int(r0["retries"]) == 1 and int(r1["retries"]) == 1
-    # after the re-plan both ranks are back on what the caller had asked for (the retry's safe kernels are a property of the
-    # retry; a rank that really faulted stays downgraded inside the library until it re-arms: DESIGN 8)
-    assert r0["fused"] and r1["fused"]
+    # the retry's safe kernels are a property of the retry (TDMPC2_TUNE_SAFE_ONCE): the caller-facing tuning keys were never
+    # touched, the flag is gone afterwards; a rank that really faulted stays downgraded inside the library until it re-arms
+    assert r0["fused"] and r1["fused"] and r0["setter_calls"] == 0 and r1["setter_calls"] == 0
+    assert not r0["safe_once"] and not r1["safe_once"]
     # two attempts on each rank, the second with the first one's call counter and the safe kernels
     for r in (r0, r1):
         assert [e[0] for e in r["log"]] == ["begin", "begin"]
