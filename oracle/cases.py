@@ -44,6 +44,10 @@ CASES = {
     # fatter pins of the large models: the benched c4 leg runs 6 CEM iterations, "c4" pins two of them
     "c3_x4": ("c3", {}, 4, False, 0.03),                # mt30 48M, four plans (tasks 3, 10, 17, 24), 6 iterations
     "c4_x2": ("c4", {}, 2, False, 0.02),                # mt80 317M, two plans x the full 6 iterations, H5 N1024
+    # the two model sizes the reference ships checkpoints for that had no fixture (VERDICT r4 missing #2)
+    "m19_mt80": ("m19_mt80", {}, 2, False, 0.04),       # 19M: L768 M1024 T96 nq5, 6 iterations
+    "m19_mt30": ("m19_mt30", {}, 2, False, 0.04),       # 19M as mt30 ships it: L512 M1024 T64
+    "m1_mt30": ("m1_mt30", {}, 3, False, 0.06),         # 1M: L128 M384 nq2 T96, full length (6 iterations, three plans)
 }
 
 
@@ -54,7 +58,7 @@ def build_case(name: str):
 
 def build_custom(cfg, E: int, eval_mode: bool = False, head_std: float = 0.06, name: str = "", t0=None):
     """A case from an arbitrary config (edge-case tests build these on the fly; no golden fixture)."""
-    if cfg.multitask and name in ("tiny_mt", "small_mt", "c3", "c4", "c4_l1024", "c3_x4", "c4_x2"):
+    if cfg.multitask and name in ("tiny_mt", "small_mt", "c3", "c4", "c4_l1024", "c3_x4", "c4_x2", "m19_mt80", "m19_mt30", "m1_mt30"):
         # heterogeneous action dims / episode lengths to exercise masks and per-task discounts
         n = len(cfg.tasks)
         cfg.action_dims = [cfg.action_dim - (i % 3) for i in range(n)]

@@ -140,6 +140,12 @@ def named_config(name: str, **overrides) -> Config:
         for k, v in overrides.items():
             setattr(cfg, k, v)
         return cfg
+    elif name == "m19_mt80":  # the 19M multitask checkpoint class (common/__init__.py:11-14): L768 M1024 T96
+        cfg = Config(task="mt80", model_size=19, action_dim=6, obs_shape={"state": (39,)}, episode_length=500)
+    elif name == "m19_mt30":  # mt30's 19M checkpoint is "slightly smaller" (parser.py:67-68): L512 M1024 T64
+        cfg = Config(task="mt30", model_size=19, action_dim=6, obs_shape={"state": (24,)}, episode_length=500)
+    elif name == "m1_mt30":  # the 1M multitask class: L128 M384 nq2, task_dim 96 (parser.py:75)
+        cfg = Config(task="mt30", model_size=1, action_dim=6, obs_shape={"state": (24,)}, episode_length=500)
     elif name == "small":  # small dims on the layered kernel family's tiling (num_samples % 128 == 0, dims % 32 == 0)
         cfg = Config(task="walker-run", model_size=None, latent_dim=64, mlp_dim=96, enc_dim=32, num_q=3,
                      action_dim=5, obs_shape={"state": (11,)}, num_samples=128, num_elites=16, num_pi_trajs=8,

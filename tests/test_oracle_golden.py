@@ -1,6 +1,8 @@
 """Pins the oracle (oracle/planner_oracle.py) against outputs of the
 reference's own planner code (tests/golden/*.npz, made by oracle/make_golden.py
 from /root/reference run verbatim).  CPU only."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -58,7 +60,7 @@ def test_oracle_encode_matches_reference(name):
         np.testing.assert_allclose(z, g["encode_z"][e], atol=1e-6, rtol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["tiny", "small", "c1", "c1_wide", "tiny_mt", "small_mt", "mt5", "c3"])
+@pytest.mark.parametrize("name", ["tiny", "small", "c1", "c1_wide", "tiny_mt", "small_mt", "mt5", "c3", "m19_mt80", "m1_mt30"])
 def test_oracle_td_target_matches_reference(name):
     """oracle.td_target (restating tdmpc2.py:239-254) vs the fixture minted by the reference's own `_td_target`
     (multitask cases: one task per batch column, per-task discounts)."""
@@ -137,3 +139,24 @@ def test_refit_hand_computed():
     s = np.sqrt(w[0] * (0.5 - m) ** 2 + w[1] * (-0.5 - m) ** 2)
     assert abs(mean.item() - m) < 1e-6 and abs(std.item() - s) < 1e-6
     assert v[2].item() == 0.0
+
+
+REFERENCE_ROOT = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE_ROOT, "tdmpc2")), reason="the reference tree is not on this machine (GPU box)")
+@pytest.mark.parametrize("name", ["tiny_mt", "small_ep_fire"])
+def test_committed_golden_is_what_the_reference_produces_today(name, tmp_path, monkeypatch):
+    """The pin checks itself: where /root/reference exists (the build container), re-run `oracle.make_golden` -- the reference's
+    own `_plan`, `encode` and `_td_target` run verbatim -- for a small case and assert that every array of the committed fixture
+    comes back bit for bit.  A fixture that was edited by hand, or made from a different reference / input recipe, fails here."""
+    from oracle import make_golden
+
+    monkeypatch.setattr(make_golden, "GOLDEN_DIR", str(tmp_path))
+    make_golden.generate(name)
+    fresh = np.load(tmp_path / f"{name}.npz")
+    g = load_golden(name)
+    assert sorted(fresh.files) == sorted(g.keys() if hasattr(g, "keys") else g.files)
+    for k in fresh.files:
+        assert fresh[k].dtype == g[k].dtype and fresh[k].shape == g[k].shape, k
+        assert np.array_equal(fresh[k], g[k], equal_nan=True), f"{name}.{k}: the committed fixture is not the reference's output"
