@@ -305,6 +305,35 @@ def run_reference_plan(cfg, state_dict, *, obs=None, z0=None, tape, prev_mean, t
     return a.detach().clone(), agent._prev_mean.detach().clone(), stages
 
 
+def time_reference_plan(cfg, state_dict, *, z0, tape, task, discount, iterations, budget_s=6.0, min_plans=3):
+    """Wall time per call of the reference's `_plan` run verbatim (no line tracer, the agent built once, the recorded noise
+    replayed per call) -- bench.py's measured `port_vs_reference` when the reference tree is on the machine.
+    Returns (ms per plan, plans timed)."""
+    import time
+
+    agent = build_agent(cfg, state_dict, discount)
+    cfg_run = copy.copy(cfg)
+    cfg_run.iterations = iterations
+    agent.cfg = cfg_run
+    agent.model.cfg = cfg_run
+    zz = torch.as_tensor(z0).reshape(1, -1).clone()
+    agent.model.encode = lambda o, tk: zz
+    obs = torch.zeros(1, 1)
+    task_t = None if task is None else torch.tensor([task])
+
+    def one(t0):
+        with TapePlayer(cfg_run, tape, iterations, False):
+            with torch.no_grad():
+                agent._plan(obs, t0=t0, eval_mode=False, task=task_t)
+
+    one(True)
+    n, t_start = 0, time.perf_counter()
+    while n < min_plans or time.perf_counter() - t_start < budget_s:
+        one(False)
+        n += 1
+    return 1e3 * (time.perf_counter() - t_start) / n, n
+
+
 def ref_plan_function():
     ref = _import_reference()
     f = ref.TDMPC2._plan
