@@ -334,9 +334,14 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
  * key TDMPC2_TUNE_SAFE_ONCE (ABI 8): 1 = the NEXT whole plan on this handle (tdmpc2_plan_run / run_obs, or shard_begin .. the last
  * shard_refit) runs on the paths without inter-workgroup waits, whatever CLUSTER / FUSE_LN say; the caller's settings, the
  * downgrade state and the re-arm counter are not touched and the flag clears itself when that plan has been enqueued (the
- * re-plan of a sharded plan after a reported wait: dist.sharded_plan). */
+ * re-plan of a sharded plan after a reported wait: dist.sharded_plan).
+ * key TDMPC2_TUNE_KSPLIT (ABI 8; layered family, f16x2-split arithmetic): 1 (default) = the 256 x 256 output tiles of a GEMM's
+ * last, partly filled round of the chip are each computed by 2-4 workgroups over disjoint K ranges whose partial sums are added
+ * in a fixed order (tdmpc2_amd/csrc/layered_wide.cuh, tile_order.h: gemm_w_order) -- same values to fp32 round-off, but a plan's
+ * bits then depend on how many plans share the call; 0 = every tile whole: a plan computes the same bits alone, in any batch and
+ * with its rows split over ranks. */
 enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0, TDMPC2_TUNE_FOLD_REFIT = 1, TDMPC2_TUNE_CLUSTER = 2, TDMPC2_TUNE_FUSE_LN = 3,
-                     TDMPC2_TUNE_REARM_AFTER = 4, TDMPC2_TUNE_SAFE_ONCE = 5 };
+                     TDMPC2_TUNE_REARM_AFTER = 4, TDMPC2_TUNE_SAFE_ONCE = 5, TDMPC2_TUNE_KSPLIT = 6 };
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
 
 /* Fault report of the paths whose workgroups wait for each other: the cluster path (TDMPC2_TUNE_CLUSTER) and the NormedLinear

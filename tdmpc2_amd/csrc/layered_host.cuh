@@ -17,11 +17,11 @@ struct LnFuse {
 // and the launch gaps of one chain hide behind the other's kernels.  PRE: fp32 pre-activations of a NormedLinear whose
 // epilogue is NOT fused (split arithmetic: the operand buffers are fragment-packed, so the LayerNorm kernel cannot work in place).
 struct LayBufs {
-    float *HA, *HB, *LG, *stats, *PRE;
+    float *HA, *HB, *LG, *stats, *PRE, *ksws;
 };
 inline LayBufs lay_bufs(const tdmpc2_plan *h, int set) {
     const Layered &L = h->lay;
-    return set == 0 ? LayBufs{L.HA, L.HB, L.LG, L.stats, L.PRE} : LayBufs{L.HA2, L.HB2, L.LG2, L.stats2, L.PRE2};
+    return set == 0 ? LayBufs{L.HA, L.HB, L.LG, L.stats, L.PRE, L.ksws} : LayBufs{L.HA2, L.HB2, L.LG2, L.stats2, L.PRE2, L.ksws2};
 }
 
 // The arrival counters of the fused launches of one stage: a fresh slice per launch, ALL counters handed out so far zeroed at
@@ -112,16 +112,33 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         constexpr int NT = 8;
         const int ncb256 = (ly.CT + NT - 1) / NT;
         const size_t stats_need = rows_p * ((ly.CT + 3) / 4) * 2;
-        if (can_fuse && ly.CT >= 8 && rows_p % 256 == 0 && rows_per_env % 256 == 0 && ncb256 <= 32 && !L.row_env && stats_need <= L.stats_cap &&
-            (long)(rows_p / 256) * ncb256 >= w256_min && w256_min >= 0 &&
-            L.arrive_off + rows_p / 256 <= L.arrive_cap /* out of arrival counters: the narrow tiles below degrade to the unfused LayerNorm */) {
-            const int nrowblk = (int)(rows_p / 256);
+        // K-split tail (tile_order.h: gemm_w_order): tiles of the launch's last, partly filled round are computed by `parts`
+        // workgroups each.  That makes the wide tile worth taking from fewer tiles on (a 180-tile SimNorm layer: 720 workgroups)
+        const int nrowblk_w = (int)(rows_p / 256);
+        const long cus_x = cus >= 8 ? cus / 8 : 1;
+        static const long ks_min = getenv("TDMPC2_GEMM_W_SPLIT_MIN") ? atol(getenv("TDMPC2_GEMM_W_SPLIT_MIN")) : 192;
+        static const int ks_maxp = getenv("TDMPC2_GEMM_W_SPLIT_MAX") ? atoi(getenv("TDMPC2_GEMM_W_SPLIT_MAX")) : 4;
+        static const int ks_ovh = getenv("TDMPC2_GEMM_W_SPLIT_OVH") ? atoi(getenv("TDMPC2_GEMM_W_SPLIT_OVH")) : 12000;
+        GemmWOrder wo{};
+        wo.parts = 1;
+        const bool w_shape = can_fuse && ly.CT >= 8 && rows_p % 256 == 0 && rows_per_env % 256 == 0 && ncb256 <= 32 && !L.row_env &&
+                             stats_need <= L.stats_cap && w256_min >= 0;
+        if (w_shape && L.ksplit && bufs->ksws && ks_maxp > 1) {
+            const int nk = q.K / 16;
+            wo = gemm_w_order(nrowblk_w, ncb256, (int)cus_x, nk, ks_maxp, ks_ovh / (nk + 25));
+            if (wo.parts > 1 && ((size_t)8 * wo.max_tail * wo.parts > L.ksws_slots || (long)wo.nblk < ks_min)) wo.parts = 1;
+        }
+        const size_t n_arrive = (size_t)nrowblk_w + (wo.parts > 1 ? (size_t)8 * wo.max_tail : 0);
+        if (w_shape && ((long)nrowblk_w * ncb256 >= w256_min || wo.parts > 1) &&
+            L.arrive_off + n_arrive <= L.arrive_cap /* out of arrival counters: the narrow tiles below degrade to the unfused LayerNorm */) {
+            const int nrowblk = nrowblk_w;
             q.ncolblk = ncb256;
             q.ln_g = ly.g; q.ln_b = ly.b; q.gb_sel_stride = sel ? ln->gb_sel_stride : 0;
             q.ascale = ly.ascale; q.asc_sel_stride = sel ? (long)(3 * sizeof(LayerScal) / sizeof(float)) : 0;
             q.width = ln->width; q.stats = bufs->stats; q.arrive = L.arrive + L.arrive_off; q.err = h->cl_err_dev; q.fault = h->cl_fault;
-            L.arrive_off += (size_t)nrowblk;
+            L.arrive_off += n_arrive;
             q.out = out; q.KBo = ldo / 16;
+            q.ks_parts = wo.parts; q.ks_full = wo.full; q.ks_max_tail = wo.max_tail; q.ks_ws = bufs->ksws; q.ks_cnt = q.arrive + nrowblk;
             // tile order: XCD-local row blocks keep the column blocks of a row block -- which wait for each other -- on consecutive
             // slots of ONE XCD (with one workgroup per CU and <= 16 column blocks two launches in flight cannot starve each other:
             // 2 x 15 waiting workgroups < 32 CUs), and read every A row through one L2
@@ -136,7 +153,7 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             q.xcd_rows = ord.xcd_rows; q.ncol_grid = ord.ncol_grid; q.nrowblk = nrowblk;
             q.timing = L.gw_timing ? L.gw_timing + (q.K >= 1024 ? 8 : 0) + (ln->act ? 16 : 0) : nullptr;  // [Mish K < 1024 | Mish K >= 1024 | SimNorm ...]
             const int epi = 1 + ln->act;
-#define GEMM_W_LAUNCH(K) hipLaunchKernelGGL(K, dim3(ord.nblk), dim3(512), 0, st, q)
+#define GEMM_W_LAUNCH(K) hipLaunchKernelGGL(K, dim3(wo.parts > 1 ? wo.nblk : ord.nblk), dim3(512), 0, st, q)
             if (epi == 1) GEMM_W_LAUNCH((g_gemm_w<1>));
             else GEMM_W_LAUNCH((g_gemm_w<2>));
 #undef GEMM_W_LAUNCH

@@ -50,6 +50,10 @@ struct GemmSParams {
     int fault;                 // test hook (TDMPC2_CLUSTER_FAULT at create): column block 0 of row block 0 never arrives
     // EPI != 0: the tile order (tile_order.h: gemm_s_order / gemm_s_tile)
     int xcd_rows, nrowblk, ncol_grid;
+    // g_gemm_w with a K-split tail (tile_order.h: gemm_w_order / gemm_w_tile); ks_parts <= 1: off, the order above applies
+    int ks_parts, ks_full, ks_max_tail;
+    float *ks_ws;              // [split tile slot][part][32 chunks][512 threads][4]: partial accumulators in register order
+    unsigned int *ks_cnt;      // [split tile slot] arrival tickets of this launch (zero on entry)
     unsigned long long *timing;  // g_gemm_w profiling builds (-DGW_TIMING), else null
     TwoHotParams th;             // EPI = 3: what the two-hot value of a row goes into (lg / ld unused: the logits stay in LDS)
 };

@@ -38,6 +38,14 @@ __device__ __forceinline__ void gw_glds(const char *g, char *l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
 #define GW_MFMA(ACC, WF, AF) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(WF), "v"(AF))
+// partial accumulators of a K-split tile: write-through (sc1) 16-byte stores, L1-bypassing (sc1) 16-byte loads -- the guide's
+// "16-B sc1 stores + drained vmcnt + flag, sc1 loads on the reader" hand-off (MI355X_MICROARCH.md, valid forms; publish-large)
+__device__ __forceinline__ void gw_st_sc1(float *p, const f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void gw_ld_sc1(f32x4 &v, const float *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+}
 
 // In-kernel phase clocks of wave 0 (profiling builds only: -DGW_TIMING; TDMPC2_GW_TIMING=1 makes the host allocate and print
 // them): cycles from kernel start to [1] end of the main loop, [2] statistics stored, [3] peers arrived, [4] row statistics,
@@ -152,6 +160,59 @@ __device__ __forceinline__ void gw_phase(f32x16 (&acc)[2][4], GwFrags (&fr)[2], 
     }
 }
 
+// The last arriver of a K-split tile: acc <- partial 0 + partial 1 + ... in PART ORDER (its own partial, index PART, from the
+// registers it is in; the others from the workspace, `ws` = the tile's slot + tid * 4 floats).  P and PART are template
+// parameters so that every register index and every branch is static (a run-time part index costs selects, zero-initialised
+// load destinations under uniform branches -- and, measured, 527 spilled registers).
+template <int P, int PART>
+__device__ __forceinline__ void gw_reduce(f32x16 (&acc)[2][4], const float *ws) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            f32x4 L[3][4];  // [other part o = 0 .. P - 2][chunk j]: 4 (P - 1) loads of 16 bytes in flight per lane
+#pragma unroll
+            for (int o = 0; o < P - 1; ++o)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    gw_ld_sc1(L[o][j], ws + (size_t)(o < PART ? o : o + 1) * 65536 + ((n * 4 + rt) * 4 + j) * 2048);
+            // the wait names its loads' destinations: nothing that reads them can be scheduled above it
+            if constexpr (P == 2)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(L[0][0]), "+v"(L[0][1]), "+v"(L[0][2]), "+v"(L[0][3])::"memory");
+            else if constexpr (P == 3)
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(L[0][0]), "+v"(L[0][1]), "+v"(L[0][2]), "+v"(L[0][3]), "+v"(L[1][0]), "+v"(L[1][1]), "+v"(L[1][2]), "+v"(L[1][3])::"memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(L[0][0]), "+v"(L[0][1]), "+v"(L[0][2]), "+v"(L[0][3]), "+v"(L[1][0]), "+v"(L[1][1]), "+v"(L[1][2]), "+v"(L[1][3]),
+                               "+v"(L[2][0]), "+v"(L[2][1]), "+v"(L[2][2]), "+v"(L[2][3])::"memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sum = PART == 0 ? acc[n][rt][4 * j + r] : L[0][j][r];
+#pragma unroll
+                    for (int q = 1; q < P; ++q) sum = __fadd_rn(sum, q == PART ? acc[n][rt][4 * j + r] : L[q < PART ? q : q - 1][j][r]);
+                    acc[n][rt][4 * j + r] = sum;
+                }
+        }
+}
+__device__ __forceinline__ void gw_reduce_any(f32x16 (&acc)[2][4], const float *ws, int P, int part) {
+    if (P == 2) {
+        if (part == 0) gw_reduce<2, 0>(acc, ws);
+        else gw_reduce<2, 1>(acc, ws);
+    } else if (P == 3) {
+        if (part == 0) gw_reduce<3, 0>(acc, ws);
+        else if (part == 1) gw_reduce<3, 1>(acc, ws);
+        else gw_reduce<3, 2>(acc, ws);
+    } else {
+        if (part == 0) gw_reduce<4, 0>(acc, ws);
+        else if (part == 1) gw_reduce<4, 1>(acc, ws);
+        else if (part == 2) gw_reduce<4, 2>(acc, ws);
+        else gw_reduce<4, 3>(acc, ws);
+    }
+}
+
 // EPI = 1: LayerNorm + Mish, 2: LayerNorm + SimNorm(8).  Grid / tile order: tile_order.h with 256-row blocks.
 template <int EPI>
 __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
@@ -162,11 +223,18 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;  // this wave's accumulators: row tiles 4 wr .. + 3, column tiles 2 wc, 2 wc + 1
-    int rb, cb;
-    if (!gemm_s_tile(blockIdx.x, p.nrowblk, p.ncolblk, p.xcd_rows, p.ncol_grid, rb, cb)) return;
+    int rb, cb, part = 0, slot = -1;
+    if (p.ks_parts > 1) {
+        if (!gemm_w_tile(blockIdx.x, p.nrowblk, p.ncolblk, p.ks_full, p.ks_parts, p.ks_max_tail, rb, cb, part, slot)) return;
+    } else if (!gemm_s_tile(blockIdx.x, p.nrowblk, p.ncolblk, p.xcd_rows, p.ncol_grid, rb, cb)) {
+        return;
+    }
     const int row0 = rb * TM;
     const int sel = p.sel ? p.sel[(size_t)(row0 / p.rows_per_env) * p.sel_stride] : 0;
-    const int nk = p.K / 16;
+    // this workgroup's k16-slabs: all of them, or -- a tile of the launch's last, partly filled round -- part `part` of ks_parts
+    const int nk_all = p.K / 16;
+    const int ks0 = slot >= 0 ? part * nk_all / p.ks_parts : 0;
+    const int nk = slot >= 0 ? (part + 1) * nk_all / p.ks_parts - ks0 : nk_all;
     // the epilogue's vectors: in flight behind the prologue's DMA requests (one env per 256-row block: rows_per_env % 256 == 0)
     float vb = 0.f, vg = 0.f, vbe = 0.f;
     if (tid < 256) {
@@ -181,8 +249,8 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
     }
     // DMA role of this wave: row tile `wave` of A and column tile `wave` of W (a column tile past the matrix re-reads the last one)
     const int ctl = cb * 8 + wave < p.CT ? cb * 8 + wave : p.CT - 1;
-    const char *pa = reinterpret_cast<const char *>(p.A) + ((size_t)((row0 >> 5) + wave) * p.KBa + p.a_kb0) * 2048;
-    const char *pw = reinterpret_cast<const char *>(p.wp + (size_t)sel * p.w_sel_stride) + ((size_t)ctl * (p.kbs ? p.kbs : nk) + p.kb0) * 2048;
+    const char *pa = reinterpret_cast<const char *>(p.A) + ((size_t)((row0 >> 5) + wave) * p.KBa + p.a_kb0 + ks0) * 2048;
+    const char *pw = reinterpret_cast<const char *>(p.wp + (size_t)sel * p.w_sel_stride) + ((size_t)ctl * (p.kbs ? p.kbs : nk_all) + p.kb0 + ks0) * 2048;
     unsigned voff = (unsigned)lane * 16u;
     asm volatile("" : "+v"(voff));
     char *ring_w = ring + wave * 2048;
@@ -247,6 +315,38 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
 #undef GW_STEADY
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // XDL write -> VALU read of the accumulators
     GW_T(1)
+
+    // ---------------------------------------------------------------- K-split tile: partial sums meet in the workspace
+    // Every part stores its accumulators in register order (chunk c = ((n 4 + rt) 4 + j): 512 threads x 16 bytes = 8 KiB,
+    // 1 KiB contiguous per wave instruction) with write-through stores, drains them, and takes a ticket; the part that draws the
+    // last one adds the partials IN PART ORDER -- its own from registers -- and carries on into the epilogue as if it had run the
+    // whole contraction.  Nobody waits: the others leave.  The sum differs from the unsplit tile's in the last bits (fp32
+    // association), by less than the f16x2 split's own error; TDMPC2_TUNE_KSPLIT = 0 keeps every tile whole.
+    if (slot >= 0) {
+        const int P = p.ks_parts;
+        float *ws = p.ks_ws + (size_t)slot * P * 65536 + tid * 4;
+        {
+            float *mine = ws + (size_t)part * 65536;
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[n][rt][4 * j + r];
+                        gw_st_sc1(mine + ((n * 4 + rt) * 4 + j) * 2048, v);
+                    }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave's stores are acknowledged (and every wave is done with the ring)
+        int *flag = reinterpret_cast<int *>(ring);
+        if (tid == 0) *flag = (int)__hip_atomic_fetch_add(p.ks_cnt + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != P - 1) return;
+        gw_reduce_any(acc, ws, P, part);
+    }
 
     // ---------------------------------------------------------------- NormedLinear epilogue (the protocol of g_gemm_s<.., EPI>)
     const int i32 = lane & 31, hh = lane >> 5;

@@ -870,6 +870,18 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             }
             L.fuse_ln = true;
             if (const char *fl = getenv("TDMPC2_FUSE_LN")) L.fuse_ln = atoi(fl) != 0;
+            // g_gemm_w's K-split tail: 256 KiB per (split tile, part); at most 32 tail tiles per XCD x 4 parts, or all the tiles
+            // of the handle's largest call (one workspace per chain)
+            if (const char *ks = getenv("TDMPC2_KSPLIT")) L.ksplit = atoi(ks) != 0;
+            if (Rp % 256 == 0 && maxct >= 8) {
+                const size_t tiles = (Rp / 256) * ((maxct + 7) / 8);
+                L.ksws_slots = std::min<size_t>(8 * 32 * 4, tiles * 4);
+                if ((rc = dev_alloc(h, (void **)&L.ksws, L.ksws_slots * 65536 * 4)) ||
+                    (L.side && (rc = dev_alloc(h, (void **)&L.ksws2, L.ksws_slots * 65536 * 4)))) {
+                    tdmpc2_plan_destroy(h);
+                    return rc;
+                }
+            }
             // fp32 pre-activations of the NormedLinear layers whose epilogue is not fused (the fallback after a reported wait,
             // TDMPC2_TUNE_FUSE_LN = 0, tiles the fused path does not take): one buffer per chain
             if (getenv("TDMPC2_GW_TIMING")) {
@@ -1799,6 +1811,11 @@ int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value) {
         if (value < 0 || value > 1) return fail(TDMPC2_ERR_INVALID, "safe_once must be 0 or 1");
         h->safe_once = value != 0;
         apply_modes(h);
+        return TDMPC2_OK;
+    }
+    if (key == TDMPC2_TUNE_KSPLIT) {
+        if (value < 0 || value > 1) return fail(TDMPC2_ERR_INVALID, "ksplit must be 0 or 1");
+        h->lay.ksplit = value != 0;
         return TDMPC2_OK;
     }
     if (key == TDMPC2_TUNE_FOLD_REFIT) {

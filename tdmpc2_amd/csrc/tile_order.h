@@ -59,3 +59,75 @@ __host__ __device__ inline bool gemm_s_tile(int b, int nrowblk, int ncolblk, int
     cb = b - rb * ncg;
     return cb < ncolblk;
 }
+
+// ---------------------------------------------------------------- g_gemm_w with a K-split tail (round 5)
+// 256 x 256 tiles on one workgroup per CU quantise badly: the 48M model's hidden layers are 60 x 7 = 420 tiles on 256 CUs,
+// 1.64 rounds paid as 2 (as 4 for the two chains of a stage).  The cure is a finer grain for the LAST, partly filled round only:
+// per XCD the first `full` tiles of its list (whole rounds of its CUs) are computed as before, every remaining tile is split
+// along K into `parts` workgroups whose partial accumulators meet in an L2 / Infinity-Cache workspace; the part that arrives
+// last adds them IN PART ORDER and runs the tile's NormedLinear epilogue (layered_wide.cuh).  Lists: XCD x owns the row blocks
+// x, x + 8, ... below 8 q (q = nrowblk / 8) -- the XCD-local order of gemm_s_tile: the peers of a row block consecutive on one
+// XCD --; the tiles of the nrowblk % 8 remaining row blocks are dealt out in contiguous runs, so that the lists differ by at
+// most one tile (the plain XCD-local order gives 4 XCDs a whole row block more: 56 against 49 tiles for the 48M model).
+struct GemmWOrder {
+    int parts;     // K-parts of a tail tile (1: nothing is split -- the caller then keeps the order of gemm_s_order)
+    int full;      // per XCD: tiles [0, full) of its list are whole
+    int max_tail;  // most tail tiles on any XCD (slots of the partial-sum workspace per XCD)
+    int per_xcd;   // workgroup slots per XCD = full + max_tail * parts
+    int nblk;      // 8 * per_xcd
+    int rounds1k;  // the rule's estimate of the launch's duration in 1/1000 tile times (tests / logs)
+};
+
+__host__ __device__ inline int gemm_w_list_len(int nrowblk, int ncolblk, int x) {
+    const int q = nrowblk / 8, S = (nrowblk - 8 * q) * ncolblk;
+    return q * ncolblk + (S * (x + 1) / 8 - S * x / 8);
+}
+
+// cus_per_xcd: resident workgroups per XCD (one per CU: 32); nk: k16-slabs of the contraction; max_parts <= 4;
+// ovh1k: what a split tile costs beyond its share of the slabs -- partial store, the last arriver's reads -- in 1/1000 of a
+// whole tile's time (the caller derives it from nk)
+__host__ __device__ inline GemmWOrder gemm_w_order(int nrowblk, int ncolblk, int cus_per_xcd, int nk, int max_parts, int ovh1k) {
+    GemmWOrder o;
+    const int q = nrowblk / 8, S = (nrowblk - 8 * q) * ncolblk;
+    const int n_min = q * ncolblk + S / 8, n_max = q * ncolblk + (S + 7) / 8;
+    o.full = n_min / cus_per_xcd * cus_per_xcd;
+    o.max_tail = n_max - o.full;
+    o.parts = 1;
+    int best = o.max_tail > 0 ? 1000 * ((o.max_tail + cus_per_xcd - 1) / cus_per_xcd) : 0;
+    for (int P = 2; P <= max_parts && P <= 4; ++P) {
+        if (nk / P < 8) break;  // too few slabs per part to amortise the ring's fill
+        const int c = 1000 * ((o.max_tail * P + cus_per_xcd - 1) / cus_per_xcd) / P + ovh1k;
+        if (c < best - 50) {  // at least a twentieth of a tile time better
+            best = c;
+            o.parts = P;
+        }
+    }
+    o.rounds1k = 1000 * (o.full / cus_per_xcd) + best;
+    o.per_xcd = o.full + o.max_tail * o.parts;
+    o.nblk = 8 * o.per_xcd;
+    return o;
+}
+
+// Block b -> (row block, column block, K-part, workspace slot of a split tile or -1); false: the block has no tile.
+__host__ __device__ inline bool gemm_w_tile(int b, int nrowblk, int ncolblk, int full, int parts, int max_tail, int &rb, int &cb, int &part,
+                                            int &slot) {
+    const int x = b & 7, t = b >> 3;
+    const int q = nrowblk / 8, S = (nrowblk - 8 * q) * ncolblk, s0 = S * x / 8;
+    const int n = q * ncolblk + (S * (x + 1) / 8 - s0);
+    int i;
+    if (t < full) {
+        i = t; part = 0; slot = -1;
+    } else {
+        const int u = t - full;
+        i = full + u / parts; part = u - (u / parts) * parts; slot = x * max_tail + (i - full);
+    }
+    if (i >= n) return false;
+    if (i < q * ncolblk) {
+        const int rbl = i / ncolblk;
+        rb = rbl * 8 + x; cb = i - rbl * ncolblk;
+    } else {
+        const int s = s0 + i - q * ncolblk;
+        rb = 8 * q + s / ncolblk; cb = s - (s / ncolblk) * ncolblk;
+    }
+    return true;
+}

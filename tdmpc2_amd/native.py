@@ -383,6 +383,11 @@ class NativePlanner:
         self._check(self.lib.tdmpc2_plan_fault_info(self._h, C.byref(fi)))
         return {k: getattr(fi, k) for k, _ in FaultInfo._fields_ if k != "reserved"}
 
+    def set_ksplit(self, on):
+        """TDMPC2_TUNE_KSPLIT: layered family -- split the 256 x 256 tiles of a GEMM's last, partly filled round along K (1,
+        default) or keep every tile whole (0: a plan's bits do not depend on the size of the call it is part of)."""
+        self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 6, int(bool(on))))
+
     def plan_safely_once(self, on: bool = True):
         """TDMPC2_TUNE_SAFE_ONCE: the next whole plan (plan(), or shard_begin .. the last shard_refit) runs on the paths without
         inter-workgroup waits; the settings asked for, the downgrade state and the re-arm counter stay as they are."""

@@ -114,6 +114,8 @@ def _two_proc_worker(rank, world, port, out_dir, name, path):
         model = po.OracleModel(cfg, {k: torch.as_tensor(v) for k, v in c["sd"].items()})
         planner = NativePlanner(cfg, c["iterations"], d, max_envs=max(E, 2), path=path)
         planner.bind_state_dict(model.sd)
+        if path == 2:
+            planner.set_ksplit(0)  # every GEMM tile whole: the bits of a row do not depend on how many rows share the call
         inp = plan_inputs(c, model)
         kw = dict(task_emb=inp["task_emb"], act_mask=inp["act_mask"])
         # (1) ONE plan, its sample rows split over the two processes; no tape: in-kernel Philox.  Rank 1's handle has planned
@@ -188,6 +190,8 @@ def test_two_processes_on_one_gpu_shard_a_plan_bit_identically(name, path, tmp_p
     c, model, _ = case_on_gpu(name, path, 2)
     planner = NativePlanner(c["cfg"], c["iterations"], dev(), max_envs=max(c["n_envs"], 2), path=path)
     planner.bind_state_dict(model.sd)
+    if path == 2:
+        planner.set_ksplit(0)
     inp = plan_inputs(c, model)
     pm = inp["prev_mean"].clone()
     stages = planner.debug_buffers(c["n_envs"])

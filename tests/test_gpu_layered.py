@@ -287,7 +287,9 @@ def test_a_plan_computes_the_same_bits_alone_and_in_a_batch_that_switches_tiles(
     statistics are combined in an order that depends on the layer only (32-column tiles -> 128-column groups -> the row, left
     to right), so the values agree BIT FOR BIT (and so do the rows of a plan split over ranks, test_gpu_dist.py).  Sixteen
     plans (224 workgroups of 256 x 256) and thirty (the benched c3 leg: 60 row blocks x 7, XCD-local tile order) run the
-    hidden layers on g_gemm_w -- the 8-wave LDS-DMA tile -- same bits again."""
+    hidden layers on g_gemm_w -- the 8-wave LDS-DMA tile -- same bits again.  The property belongs to WHOLE tiles
+    (TDMPC2_TUNE_KSPLIT = 0): with the K-split tail (the default, round 5) the tiles of a launch's last round add their partial
+    sums in a different association -- test_k_split_tail_* pins that path."""
     from oracle import cases
     from oracle import planner_oracle as po
     from tdmpc2_amd import synth
@@ -300,6 +302,7 @@ def test_a_plan_computes_the_same_bits_alone_and_in_a_batch_that_switches_tiles(
     H, N, A = cfg.horizon, cfg.num_samples, cfg.action_dim
     planner = NativePlanner(cfg, c["iterations"], dev(), max_envs=E, path=PATH_LAYERED, precision=2)
     planner.bind_state_dict(sd)
+    planner.set_ksplit(0)
     z0 = torch.as_tensor(synth.make_latents(cfg, E, seed=11)).to(dev())
     tasks = [(4 * e + 1) % len(cfg.tasks) for e in range(E)]
     embs = []
@@ -340,6 +343,7 @@ def test_a_317m_plan_computes_the_same_bits_alone_and_on_the_wide_tile():
     H, N, A = cfg.horizon, cfg.num_samples, cfg.action_dim
     planner = NativePlanner(cfg, c["iterations"], dev(), max_envs=E, path=PATH_LAYERED, precision=2)
     planner.bind_state_dict(sd)
+    planner.set_ksplit(0)  # (a single 317M plan is 64 tiles: with the K-split tail each would be four workgroups -- other bits)
     z0 = torch.as_tensor(synth.make_latents(cfg, E, seed=12)).to(dev())
     tasks = [(9 * e + 2) % len(cfg.tasks) for e in range(E)]
     embs = []
@@ -478,7 +482,7 @@ def test_graph_replay_after_a_smaller_eager_call_resets_every_arrival_counter():
         assert torch.equal(out, want) and torch.equal(pm_static, pm0) and planner.take_fault() == 0, i
 
 
-@pytest.mark.parametrize("name,E,default_stages", [("c3", 16, 1500), ("c4", 8, 300)])
+@pytest.mark.parametrize("name,E,default_stages", [("c3", 16, 1500), ("c3", 30, 600), ("c4", 8, 300)])
 def test_two_chains_in_flight_never_starve_each_other(name, E, default_stages):
     """The two chains of a layered stage run fused-epilogue GEMMs -- workgroups that wait for their row block's peers -- on two
     hardware queues at once.  Many stages back to back, with random host-side skew between the launches of the two
@@ -486,7 +490,9 @@ def test_two_chains_in_flight_never_starve_each_other(name, E, default_stages):
     block's peers on consecutive slots of one XCD; 2 x (column blocks - 1) waiting workgroups never fill an XCD's 32 CUs).
     c4: 16 column blocks, the limit of that argument (2 x 15 = 30 < 32).  (XCD rectangles -- a row block on TWO XCDs,
     TDMPC2_GEMM_W_XCD_ROWS=2, 1 % faster on c4 -- lost 3 waits in 6 300 stages of this test and are therefore not the default:
-    profiles/README.md r4za.)"""
+    profiles/README.md r4za.)  c3 at E = 30 (round 5) adds the K-split tail: 3 parts per tile of the last round, whose last
+    arriver joins the row block's wait -- and repeated stages must give the same bits (the partial sums are added in part order,
+    whoever arrives last)."""
     import os
     import random
     import time
@@ -538,4 +544,58 @@ def test_two_chains_in_flight_never_starve_each_other(name, E, default_stages):
     fi = planner.fault_info()
     print(f"[stress] {stages} stages of {name} E={E} in {time.perf_counter() - t0:.1f} s, faults {fi['faults_total']}")
     assert planner.take_fault() == 0 and fi["faults_total"] == 0 and fi["degraded"] == 0
+    planner.close()
+
+
+def _ksplit_inputs(name, E, seed=21):
+    from oracle import cases
+    from tdmpc2_amd import synth
+    from tdmpc2_amd.native import NativePlanner
+    from tests.gpu_common import dev, disc_pow
+
+    c = cases.build_case(name)
+    cfg = c["cfg"]
+    sd = {k: torch.as_tensor(v) for k, v in c["sd"].items()}
+    H, N, A = cfg.horizon, cfg.num_samples, cfg.action_dim
+    planner = NativePlanner(cfg, c["iterations"], dev(), max_envs=E, path=PATH_LAYERED, precision=2)
+    planner.bind_state_dict(sd)
+    z0 = torch.as_tensor(synth.make_latents(cfg, E, seed=seed)).to(dev())
+    tasks = [(4 * e + 1) % len(cfg.tasks) for e in range(E)]
+    embs = []
+    for t in tasks:
+        v = sd["_task_emb.weight"][t]
+        n = v.norm(2)
+        embs.append(v * (1.0 / (n + 1e-7)) if n > 1.0 else v)
+    kw = dict(task_emb=torch.stack(embs).to(dev()).contiguous(), act_mask=sd["_action_masks"][torch.tensor(tasks)].to(dev()).contiguous())
+    disc = disc_pow(cfg, [0.99] * E).to(dev())
+    g = torch.Generator().manual_seed(seed)
+    actions = ((torch.rand(E, H, N, A, generator=g) * 2 - 1) * sd["_action_masks"][torch.tensor(tasks)].view(E, 1, 1, A)).to(dev()).contiguous()
+    eps = torch.randn(E, N, A, generator=g).to(dev())
+    qidx = (torch.tensor(([[0, 4], [3, 1], [2, 0], [1, 2], [4, 3], [0, 1]] * 6)[:E], dtype=torch.int32, device=dev()) % cfg.num_q).contiguous()
+    return planner, (z0, disc, actions, eps, qidx), kw
+
+
+@pytest.mark.parametrize("name,E", [("c3", 30), ("c3", 23), ("c4", 1), ("c4", 3)])
+def test_k_split_tail_agrees_with_whole_tiles_and_is_deterministic(name, E):
+    """g_gemm_w's K-split tail (tile_order.h: gemm_w_order; layered_wide.cuh) against the same launches with every tile whole
+    (TDMPC2_TUNE_KSPLIT = 0): c3 at E = 30 is the benched leg (60 x 7 tiles: per XCD 32 whole + 20-21 tiles in 3 parts; the
+    SimNorm layer's 180 tiles in 4), E = 23 an odd shape (46 row blocks), a single 317M plan 64 tiles in 4 parts each, three plans
+    192 tiles.  The partial sums are added in part order by whichever part arrives last: the values differ from the whole tiles'
+    by fp32 association only (<= 5e-6 of max(1, |v|); the parity gate against the reference stays 1e-4, held by
+    test_benched_layered_geometry_matches_the_oracle_on_its_own_draws), and a repeated call returns the SAME bits."""
+    from tests.helpers import value_err
+
+    planner, args, kw = _ksplit_inputs(name, E)
+    v_split = planner.estimate_value(*args, **kw).clone()
+    again = planner.estimate_value(*args, **kw).clone()
+    planner.set_ksplit(0)
+    v_whole = planner.estimate_value(*args, **kw).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(v_split).all() and v_split.std() > 0
+    assert torch.equal(v_split, again), "the K-split sum must not depend on which part arrives last"
+    err = value_err(v_split.cpu().numpy(), v_whole.cpu().numpy())
+    ndiff = int((v_split != v_whole).sum())
+    print(f"[{name} E={E}] K-split tail vs whole tiles: rel err {err:.2e}, {ndiff} of {v_split.numel()} values differ in the last bits")
+    assert err < 5e-6
+    assert planner.take_fault() == 0
     planner.close()

@@ -28,6 +28,13 @@ extern "C" void order(int nrowblk, int ncolblk, int force_xcd_rows, int col_pad,
 extern "C" int tile(int b, int nrowblk, int ncolblk, int xcd_rows, int ncol_grid, int *rb, int *cb) {
     return gemm_s_tile(b, nrowblk, ncolblk, xcd_rows, ncol_grid, *rb, *cb) ? 1 : 0;
 }
+extern "C" void w_order(int nrowblk, int ncolblk, int cus_per_xcd, int nk, int max_parts, int ovh1k, int *out) {
+    const GemmWOrder o = gemm_w_order(nrowblk, ncolblk, cus_per_xcd, nk, max_parts, ovh1k);
+    out[0] = o.parts; out[1] = o.full; out[2] = o.max_tail; out[3] = o.per_xcd; out[4] = o.nblk; out[5] = o.rounds1k;
+}
+extern "C" int w_tile(int b, int nrowblk, int ncolblk, int full, int parts, int max_tail, int *rb, int *cb, int *part, int *slot) {
+    return gemm_w_tile(b, nrowblk, ncolblk, full, parts, max_tail, *rb, *cb, *part, *slot) ? 1 : 0;
+}
 """
 
 
@@ -112,3 +119,75 @@ def test_the_rule_is_the_measured_one(lib):
     assert order(lib, 60, 7, force=2)["xcd_rows"] == 1  # 7 column blocks do not split over 2 XCDs
     # the switches
     assert order(lib, 120, 7, force=0)["xcd_rows"] == 0 and order(lib, 8, 16, force=1)["xcd_rows"] == 1
+
+
+# ---------------------------------------------------------------- g_gemm_w's K-split tail (round 5)
+def w_order(lib, nrowblk, ncolblk, nk=112, cus=32, max_parts=4, ovh=88):
+    out = (ctypes.c_int * 6)()
+    lib.w_order(nrowblk, ncolblk, cus, nk, max_parts, ovh, out)
+    return dict(zip(("parts", "full", "max_tail", "per_xcd", "nblk", "rounds1k"), out))
+
+
+def w_tiles(lib, nrowblk, ncolblk, o):
+    rb, cb, part, slot = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    res = []
+    for b in range(o["nblk"]):
+        if lib.w_tile(b, nrowblk, ncolblk, o["full"], o["parts"], o["max_tail"], ctypes.byref(rb), ctypes.byref(cb), ctypes.byref(part),
+                      ctypes.byref(slot)):
+            res.append((b, rb.value, cb.value, part.value, slot.value))
+    return res
+
+
+@pytest.mark.parametrize("nrowblk,ncolblk", [(nr, nc) for nr in (1, 2, 4, 7, 8, 12, 23, 46, 60, 64, 130) for nc in (1, 3, 7, 16)])
+def test_k_split_order_covers_every_tile_with_all_its_parts(lib, nrowblk, ncolblk):
+    """gemm_w_order / gemm_w_tile: every tile is either whole (one workgroup, no workspace slot) or split into exactly `parts`
+    workgroups with part indices 0 .. parts - 1 that share ONE workspace slot, sit on ONE XCD and are consecutive in its
+    dispatch order; slots are unique per split tile and below 8 x max_tail; whole tiles come first in every XCD's order; the
+    XCDs' lists differ by at most one tile; the peers of a row block below 8 (nrowblk / 8) stay on one XCD, consecutively."""
+    for nk in (16, 50, 112, 256):
+        o = w_order(lib, nrowblk, ncolblk, nk=nk, ovh=12000 // (nk + 25))
+        t = w_tiles(lib, nrowblk, ncolblk, o)
+        by_tile = {}
+        for b, rb, cb, part, slot in t:
+            by_tile.setdefault((rb, cb), []).append((b, part, slot))
+        assert sorted(by_tile) == [(r, c) for r in range(nrowblk) for c in range(ncolblk)]
+        if o["parts"] == 1:  # nothing split: the launch keeps gemm_s_order's order (the kernel reads this one with parts > 1 only)
+            assert nk // 2 < 8 or o["max_tail"] == 0 or o["rounds1k"] % 1000 == 0
+            continue
+        slots = set()
+        per_xcd = [0] * 8
+        for (rb, cb), ws in by_tile.items():
+            xs = {b % 8 for b, _, _ in ws}
+            assert len(xs) == 1
+            per_xcd[xs.pop()] += 1
+            if len(ws) == 1 and ws[0][2] < 0:
+                assert ws[0][1] == 0 and ws[0][0] // 8 < o["full"]
+                continue
+            assert o["parts"] > 1 and sorted(p for _, p, _ in ws) == list(range(o["parts"]))
+            assert len({s for _, _, s in ws}) == 1 and 0 <= ws[0][2] < 8 * o["max_tail"] and ws[0][2] not in slots
+            slots.add(ws[0][2])
+            ts = sorted(b // 8 for b, _, _ in ws)
+            assert ts == list(range(ts[0], ts[0] + o["parts"])) and ts[0] >= o["full"]
+        assert max(per_xcd) - min(per_xcd) <= 1
+        q = nrowblk // 8
+        for rb in range(8 * q):
+            peers = sorted(b for (r, _), ws in by_tile.items() if r == rb for b, _, _ in ws)
+            assert {b % 8 for b in peers} == {rb % 8}
+
+
+def test_k_split_rule_picks_what_the_round_arithmetic_says(lib):
+    """The shapes the rule was made for: the 48M model's hidden layers at the benched E = 30 (60 x 7 tiles: per XCD 32 whole +
+    20 / 21 tail tiles -> 3 parts: 63 workgroups = two sub-rounds of a third), its SimNorm layer (60 x 3 = 180 tiles, none whole
+    -> 4 parts), one 317M plan (4 x 16 = 64 tiles -> 4 parts fill the 256 CUs), and launches that already fill their rounds
+    (317M, 8 plans: 512 tiles -> nothing split)."""
+    o = w_order(lib, 60, 7, nk=112, ovh=88)
+    assert (o["parts"], o["full"], o["max_tail"]) == (3, 32, 21) and o["nblk"] == 8 * (32 + 63)
+    assert 1600 < o["rounds1k"] < 1800  # 1 + 2/3 + overhead, against 2 rounds unsplit
+    o = w_order(lib, 60, 3, nk=112, ovh=88)
+    assert (o["parts"], o["full"]) == (4, 0)
+    o = w_order(lib, 4, 16, nk=256, ovh=43)
+    assert (o["parts"], o["full"], o["max_tail"], o["nblk"]) == (4, 0, 8, 256)
+    o = w_order(lib, 32, 16, nk=256, ovh=43)
+    assert o["parts"] == 1
+    o = w_order(lib, 60, 7, nk=2, ovh=400)  # the t = 0 first layers contract the action columns only: K = 32
+    assert o["parts"] == 1
