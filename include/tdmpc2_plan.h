@@ -335,11 +335,13 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
  * shard_refit) runs on the paths without inter-workgroup waits, whatever CLUSTER / FUSE_LN say; the caller's settings, the
  * downgrade state and the re-arm counter are not touched and the flag clears itself when that plan has been enqueued (the
  * re-plan of a sharded plan after a reported wait: dist.sharded_plan).
- * key TDMPC2_TUNE_KSPLIT (ABI 8; layered family, f16x2-split arithmetic): 1 (default) = the 256 x 256 output tiles of a GEMM's
- * last, partly filled round of the chip are each computed by 2-4 workgroups over disjoint K ranges whose partial sums are added
- * in a fixed order (tdmpc2_amd/csrc/layered_wide.cuh, tile_order.h: gemm_w_order) -- same values to fp32 round-off, but a plan's
- * bits then depend on how many plans share the call; 0 = every tile whole: a plan computes the same bits alone, in any batch and
- * with its rows split over ranks. */
+ * key TDMPC2_TUNE_KSPLIT (ABI 8; layered family, f16x2-split arithmetic): the 256 x 256 output tiles of a GEMM's last, partly
+ * filled round of the chip can each be computed by 2-4 workgroups over disjoint K ranges whose partial sums meet in a workspace
+ * and are added in a fixed order (tdmpc2_amd/csrc/layered_wide.cuh, tile_order.h: gemm_w_order).  0 = never: every tile whole -- a
+ * plan then computes the same bits alone, in any batch and with its rows split over ranks; 1 = whenever the round arithmetic
+ * says so (measured: slower on launches that fill the chip -- the partial sums' traffic); 2 (default) = only for launches of
+ * 32 .. 128 tiles, which leave most of the chip idle (one or two plans of the 317M model: single-plan latency -7 %).  Same values
+ * to fp32 round-off (1e-5 of the trajectory values); the bits of a plan then depend on how many plans share the call. */
 enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0, TDMPC2_TUNE_FOLD_REFIT = 1, TDMPC2_TUNE_CLUSTER = 2, TDMPC2_TUNE_FUSE_LN = 3,
                      TDMPC2_TUNE_REARM_AFTER = 4, TDMPC2_TUNE_SAFE_ONCE = 5, TDMPC2_TUNE_KSPLIT = 6 };
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
@@ -360,6 +362,13 @@ int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
  * call -- a lower bound on the waits that gave up).  The later calls of a
  * sharded plan (shard_values / shard_refit) do not clear it: a wait that gave up in any iteration invalidates the final pick. */
 int tdmpc2_plan_take_fault(tdmpc2_plan_t *h, int *faults);
+
+/* The verdict of the call(s) in flight WITHOUT a host synchronisation (ABI 8): enqueues a 4-byte copy of the device-visible
+ * verdict word (0 = no bounded wait has given up since the last call that cleared it: tdmpc2_plan_run*, shard_begin, ...) into
+ * dst_dev[0] on `stream`, behind the kernels enqueued so far.  A rank of a sharded plan appends the word to the value slice it
+ * all-gathers anyway, so that every rank learns every rank's verdict with the one synchronisation the caller needs for the
+ * action (dist.sharded_plan); the host-side bookkeeping (downgrade, re-arm, take_fault) is untouched.  No reference analogue. */
+int tdmpc2_plan_fault_word(tdmpc2_plan_t *h, uint32_t *dst_dev, void *stream);
 
 /* The fault history of a handle (no synchronisation, nothing consumed): how often a bounded wait has given up, how long ago the
  * last one was, whether the handle is currently on the downgraded paths and how far the re-arm counter has got. */

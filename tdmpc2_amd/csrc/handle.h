@@ -79,7 +79,7 @@ struct Layered {
     // g_gemm_w's K-split tail (layered_wide.cuh): partial accumulators of the split tiles, one workspace per chain
     float *ksws = nullptr, *ksws2 = nullptr;
     size_t ksws_slots = 0;                  // 256 KiB slots (split tile x part) per workspace
-    bool ksplit = true;                     // TDMPC2_TUNE_KSPLIT
+    int ksplit = 2;                         // TDMPC2_TUNE_KSPLIT: 0 never, 1 whenever the rule says so, 2 few-tile launches only (layered_host.cuh)
 };
 
 struct tdmpc2_plan {

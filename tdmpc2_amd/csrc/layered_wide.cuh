@@ -164,57 +164,79 @@ __device__ __forceinline__ void gw_phase(f32x16 (&acc)[2][4], GwFrags (&fr)[2], 
 // registers it is in; the others from the workspace, `ws` = the tile's slot + tid * 4 floats).  P and PART are template
 // parameters so that every register index and every branch is static (a run-time part index costs selects, zero-initialised
 // load destinations under uniform branches -- and, measured, 527 spilled registers).
-template <int P, int PART>
-__device__ __forceinline__ void gw_reduce(f32x16 (&acc)[2][4], const float *ws) {
+// THE LOADS OF A BATCH AND THEIR WAIT ARE ONE asm STATEMENT: the compiler does not know that an inline-asm load completes
+// later; a destination register it moved or spilled between a load statement and a separate wait statement would be read
+// before the data has landed (the first version did that under register pressure: wrong sums, r5a).
+// Addresses: ONE wave-uniform base per part (an SGPR pair) + four per-lane byte offsets (tid * 16 + j * 8192) shared by every
+// part and accumulator tile -- 64-bit per-load VGPR addresses (24 registers for 12 loads) pushed the routine into scratch, and a
+// kernel that uses scratch ran into the bounded waits on the 317M model (16 peers per row block; profiles/README.md r5c).
+// s_nop 4: a VALU-written SGPR needs 5 wait states before a VMEM instruction reads it (the hazard recognizer does not look
+// inside inline asm).
+#define GW_LD_ "global_load_dwordx4 %"
+__device__ __forceinline__ void gw_ld4(f32x4 (&a)[4], const unsigned (&o)[4], const char *pa) {
+    asm volatile("s_nop 4\n\t" GW_LD_ "0, %4, %8 sc1\n\t" GW_LD_ "1, %5, %8 sc1\n\t" GW_LD_ "2, %6, %8 sc1\n\t" GW_LD_ "3, %7, %8 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3])
+                 : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "s"(pa)
+                 : "memory");
+}
+__device__ __forceinline__ void gw_ld8(f32x4 (&a)[4], f32x4 (&b)[4], const unsigned (&o)[4], const char *pa, const char *pb) {
+    asm volatile("s_nop 4\n\t" GW_LD_ "0, %8, %12 sc1\n\t" GW_LD_ "1, %9, %12 sc1\n\t" GW_LD_ "2, %10, %12 sc1\n\t" GW_LD_ "3, %11, %12 sc1\n\t"
+                 GW_LD_ "4, %8, %13 sc1\n\t" GW_LD_ "5, %9, %13 sc1\n\t" GW_LD_ "6, %10, %13 sc1\n\t" GW_LD_ "7, %11, %13 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+                 : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "s"(pa), "s"(pb)
+                 : "memory");
+}
+__device__ __forceinline__ void gw_ld12(f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&c)[4], const unsigned (&o)[4], const char *pa, const char *pb,
+                                        const char *pc) {
+    asm volatile("s_nop 4\n\t" GW_LD_ "0, %12, %16 sc1\n\t" GW_LD_ "1, %13, %16 sc1\n\t" GW_LD_ "2, %14, %16 sc1\n\t" GW_LD_ "3, %15, %16 sc1\n\t"
+                 GW_LD_ "4, %12, %17 sc1\n\t" GW_LD_ "5, %13, %17 sc1\n\t" GW_LD_ "6, %14, %17 sc1\n\t" GW_LD_ "7, %15, %17 sc1\n\t"
+                 GW_LD_ "8, %12, %18 sc1\n\t" GW_LD_ "9, %13, %18 sc1\n\t" GW_LD_ "10, %14, %18 sc1\n\t" GW_LD_ "11, %15, %18 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]),
+                   "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+                 : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "s"(pa), "s"(pb), "s"(pc)
+                 : "memory");
+}
+#undef GW_LD_
+// ws: the tile's workspace slot (wave-uniform); off: tid * 16 + {0, 1, 2, 3} * 8192 bytes.  EVERY partial comes from the
+// workspace -- the last arriver's own too (it was stored like the others): the accumulators are then dead across the ticket and
+// the routine needs no scratch (keeping the own partial in registers saved a 256 KiB read per tile and cost 380 spilled
+// registers in nine (P, part) variants).
+template <int P>
+__device__ __forceinline__ void gw_reduce(f32x16 (&acc)[2][4], const char *ws, const unsigned (&off)[4]) {
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-            f32x4 L[3][4];  // [other part o = 0 .. P - 2][chunk j]: 4 (P - 1) loads of 16 bytes in flight per lane
-#pragma unroll
-            for (int o = 0; o < P - 1; ++o)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    gw_ld_sc1(L[o][j], ws + (size_t)(o < PART ? o : o + 1) * 65536 + ((n * 4 + rt) * 4 + j) * 2048);
-            // the wait names its loads' destinations: nothing that reads them can be scheduled above it
-            if constexpr (P == 2)
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(L[0][0]), "+v"(L[0][1]), "+v"(L[0][2]), "+v"(L[0][3])::"memory");
-            else if constexpr (P == 3)
-                asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(L[0][0]), "+v"(L[0][1]), "+v"(L[0][2]), "+v"(L[0][3]), "+v"(L[1][0]), "+v"(L[1][1]), "+v"(L[1][2]), "+v"(L[1][3])::"memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(L[0][0]), "+v"(L[0][1]), "+v"(L[0][2]), "+v"(L[0][3]), "+v"(L[1][0]), "+v"(L[1][1]), "+v"(L[1][2]), "+v"(L[1][3]),
-                               "+v"(L[2][0]), "+v"(L[2][1]), "+v"(L[2][2]), "+v"(L[2][3])::"memory");
+            const char *b = ws + (size_t)((n * 4 + rt) * 4) * 8192;
+            f32x4 A[4], L[3][4];  // part 0; parts 1 .. P - 1
+            gw_ld4(A, off, b);
+            if constexpr (P == 2) gw_ld4(L[0], off, b + 262144);
+            else if constexpr (P == 3) gw_ld8(L[0], L[1], off, b + 262144, b + 2 * 262144);
+            else gw_ld12(L[0], L[1], L[2], off, b + 262144, b + 2 * 262144, b + 3 * 262144);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float sum = PART == 0 ? acc[n][rt][4 * j + r] : L[0][j][r];
+                    float sum = A[j][r];
 #pragma unroll
-                    for (int q = 1; q < P; ++q) sum = __fadd_rn(sum, q == PART ? acc[n][rt][4 * j + r] : L[q < PART ? q : q - 1][j][r]);
+                    for (int q = 1; q < P; ++q) sum = __fadd_rn(sum, L[q - 1][j][r]);  // in part order, whoever arrived last
                     acc[n][rt][4 * j + r] = sum;
                 }
         }
 }
-__device__ __forceinline__ void gw_reduce_any(f32x16 (&acc)[2][4], const float *ws, int P, int part) {
-    if (P == 2) {
-        if (part == 0) gw_reduce<2, 0>(acc, ws);
-        else gw_reduce<2, 1>(acc, ws);
-    } else if (P == 3) {
-        if (part == 0) gw_reduce<3, 0>(acc, ws);
-        else if (part == 1) gw_reduce<3, 1>(acc, ws);
-        else gw_reduce<3, 2>(acc, ws);
-    } else {
-        if (part == 0) gw_reduce<4, 0>(acc, ws);
-        else if (part == 1) gw_reduce<4, 1>(acc, ws);
-        else if (part == 2) gw_reduce<4, 2>(acc, ws);
-        else gw_reduce<4, 3>(acc, ws);
-    }
+__device__ __forceinline__ void gw_reduce_any(f32x16 (&acc)[2][4], const char *ws, const unsigned (&off)[4], int P) {
+    if (P == 2) gw_reduce<2>(acc, ws, off);
+    else if (P == 3) gw_reduce<3>(acc, ws, off);
+    else gw_reduce<4>(acc, ws, off);
 }
 
 // EPI = 1: LayerNorm + Mish, 2: LayerNorm + SimNorm(8).  Grid / tile order: tile_order.h with 256-row blocks.
-template <int EPI>
+// KS = 1: the instantiation with the K-split tail (TDMPC2_TUNE_KSPLIT = 1, not the default: see the measurement in DESIGN 10);
+// KS = 0 carries none of its code (no scratch, the round-4 machine code).
+template <int EPI, int KS = 0>
 __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
     static_assert(EPI == 1 || EPI == 2, "the wide tile exists for the NormedLinear layers");
     constexpr int NS = GW_NSLOT, TM = 256;
@@ -224,7 +246,7 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;  // this wave's accumulators: row tiles 4 wr .. + 3, column tiles 2 wc, 2 wc + 1
     int rb, cb, part = 0, slot = -1;
-    if (p.ks_parts > 1) {
+    if (KS && p.ks_parts > 1) {
         if (!gemm_w_tile(blockIdx.x, p.nrowblk, p.ncolblk, p.ks_full, p.ks_parts, p.ks_max_tail, rb, cb, part, slot)) return;
     } else if (!gemm_s_tile(blockIdx.x, p.nrowblk, p.ncolblk, p.xcd_rows, p.ncol_grid, rb, cb)) {
         return;
@@ -319,10 +341,10 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
     // ---------------------------------------------------------------- K-split tile: partial sums meet in the workspace
     // Every part stores its accumulators in register order (chunk c = ((n 4 + rt) 4 + j): 512 threads x 16 bytes = 8 KiB,
     // 1 KiB contiguous per wave instruction) with write-through stores, drains them, and takes a ticket; the part that draws the
-    // last one adds the partials IN PART ORDER -- its own from registers -- and carries on into the epilogue as if it had run the
+    // last one adds the partials IN PART ORDER and carries on into the epilogue as if it had run the
     // whole contraction.  Nobody waits: the others leave.  The sum differs from the unsplit tile's in the last bits (fp32
     // association), by less than the f16x2 split's own error; TDMPC2_TUNE_KSPLIT = 0 keeps every tile whole.
-    if (slot >= 0) {
+    if (KS && slot >= 0) {
         const int P = p.ks_parts;
         float *ws = p.ks_ws + (size_t)slot * P * 65536 + tid * 4;
         {
@@ -345,7 +367,13 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
         if (tid == 0) *flag = (int)__hip_atomic_fetch_add(p.ks_cnt + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (*flag != P - 1) return;
-        gw_reduce_any(acc, ws, P, part);
+        {
+            const char *wsu = reinterpret_cast<const char *>(p.ks_ws + (size_t)slot * P * 65536);  // wave-uniform
+            unsigned off[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) off[j] = (unsigned)tid * 16u + (unsigned)j * 8192u;
+            gw_reduce_any(acc, wsu, off, P);
+        }
     }
 
     // ---------------------------------------------------------------- NormedLinear epilogue (the protocol of g_gemm_s<.., EPI>)
@@ -423,7 +451,9 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
         WaitClock wc;
         while (__hip_atomic_load(p.arrive + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.ncolblk) {
             if (wc.expired()) {
-                if (p.err) raise_fault(p.err, 2u);
+                // code: 2 | row block << 4 | column block << 16 | arrivals seen << 24 (TDMPC2_DEBUG_FAULT=1 prints it)
+                if (p.err) raise_fault(p.err, 2u | ((unsigned)rb << 4) | ((unsigned)cb << 16) |
+                                                  (__hip_atomic_load(p.arrive + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 24));
                 break;
             }
             __builtin_amdgcn_s_sleep(2);

@@ -507,6 +507,7 @@ bool fault_poll(tdmpc2_plan *h) {
     unsigned int *w = h->cl_err_host;
     // read-and-clear in ONE step: a device store that lands between a separate read and clear would be lost
     if (!w || !__atomic_exchange_n(w + 8, 0u, __ATOMIC_RELAXED)) return false;
+    if (getenv("TDMPC2_DEBUG_FAULT")) fprintf(stderr, "[tdmpc2_plan] a bounded wait gave up: code 0x%08x (kind = code & 15)\n", w[0]);
     fault_note(h);
     return true;
 }
@@ -872,7 +873,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             if (const char *fl = getenv("TDMPC2_FUSE_LN")) L.fuse_ln = atoi(fl) != 0;
             // g_gemm_w's K-split tail: 256 KiB per (split tile, part); at most 32 tail tiles per XCD x 4 parts, or all the tiles
             // of the handle's largest call (one workspace per chain)
-            if (const char *ks = getenv("TDMPC2_KSPLIT")) L.ksplit = atoi(ks) != 0;
+            if (const char *ks = getenv("TDMPC2_KSPLIT")) L.ksplit = std::min(2, std::max(0, atoi(ks)));
             if (Rp % 256 == 0 && maxct >= 8) {
                 const size_t tiles = (Rp / 256) * ((maxct + 7) / 8);
                 L.ksws_slots = std::min<size_t>(8 * 32 * 4, tiles * 4);
@@ -1757,6 +1758,16 @@ int tdmpc2_plan_set_call_counter(tdmpc2_plan_t *h, uint32_t next_call) {
     return TDMPC2_OK;
 }
 
+int tdmpc2_plan_fault_word(tdmpc2_plan_t *h, uint32_t *dst_dev, void *stream) {
+    if (!h || !dst_dev) return fail(TDMPC2_ERR_INVALID, "null argument");
+    ENTER_ON(h, stream);
+    hipStream_t st = (hipStream_t)stream;
+    // word 0 of the host-mapped error line, copied IN STREAM ORDER: what the kernels enqueued so far have raised when the copy runs
+    if (h->cl_err_dev) HIP_TRY(hipMemcpyAsync(dst_dev, h->cl_err_dev, 4, hipMemcpyDefault, st));
+    else HIP_TRY(hipMemsetAsync(dst_dev, 0, 4, st));
+    return TDMPC2_OK;
+}
+
 int tdmpc2_plan_take_fault(tdmpc2_plan_t *h, int *faults) {
     if (!h || !faults) return fail(TDMPC2_ERR_INVALID, "null argument");
     ENTER(h);
@@ -1814,8 +1825,8 @@ int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value) {
         return TDMPC2_OK;
     }
     if (key == TDMPC2_TUNE_KSPLIT) {
-        if (value < 0 || value > 1) return fail(TDMPC2_ERR_INVALID, "ksplit must be 0 or 1");
-        h->lay.ksplit = value != 0;
+        if (value < 0 || value > 2) return fail(TDMPC2_ERR_INVALID, "ksplit must be 0 (never), 1 (always) or 2 (few-tile launches)");
+        h->lay.ksplit = value;
         return TDMPC2_OK;
     }
     if (key == TDMPC2_TUNE_FOLD_REFIT) {

@@ -69,6 +69,16 @@ __host__ __device__ inline bool gemm_s_tile(int b, int nrowblk, int ncolblk, int
 // x, x + 8, ... below 8 q (q = nrowblk / 8) -- the XCD-local order of gemm_s_tile: the peers of a row block consecutive on one
 // XCD --; the tiles of the nrowblk % 8 remaining row blocks are dealt out in contiguous runs, so that the lists differ by at
 // most one tile (the plain XCD-local order gives 4 XCDs a whole row block more: 56 against 49 tiles for the 48M model).
+// Order of the tail inside an XCD: groups of GW_SE tiles, PART-MAJOR inside a group (t0.p0 t1.p0 t2.p0 t3.p0 t0.p1 ...).  An
+// XCD does not hand its share of a grid to "whichever CU is free": consecutive workgroups go round-robin to its 4 shader engines
+// (8 CUs each), and a workgroup only ever runs on its engine.  With the parts of a tile on consecutive slots (tile-major), the
+// parts p of ALL tiles land on engine p; the last arrivers -- which wait for their row block's peers -- pile up on one engine, fill
+// its 8 CUs, and the parts still queued for that engine never start (317M model, 16 peers per row block: 8 or 15 of 16 arrivals,
+// then the bounded wait gave up; fault codes in profiles/README.md r5c).  Part-major in groups of 4 keeps every part of a tile on
+// ONE engine and spreads the tiles -- and so the waiters -- over all four, as the whole tiles are.
+#ifndef GW_SE
+#define GW_SE 4
+#endif
 struct GemmWOrder {
     int parts;     // K-parts of a tail tile (1: nothing is split -- the caller then keeps the order of gemm_s_order)
     int full;      // per XCD: tiles [0, full) of its list are whole
@@ -103,7 +113,7 @@ __host__ __device__ inline GemmWOrder gemm_w_order(int nrowblk, int ncolblk, int
         }
     }
     o.rounds1k = 1000 * (o.full / cus_per_xcd) + best;
-    o.per_xcd = o.full + o.max_tail * o.parts;
+    o.per_xcd = o.full + (o.max_tail + GW_SE - 1) / GW_SE * GW_SE * o.parts;  // whole groups of GW_SE tiles
     o.nblk = 8 * o.per_xcd;
     return o;
 }
@@ -117,9 +127,11 @@ __host__ __device__ inline bool gemm_w_tile(int b, int nrowblk, int ncolblk, int
     int i;
     if (t < full) {
         i = t; part = 0; slot = -1;
-    } else {
-        const int u = t - full;
-        i = full + u / parts; part = u - (u / parts) * parts; slot = x * max_tail + (i - full);
+    } else {  // groups of GW_SE tiles, part-major inside a group (see above)
+        const int u = t - full, gsz = GW_SE * parts, g = u / gsz, r = u - g * gsz;
+        part = r / GW_SE;
+        i = full + g * GW_SE + (r - part * GW_SE);
+        slot = x * max_tail + (i - full);
     }
     if (i >= n) return false;
     if (i < q * ncolblk) {

@@ -84,25 +84,12 @@ def _host_staged(group=None) -> bool:
     return dist.get_backend(group) == "gloo"
 
 
-def _agree_on_stream(backend, seed: int, device, group=None):
-    """Make the ranks of a sharded plan draw identical noise: compare the seeds (raise on mismatch) and adopt rank 0's call
-    counter (NativePlanner.call_counter / set_call_counter; stand-ins without a counter have no hidden state to align)."""
-    seed = int(seed) & (2**64 - 1)
-    has_counter = hasattr(backend, "call_counter") and hasattr(backend, "set_call_counter")
-    src = dist.get_global_rank(group, 0) if group is not None else 0
-    if _host_staged(group):
-        device = torch.device("cpu")
-    # int64 cannot hold a u64 seed: ship it as two 32-bit halves
-    mine = torch.tensor([seed >> 32, seed & 0xFFFFFFFF, backend.call_counter() if has_counter else 0], dtype=torch.int64, device=device)
-    ref = mine.clone()
-    dist.broadcast(ref, src=src, group=group)
-    bad = torch.tensor([int(not torch.equal(mine[:2], ref[:2]))], dtype=torch.int64, device=device)
-    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
-    if int(bad.item()):
-        raise ValueError("sharded_plan: the Philox seed differs between ranks (it must not depend on the rank: every rank has to "
-                         f"sample the same actions); this rank passed {seed:#x}")
-    if has_counter:
-        backend.set_call_counter(int(ref[2].item()))
+def _meta_words(seed: int, counter: int) -> list:
+    """[seed high, seed low, call counter, verdict] as int32 bit patterns (an int64 tensor cannot hold a u64 seed either)."""
+    def s32(x):
+        x &= 0xFFFFFFFF
+        return x - (1 << 32) if x >= (1 << 31) else x
+    return [s32(seed >> 32), s32(seed), s32(counter), 0]
 
 
 def sharded_plan(backend, z0, disc_pow, prev_mean, t0, eval_mode: bool = False, task_emb=None, act_mask=None, tape=None,
@@ -129,49 +116,80 @@ def sharded_plan(backend, z0, disc_pow, prev_mean, t0, eval_mode: bool = False, 
     value = torch.zeros(E, N, dtype=torch.float32, device=z0.device)
     action = torch.empty(E, cfg.action_dim, dtype=torch.float32, device=z0.device)
     can_fault = hasattr(backend, "take_fault")
-    prev_in = prev_mean.clone() if can_fault else None
-    backend.last_shard_retries = 0
-    call0 = None
+    has_counter = hasattr(backend, "call_counter") and hasattr(backend, "set_call_counter")
+    has_word = hasattr(backend, "fault_word") and z0.is_cuda
+    prev_in = prev_mean.clone() if (can_fault or has_counter) else None
+    backend.last_shard_retries = 0   # re-plans because a bounded inter-workgroup wait gave up on some rank
+    backend.last_shard_realigns = 0  # re-plans because the ranks' Philox call counters differed (first call after a desync)
+    seed = int(seed) & (2**64 - 1)
     if can_fault:
         backend.take_fault()  # a fault left over from an EARLIER call (its caller had its chance) must not cost this plan a re-plan
-    for attempt in range(2):
-        if world > 1 and tape is None:
-            _agree_on_stream(backend, seed, z0.device, group)
-        if can_fault and hasattr(backend, "call_counter"):
-            call0 = backend.call_counter()  # (after the ranks agreed) a re-plan draws the noise of the attempt it replaces
+    staged = world > 1 and _host_staged(group)
+    stage = torch.device("cpu") if staged else z0.device
+    NM = 4  # meta words behind every rank's slice: seed (2), call counter, verdict
+    for attempt in range(3):
+        call0 = backend.call_counter() if has_counter else 0  # a re-plan draws the noise of the attempt it replaces
+        meta = torch.tensor(_meta_words(seed, call0), dtype=torch.int32, device=z0.device)
         backend.shard_begin(z0, prev_mean, t0, task_emb=task_emb, act_mask=act_mask, tape=tape, seed=seed)
+        metas = None
+        last = backend.iterations - 1
         for it in range(backend.iterations):
             backend.shard_values(it, r0, r1, z0, disc_pow, value, act_mask=act_mask, seed=seed)
             if world > 1:
-                local = value[:, r0:r1].contiguous()
+                # ONE collective per iteration carries everything the ranks have to agree on (no host round trip
+                # of its own for the Philox stream or for the verdict): behind the value slice ride four words -- the seed and the call
+                # counter (checked after the plan: ranks that differ re-plan once with rank 0's counter and then stay in step) and,
+                # with the last slice, the verdict word of this rank's kernels, copied on the device in stream order.
+                if it == last and has_word:
+                    backend.fault_word(meta[3:4])
+                send = torch.empty(E * per + NM, dtype=torch.float32, device=z0.device)
+                send[:E * per].copy_(value[:, r0:r1].reshape(-1))
+                send[E * per:].copy_(meta.view(torch.float32))
                 # RCCL gathers device tensors in place; gloo (CPU tests, and ranks that SHARE one GPU -- RCCL refuses two ranks
-                # on one device) takes the 4 KB slices through host memory
-                stage = torch.device("cpu") if _host_staged(group) else value.device
-                gathered = torch.empty(world, E, per, dtype=value.dtype, device=stage)
-                dist.all_gather_into_tensor(gathered.view(-1), local.to(stage).view(-1), group=group)
-                value.copy_(gathered.permute(1, 0, 2).reshape(E, N))
+                # on one device) takes the slices through host memory
+                gathered = torch.empty(world, E * per + NM, dtype=torch.float32, device=stage)
+                dist.all_gather_into_tensor(gathered.view(-1), send.to(stage), group=group)
+                value.copy_(gathered[:, :E * per].reshape(world, E, per).permute(1, 0, 2).reshape(E, N))
+                if it == 0 or it == last:
+                    m = gathered[:, E * per:].contiguous().view(torch.int32)
+                    metas = m.clone() if it == 0 else torch.cat([metas[:, :3], m[:, 3:4]], dim=1)
             backend.shard_refit(it, value, prev_mean, action, act_mask=act_mask, eval_mode=eval_mode, seed=seed, stages=stages)
-        if not can_fault:
-            break
-        # A bounded inter-workgroup wait of the planner kernels that gave up on ANY rank (another process or kernel held the
-        # compute units) made that rank's value slice garbage, and every rank has refitted on it: the ranks agree on the
-        # verdict, switch to the kernels without inter-workgroup waits and plan the step again (once: those cannot fault).
-        if z0.is_cuda:
-            torch.cuda.synchronize(z0.device)
-        bad = torch.tensor([int(backend.take_fault() > 0)], dtype=torch.int64,
-                           device=torch.device("cpu") if (world > 1 and _host_staged(group)) else z0.device)
+        # ---- the one look the host takes (the caller synchronises for the action anyway)
+        bad = realign = False
+        counter0 = call0
         if world > 1:
-            dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
-        if not int(bad.item()) or attempt == 1:
+            mh = metas.cpu()  # [world, 4]
+            if tape is None:
+                if not bool((mh[:, :2] == mh[0, :2]).all()):
+                    raise ValueError("sharded_plan: the Philox seed differs between ranks (it must not depend on the rank: every rank "
+                                     f"has to sample the same actions); this rank passed {seed:#x}")
+                realign = has_counter and not bool((mh[:, 2] == mh[0, 2]).all())
+                counter0 = int(mh[0, 2]) & 0xFFFFFFFF
+            bad = bool((mh[:, 3] != 0).any())
+        if can_fault:
+            if z0.is_cuda and not (world > 1 and has_word):
+                torch.cuda.synchronize(z0.device)
+            mine = backend.take_fault() > 0  # (host-side bookkeeping: the library's downgrade / re-arm logic takes its look here)
+            if world == 1 or not has_word:
+                bad = mine
+                if world > 1:  # stand-ins without a device-side verdict word: the verdict travels by itself
+                    t = torch.tensor([int(mine)], dtype=torch.int64, device=stage)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+                    bad = bool(int(t.item()))
+        if not (bad or realign) or attempt == 2:
             break
-        # The retry is a property of the retry: TDMPC2_TUNE_SAFE_ONCE covers exactly the next shard_begin .. last shard_refit and
-        # touches neither the caller's CLUSTER / FUSE_LN settings (explicit or from the environment) nor the handle's own
-        # downgrade / re-arm bookkeeping -- a rank that really faulted stays on the safe paths for `rearm_after` calls, with the
-        # library's back-off, instead of running into the same wait on every step.
-        backend.last_shard_retries += 1
-        if hasattr(backend, "plan_safely_once"):
-            backend.plan_safely_once(True)
+        # A wait that gave up on ANY rank made that rank's value slice garbage, and every rank has refitted on it; ranks whose call
+        # counters differed have sampled different actions.  Either way every rank restores prev_mean, adopts rank 0's counter of
+        # the attempt and plans the step again -- after a fault on the kernels without inter-workgroup waits (TDMPC2_TUNE_SAFE_ONCE:
+        # a property of the retry; the caller's CLUSTER / FUSE_LN settings and the handle's own downgrade / re-arm bookkeeping are
+        # not touched -- a rank that really faulted stays on the safe paths for `rearm_after` calls by itself).
+        if bad:
+            backend.last_shard_retries += 1
+            if hasattr(backend, "plan_safely_once"):
+                backend.plan_safely_once(True)
+        else:
+            backend.last_shard_realigns += 1
         prev_mean.copy_(prev_in)
-        if call0 is not None:
-            backend.set_call_counter(call0)
+        if has_counter:
+            backend.set_call_counter(counter0)
     return action

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "tdmpc2_plan_packed_size", "tdmpc2_plan_export_packed", "tdmpc2_plan_import_packed",
     "tdmpc2_plan_shard_begin", "tdmpc2_plan_shard_values", "tdmpc2_plan_shard_refit",
     "tdmpc2_plan_export_noise", "tdmpc2_plan_call_counter", "tdmpc2_plan_set_call_counter", "tdmpc2_plan_take_fault",
-    "tdmpc2_plan_fault_info",
+    "tdmpc2_plan_fault_info", "tdmpc2_plan_fault_word",
 ]
 
 NET_DYNAMICS, NET_REWARD, NET_PI, NET_Q, NET_TERMINATION, NET_TARGET_Q = range(6)
@@ -142,6 +142,8 @@ def load_library():
     lib.tdmpc2_plan_set_call_counter.restype = i32
     lib.tdmpc2_plan_take_fault.argtypes = [vp, C.POINTER(i32)]
     lib.tdmpc2_plan_take_fault.restype = i32
+    lib.tdmpc2_plan_fault_word.argtypes = [vp, vp, vp]
+    lib.tdmpc2_plan_fault_word.restype = i32
     lib.tdmpc2_plan_fault_info.argtypes = [vp, C.POINTER(FaultInfo)]
     lib.tdmpc2_plan_fault_info.restype = i32
     lib.tdmpc2_plan_set_tuning.argtypes = [vp, i32, i32]
@@ -376,6 +378,13 @@ class NativePlanner:
         self._check(self.lib.tdmpc2_plan_take_fault(self._h, C.byref(n)))
         return int(n.value)
 
+    def fault_word(self, dst):
+        """tdmpc2_plan_fault_word: the device-visible verdict word of the calls in flight copied into dst[0] (int32, on this device)
+        in stream order -- no host synchronisation (dist.sharded_plan appends it to the slice it all-gathers)."""
+        _chk_tensor("dst", dst, torch.int32, (1,), self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.tdmpc2_plan_fault_word(self._h, _ptr(dst), self._stream()))
+
     def fault_info(self) -> dict:
         """The handle's fault history (tdmpc2_plan_fault_info): faults_total, rearms, degraded, clean_calls, rearm_after,
         seconds_since_fault (-1: never).  Nothing is consumed."""
@@ -383,10 +392,11 @@ class NativePlanner:
         self._check(self.lib.tdmpc2_plan_fault_info(self._h, C.byref(fi)))
         return {k: getattr(fi, k) for k, _ in FaultInfo._fields_ if k != "reserved"}
 
-    def set_ksplit(self, on):
-        """TDMPC2_TUNE_KSPLIT: layered family -- split the 256 x 256 tiles of a GEMM's last, partly filled round along K (1,
-        default) or keep every tile whole (0: a plan's bits do not depend on the size of the call it is part of)."""
-        self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 6, int(bool(on))))
+    def set_ksplit(self, mode):
+        """TDMPC2_TUNE_KSPLIT: layered family -- split 256 x 256 GEMM tiles along K over 2-4 workgroups: 0 never (a plan's bits do
+        not depend on the size of the call it is part of), 1 whenever the round arithmetic says so, 2 (default) only for
+        launches that leave most of the chip idle (single plans of the 317M model)."""
+        self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 6, int(mode)))
 
     def plan_safely_once(self, on: bool = True):
         """TDMPC2_TUNE_SAFE_ONCE: the next whole plan (plan(), or shard_begin .. the last shard_refit) runs on the paths without

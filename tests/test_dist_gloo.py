@@ -329,33 +329,43 @@ def test_broadcast_streams_in_buckets():
     mp.spawn(_bcast_worker, args=(2, _free_port()), nprocs=2, join=True)
 
 
-class _CounterBackend:
-    """Only the hidden state sharded_plan has to align across ranks (NativePlanner.call_counter / set_call_counter)."""
+class PhiloxLikeBackend(FaultyShardBackend):
+    """The stand-in WITHOUT a tape: like the library's in-kernel Philox, the noise is a function of (seed, call counter at
+    shard_begin) -- ranks whose counters differ sample different actions."""
 
-    def __init__(self, n):
-        self.n = n
+    def shard_begin(self, z0, prev_mean, t0, task_emb=None, act_mask=None, tape=None, seed=0):
+        from tdmpc2_amd import synth
 
-    def call_counter(self):
-        return self.n
-
-    def set_call_counter(self, v):
-        self.n = int(v)
+        assert tape is None
+        drawn = synth.make_noise_tape(self.cfg, 1, self.iterations, seed=(int(seed) * 1000003 + self.counter) % (2**31))
+        return super().shard_begin(z0, prev_mean, t0, task_emb=task_emb, act_mask=act_mask, tape=drawn, seed=seed)
 
 
 def _stream_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from tdmpc2_amd.dist import _agree_on_stream
+        from oracle import cases
+        from tdmpc2_amd.dist import sharded_plan
 
+        c = cases.build_case("tiny")
+        be = PhiloxLikeBackend(c, faulty=False)
         # rank 1's handle has planned on its own in the meantime (ADVICE r2): its counter ran ahead
-        be = _CounterBackend(5 if rank == 0 else 9)
-        _agree_on_stream(be, (1 << 40) + 7, torch.device("cpu"))
-        assert be.n == 5
+        be.counter = 5 if rank == 0 else 9
+        prev = torch.as_tensor(c["prev_mean"][:1]).clone()
+        z0, t0 = torch.as_tensor(c["z0"][:1]), torch.tensor([0], dtype=torch.uint8)
+        a = sharded_plan(be, z0, None, prev, t0, tape=None, seed=(1 << 40) + 7)
+        # the counters are compared with the FIRST value all-gather (no round trip of their own): the ranks found out after the
+        # plan, adopted rank 0's counter and planned again -- once; from then on they stay in step
+        assert be.last_shard_realigns == 1 and be.last_shard_retries == 0 and be.counter == 6
+        a2 = sharded_plan(be, z0, None, prev.clone(), t0, tape=None, seed=(1 << 40) + 7)
+        assert be.last_shard_realigns == 0 and be.counter == 7
+        torch.save({"action": a, "prev_mean": prev, "action2": a2, "log": be.log}, os.path.join(out_dir, f"stream{rank}.pt"))
         # a seed that carries the rank (what TDMPC2._seed does) must be refused on EVERY rank, not diverge silently
         raised = False
         try:
-            _agree_on_stream(be, (rank << 32) ^ 3, torch.device("cpu"))
+            sharded_plan(be, z0, None, prev.clone(), t0, tape=None, seed=(rank << 32) ^ 3)
         except ValueError as ex:
             raised = "seed differs between ranks" in str(ex)
         open(os.path.join(out_dir, f"ok{rank}"), "w").write(str(int(raised)))
@@ -365,7 +375,23 @@ def _stream_worker(rank, world, port, out_dir):
 
 
 def test_sharded_plan_ranks_agree_on_the_philox_stream(tmp_path):
-    """Without a tape the ranks of a sharded plan must draw identical noise: rank 0's call counter is adopted, a
+    """Without a tape the ranks of a sharded plan must draw identical noise.  The seed and the call counter ride with the first
+    value all-gather (no host round trip of their own): ranks whose counters differ re-plan ONCE with rank
+    0's counter -- the result is the plan a single process makes with that counter -- and stay in step afterwards; a
     rank-dependent seed raises everywhere."""
+    from oracle import cases
+    from tdmpc2_amd.dist import sharded_plan
+
     mp.spawn(_stream_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").read_text() == "1" and (tmp_path / "ok1").read_text() == "1"
+    r0 = torch.load(tmp_path / "stream0.pt", weights_only=False)
+    r1 = torch.load(tmp_path / "stream1.pt", weights_only=False)
+    assert torch.equal(r0["action"], r1["action"]) and torch.equal(r0["prev_mean"], r1["prev_mean"]) and torch.equal(r0["action2"], r1["action2"])
+    # rank 0 planned with 5 twice (attempt, re-plan), rank 1 with 9 then 5; the second plan used 6 on both
+    assert [e[1] for e in r0["log"]][:3] == [5, 5, 6] and [e[1] for e in r1["log"]][:3] == [9, 5, 6]
+    c = cases.build_case("tiny")
+    be = PhiloxLikeBackend(c, faulty=False)
+    be.counter = 5
+    prev = torch.as_tensor(c["prev_mean"][:1]).clone()
+    a = sharded_plan(be, torch.as_tensor(c["z0"][:1]), None, prev, torch.tensor([0], dtype=torch.uint8), tape=None, seed=(1 << 40) + 7)
+    assert torch.equal(a, r0["action"]) and torch.equal(prev, r0["prev_mean"])

@@ -142,7 +142,7 @@ def w_tiles(lib, nrowblk, ncolblk, o):
 def test_k_split_order_covers_every_tile_with_all_its_parts(lib, nrowblk, ncolblk):
     """gemm_w_order / gemm_w_tile: every tile is either whole (one workgroup, no workspace slot) or split into exactly `parts`
     workgroups with part indices 0 .. parts - 1 that share ONE workspace slot, sit on ONE XCD and are consecutive in its
-    dispatch order; slots are unique per split tile and below 8 x max_tail; whole tiles come first in every XCD's order; the
+    dispatch order's same shader engine (every 4th slot); slots are unique per split tile and below 8 x max_tail; whole tiles come first in every XCD's order; the
     XCDs' lists differ by at most one tile; the peers of a row block below 8 (nrowblk / 8) stay on one XCD, consecutively."""
     for nk in (16, 50, 112, 256):
         o = w_order(lib, nrowblk, ncolblk, nk=nk, ovh=12000 // (nk + 25))
@@ -166,8 +166,9 @@ def test_k_split_order_covers_every_tile_with_all_its_parts(lib, nrowblk, ncolbl
             assert o["parts"] > 1 and sorted(p for _, p, _ in ws) == list(range(o["parts"]))
             assert len({s for _, _, s in ws}) == 1 and 0 <= ws[0][2] < 8 * o["max_tail"] and ws[0][2] not in slots
             slots.add(ws[0][2])
-            ts = sorted(b // 8 for b, _, _ in ws)
-            assert ts == list(range(ts[0], ts[0] + o["parts"])) and ts[0] >= o["full"]
+            # part-major in groups of 4 tiles: the parts of a tile sit 4 slots apart -- on ONE shader engine (slot % 4), in part order
+            ts = [b // 8 for b, _, _ in sorted(ws, key=lambda w: w[1])]
+            assert ts == list(range(ts[0], ts[0] + 4 * o["parts"], 4)) and ts[0] >= o["full"] and len({t % 4 for t in ts}) == 1
         assert max(per_xcd) - min(per_xcd) <= 1
         q = nrowblk // 8
         for rb in range(8 * q):
@@ -181,7 +182,7 @@ def test_k_split_rule_picks_what_the_round_arithmetic_says(lib):
     -> 4 parts), one 317M plan (4 x 16 = 64 tiles -> 4 parts fill the 256 CUs), and launches that already fill their rounds
     (317M, 8 plans: 512 tiles -> nothing split)."""
     o = w_order(lib, 60, 7, nk=112, ovh=88)
-    assert (o["parts"], o["full"], o["max_tail"]) == (3, 32, 21) and o["nblk"] == 8 * (32 + 63)
+    assert (o["parts"], o["full"], o["max_tail"]) == (3, 32, 21) and o["nblk"] == 8 * (32 + 24 * 3)  # (21 tail tiles: 6 groups of 4)
     assert 1600 < o["rounds1k"] < 1800  # 1 + 2/3 + overhead, against 2 rounds unsplit
     o = w_order(lib, 60, 3, nk=112, ovh=88)
     assert (o["parts"], o["full"]) == (4, 0)

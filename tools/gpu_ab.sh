@@ -10,7 +10,7 @@ out=gpurun_out/${TAG}_ab.txt; : > $out
 for rep in 1 2; do
   for v in $NAMES; do
     TDMPC2_BENCH_EXACT_STEPS=1 TDMPC2_PLAN_LIB=build/ablate/lib_${v}.so timeout 300 python bench.py $ARGS 2>/dev/null \
-      | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', 'plans/s', d['value'], 'launch_ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'lat1_ms', d['extra'].get('latency_ms_single_env'))" >> $out
+      | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', 'plans/s', d['value'], 'launch_ms', d['roofline']['avg_launch_ms'], 'frac', d['roofline']['frac'], 'lat1_ms', d['extra'].get('latency_ms_single_env'), 'sha', d['extra'].get('action_sha1'), 'parity', (d['extra'].get('parity') or {}).get('action_max_abs_diff'))" >> $out
   done
 done
 cat $out
