@@ -119,10 +119,7 @@ __device__ __forceinline__ void split4(const f32x4 y, f16x4 &hi, f16x4 &lo, cons
 // v_mfma_f32_32x32x16_f16: lane l supplies A[i = l & 31][k = 8 (l >> 5) .. +7] and B[k = 8 (l >> 5) .. +7][j = l & 31].
 // Wave w of 8 owns output columns [64 w, 64 w + 64) for both 32-row tiles: acc[set][row tile][col tile].
 // B fragments are prefetched PF k-blocks ahead (PF x 16 VGPRs) through a register ring.
-#ifndef SPLIT_PF
-#define SPLIT_PF 2  // measured: 2, 3 and 4 k-blocks of prefetch run within 1 % of each other; 6 spills
-#endif
-constexpr int PF = SPLIT_PF;
+constexpr int PF = 2;  // measured: 2, 3 and 4 k-blocks of prefetch run within 1 % of each other; 6 spills
 template <int FT>
 struct BFragT {
     f16x8 h[FT], l[FT];
@@ -130,27 +127,12 @@ struct BFragT {
 // B-fragment addressing: wave-uniform byte pointers (SGPR pairs, advanced by scalar arithmetic) + ONE 32-bit lane
 // offset, made opaque so that the compiler cannot fully unroll the k-loop into per-k-block 64-bit VGPR addresses and
 // hoist them out of the step loop (that cost ~1000 spilled registers).
-// SPLIT_ABL_* macros exist for ablation timing builds only (tools/ablate.sh); the shipped library defines none.
+// (The ablation builds of rounds 1-4 -- no MFMA, no weight loads, no epilogue math, ring depths 4 / 6, the compiler-scheduled
+// loop -- live in tools/variants/ as patches; the shipped kernels carry no experiment switches.)
 __device__ __forceinline__ f16x8 ldw(const char *ubase, unsigned voff, int imm) {
-#ifdef SPLIT_ABL_NO_BLOAD
-    f16x8 r;
-    const _Float16 v = (_Float16)(float)(voff + imm);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = v;
-    return r;
-#else
     return *reinterpret_cast<const f16x8 *>(ubase + voff + imm);
-#endif
 }
-#ifdef SPLIT_ABL_NO_MFMA
-__device__ __forceinline__ f32x16 fake_mfma(f16x8 a, f16x8 b, f32x16 c) {
-    c[0] += (float)a[0] * (float)b[0];  // keeps the dependence on the operand loads, costs one VALU op
-    return c;
-}
-#define SPLIT_MFMA(a, b, c) fake_mfma(a, b, c)
-#else
 #define SPLIT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
-#endif
 template <int FT>
 __device__ __forceinline__ void load_b(BFragT<FT> &b, const char *u0, size_t ct_stride, unsigned voff) {
 #pragma unroll
@@ -255,13 +237,6 @@ __device__ __forceinline__ void kloop_f32(const CT &c, const LayerS &ly, int kb0
 // the compiler still has in flight is older: the wait is merely conservative), lgkmcnt is only ever waited to 0 (scalar
 // loads share that counter and return out of order), no load is in flight when the loop ends (the compiler reuses the
 // destination registers), and 16 wait states separate the last MFMA from the compiler's first read of an accumulator.
-#ifndef SPLIT_NO_ASM_KLOOP
-#define SPLIT_ASM_KLOOP 1
-#endif
-#ifndef KLOOP_RING
-#define KLOOP_RING 2
-#endif
-#ifdef SPLIT_ASM_KLOOP
 #define A_MFMA(ACC, WF, AF) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(WF), "v"(AF))
 template <int OFF>
 __device__ __forceinline__ void a_dsrd(f16x8 &dst, unsigned addr) {
@@ -319,10 +294,10 @@ __device__ __forceinline__ void kloop_asm(const CT &c, const LayerS &ly, int kb0
     const size_t cts = (size_t)ly.KB * 2048;
     const unsigned voff = (unsigned)c.lane * 16u;
     const int nk = kb1 - kb0;
-    // weight ring of RD k-blocks (KLOOP_RING, 16 VGPRs each): at step k blocks k + 1 .. k + RD - 1 are in flight behind the 12
-    // MFMAs of block k -- RD - 1 steps (768 cycles each with the partner wave's) to cover the L2's latency
-    constexpr int RD = KLOOP_RING;
-    static_assert(RD == 2 || RD == 4 || RD == 6, "ring depth: even (the activation fragments alternate with the step)");
+    // weight ring of RD = 2 k-blocks (16 VGPRs each): at step k block k + 1 is in flight behind the 12 MFMAs of block k (768 cycles
+    // with the partner wave's).  (A ring of 4 lost 3.3 %: the kernel fills its VGPR budget and the loop does not wait for L2
+    // latency -- profiles/r4w_kloop_ring4_ab.txt.)
+    constexpr int RD = 2;
     BFragT<2> ring[RD];
     AFragT<CT::NST> a2[2];
 #pragma unroll
@@ -340,9 +315,7 @@ __device__ __forceinline__ void kloop_asm(const CT &c, const LayerS &ly, int kb0
             la0 += 32;
             la1 += 32;
             a_load_act<CT>(a2[(d & 1) ^ 1], la0, la1);
-            if constexpr (RD == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if constexpr (RD == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             a_mfma12<CT>(acc, ring[d], a2[d & 1]);
             a_load_w(ring[d], voff, pn, pn + cts);
             pn += 2048;
@@ -362,6 +335,7 @@ __device__ __forceinline__ void kloop_asm(const CT &c, const LayerS &ly, int kb0
                     a_load_act<CT>(a2[(d & 1) ^ 1], la0, la1);
                 }
                 // blocks behind block kk that are still in flight: those issued and not yet consumed
+                // blocks behind block kk that are still in flight: those issued and not yet consumed
                 const int behind = nk - 1 - kk < RD - 1 ? nk - 1 - kk : RD - 1;
                 if (behind >= 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
                 else if (behind == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -379,7 +353,6 @@ __device__ __forceinline__ void kloop_asm(const CT &c, const LayerS &ly, int kb0
     }
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // XDL write -> VALU read of the accumulators
 }
-#endif
 
 template <class CT>
 __device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, int kb1, f32x16 (&acc)[CT::NST][CT::FT]) {
@@ -387,12 +360,10 @@ __device__ __forceinline__ void kloop_s(const CT &c, const LayerS &ly, int kb0, 
         kloop_f32(c, ly, kb0, kb1, acc);
         return;
     }
-#ifdef SPLIT_ASM_KLOOP
     if constexpr (CT::ARITH == 0 && CT::FT == 2) {
         kloop_asm(c, ly, kb0, kb1, acc);
         return;
     }
-#endif
     constexpr int FT = CT::FT;
     constexpr int PFD = FT == 2 ? PF : (PF > 1 ? PF / 2 : 1);  // ring depth in k-blocks: FT x 8 VGPRs per block
     const int i = c.lane & 31, hh = c.lane >> 5;
@@ -483,10 +454,7 @@ __device__ __forceinline__ void kloop_tile_s(const CT &c, const LayerS &ly, int 
         }
         return;
     }
-#ifndef SPLIT_PFT
-#define SPLIT_PFT 4
-#endif
-    constexpr int PFT = SPLIT_PFT;
+    constexpr int PFT = 4;  // weight blocks in flight (2 / 4 / 8 measured equal: profiles/r4zb_head_prefetch_depth_ab.txt)
     const int i = c.lane & 31, hh = c.lane >> 5;
     const _Float16 *a0p = c.act + i * c.RSH + 8 * hh + kb0 * 16;
     const char *u = reinterpret_cast<const char *>(ly.wp) + ((size_t)ct * ly.KB + kb0) * 2048;  // uniform
@@ -738,9 +706,6 @@ __device__ __forceinline__ void epi_t(const CT &c, f32x16 (&acc)[CT::NST][CT::FT
         shift[st] = -mean * rstd[st];
     }
     TIMER_MARK(c, T_EPI_COMB)
-#ifdef SPLIT_ABL_NO_EPI
-    if (rstd[0] == 12345.f)  // never true: the activation math below is skipped
-#endif
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft) {
         f32x4 gq[4], bq[4];
