@@ -340,7 +340,7 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
  * and are added in a fixed order (tdmpc2_amd/csrc/layered_wide.cuh, tile_order.h: gemm_w_order).  0 = never: every tile whole -- a
  * plan then computes the same bits alone, in any batch and with its rows split over ranks; 1 = whenever the round arithmetic
  * says so (measured: slower on launches that fill the chip -- the partial sums' traffic); 2 (default) = only for launches of
- * 32 .. 128 tiles, which leave most of the chip idle (one or two plans of the 317M model: single-plan latency -7 %).  Same values
+ * 16 .. 128 tiles, which leave most of the chip idle (one or two plans of the 317M model: single-plan latency -9 %).  Same values
  * to fp32 round-off (1e-5 of the trajectory values); the bits of a plan then depend on how many plans share the call. */
 enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0, TDMPC2_TUNE_FOLD_REFIT = 1, TDMPC2_TUNE_CLUSTER = 2, TDMPC2_TUNE_FUSE_LN = 3,
                      TDMPC2_TUNE_REARM_AFTER = 4, TDMPC2_TUNE_SAFE_ONCE = 5, TDMPC2_TUNE_KSPLIT = 6 };

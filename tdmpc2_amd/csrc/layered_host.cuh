@@ -124,16 +124,18 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         const bool w_shape = can_fuse && ly.CT >= 8 && rows_p % 256 == 0 && rows_per_env % 256 == 0 && ncb256 <= 32 && !L.row_env &&
                              stats_need <= L.stats_cap && w256_min >= 0;
         // L.ksplit (TDMPC2_TUNE_KSPLIT): 0 never; 1 whenever the round arithmetic says so; 2 (default) only for launches that leave
-        // most of the chip idle -- 32 .. 128 tiles, i.e. one or two plans of the 317M model (64 tiles -> 256 workgroups of a quarter
-        // of K: single-plan latency 17.6 -> 16.3 ms).  On launches that fill the chip the partial sums' traffic (256 KiB per part
+        // most of the chip idle -- 16 .. 128 tiles, i.e. one or two plans of the 317M model (64 tiles -> 256 workgroups of a quarter
+        // of K: single-plan latency 17.85 -> 16.2 ms, +9.7 % plans/s at E = 1; the 48M model at E = 4: +6 %; profiles/r5j_*).  On launches that fill the chip the partial sums' traffic (256 KiB per part
         // through the fabric, +210 MB per hidden GEMM of the 48M model at E = 30) costs more than the better fill buys: c3 -10 ... -13 %,
         // c4 -2.7 % (profiles/README.md r5d).
         const long tiles_w = (long)nrowblk_w * ncb256;
-        const bool ks_want = L.ksplit == 1 || (L.ksplit == 2 && tiles_w >= 32 && tiles_w <= cus / 2);
+        static const long ks_auto_lo = getenv("TDMPC2_KSPLIT_AUTO_LO") ? atol(getenv("TDMPC2_KSPLIT_AUTO_LO")) : 16;
+        static const long ks_auto_min = getenv("TDMPC2_KSPLIT_AUTO_MIN") ? atol(getenv("TDMPC2_KSPLIT_AUTO_MIN")) : cus / 4;
+        const bool ks_want = L.ksplit == 1 || (L.ksplit == 2 && tiles_w >= ks_auto_lo && tiles_w <= cus / 2);
         if (w_shape && ks_want && bufs->ksws && ks_maxp > 1) {
             const int nk = q.K / 16;
             wo = gemm_w_order(nrowblk_w, ncb256, (int)cus_x, nk, ks_maxp, ks_ovh / (nk + 25));
-            if (wo.parts > 1 && ((size_t)8 * wo.max_tail * wo.parts > L.ksws_slots || (long)wo.nblk < (L.ksplit == 2 ? cus / 2 : ks_min))) wo.parts = 1;
+            if (wo.parts > 1 && ((size_t)8 * wo.max_tail * wo.parts > L.ksws_slots || (long)wo.nblk < (L.ksplit == 2 ? ks_auto_min : ks_min))) wo.parts = 1;
         }
         const size_t n_arrive = (size_t)nrowblk_w + (wo.parts > 1 ? (size_t)8 * wo.max_tail : 0);
         if (w_shape && ((long)nrowblk_w * ncb256 >= w256_min || wo.parts > 1) &&

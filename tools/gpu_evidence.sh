@@ -40,7 +40,7 @@ if has pmc_layered; then  # the layered family's GEMMs at the c3 / c4 geometry o
   python tools/pmc_summary.py gpurun_out/pmc_${TAG}_c3 g_gemm > gpurun_out/${TAG}_c3_pmc.txt 2>&1
   PMC_PASSES="${PMC_PASSES_LAYERED:-sq1 grbm fetch}" bash tools/gpu_pmc.sh ${TAG}_c4 --config c4 --envs 8 --steps 1 --warmup 1 --skip-cpu-baseline --skip-extra-configs --skip-traffic
   python tools/pmc_summary.py gpurun_out/pmc_${TAG}_c4 g_gemm > gpurun_out/${TAG}_c4_pmc.txt 2>&1
-  grep -A16 "g_gemm_w<1>  workgroups=448\|g_gemm_w<1>  workgroups=512" gpurun_out/${TAG}_c3_pmc.txt gpurun_out/${TAG}_c4_pmc.txt | grep -E "g_gemm_w|pipe|clock|HBM" | head -20
+  grep -A16 "g_gemm_w<1, 0>  workgroups=448\|g_gemm_w<1, 0>  workgroups=512" gpurun_out/${TAG}_c3_pmc.txt gpurun_out/${TAG}_c4_pmc.txt | grep -E "g_gemm_w|pipe|clock|HBM" | head -20
   rm -rf gpurun_out/pmc_${TAG}_c3/*/ gpurun_out/pmc_${TAG}_c4/*/ 2>/dev/null
 fi
 if has ab; then  # environment-switch A/B of the in-tree library (interleaved twice), e.g. AB_SPEC="c3 30 8" AB_ENVS="A=0|TDMPC2_GEMM_XCD_ROWS=0"
