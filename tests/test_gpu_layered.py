@@ -620,3 +620,74 @@ def test_k_split_single_317m_plan_matches_the_reference_golden():
     whole = _run_native(c, model, planner)
     assert not np.array_equal(got["value"], whole["value"]), "the single 317M plan did not take the K-split path"
     assert value_err(got["value"][:, 0], whole["value"][:, 0]) < 5e-5
+
+
+def test_safe_once_covers_one_plan_and_the_verdict_word_is_readable_on_the_device(monkeypatch):
+    """ABI 8: (i) the bounded wait gives up after 5 ms of wall clock, not a third of a second; (ii) tdmpc2_plan_fault_word copies the
+    verdict of the calls in flight into device memory in stream order -- non-zero behind a plan whose wait gave up, zero behind a
+    clean one -- without a host synchronisation; (iii) TDMPC2_TUNE_SAFE_ONCE puts exactly the NEXT plan on the paths without
+    inter-workgroup waits and touches neither the caller's settings nor the re-arm bookkeeping: with one workgroup muted
+    (TDMPC2_CLUSTER_FAULT=1) that plan is clean, bit for bit what a handle with the fused epilogue switched off computes, and the
+    plan after it faults again (what dist.sharded_plan's re-plan relies on)."""
+    import time
+
+    from tdmpc2_amd.native import NativePlanner
+    from tests.gpu_common import case_on_gpu, dev, plan_inputs
+
+    c, model, ref = case_on_gpu("small", PATH_LAYERED, 2)
+    monkeypatch.setenv("TDMPC2_CLUSTER_FAULT", "1")
+    planner = NativePlanner(c["cfg"], c["iterations"], dev(), max_envs=c["n_envs"], path=PATH_LAYERED, precision=2)
+    monkeypatch.delenv("TDMPC2_CLUSTER_FAULT")
+    planner.bind_state_dict(model.sd)
+    planner.set_rearm_after(1)  # the library's own downgrade lasts one call here: every other plan is back on the muted path
+    inp = plan_inputs(c, model)
+    kw = dict(eval_mode=c["eval_mode"], task_emb=inp["task_emb"], act_mask=inp["act_mask"], tape=inp["tape"])
+    word = torch.full((1,), -1, dtype=torch.int32, device=dev())
+
+    def plan():
+        pm = inp["prev_mean"].clone()
+        a = planner.plan(inp["z0"], inp["disc_pow"], pm, inp["t0"], **kw).clone()
+        planner.fault_word(word)  # enqueued behind the plan: no sync in between
+        return a, pm
+
+    planner.plan(inp["z0"], inp["disc_pow"], inp["prev_mean"].clone(), inp["t0"], **kw)  # (module load, first-launch costs)
+    torch.cuda.synchronize()
+    planner.take_fault()
+    planner.plan(inp["z0"], inp["disc_pow"], inp["prev_mean"].clone(), inp["t0"], **kw)  # the downgraded call; the next is re-armed
+    torch.cuda.synchronize()
+    assert planner.take_fault() == 0 and planner.fault_info()["degraded"] == 1
+    t = time.perf_counter()
+    bad, _ = plan()
+    torch.cuda.synchronize()
+    took = time.perf_counter() - t
+    assert torch.isnan(bad).all() and int(word.item()) != 0
+    # (the hook mutes a workgroup in EVERY fused launch of the plan -- some sixty here, each waiting out its own bound: 0.26 s
+    # measured; with round 4's 0.3 s per wait this plan took 18 s.  A real fault is one wait.)
+    assert took < 1.0, f"a plan whose waits gave up took {took * 1e3:.0f} ms: the bound is 5 ms per wait, not 0.3 s"
+    assert planner.take_fault() == 1
+    # the library's downgrade covers the next call; re-armed after it (rearm_after = 1, doubled to 2 by the re-arm)
+    planner.set_rearm_after(0)       # from here on: never re-arm by itself ...
+    planner.set_fuse_ln(1)           # ... and an explicit setting re-arms at once: the muted path is what the handle runs
+    bad2, _ = plan()
+    torch.cuda.synchronize()
+    assert torch.isnan(bad2).all() and int(word.item()) != 0 and planner.take_fault() == 1
+    planner.set_fuse_ln(1)
+    fi0 = planner.fault_info()
+    planner.plan_safely_once(True)
+    good, pm_good = plan()
+    torch.cuda.synchronize()
+    assert int(word.item()) == 0 and torch.isfinite(good).all() and planner.take_fault() == 0
+    fi1 = planner.fault_info()
+    assert (fi1["degraded"], fi1["rearms"], fi1["rearm_after"]) == (fi0["degraded"], fi0["rearms"], fi0["rearm_after"])
+    ref.set_fuse_ln(0)
+    try:
+        pm_ref = inp["prev_mean"].clone()
+        want = ref.plan(inp["z0"], inp["disc_pow"], pm_ref, inp["t0"], **kw).clone()
+    finally:
+        ref.set_fuse_ln(1)
+    torch.cuda.synchronize()
+    assert torch.equal(good, want) and torch.equal(pm_good, pm_ref)
+    bad3, _ = plan()  # the flag covered exactly one plan
+    torch.cuda.synchronize()
+    assert torch.isnan(bad3).all() and int(word.item()) != 0 and planner.take_fault() == 1
+    planner.close()
