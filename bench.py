@@ -903,6 +903,16 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, I, sd_np, args.cpu_budget)
         except Exception as ex:  # the baseline is a reported number, never a reason to lose the measurement
             line["cpu_baseline"] = {"value": None, "error": repr(ex)}
+        if args.config == "c2" and not args.skip_extra_configs:
+            # BASELINE.json configs[0] -- the reference's own CPU-runnable case (cheetah-run 5M, plan() on CPU PyTorch, H3 N512 I6): the
+            # same CPU restatement on c1's dimensions, a few seconds (a reported baseline like cpu_baseline, nothing of the product)
+            try:
+                c1 = named_config("c1")
+                leg = cpu_baseline(c1, 6, synth.make_state_dict(c1, seed=0), budget_s=4.0)
+                leg["config"] = {"workload": "c1: cheetah-run 5M (L512 M512 A6 nq5), plan() H=3 N=512 I=6 on the host CPU (torch), 1 env"}
+                line["extra"].setdefault("configs", {})["c1_cpu"] = leg
+            except Exception as ex:
+                line["extra"].setdefault("configs", {})["c1_cpu"] = {"error": repr(ex)}
     # last (a counter pass that times out cannot cost the baselines above): roofline.traffic from rocprofv3 --pmc children
     if world == 1 and not args.skip_traffic and args.path == "auto" and args.precision == "auto" and not STUB:
         log("measuring roofline.traffic (rocprofv3 --pmc children)")

@@ -72,6 +72,13 @@ typedef struct tdmpc2_plan_cfg {
     int32_t device;                   /* HIP device ordinal */
     int32_t path;                     /* enum tdmpc2_path: which kernel family runs the rollout */
     int32_t precision;                /* enum tdmpc2_precision: how the fp32 contractions are carried out */
+    int32_t num_valid_samples;        /* ABI 8.  0 = num_samples.  Otherwise (num_elites <= . <= num_samples): the reference's
+                                       * cfg.num_samples when that is not a multiple of the kernels' row tile (config.yaml:36 allows
+                                       * any value; the kernels want 64 / 128): create the handle with num_samples rounded UP, pass the
+                                       * true count here, and pad the noise tapes' sample axis to the rounded count.  The padding rows
+                                       * are rolled out like the others but can never be elites: they sort behind every real row
+                                       * in the top-k of tdmpc2.py:185 (as the -inf rows of a masked topk would), so mean / std / action
+                                       * are those of a plan over the true count.  tdmpc2_amd.NativePlanner does all of this itself. */
 } tdmpc2_plan_cfg;
 
 /* Two kernel families implement the same math (results agree to fp32 round-off):

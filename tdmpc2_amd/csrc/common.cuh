@@ -95,6 +95,7 @@ __device__ __forceinline__ void raise_fault(unsigned int *err, unsigned int code
 
 struct RefitParams {
     int E, N, H, A, K, iter, last, eval_mode;
+    int Nvalid;            // rows >= Nvalid (> 0) are padding of num_samples to the row tile: never elites (tdmpc2_plan_cfg::num_valid_samples)
     int stage;             // elite actions are staged in LDS ([K][H*A] floats after the other arrays): see refit_lds_bytes
     float temperature, min_std, max_std;
     float *value;          // [E,N] in/out (nan_to_num)
@@ -402,7 +403,12 @@ __device__ __forceinline__ void refit_plan(const RefitParams &p, int e, float *s
     const bool sorted_path = M <= nthr;  // one key per thread
     // value.nan_to_num(0): nan -> 0, +-inf -> +-FLT_MAX (tdmpc2.py:184)
     unsigned long long key = 0ull;  // padding keys sort last
+    const int NV = p.Nvalid > 0 ? p.Nvalid : p.N;
     for (int i = tid; i < p.N; i += nthr) {
+        if (i >= NV) {  // padding of num_samples to the row tile: behind every real row, whatever it evaluated to
+            if (!sorted_path) sv[i] = -INFINITY;  // (real rows are finite after nan_to_num; ties go by index: lower first)
+            continue;                             // sorted path: key stays 0, below every real key
+        }
         // in-launch refit: the values of the plan's other workgroups arrive as write-through stores from other XCDs; read
         // them with agent-scope (sc1) loads -- past the L1, from lines this XCD's L2 cannot hold yet -- and do NOT
         // invalidate caches (an agent-scope acquire here, buffer_inv sc1, drops the XCD's L2-resident weights: +13 %)

@@ -612,7 +612,7 @@ int fused_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const floa
         }
         RefitParams &fp = rp.rf;
         fp = RefitParams{};
-        fp.E = E; fp.N = N; fp.H = H; fp.A = A; fp.K = K; fp.iter = it; fp.last = (it == I - 1); fp.eval_mode = eval_mode; fp.stage = refit_stage;
+        fp.Nvalid = c.num_valid_samples; fp.E = E; fp.N = N; fp.H = H; fp.A = A; fp.K = K; fp.iter = it; fp.last = (it == I - 1); fp.eval_mode = eval_mode; fp.stage = refit_stage;
         fp.temperature = c.temperature; fp.min_std = c.min_std; fp.max_std = c.max_std;
         fp.value = h->value; fp.actions = h->actions; fp.act_mask = act_mask; fp.mean = h->mean; fp.std = h->std;
         fp.gumbel_exp = tape ? tape->gumbel_exp : nullptr; fp.final_eps = tape ? tape->final_eps : nullptr;
@@ -709,6 +709,10 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
     if (c.num_pi_trajs < 0 || c.num_pi_trajs > ROWS || c.num_pi_trajs >= c.num_samples)
         return fail(TDMPC2_ERR_UNSUPPORTED, "num_pi_trajs %d outside [0, %d]", c.num_pi_trajs, ROWS);
     if (c.num_elites < 1 || c.num_elites > c.num_samples) return fail(TDMPC2_ERR_INVALID, "num_elites %d", c.num_elites);
+    if (c.num_valid_samples != 0 && (c.num_valid_samples < c.num_elites || c.num_valid_samples > c.num_samples ||
+                                     c.num_valid_samples <= c.num_pi_trajs || c.num_samples - c.num_valid_samples >= GBM))
+        return fail(TDMPC2_ERR_INVALID, "num_valid_samples %d: 0, or the true sample count behind num_samples %d rounded up to the row tile "
+                    "(>= num_elites %d, > num_pi_trajs %d)", c.num_valid_samples, c.num_samples, c.num_elites, c.num_pi_trajs);
     if (c.simnorm_dim != 8) return fail(TDMPC2_ERR_UNSUPPORTED, "simnorm_dim %d (kernels are built for 8)", c.simnorm_dim);
     if (c.multitask && c.task_dim < 1) return fail(TDMPC2_ERR_INVALID, "multitask needs task_dim > 0");
     if (c.multitask && c.episodic)  // the reference asserts the same: tdmpc2/common/world_model.py:136
@@ -1422,7 +1426,7 @@ void fill_refit(tdmpc2_plan *h, RefitParams &fp, int E, int it, int eval_mode, f
     const tdmpc2_plan_cfg &c = h->cfg;
     const int H = c.horizon, N = c.num_samples, A = c.action_dim, K = c.num_elites, I = c.iterations;
     fp = RefitParams{};
-    fp.E = E; fp.N = N; fp.H = H; fp.A = A; fp.K = K; fp.iter = it; fp.last = (it == I - 1); fp.eval_mode = eval_mode; fp.stage = stage;
+    fp.Nvalid = c.num_valid_samples; fp.E = E; fp.N = N; fp.H = H; fp.A = A; fp.K = K; fp.iter = it; fp.last = (it == I - 1); fp.eval_mode = eval_mode; fp.stage = stage;
     fp.temperature = c.temperature; fp.min_std = c.min_std; fp.max_std = c.max_std;
     fp.value = value; fp.actions = h->actions; fp.act_mask = act_mask; fp.mean = h->mean; fp.std = h->std;
     fp.gumbel_exp = tape ? tape->gumbel_exp : nullptr; fp.final_eps = tape ? tape->final_eps : nullptr;
@@ -1948,7 +1952,7 @@ int tdmpc2_plan_refit(tdmpc2_plan_t *h, int n_envs, float *value, const float *a
     int refit_stage = 0;
     const size_t refit_lds = refit_lds_bytes(c.num_samples, c.num_elites, c.horizon, c.action_dim, &refit_stage);
     RefitParams fp{};
-    fp.E = n_envs; fp.N = c.num_samples; fp.H = c.horizon; fp.A = c.action_dim; fp.K = c.num_elites; fp.last = 0; fp.stage = refit_stage;
+    fp.Nvalid = c.num_valid_samples; fp.E = n_envs; fp.N = c.num_samples; fp.H = c.horizon; fp.A = c.action_dim; fp.K = c.num_elites; fp.last = 0; fp.stage = refit_stage;
     fp.temperature = c.temperature; fp.min_std = c.min_std; fp.max_std = c.max_std;
     fp.value = value; fp.actions = actions; fp.act_mask = c.multitask ? act_mask : nullptr;
     fp.mean = mean ? mean : h->mean; fp.std = std ? std : h->std; fp.score = score; fp.elite_idx = elite_idx;

@@ -48,7 +48,7 @@ class PlanCfg(C.Structure):
                                           "simnorm_dim")] + \
                [(n, C.c_float) for n in ("vmin", "vmax", "min_std", "max_std", "temperature", "log_std_min",
                                          "log_std_dif")] + \
-               [(n, C.c_int32) for n in ("multitask", "episodic", "max_envs", "device", "path", "precision")]
+               [(n, C.c_int32) for n in ("multitask", "episodic", "max_envs", "device", "path", "precision", "num_valid_samples")]
 
 
 class Noise(C.Structure):
@@ -197,7 +197,15 @@ class NativePlanner:
         self.max_envs = int(max_envs)
         lsmin = float(cfg.log_std_min) if log_std_min is None else float(log_std_min)
         lsdif = float(cfg.log_std_max) - float(cfg.log_std_min) if log_std_dif is None else float(log_std_dif)
-        c = PlanCfg(horizon=cfg.horizon, num_samples=cfg.num_samples, num_elites=cfg.num_elites,
+        # cfg.num_samples may be anything (config.yaml:36); the kernels own 64- / 128-row tiles.  The handle is created with the
+        # count rounded UP to 128 and told the true one (tdmpc2_plan_cfg::num_valid_samples): the padding rows are rolled out but
+        # can never be elites.  self.cfg keeps the caller's count; tapes are padded and stages sliced at this boundary.
+        n_true = int(cfg.num_samples)
+        fused_ok = int(cfg.latent_dim) == 512 and int(cfg.mlp_dim) == 512 and int(path) != PATH_LAYERED
+        tile = 64 if fused_ok else 128  # rows a workgroup owns: fused family 64, layered family 128
+        self._npad = (n_true + tile - 1) // tile * tile
+        c = PlanCfg(horizon=cfg.horizon, num_samples=self._npad, num_valid_samples=(n_true if self._npad != n_true else 0),
+                    num_elites=cfg.num_elites,
                     num_pi_trajs=cfg.num_pi_trajs, iterations=self.iterations, action_dim=cfg.action_dim,
                     latent_dim=cfg.latent_dim, mlp_dim=cfg.mlp_dim, task_dim=cfg.task_dim, num_bins=cfg.num_bins,
                     num_q=cfg.num_q, simnorm_dim=cfg.simnorm_dim, vmin=cfg.vmin, vmax=cfg.vmax, min_std=cfg.min_std,
@@ -339,7 +347,20 @@ class NativePlanner:
         shapes = self.noise_shapes(E)
         for k, (shp, dt) in shapes.items():
             _chk_tensor(f"tape[{k}]", tape[k], dt, shp, self.device)
+        if self._npad != self.cfg.num_samples:  # pad the sample axis with zeros: the padding rows' draws are irrelevant
+            cfg, N, NP, P = self.cfg, self.cfg.num_samples, self._npad, self.cfg.num_pi_trajs
+            se = torch.zeros(E, self.iterations, cfg.horizon, NP - P, cfg.action_dim, device=self.device)
+            se[:, :, :, :N - P] = tape["sample_eps"]
+            pe = torch.zeros(E, self.iterations, NP, cfg.action_dim, device=self.device)
+            pe[:, :, :N] = tape["pi_eps"]
+            tape = dict(tape, sample_eps=se, pi_eps=pe)
+            self._padded_tape = tape  # (kept alive until the next call)
         return Noise(**{k: tape[k].data_ptr() for k in shapes})
+
+    def _whole_tiles_only(self, what):
+        if self._npad != self.cfg.num_samples:
+            raise NativeError(f"{what} is a stage-wise entry point: it needs num_samples ({self.cfg.num_samples}) to be a multiple of the "
+                              f"kernels' row tile; plan() / plan_obs() pad to {self._npad} themselves")
 
     def noise_shapes(self, E):
         """Shapes / dtypes of the six tensors of a noise tape for E environments (struct tdmpc2_noise)."""
@@ -362,6 +383,7 @@ class NativePlanner:
         """The draws a tape = None plan makes under (seed, call = call_counter() read BEFORE that plan) for environments
         [env_first, env_first + n_envs), as a noise-tape dict: feeding it back as `tape` reproduces the plan bit for bit,
         and the same tensors replay through the CPU oracle (tdmpc2_plan_export_noise)."""
+        self._whole_tiles_only("export_noise")
         shapes = self.noise_shapes(n_envs)
         out = {k: torch.empty(shp, dtype=dt, device=self.device) for k, (shp, dt) in shapes.items() if fields is None or k in fields}
         noise = Noise(**{k: v.data_ptr() for k, v in out.items()})
@@ -529,21 +551,26 @@ class NativePlanner:
             noise_p = C.byref(noise)
         dbg_p, stages = None, None
         if debug:
-            stages = {"value": torch.empty(E, I, N, device=dev), "elite_idx": torch.empty(E, I, K, device=dev, dtype=torch.int32),
+            NP = self._npad  # (stages come back sliced to the caller's num_samples)
+            stages = {"value": torch.empty(E, I, NP, device=dev), "elite_idx": torch.empty(E, I, K, device=dev, dtype=torch.int32),
                       "score": torch.empty(E, I, K, device=dev), "mean": torch.empty(E, I, H, A, device=dev),
-                      "std": torch.empty(E, I, H, A, device=dev), "actions": torch.empty(E, I, H, N, A, device=dev)}
+                      "std": torch.empty(E, I, H, A, device=dev), "actions": torch.empty(E, I, H, NP, A, device=dev)}
             dbg = Debug(**{k: v.data_ptr() for k, v in stages.items()})
             dbg_p = C.byref(dbg)
         with torch.cuda.device(dev):
             self._check(self.lib.tdmpc2_plan_run(self._h, E, _ptr(z0), _ptr(task_emb), _ptr(act_mask), _ptr(disc_pow),
                                                  _ptr(prev_mean), _ptr(t0), int(bool(eval_mode)), noise_p,
                                                  C.c_uint64(int(seed) & (2**64 - 1)), _ptr(action), dbg_p, self._stream()))
+        if debug and self._npad != N:
+            stages["value"] = stages["value"][:, :, :N].contiguous()
+            stages["actions"] = stages["actions"][:, :, :, :N].contiguous()
         return (action, stages) if debug else action
 
     def estimate_value(self, z0, disc_pow, actions, pi_eps, qidx, task_emb=None, act_mask=None, trace=False):
         """TDMPC2._estimate_value (tdmpc2/tdmpc2.py:122-136) on given action sequences -> value [E,N].
         With `trace`, also returns (tiles [E*N/64, 5H+7, 64, L], scalars [E, N, H+2+A])."""
         cfg, dev = self.cfg, self.device
+        self._whole_tiles_only("estimate_value")
         E = int(z0.shape[0])
         self._common_inputs(E, z0, task_emb, act_mask, disc_pow)
         _chk_tensor("actions", actions, torch.float32, (E, cfg.horizon, cfg.num_samples, cfg.action_dim), dev)
@@ -564,6 +591,7 @@ class NativePlanner:
     def refit(self, value, actions, act_mask=None):
         """Elite select + refit (tdmpc2/tdmpc2.py:184-197).  `value` [E,N] gets nan_to_num in place.
         Returns (mean, std, score, elite_idx)."""
+        self._whole_tiles_only("refit")
         cfg, dev = self.cfg, self.device
         E = int(value.shape[0])
         H, N, K, A = cfg.horizon, cfg.num_samples, cfg.num_elites, cfg.action_dim
@@ -587,6 +615,7 @@ class NativePlanner:
     def shard_begin(self, z0, prev_mean, t0, task_emb=None, act_mask=None, tape=None, seed: int = 0):
         """Prologue of a plan whose sample rows are split over ranks: warm start + policy-prior trajectories
         (tdmpc2.py:154-170), replicated on every rank."""
+        self._whole_tiles_only("shard_begin")
         cfg, dev = self.cfg, self.device
         E = int(z0.shape[0])
         _chk_tensor("z0", z0, torch.float32, (E, cfg.latent_dim), dev)
@@ -638,6 +667,7 @@ class NativePlanner:
     # ------------------------------------------------------------------ tuning / profiling
     def set_rows_per_workgroup(self, rows: int):
         """0 = automatic (32-row workgroups for calls with few plans: latency), or force 32 / 64 sample rows."""
+        self._whole_tiles_only("debug_buffers")
         self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 0, int(rows)))
 
     def set_fold_refit(self, mode):

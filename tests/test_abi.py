@@ -44,8 +44,8 @@ def test_library_exports_every_declared_symbol(lib):
 def test_cfg_struct_matches_header_layout():
     from tdmpc2_amd import native
 
-    # 12 int32 + 7 float + 6 int32, no padding
-    assert ctypes.sizeof(native.PlanCfg) == 25 * 4
+    # 12 int32 + 7 float + 7 int32, no padding
+    assert ctypes.sizeof(native.PlanCfg) == 26 * 4
     assert ctypes.sizeof(native.Noise) == 6 * ctypes.sizeof(ctypes.c_void_p)
     assert ctypes.sizeof(native.Debug) == 6 * ctypes.sizeof(ctypes.c_void_p)
 

@@ -1,7 +1,7 @@
 """-m gpu: edge configurations of plan() against the oracle on the same seeded inputs (no golden fixture: the
 oracle itself is pinned against the reference in tests/test_oracle_golden.py): minimum / maximum sizes of the
 kernels' envelope, no policy-prior trajectories, every sample an elite, horizon 1, eval mode, all-warm starts,
-two-member Q ensembles, odd action widths, episodic planning at horizon 1."""
+two-member Q ensembles, odd action widths, episodic planning at horizon 1, sample counts that are not tile multiples."""
 import numpy as np
 import pytest
 import torch
@@ -28,6 +28,13 @@ def _edge_cases():
         "layered_1m_model": (named_config("c1", model_size=1, task="mt30", action_dim=4, iterations=2), 2, False, None, 0, 0),
         "fused_episodic_h1_eval": (named_config("c1", horizon=1, episodic=True, iterations=2), 2, True, [True, False], 1, 2),
         "fused_episodic_h5_rows32": (named_config("c1", horizon=5, episodic=True, iterations=2, num_samples=128, num_elites=16), 1, False, None, 1, 1),
+        # num_samples that are NOT multiples of the kernels' row tile (config.yaml:36 allows any value): NativePlanner creates the
+        # handle with the count rounded up (512 / 256 / 128) and tdmpc2_plan_cfg::num_valid_samples = the true one -- the padding
+        # rows are rolled out but never elites; values, elite sets, mean / std and the action are those of the oracle at the true count
+        "fused_500_samples": (named_config("c1", num_samples=500, iterations=3), 2, False, None, 0, 0),
+        "fused_500_samples_one_plan_cluster_path": (named_config("c1", num_samples=500, iterations=2), 1, False, None, 0, 0),
+        "layered_200_samples": (named_config("small", num_samples=200, num_elites=16), 3, False, None, 0, 0),
+        "layered_mt_72_samples_eval": (named_config("small", task="mt30", num_samples=72, num_elites=9, num_pi_trajs=5), 2, True, None, 0, 0),
     }
 
 
