@@ -65,6 +65,8 @@ typedef struct tdmpc2_plan tdmpc2_plan_t;
 typedef struct tdmpc2_plan_cfg {
     int32_t horizon, num_samples, num_elites, num_pi_trajs, iterations;
     int32_t action_dim, latent_dim, mlp_dim, task_dim, num_bins, num_q, simnorm_dim;
+    /* num_bins: 2 .. 128 two-hot bins, or 0 / 1 = the reference's regression heads (one output column; two_hot_inv is the
+     * identity / symexp, common/math.py:76-79).  simnorm_dim: 8 (layers.py:84-88; every released model). */
     float vmin, vmax, min_std, max_std, temperature;
     float log_std_min, log_std_dif;   /* WorldModel buffers, world_model.py:34-35 */
     int32_t multitask, episodic;

@@ -83,7 +83,7 @@ class Config:
 def parse_cfg(cfg: Config) -> Config:
     """Apply the reference's derivations (parser.py:59-78) to a Config."""
     cfg = dataclasses.replace(cfg)
-    cfg.bin_size = (cfg.vmax - cfg.vmin) / (cfg.num_bins - 1)  # parser.py:59
+    cfg.bin_size = (cfg.vmax - cfg.vmin) / (cfg.num_bins - 1) if cfg.num_bins != 1 else 0.0  # parser.py:59 (which divides by zero at 1)
     if cfg.model_size is not None:  # parser.py:62-68
         if cfg.model_size not in MODEL_SIZE:
             raise ValueError(f"Invalid model size {cfg.model_size}. Must be one of {list(MODEL_SIZE)}")

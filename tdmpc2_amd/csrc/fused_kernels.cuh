@@ -796,6 +796,10 @@ __device__ __forceinline__ float twohot_rows_s(const CT &c, const float *bins, i
     const bool live = (c.tid >> 3) < CT::TROWS;  // ST = 1: the upper half of the workgroup has no row
     const int row = live ? c.tid >> 3 : 0;
     const float *rp = c.f32() + row * c.RSF();
+    if (num_bins <= 1) {  // regression head (one output column): two_hot_inv is the identity (0) or symexp (1), math.py:76-79
+        const float x1 = rp[0];
+        return num_bins == 0 ? x1 : symexp_f(x1);
+    }
     float v[16];
     float m = -INFINITY;
 #pragma unroll

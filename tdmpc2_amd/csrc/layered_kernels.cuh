@@ -229,6 +229,7 @@ __global__ __launch_bounds__(RW_THREADS) void l_ln_act(LnActParams p) {
 
 // two_hot_inv of one row of logits (tdmpc2/common/math.py:74-83); result in every lane.
 __device__ __forceinline__ float twohot_wave(const float *lg, const float *bins, int num_bins, int lane) {
+    if (num_bins <= 1) return num_bins == 0 ? lg[0] : symexp_f(lg[0]);  // regression head: identity / symexp (math.py:76-79)
     float v0 = lane < num_bins ? lg[lane] : -INFINITY;
     float v1 = lane + 64 < num_bins ? lg[lane + 64] : -INFINITY;
     const float m = group_max<64>(fmaxf(v0, v1));

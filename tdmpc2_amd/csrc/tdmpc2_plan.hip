@@ -701,7 +701,8 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
     const tdmpc2_plan_cfg &c = *cfg;
     // ---- limits common to both kernel families
     if (c.action_dim < 1 || c.action_dim > 64) return fail(TDMPC2_ERR_UNSUPPORTED, "action_dim %d outside [1, 64]", c.action_dim);
-    if (c.num_bins < 2 || c.num_bins > 128) return fail(TDMPC2_ERR_UNSUPPORTED, "num_bins %d outside [2, 128]", c.num_bins);
+    // num_bins 0 / 1: the reference's regression heads -- one output column, two_hot_inv = identity / symexp (math.py:76-79)
+    if (c.num_bins < 0 || c.num_bins > 128) return fail(TDMPC2_ERR_UNSUPPORTED, "num_bins %d outside [0, 128]", c.num_bins);
     if (c.num_q < 2 || c.num_q > MAXQ) return fail(TDMPC2_ERR_UNSUPPORTED, "num_q %d outside [2, %d]", c.num_q, MAXQ);
     if (c.horizon < 1 || c.horizon > MAXH) return fail(TDMPC2_ERR_UNSUPPORTED, "horizon %d outside [1, %d]", c.horizon, MAXH);
     if (c.num_samples % ROWS != 0 || c.num_samples < ROWS || c.num_samples > 1024)
@@ -776,7 +777,8 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
         }
     }
     // torch.linspace(vmin, vmax, num_bins) in fp32 (math.py:80): float step, product rounded once
-    std::vector<float> bins(c.num_bins);
+    std::vector<float> bins(c.num_bins > 1 ? c.num_bins : 2, 0.f);
+    if (c.num_bins > 1)
     {
         const float step = (c.vmax - c.vmin) / (float)(c.num_bins - 1);
         for (int i = 0; i < c.num_bins; ++i)
@@ -1054,7 +1056,7 @@ LayerShape layer_shape(const tdmpc2_plan *h, int net, int layer) {
     } else {
         s.in = c.mlp_dim;
         s.out = net == TDMPC2_NET_DYNAMICS ? c.latent_dim : net == TDMPC2_NET_PI ? 2 * c.action_dim
-                : net == TDMPC2_NET_TERMINATION ? 1 : c.num_bins;
+                : net == TDMPC2_NET_TERMINATION ? 1 : (c.num_bins > 1 ? c.num_bins : 1);
     }
     s.has_ln = (layer < 2) || net == TDMPC2_NET_DYNAMICS;
     s.mish = layer < 2;

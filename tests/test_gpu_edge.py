@@ -34,6 +34,11 @@ def _edge_cases():
         "fused_500_samples": (named_config("c1", num_samples=500, iterations=3), 2, False, None, 0, 0),
         "fused_500_samples_one_plan_cluster_path": (named_config("c1", num_samples=500, iterations=2), 1, False, None, 0, 0),
         "layered_200_samples": (named_config("small", num_samples=200, num_elites=16), 3, False, None, 0, 0),
+        # the reference's regression heads (math.py:76-79): one output column, two_hot_inv = identity (num_bins 0) / symexp (1)
+        "fused_num_bins_0": (named_config("c1", num_bins=0, iterations=2), 2, False, None, 0, 0),
+        "fused_num_bins_1_one_plan": (named_config("c1", num_bins=1, iterations=2), 1, False, None, 0, 0),
+        "layered_num_bins_0": (named_config("small", num_bins=0), 2, False, None, 0, 0),
+        "layered_num_bins_1_episodic": (named_config("small", num_bins=1, episodic=True), 2, False, None, 0, 0),
         "layered_mt_72_samples_eval": (named_config("small", task="mt30", num_samples=72, num_elites=9, num_pi_trajs=5), 2, True, None, 0, 0),
     }
 
