@@ -65,8 +65,10 @@ struct ClState {
 __device__ __forceinline__ void cl_st16(float *p, f32x4 v, int fast) {
     // members on one XCD share its L2: a plain (write-through-to-L2) store is visible to the others' agent-scope loads;
     // otherwise the line has to leave the XCD: agent-scope write-through
-    if (fast) asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    // s_nop 1 in the same statement: the store reads its 128 bits of data after issue, a VALU write of those registers needs
+    // 2 wait states behind it on gfx940+, and the hazard recognizer does not look inside inline asm (layered_wide.cuh: gw_st_sc1)
+    if (fast) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void cl_ld16(f32x4 &v, const float *p) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");

@@ -37,14 +37,21 @@ __device__ __forceinline__ void gw_dsrd(f16x8 &dst, unsigned addr) {
 __device__ __forceinline__ void gw_glds(const char *g, char *l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
 }
+#define KS_ST "sc1"
+#define KS_LD "sc1"
 #define GW_MFMA(ACC, WF, AF) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(WF), "v"(AF))
 // partial accumulators of a K-split tile: write-through (sc1) 16-byte stores, L1-bypassing (sc1) 16-byte loads -- the guide's
 // "16-B sc1 stores + drained vmcnt + flag, sc1 loads on the reader" hand-off (MI355X_MICROARCH.md, valid forms; publish-large)
+// s_nop 1 BEHIND THE STORE, IN THE SAME STATEMENT: a VMEM store of more than 64 bits reads its data registers after it has
+// issued, and a VALU write of one of them needs 2 wait states behind it on gfx940+.  The compiler's hazard recognizer inserts
+// them for its own stores but does not look inside inline asm: it reused the just-stored accumulator registers for the next
+// store's address one s_mov later, and -- depending on how the CU's waves interleaved -- lanes 12..15 of a quarter wave stored
+// address bits (r5z: 1 plan in 2 of the 317M model wrong with two chains in flight, never with one).
 __device__ __forceinline__ void gw_st_sc1(float *p, const f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off " KS_ST "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void gw_ld_sc1(f32x4 &v, const float *p) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off " KS_LD : "=v"(v) : "v"(p) : "memory");
 }
 
 // In-kernel phase clocks of wave 0 (profiling builds only: -DGW_TIMING; TDMPC2_GW_TIMING=1 makes the host allocate and print
@@ -174,15 +181,15 @@ __device__ __forceinline__ void gw_phase(f32x16 (&acc)[2][4], GwFrags (&fr)[2], 
 // inside inline asm).
 #define GW_LD_ "global_load_dwordx4 %"
 __device__ __forceinline__ void gw_ld4(f32x4 (&a)[4], const unsigned (&o)[4], const char *pa) {
-    asm volatile("s_nop 4\n\t" GW_LD_ "0, %4, %8 sc1\n\t" GW_LD_ "1, %5, %8 sc1\n\t" GW_LD_ "2, %6, %8 sc1\n\t" GW_LD_ "3, %7, %8 sc1\n\t"
+    asm volatile("s_nop 4\n\t" GW_LD_ "0, %4, %8 " KS_LD "\n\t" GW_LD_ "1, %5, %8 " KS_LD "\n\t" GW_LD_ "2, %6, %8 " KS_LD "\n\t" GW_LD_ "3, %7, %8 " KS_LD "\n\t"
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3])
                  : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "s"(pa)
                  : "memory");
 }
 __device__ __forceinline__ void gw_ld8(f32x4 (&a)[4], f32x4 (&b)[4], const unsigned (&o)[4], const char *pa, const char *pb) {
-    asm volatile("s_nop 4\n\t" GW_LD_ "0, %8, %12 sc1\n\t" GW_LD_ "1, %9, %12 sc1\n\t" GW_LD_ "2, %10, %12 sc1\n\t" GW_LD_ "3, %11, %12 sc1\n\t"
-                 GW_LD_ "4, %8, %13 sc1\n\t" GW_LD_ "5, %9, %13 sc1\n\t" GW_LD_ "6, %10, %13 sc1\n\t" GW_LD_ "7, %11, %13 sc1\n\t"
+    asm volatile("s_nop 4\n\t" GW_LD_ "0, %8, %12 " KS_LD "\n\t" GW_LD_ "1, %9, %12 " KS_LD "\n\t" GW_LD_ "2, %10, %12 " KS_LD "\n\t" GW_LD_ "3, %11, %12 " KS_LD "\n\t"
+                 GW_LD_ "4, %8, %13 " KS_LD "\n\t" GW_LD_ "5, %9, %13 " KS_LD "\n\t" GW_LD_ "6, %10, %13 " KS_LD "\n\t" GW_LD_ "7, %11, %13 " KS_LD "\n\t"
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
                  : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "s"(pa), "s"(pb)
@@ -190,9 +197,9 @@ __device__ __forceinline__ void gw_ld8(f32x4 (&a)[4], f32x4 (&b)[4], const unsig
 }
 __device__ __forceinline__ void gw_ld12(f32x4 (&a)[4], f32x4 (&b)[4], f32x4 (&c)[4], const unsigned (&o)[4], const char *pa, const char *pb,
                                         const char *pc) {
-    asm volatile("s_nop 4\n\t" GW_LD_ "0, %12, %16 sc1\n\t" GW_LD_ "1, %13, %16 sc1\n\t" GW_LD_ "2, %14, %16 sc1\n\t" GW_LD_ "3, %15, %16 sc1\n\t"
-                 GW_LD_ "4, %12, %17 sc1\n\t" GW_LD_ "5, %13, %17 sc1\n\t" GW_LD_ "6, %14, %17 sc1\n\t" GW_LD_ "7, %15, %17 sc1\n\t"
-                 GW_LD_ "8, %12, %18 sc1\n\t" GW_LD_ "9, %13, %18 sc1\n\t" GW_LD_ "10, %14, %18 sc1\n\t" GW_LD_ "11, %15, %18 sc1\n\t"
+    asm volatile("s_nop 4\n\t" GW_LD_ "0, %12, %16 " KS_LD "\n\t" GW_LD_ "1, %13, %16 " KS_LD "\n\t" GW_LD_ "2, %14, %16 " KS_LD "\n\t" GW_LD_ "3, %15, %16 " KS_LD "\n\t"
+                 GW_LD_ "4, %12, %17 " KS_LD "\n\t" GW_LD_ "5, %13, %17 " KS_LD "\n\t" GW_LD_ "6, %14, %17 " KS_LD "\n\t" GW_LD_ "7, %15, %17 " KS_LD "\n\t"
+                 GW_LD_ "8, %12, %18 " KS_LD "\n\t" GW_LD_ "9, %13, %18 " KS_LD "\n\t" GW_LD_ "10, %14, %18 " KS_LD "\n\t" GW_LD_ "11, %15, %18 " KS_LD "\n\t"
                  "s_waitcnt vmcnt(0)"
                  : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]),
                    "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])

@@ -154,8 +154,11 @@ def test_layered_errors_are_loud():
     from tdmpc2_amd.config import named_config
     from tdmpc2_amd.native import NativeError, NativePlanner
 
-    with pytest.raises(NativeError):  # tiny: num_samples 64 is not a multiple of the GEMM row tile
-        NativePlanner(named_config("tiny"), 3, torch.device("cuda", 0), path=PATH_LAYERED)
+    with pytest.raises(NativeError):  # SimNorm groups other than the reference's 8 (common/__init__.py) are not built
+        NativePlanner(named_config("tiny", simnorm_dim=4), 3, torch.device("cuda", 0), path=PATH_LAYERED)
+    with pytest.raises(NativeError):  # widths that are not whole 32-column tiles
+        NativePlanner(named_config("tiny", mlp_dim=80), 3, torch.device("cuda", 0), path=PATH_LAYERED)
+    # (tiny's 64 samples -- not a whole 128-row tile -- are padded by the host mirror since round 5: tests/test_gpu_edge.py)
     with pytest.raises(NativeError):  # the fused family is built for 512-wide layers only
         NativePlanner(named_config("c3"), 6, torch.device("cuda", 0), path=PATH_FUSED)
     with pytest.raises(NativeError):  # termination head with task ids: the reference asserts the same

@@ -415,7 +415,7 @@ def test_errors_are_loud():
     from tdmpc2_amd.native import NativeError, NativePlanner
 
     with pytest.raises(NativeError):
-        NativePlanner(named_config("tiny"), 3, torch.device("cuda", 0))  # unsupported dims
+        NativePlanner(named_config("tiny", mlp_dim=80), 3, torch.device("cuda", 0))  # unsupported dims
     with pytest.raises(NativeError):
         NativePlanner(named_config("c1"), 6, torch.device("cpu"))  # no CPU fallback
     p = NativePlanner(named_config("c1"), 6, torch.device("cuda", 0), max_envs=1)
