@@ -190,9 +190,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl2(RolloutParamsT<Net
         const float *hbuf = peer_xbuf + (size_t)slot * CL_TILE;
         const int row = tid >> 4, c4 = (tid & 15) * 4;
         f32x4 v0, v1;
-        cl_ld16(v0, hbuf + row * 128 + c4);
-        cl_ld16(v1, hbuf + row * 128 + 64 + c4);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
+        cl_ld16x2(v0, v1, hbuf + row * 128 + c4, hbuf + row * 128 + 64 + c4);
         float *f = c.f32() + row * CT::RSF();  // (the staging view aliases the z columns' hi plane: z comes back from zs afterwards)
         *reinterpret_cast<f32x4 *>(f + c4) = v0;
         *reinterpret_cast<f32x4 *>(f + 64 + c4) = v1;

@@ -70,8 +70,26 @@ __device__ __forceinline__ void cl_st16(float *p, f32x4 v, int fast) {
     if (fast) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
     else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
-__device__ __forceinline__ void cl_ld16(f32x4 &v, const float *p) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+// Agent-scope 16-byte loads AND THEIR WAIT IN ONE asm STATEMENT: the compiler does not know that an inline-asm load lands
+// later -- a destination register it copied or spilled between a load statement and a separate wait statement would be read
+// before the data is there (layered_wide.cuh: gw_ld4 met exactly that under register pressure).
+__device__ __forceinline__ void cl_ld16x2(f32x4 &a, f32x4 &b, const float *pa, const float *pb) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b)
+                 : "v"(pa), "v"(pb)
+                 : "memory");
+}
+// eight of them 1 KiB apart (p, p + 256 floats, ...): two address pairs + the instruction's 12-bit offset
+__device__ __forceinline__ void cl_ld16x8(f32x4 (&v)[8], const float *p) {
+    const float *p4 = p + 1024;
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %8, off offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %2, %8, off offset:2048 sc1\n\tglobal_load_dwordx4 %3, %8, off offset:3072 sc1\n\t"
+                 "global_load_dwordx4 %4, %9, off sc1\n\tglobal_load_dwordx4 %5, %9, off offset:1024 sc1\n\t"
+                 "global_load_dwordx4 %6, %9, off offset:2048 sc1\n\tglobal_load_dwordx4 %7, %9, off offset:3072 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                 : "v"(p), "v"(p4)
+                 : "memory");
 }
 
 // What a weight request needs to know of a layer, BY VALUE: a pointer to (an element of) the kernel-argument struct --
@@ -261,10 +279,7 @@ template <class CT>
 __device__ __forceinline__ void cl_unpark(const CT &c, const ClState &x, int slot, f32x16 (&acc)[1][2]) {
     const float *src = x.xbuf + (size_t)slot * CL_TILE + ((size_t)(c.wave * 2) * 4 * 64 + c.lane) * 4;
     f32x4 v[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) cl_ld16(v[q], src + (size_t)q * 256);
-    asm volatile("s_waitcnt vmcnt(0)"
-                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])::"memory");
+    cl_ld16x8(v, src);
 #pragma unroll
     for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
@@ -379,9 +394,7 @@ __device__ __forceinline__ void cl_head_logits(const CT &c, ClState &x, const La
     {  // head tile -> staging view: thread t takes row t >> 4, columns 4 (t & 15) .. +3 and 64 + 4 (t & 15) .. +3
         const int row = c.tid >> 4, c4 = (c.tid & 15) * 4;
         f32x4 v0, v1;
-        cl_ld16(v0, hbuf + row * 128 + c4);
-        cl_ld16(v1, hbuf + row * 128 + 64 + c4);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1)::"memory");
+        cl_ld16x2(v0, v1, hbuf + row * 128 + c4, hbuf + row * 128 + 64 + c4);
         float *f = c.f32() + row * CT::RSF();
         *reinterpret_cast<f32x4 *>(f + c4) = v0;
         *reinterpret_cast<f32x4 *>(f + 64 + c4) = v1;

@@ -50,9 +50,6 @@ __device__ __forceinline__ void gw_glds(const char *g, char *l) {
 __device__ __forceinline__ void gw_st_sc1(float *p, const f32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off " KS_ST "\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
-__device__ __forceinline__ void gw_ld_sc1(f32x4 &v, const float *p) {
-    asm volatile("global_load_dwordx4 %0, %1, off " KS_LD : "=v"(v) : "v"(p) : "memory");
-}
 
 // In-kernel phase clocks of wave 0 (profiling builds only: -DGW_TIMING; TDMPC2_GW_TIMING=1 makes the host allocate and print
 // them): cycles from kernel start to [1] end of the main loop, [2] statistics stored, [3] peers arrived, [4] row statistics,
