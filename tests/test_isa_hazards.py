@@ -1,0 +1,82 @@
+"""tools/isa_hazards.py: the static scan for software-managed gfx940+ hazards around inline asm (round 5's K-split
+failure was a 16-byte inline-asm store whose data registers the compiler overwrote one instruction later).  Synthetic
+instruction streams pin every rule; the built library must scan clean."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))  # a real module: the library scan hands its work to child processes
+import isa_hazards as hz  # noqa: E402
+
+
+def _scan(lines):
+    """lines of disassembly text -> rules reported"""
+    dis = "0000000000001000 <kern>:\n" + "".join(
+        f"\t{t:<60}// {0x1000 + 8 * i:012X}: 00000000\n" if not t.endswith(":") else f"{0x1000 + 8 * i:016x} <{t[:-1]}>:\n" for i, t in enumerate(lines))
+    code, labels = hz.parse(dis)["kern"]
+    return [r[1] for r in hz.scan("kern", code, labels)]
+
+
+def test_store_data_hazard_is_the_round_5_bug():
+    # what the compiler emitted behind the inline-asm store: one s_mov between the store and the write of its data registers
+    bad = ["global_store_dwordx4 v[132:133], v[50:53], off sc1", "s_mov_b64 s[24:25], 0x2000", "v_lshl_add_u64 v[50:51], v[132:133], 0, s[24:25]"]
+    assert _scan(bad) == ["store-data"]
+    good = [bad[0], "s_nop 1", bad[1], bad[2]]
+    assert _scan(good) == []
+    assert _scan([bad[0], "s_mov_b64 s[24:25], 0x2000", "s_nop 0", bad[2]]) == []  # two wait states by any means
+    # 64 bits of data or fewer: no hazard; a write of the ADDRESS registers: none either
+    assert _scan(["global_store_dwordx2 v[132:133], v[50:51], off", "v_mov_b32 v50, 0"]) == []
+    assert _scan(["global_store_dwordx4 v[132:133], v[50:53], off", "v_mov_b32 v132, 0"]) == []
+    assert _scan(["buffer_store_dwordx4 v[4:7], v1, s[8:11], 0 offen", "v_mov_b32 v5, 0"]) == ["store-data"]
+    assert _scan(["buffer_store_dwordx4 v[4:7], v1, s[8:11], 0 offen", "v_mov_b32 v1, 0"]) == []
+
+
+def test_mfma_results_need_their_passes():
+    mfma = "v_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]"
+    assert _scan([mfma, "v_add_f32 v30, v0, v1"]) == ["mfma-read"]
+    assert _scan([mfma, "s_nop 7", "v_add_f32 v30, v0, v1"]) == ["mfma-read"]            # 8 passes on gfx950: 12 wait states
+    assert _scan([mfma, "s_nop 7", "s_nop 2", "v_add_f32 v30, v0, v1"]) == ["mfma-read"]  # 11
+    assert _scan([mfma, "s_nop 7", "s_nop 3", "v_add_f32 v30, v0, v1"]) == []            # 12
+    assert _scan([mfma, "global_store_dword v[40:41], v3, off"]) == ["mfma-read"]
+    assert _scan([mfma, "ds_write_b32 v40, v3"]) == ["mfma-read"]
+    # back-to-back accumulation into the same tuple is what the pipe is built for; A / B operands are not
+    assert _scan([mfma, mfma]) == []
+    assert _scan([mfma, "v_mfma_f32_32x32x16_f16 v[32:47], v[0:3], v[20:23], v[32:47]"]) == ["mfma-ab"]
+    assert _scan([mfma, "v_mfma_f32_32x32x16_f16 v[8:23], v[40:43], v[44:47], v[8:23]"]) == ["mfma-ab"]  # overlapping, not the same C
+    fp32 = "v_mfma_f32_32x32x2_f32 v[0:15], v16, v17, v[0:15]"  # 16 passes, fp32 inputs: 18
+    assert _scan([fp32, "s_nop 7", "s_nop 7", "v_add_f32 v30, v0, v1"]) == ["mfma-read"]
+    assert _scan([fp32, "s_nop 7", "s_nop 7", "s_nop 1", "v_add_f32 v30, v0, v1"]) == []
+
+
+def test_valu_written_sgprs():
+    assert _scan(["v_readfirstlane_b32 s4, v0", "global_load_dword v1, v2, s[4:5]"]) == ["sgpr-vmem"]
+    assert _scan(["v_readfirstlane_b32 s4, v0", "s_nop 4", "global_load_dword v1, v2, s[4:5]"]) == []
+    assert _scan(["s_mov_b32 s4, 0", "global_load_dword v1, v2, s[4:5]"]) == []  # SALU-written: interlocked
+    assert _scan(["v_cmp_lt_f32 vcc, v0, v1", "v_div_fmas_f32 v2, v3, v4, v5"]) == ["vcc-divfmas"]
+    assert _scan(["v_readfirstlane_b32 s7, v0", "v_readlane_b32 s8, v1, s7"]) == ["lane-select"]
+
+
+def test_forwarding_hazards():
+    assert _scan(["v_exp_f32 v1, v0", "v_add_f32 v2, v1, v1"]) == ["trans-fwd"]
+    assert _scan(["v_exp_f32 v1, v0", "v_rcp_f32 v2, v1"]) == []
+    assert _scan(["v_exp_f32 v1, v0", "s_nop 0", "v_add_f32 v2, v1, v1"]) == []
+    assert _scan(["v_cvt_f32_f16_sdwa v1, v0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1", "v_add_f32 v2, v1, v1"]) == []
+    assert _scan(["v_fma_mixhi_f16 v1, v0, v2, v3", "v_add_f32 v2, v1, v1"]) == ["dstsel-fwd"]
+
+
+def test_branch_targets_are_followed():
+    store = "global_store_dwordx4 v[132:133], v[50:53], off"
+    assert _scan([store, "s_cbranch_scc1 L1", "s_endpgm", "L1:", "v_mov_b32 v50, 0"]) == ["store-data"]
+    assert _scan([store, "s_nop 0", "s_cbranch_scc1 L1", "s_endpgm", "L1:", "v_mov_b32 v50, 0"]) == []
+
+
+@pytest.mark.skipif(not os.path.exists(hz.OBJDUMP), reason="llvm-objdump of the ROCm toolchain not found")
+def test_the_built_library_scans_clean():
+    lib = os.path.join(ROOT, "tdmpc2_amd", "libtdmpc2_plan.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built (python -c 'import __graft_entry__ as g; g.build()')")
+    nk, ni, reports = hz.scan_library(lib)
+    assert nk >= 100 and ni > 1_000_000, (nk, ni)  # every family's code object was found and disassembled
+    assert not reports, reports[:5]
