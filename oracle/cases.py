@@ -48,6 +48,10 @@ CASES = {
     "m19_mt80": ("m19_mt80", {}, 2, False, 0.04),       # 19M: L768 M1024 T96 nq5, 6 iterations
     "m19_mt30": ("m19_mt30", {}, 2, False, 0.04),       # 19M as mt30 ships it: L512 M1024 T64
     "m1_mt30": ("m1_mt30", {}, 3, False, 0.06),         # 1M: L128 M384 nq2 T96, full length (6 iterations, three plans)
+    # the reference's regression heads (common/math.py:60-63, 76-79: one output column; two_hot_inv = identity at num_bins 0,
+    # symexp at 1) through the reference's own planner -- its parser.py:59 divides by num_bins - 1, the code behind it does not
+    "c1_nb0": ("c1", dict(num_bins=0, iterations=3), 2, False, 0.06),
+    "small_nb1_ep": ("small", dict(num_bins=1, episodic=True), 2, False, 0.06),
 }
 
 

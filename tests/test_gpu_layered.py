@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 PATH_FUSED, PATH_LAYERED = 1, 2
 # c3_x4 / c4_x2: the fat pins of the large models (four 48M plans; two 317M plans x the full six iterations: VERDICT r3 #4)
 LAYERED_CASES = ["small", "small_ep", "small_ep_fire", "small_mt", "c1_ep", "c3", "c4", "c4_l1024", "c3_x4", "c4_x2",
-                 "m19_mt80", "m19_mt30", "m1_mt30"]  # every model size the reference ships checkpoints for: 1M, 5M, 19M (both), 48M, 317M
+                 "m19_mt80", "m19_mt30", "m1_mt30",  # every model size the reference ships checkpoints for: 1M, 5M, 19M (both), 48M, 317M
+                 "small_nb1_ep"]  # the regression head (num_bins 1: symexp of one logit) with the termination head, minted by the reference
 _PN = {1: "fp32", 2: "split"}
 # both arithmetic modes of the layered family: exact-fp32 MFMA GEMMs (1) and the f16x2 split (2)
 PRECS = pytest.mark.parametrize("prec", [1, 2], ids=["fp32", "split"])

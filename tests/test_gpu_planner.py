@@ -12,7 +12,7 @@ from tests.helpers import ACT_ATOL, VALUE_RTOL, boundary_gap, elite_sets_equal, 
 
 pytestmark = pytest.mark.gpu
 
-FUSED_CASES = ["c1", "c1_wide", "c2", "c2_i6", "mt5"]
+FUSED_CASES = ["c1", "c1_wide", "c2", "c2_i6", "mt5", "c1_nb0"]  # c1_nb0: the regression head (num_bins 0), minted by the reference
 GOLDEN_ONLY_CASES = ["c1_x8"]  # larger fixtures: whole-plan comparison only
 # Gates (north_star: "within 1e-4 fp32").  The DEFAULT arithmetic (f16x2 split) and everything the bench runs is held to 1e-4
 # on every quantity a plan returns or chains through: trajectory values of every iteration (relative to max(1, |v|)), the

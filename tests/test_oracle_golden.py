@@ -60,7 +60,7 @@ def test_oracle_encode_matches_reference(name):
         np.testing.assert_allclose(z, g["encode_z"][e], atol=1e-6, rtol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["tiny", "small", "c1", "c1_wide", "tiny_mt", "small_mt", "mt5", "c3", "m19_mt80", "m1_mt30"])
+@pytest.mark.parametrize("name", ["tiny", "small", "c1", "c1_wide", "tiny_mt", "small_mt", "mt5", "c3", "m19_mt80", "m1_mt30", "c1_nb0", "small_nb1_ep"])
 def test_oracle_td_target_matches_reference(name):
     """oracle.td_target (restating tdmpc2.py:239-254) vs the fixture minted by the reference's own `_td_target`
     (multitask cases: one task per batch column, per-task discounts)."""
