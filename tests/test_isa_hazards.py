@@ -80,3 +80,29 @@ def test_the_built_library_scans_clean():
     nk, ni, reports = hz.scan_library(lib)
     assert nk >= 100 and ni > 1_000_000, (nk, ni)  # every family's code object was found and disassembled
     assert not reports, reports[:5]
+
+
+def _waits(lines):
+    dis = "0000000000001000 <kern>:\n" + "".join(
+        f"\t{t:<60}// {0x1000 + 8 * i:012X}: 00000000\n" if not t.endswith(":") else f"{0x1000 + 8 * i:016x} <{t[:-1]}>:\n" for i, t in enumerate(lines))
+    code, labels = hz.parse(dis)["kern"]
+    return [r[1] for r in hz.scan_waits("kern", code, labels)]
+
+
+def test_counted_waits_model():
+    """the opt-in --waits pass: loads return in issue order per counter, scalar loads out of order"""
+    ld = ["global_load_dwordx4 v[0:3], v20, s[4:5]", "global_load_dwordx4 v[4:7], v20, s[4:5] offset:1024"]
+    assert _waits(ld + ["v_add_f32 v8, v0, v0"]) == ["vmcnt-use"]
+    assert _waits(ld + ["s_waitcnt vmcnt(1)", "v_add_f32 v8, v0, v0"]) == []          # the older of two has landed
+    assert _waits(ld + ["s_waitcnt vmcnt(1)", "v_add_f32 v8, v4, v4"]) == ["vmcnt-use"]
+    assert _waits(ld + ["s_waitcnt vmcnt(0)", "v_add_f32 v8, v4, v4"]) == []
+    assert _waits(ld + ["global_load_dwordx4 v[0:3], v20, s[4:5]"]) == []               # reload of the same registers: in order
+    assert _waits(ld + ["global_load_dword v9, v0, s[4:5]"]) == ["vmcnt-use"]           # ... but not as an address
+    assert _waits(["global_load_lds_dwordx4 v[2:3], off", "v_mov_b32 v2, 0"]) == []     # LDS-DMA: v[2:3] is the address
+    assert _waits(["global_store_dwordx4 v[2:3], v[4:7], off", "global_load_dword v9, v20, s[4:5]", "s_waitcnt vmcnt(1)",
+                   "v_mov_b32 v10, v9"]) == ["vmcnt-use"]                                # the store counts, the load is the newest
+    assert _waits(["ds_read_b128 v[0:3], v20", "ds_read_b128 v[4:7], v20 offset:16", "s_waitcnt lgkmcnt(1)", "v_add_f32 v8, v0, v1"]) == []
+    assert _waits(["s_load_dwordx2 s[4:5], s[0:1], 0x0", "ds_read_b32 v1, v20", "s_waitcnt lgkmcnt(1)", "s_add_u32 s6, s4, 1"]) == ["lgkmcnt-use"]
+    assert _waits(["s_load_dwordx2 s[4:5], s[0:1], 0x0", "s_waitcnt lgkmcnt(0)", "s_add_u32 s6, s4, 1"]) == []
+    # a loop: the second trip sees what the first left in flight
+    assert _waits(["L0:", "v_add_f32 v8, v0, v0", "global_load_dwordx4 v[0:3], v20, s[4:5]", "s_cbranch_scc1 L0", "s_waitcnt vmcnt(0)"]) == ["vmcnt-use"]

@@ -5,7 +5,7 @@ an asm statement).  Written after round 5's K-split failure: a 16-byte inline-as
 overwrote one instruction later.  The scan works on the final instruction stream of every kernel, whoever
 emitted the instructions.
 
-    python tools/isa_hazards.py [path/to/libtdmpc2_plan.so]        exit code 1 if anything is reported
+    python tools/isa_hazards.py [--waits] [path/to/libtdmpc2_plan.so | x.hsaco]        exit code 1 if anything is reported
 
 Rules (wait states: every instruction counts one, `s_nop N` counts N + 1; gfx940 / gfx950 figures as LLVM's
 GCNHazardRecognizer applies them to compiler-emitted code):
@@ -18,6 +18,15 @@ GCNHazardRecognizer applies them to compiler-emitted code):
   vcc-divfmas  VALU writes VCC -> v_div_fmas: 4
   trans-fwd    transcendental VALU result -> read by the next non-transcendental VALU instruction: 1
   dstsel-fwd   VALU write of half a register (op_sel high half, SDWA, *_mixhi, cvt_*_sr / pk hi forms) -> VALU read: 1
+With --waits also (PATH-INSENSITIVE: a wait under a wave-uniform branch is taken as the branch falls, so the hand-written
+rings, whose counted waits depend on "is there a next slab" flags, produce reports that a person has to read; every kernel
+without such a ring -- 1.5 M compiler-scheduled instructions -- scans clean, which is what validates the counter model):
+  vmcnt-use    a register that a VMEM load / returning atomic still in flight will write is read or written before an
+               `s_waitcnt vmcnt(N)` small enough to cover it (returns are in issue order; stores and LDS-DMA loads count too)
+  lgkmcnt-use  the same for DS reads (in order) and scalar memory loads (out of order: only lgkmcnt(0) covers them)
+               -- the compiler inserts these waits for its own loads; an inline-asm load is invisible to it, so the asm (or the
+               code around it) must carry the wait: a too-weak counted wait in a hand-written ring is exactly the kind of bug that
+               passes most runs
 Branches: the scan follows the fall-through path and, at every branch, also the first instructions of the target with the
 state it has there.  It does not prove absence (indirect control flow, waits across calls); it finds the straight-line cases,
 which is where inline asm sits.
@@ -107,7 +116,7 @@ class Ins:
             if "_store_" in mn or "_atomic_" in mn and not any(" sc0" in " " + o or o.endswith("glc") for o in ops):
                 for o in ops:
                     src |= regs(o)
-            elif " lds" in " " + " ".join(ops):
+            elif " lds" in " " + " ".join(ops) or "_lds_" in mn:  # LDS-DMA: no register destination
                 for o in ops:
                     src |= regs(o)
             else:
@@ -278,6 +287,101 @@ def scan(kernel, code, labels):
     return out
 
 
+WAITCNT = re.compile(r"(vmcnt|lgkmcnt|expcnt)\((\d+)\)")
+
+
+class Waits:
+    """memory operations in flight: vm = [(regs the op will write, Ins)], lgkm = [(kind 'ds' | 'smem', regs, Ins)]"""
+
+    def __init__(self, vm=None, lgkm=None):
+        self.vm, self.lgkm = list(vm or []), list(lgkm or [])
+
+    def copy(self):
+        return Waits(self.vm, self.lgkm)
+
+
+def wait_step(ins, w, found, kernel):
+    touched = ins.src | ins.dst
+    if touched:
+        for q, rule in ((w.vm, "vmcnt-use"), (w.lgkm, "lgkmcnt-use")):
+            # a second load into the same registers behind the first needs no wait: returns of one counter are in order
+            same_q = (rule == "vmcnt-use" and ins.kind == "vmem") or (rule == "lgkmcnt-use" and ins.kind == "ds")
+            look = ins.src if same_q else touched
+            for k, ent in enumerate(q):
+                g = ent[-2]
+                if rule == "lgkmcnt-use" and same_q and ent[0] == "smem":
+                    g = g and (touched & g)
+                if g and look & g:
+                    found.append((kernel, rule, ent[-1], ins, len(q) - k, sorted(touched & g)[:4]))
+                    q[k] = ent[:-2] + (frozenset(), ent[-1])  # reported once
+    mn = ins.mn
+    if mn == "s_waitcnt":
+        m = WAITCNT.findall(ins.text)
+        if not m and ins.ops:  # raw immediate: treat as a wait for everything
+            m = [("vmcnt", "0"), ("lgkmcnt", "0")]
+        for name, n in m:
+            n = int(n)
+            if name == "vmcnt":
+                w.vm = w.vm[len(w.vm) - n:] if n else []
+            elif name == "lgkmcnt":
+                if n == 0:
+                    w.lgkm = []
+                elif not any(e[0] == "smem" for e in w.lgkm):
+                    w.lgkm = w.lgkm[len(w.lgkm) - n:]
+        return
+    if ins.kind == "vmem":
+        w.vm.append((frozenset(r for r in ins.dst if r[0] in "va"), ins))
+        if mn.startswith("flat_"):
+            w.lgkm.append(("smem", frozenset(r for r in ins.dst if r[0] in "va"), ins))  # may return through either path, out of order
+    elif ins.kind == "ds":
+        w.lgkm.append(("ds", frozenset(r for r in ins.dst if r[0] in "va"), ins))
+    elif mn.startswith(("s_load_", "s_buffer_load_", "s_memtime", "s_memrealtime", "s_scratch_load")):
+        w.lgkm.append(("smem", frozenset(ins.dst), ins))
+    elif mn.startswith(("s_sendmsg", "s_store_", "s_dcache", "s_atc_probe")):
+        w.lgkm.append(("smem", frozenset(), ins))
+
+
+def scan_waits(kernel, code, labels, follow_limit=256):
+    found = []
+
+    def target(ins):
+        m = re.search(r"\b(L\d+)\b", ins.text)
+        return labels.get(m.group(1)) if m else None
+
+    def run(i, w, budget, follow):
+        while i < len(code) and (budget is None or budget > 0):
+            ins = code[i]
+            wait_step(ins, w, found, kernel)
+            if budget is not None:
+                budget -= 1
+            if ins.mn.startswith(("s_cbranch", "s_branch")):
+                t = target(ins)
+                if follow and t is not None and (w.vm or w.lgkm):
+                    run(t, w.copy(), follow_limit, False)
+                if ins.mn == "s_branch":
+                    if follow:
+                        w.vm, w.lgkm = [], []  # the fall-through below is reached from elsewhere
+                    elif t is not None:
+                        i = t  # a followed path takes the jump
+                        continue
+                    else:
+                        return
+            if ins.mn in ("s_endpgm", "s_setpc_b64", "s_swappc_b64"):
+                if not follow:
+                    return
+                w.vm, w.lgkm = [], []
+            i += 1
+
+    run(0, Waits(), None, True)
+    seen, out = set(), []
+    for f in found:
+        key = (f[1], f[2].addr, f[3].addr)
+        if key not in seen:
+            seen.add(key)
+            out.append(f)
+    return out
+
+
 def code_objects(lib, tmp):
     """the gfx950 code objects bundled in a host library"""
     cp = os.path.join(tmp, "lib.so")
@@ -287,7 +391,7 @@ def code_objects(lib, tmp):
     return sorted(os.path.join(tmp, n) for n in os.listdir(tmp) if "amdgcn" in n)
 
 
-def scan_object(co):
+def scan_object(co, waits=False):
     dis = subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", "--symbolize-operands", co], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
                          text=True).stdout
     nk = ni = 0
@@ -297,11 +401,13 @@ def scan_object(co):
             nk += 1
             ni += len(code)
             reports += scan(name, code, labels)
+            if waits:
+                reports += scan_waits(name, code, labels)
     # plain tuples: the result crosses a process boundary
     return nk, ni, [(k, rule, prod.addr, prod.text, cons.addr, cons.text, left, rg) for (k, rule, prod, cons, left, rg) in reports]
 
 
-def scan_library(lib, jobs=None):
+def scan_library(lib, jobs=None, waits=False):
     """-> (kernels, instructions, [(kernel, rule, producer address, producer, consumer address, consumer, wait states short, registers)])"""
     from concurrent.futures import ProcessPoolExecutor
 
@@ -310,13 +416,15 @@ def scan_library(lib, jobs=None):
         if not objs:
             raise RuntimeError(f"no gfx950 code object found in {lib}")
         with ProcessPoolExecutor(max_workers=jobs or min(len(objs), os.cpu_count() or 1)) as ex:
-            parts = list(ex.map(scan_object, objs))
+            parts = list(ex.map(scan_object, objs, [waits] * len(objs)))
     return sum(p[0] for p in parts), sum(p[1] for p in parts), [r for p in parts for r in p[2]]
 
 
 def main(argv):
+    waits = "--waits" in argv
+    argv = [a for a in argv if a != "--waits"]
     lib = argv[1] if len(argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tdmpc2_amd", "libtdmpc2_plan.so")
-    nk, ni, reports = scan_library(lib)
+    nk, ni, reports = scan_library(lib, waits=waits)
     print(f"{nk} kernels, {ni} instructions scanned")
     by = {}
     for r in reports:
@@ -324,7 +432,8 @@ def main(argv):
     for (kernel, rule), rs in sorted(by.items()):
         print(f"\n{rule}: {len(rs)} in {kernel}")
         for _, _, pa, pt, ca, ct, left, rg in rs[:6]:
-            print(f"    {pa:08x}  {pt}\n    {ca:08x}  {ct}      <- {left} more wait state(s) needed, registers {rg}")
+            what = "still in flight, position from the newest" if rule.endswith("-use") else "wait states short"
+            print(f"    {pa:08x}  {pt}\n    {ca:08x}  {ct}      <- {what}: {left}, registers {rg}")
     print(f"\n{len(reports)} potential hazard(s)")
     return 1 if reports else 0
 
