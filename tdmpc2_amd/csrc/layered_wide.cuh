@@ -118,9 +118,10 @@ __device__ __forceinline__ void gw_phase(f32x16 (&acc)[2][4], GwFrags (&fr)[2], 
     constexpr int NS = GW_NSLOT, SL = PH % NS, SN = (PH + 1) % NS;
     GwFrags &c = fr[PH & 1], &n = fr[(PH + 1) & 1];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (STEADY || vmc >= 4 * (NS - 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
-    else if (vmc == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (vmc == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    const int wv = gw_phase_vmcnt(STEADY, vmc, NS);  // tile_order.h: the ring's schedule arithmetic (tests/test_ring_schedule.py)
+    if (wv == gw_steady_vmcnt(NS)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
+    else if (wv == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (wv == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
     GwFrags fr[2];
 
     // prologue: slabs 0 .. NS - 1 requested; slab 0 into registers
-    const int npro = nk < NS ? nk : NS;
+    const int npro = gw_prologue_slabs(nk, NS);
 #pragma unroll
     for (int d = 0; d < NS; ++d)
         if (d < npro) {
@@ -311,6 +312,7 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
             pw += 2048;
         }
     __builtin_amdgcn_sched_barrier(0);
+    // slab 0 has landed: gw_prologue_vmcnt(npro) = 4 (npro - 1) requests may stay in flight (the ladder is over npro: s_waitcnt takes constants)
     if (npro >= 5) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (npro == 4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if (npro == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -321,16 +323,16 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
     gw_read<0>(fr[0], la, lw);
 
     int s = 0;
-#define GW_STEADY(PH) gw_phase<PH, true>(acc, fr, la, lw, ring_w, pa, pw, voff, true, true, 4 * (NS - 2));
-    // a phase with wave-uniform flags: the newest slab requested so far is min(nk - 1, ss + NS - 1); slab ss + 1 must have landed
+#define GW_STEADY(PH) gw_phase<PH, true>(acc, fr, la, lw, ring_w, pa, pw, voff, true, true, gw_steady_vmcnt(NS));
+    // a phase with wave-uniform flags (tile_order.h: gw_tail_step -- the newest slab requested so far is min(nk - 1, ss + NS - 1);
+    // slab ss + 1 must have landed)
 #define GW_TAIL(PH)                                                                                         \
     if (s + PH < nk) {                                                                                      \
-        const int ss = s + PH, last_req = ss + NS - 1 < nk - 1 ? ss + NS - 1 : nk - 1;                        \
-        const int inflight = last_req - (ss + 1);                                                           \
-        gw_phase<PH, false>(acc, fr, la, lw, ring_w, pa, pw, voff, ss + NS < nk, ss + 1 < nk, inflight > 0 ? 4 * inflight : 0); \
+        const GwTailStep ts = gw_tail_step(s + PH, nk, NS);                                                 \
+        gw_phase<PH, false>(acc, fr, la, lw, ring_w, pa, pw, voff, ts.issue, ts.next, ts.vmc);              \
     }
 #pragma unroll 1
-    for (; s + GW_U - 1 + NS < nk; s += GW_U) {  // steady state: every phase of the trip has a slab s' + NS <= nk - 1 to request
+    for (; gw_steady_trip(s, nk, NS, GW_U); s += GW_U) {  // steady state: every phase of the trip has a slab s' + NS <= nk - 1 to request
         GW_STEADY(0) GW_STEADY(1) GW_STEADY(2) GW_STEADY(3)
     }
 #pragma unroll 1

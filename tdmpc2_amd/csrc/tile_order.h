@@ -78,6 +78,33 @@ __host__ __device__ inline bool gemm_s_tile(int b, int nrowblk, int ncolblk, int
 // ONE engine and spreads the tiles -- and so the waiters -- over all four, as the whole tiles are.
 #ifndef GW_SE
 #define GW_SE 4
+// ---------------------------------------------------------------------------------------------------------------------------
+// g_gemm_w's DMA ring (layered_wide.cuh): the schedule arithmetic -- which slabs a phase requests, reads, and how many DMA
+// requests it may leave in flight -- in one place, shared by the kernel and by tests/test_ring_schedule.py, which replays the
+// ring for every contraction length and checks that no slab is read before it has landed or overwritten before it was read.
+// A slab = one k16-step of the tile = 4 DMA requests per wave; `ns` = ring slots (GW_NSLOT).
+struct GwTailStep {
+    bool issue;  // slab ss + ns exists: request it into the slot slab ss has just left
+    bool next;   // slab ss + 1 exists: read it from LDS during this phase's MFMAs
+    int vmc;     // requests that may stay in flight at the top of the phase (slab ss + 1 must have landed)
+};
+__host__ __device__ inline int gw_prologue_slabs(int nk, int ns) { return nk < ns ? nk : ns; }
+// after the prologue slab 0 must have landed: every later slab's requests may stay in flight
+__host__ __device__ inline int gw_prologue_vmcnt(int npro) { return npro > 1 ? 4 * (npro - 1) : 0; }
+// a whole trip of `u` steady phases from slab s on: each of them has a slab s' + ns <= nk - 1 to request
+__host__ __device__ inline bool gw_steady_trip(int s, int nk, int ns, int u) { return s + u - 1 + ns < nk; }
+__host__ __device__ inline int gw_steady_vmcnt(int ns) { return 4 * (ns - 2); }
+__host__ __device__ inline GwTailStep gw_tail_step(int ss, int nk, int ns) {
+    const int last_req = ss + ns - 1 < nk - 1 ? ss + ns - 1 : nk - 1;  // the newest slab requested so far
+    const int inflight = last_req - (ss + 1);                         // slabs behind ss + 1 that may still be on their way
+    return GwTailStep{ss + ns < nk, ss + 1 < nk, inflight > 0 ? 4 * inflight : 0};
+}
+// the immediate gw_phase waits with (s_waitcnt takes constants: a ladder over the values that occur)
+__host__ __device__ inline int gw_phase_vmcnt(bool steady, int vmc, int ns) {
+    if (steady || vmc >= gw_steady_vmcnt(ns)) return gw_steady_vmcnt(ns);
+    return vmc == 8 ? 8 : vmc == 4 ? 4 : 0;
+}
+
 #endif
 struct GemmWOrder {
     int parts;     // K-parts of a tail tile (1: nothing is split -- the caller then keeps the order of gemm_s_order)

@@ -1,0 +1,172 @@
+"""g_gemm_w's DMA ring (tdmpc2_amd/csrc/layered_wide.cuh), replayed on the CPU.
+
+The kernel's main loop overlaps three things per k16-slab: the DMA request of slab s + NS into the ring slot slab s has just
+left (`global_load_lds`, counted by vmcnt), the LDS reads of slab s + 1 into the other register set, and the MFMAs of slab s.
+What it may leave in flight at each barrier is arithmetic on (s, nk): tile_order.h's gw_* helpers, which the kernel calls.
+This test compiles those helpers with g++ and replays the ring of ONE wave for every contraction length (a K-split part can be
+any length from 1 up), with the memory system's one guarantee -- requests complete in issue order, `s_waitcnt vmcnt(n)` returns
+when at most n are outstanding -- and an adversary that lands nothing before it must:
+
+* a slab is read from LDS only after all of its requests have landed (and after the barrier that follows the wait);
+* a ring slot is overwritten only after the slab in it has been read, and never while its own requests are in flight;
+* every slab is multiplied exactly once, in order; nothing is in flight at the end;
+* the waits are as weak as they can be: one request more in flight at any wait would break the first property
+  (the counted waits are not conservative vmcnt(0)s in disguise).
+"""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "tdmpc2_amd", "csrc")
+SHIM = r"""
+#include "tile_order.h"
+extern "C" int prologue_slabs(int nk, int ns) { return gw_prologue_slabs(nk, ns); }
+extern "C" int prologue_vmcnt(int npro) { return gw_prologue_vmcnt(npro); }
+extern "C" int steady_trip(int s, int nk, int ns, int u) { return gw_steady_trip(s, nk, ns, u) ? 1 : 0; }
+extern "C" int steady_vmcnt(int ns) { return gw_steady_vmcnt(ns); }
+extern "C" void tail_step(int ss, int nk, int ns, int *out) {
+    const GwTailStep t = gw_tail_step(ss, nk, ns);
+    out[0] = t.issue; out[1] = t.next; out[2] = t.vmc;
+}
+extern "C" int phase_vmcnt(int steady, int vmc, int ns) { return gw_phase_vmcnt(steady != 0, vmc, ns); }
+"""
+REQ = 4  # DMA requests per slab and wave: A and W, two 1 KiB planes each
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    d = tmp_path_factory.mktemp("ring")
+    (d / "shim.cpp").write_text(SHIM)
+    so = d / "libring.so"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I", CSRC, str(d / "shim.cpp"), "-o", str(so)], check=True)
+    return ctypes.CDLL(str(so))
+
+
+def _constants():
+    src = open(os.path.join(CSRC, "layered_wide.cuh")).read()
+    ns = int(re.search(r"constexpr int GW_NSLOT = (\d+);", src).group(1))
+    u = 2 * ns if ns % 2 else ns
+    # the kernel really calls the helpers this test replays
+    for name in ("gw_prologue_slabs(nk, NS)", "gw_steady_trip(s, nk, NS, GW_U)", "gw_tail_step(s + PH, nk, NS)", "gw_phase_vmcnt(STEADY, vmc, NS)",
+                 "gw_steady_vmcnt(NS)"):
+        assert name in src, name
+    return ns, u
+
+
+class Ring:
+    """one wave's view: `fly` = issued requests not yet known to have landed (oldest first), `slot[i]` = slab in ring slot i"""
+
+    def __init__(self, ns, slack=0):
+        self.ns, self.slack = ns, slack
+        self.fly, self.slot, self.landed, self.read = [], [None] * ns, set(), set()
+
+    def request(self, slab):
+        i = slab % self.ns
+        old = self.slot[i]
+        assert old is None or old in self.read, f"slab {slab} overwrites slab {old}, which was never read"
+        assert all(f != old for f in self.fly), f"slab {slab} requested into a slot whose slab {old} is still landing"
+        self.slot[i] = slab
+        self.fly += [slab] * REQ
+
+    def wait(self, n):
+        n += self.slack  # the adversary: only what the wait forces has landed
+        while len(self.fly) > n:
+            s = self.fly.pop(0)
+            if s not in self.fly:
+                self.landed.add(s)
+
+    def lds_read(self, slab):
+        assert self.slot[slab % self.ns] == slab, f"slab {slab} is not in its slot"
+        assert slab in self.landed, f"slab {slab} read before its requests have landed"
+        self.read.add(slab)
+
+
+def replay(lib, nk, ns, u, slack=0):
+    """-> slabs in the order their MFMAs ran"""
+    r = Ring(ns, slack)
+    npro = lib.prologue_slabs(nk, ns)
+    for d in range(npro):
+        r.request(d)
+    ladder = {5: 16, 4: 12, 3: 8, 2: 4}  # the kernel's prologue ladder over npro ...
+    pv = ladder.get(min(npro, 5), 0)
+    assert pv == min(lib.prologue_vmcnt(npro), 16)  # ... is gw_prologue_vmcnt
+    r.wait(pv)
+    r.lds_read(0)  # after the barrier
+    done, s, out = [], 0, (ctypes.c_int * 3)()
+
+    def phase(ss, steady, issue, nxt, vmc):
+        # top of the phase: LDS reads of slab ss (issued in the phase before) complete (lgkmcnt(0)), then the counted wait, barrier
+        r.wait(lib.phase_vmcnt(1 if steady else 0, vmc, ns))
+        if issue:
+            r.request(ss + ns)  # into the slot slab ss has just left: every wave has its copy in registers (barrier)
+        if nxt:
+            r.lds_read(ss + 1)
+        assert ss in r.read
+        done.append(ss)
+
+    while lib.steady_trip(s, nk, ns, u):
+        for ph in range(u):
+            phase(s + ph, True, True, True, lib.steady_vmcnt(ns))
+        s += u
+    while s < nk:
+        for ph in range(u):
+            if s + ph < nk:
+                lib.tail_step(s + ph, nk, ns, out)
+                phase(s + ph, False, bool(out[0]), bool(out[1]), out[2])
+        s += u
+    assert not r.fly or all(f in r.landed for f in r.fly) or slack, "requests in flight at the end of the loop"
+    r.wait(0)
+    assert not r.fly
+    return done
+
+
+@pytest.mark.parametrize("nk", list(range(1, 41)) + [63, 64, 65, 111, 112, 113, 256])
+def test_every_slab_lands_before_it_is_read_and_is_multiplied_once(lib, nk):
+    ns, u = _constants()
+    assert replay(lib, nk, ns, u) == list(range(nk))
+
+
+def test_nothing_is_left_in_flight_when_the_loop_ends(lib):
+    # the K-split tail reuses the ring's LDS for its ticket right behind the loop: the last phase must have waited for everything
+    ns, u = _constants()
+    for nk in range(1, 40):
+        r_out = (ctypes.c_int * 3)()
+        lib.tail_step(nk - 1, nk, ns, r_out)
+        assert (r_out[0], r_out[1], r_out[2]) == (0, 0, 0), nk
+        assert lib.phase_vmcnt(0, 0, ns) == 0
+
+
+@pytest.mark.parametrize("nk", [2, 3, 4, 5, 6, 9, 12, 37, 64])
+def test_the_counted_waits_are_tight(lib, nk):
+    """one more request in flight at every wait and a slab is read before it has landed"""
+    ns, u = _constants()
+    with pytest.raises(AssertionError, match="read before its requests have landed"):
+        replay(lib, nk, ns, u, slack=1)
+
+
+def test_ring_of_five_slots_would_also_be_scheduled_correctly(lib):
+    # GW_NSLOT = 5 was measured (profiles/README.md r4c): the arithmetic is written for any depth the wait ladders cover
+    for nk in range(1, 30):
+        ns, u = 5, 10
+        done = []
+        ring = Ring(ns)
+        npro = lib.prologue_slabs(nk, ns)
+        for d in range(npro):
+            ring.request(d)
+        ring.wait(min(lib.prologue_vmcnt(npro), 16))
+        ring.lds_read(0)
+        out = (ctypes.c_int * 3)()
+        for ss in range(nk):  # all phases through the tail arithmetic
+            lib.tail_step(ss, nk, ns, out)
+            ring.wait(out[2])
+            if out[0]:
+                ring.request(ss + ns)
+            if out[1]:
+                ring.lds_read(ss + 1)
+            done.append(ss)
+        ring.wait(0)
+        assert done == list(range(nk))
