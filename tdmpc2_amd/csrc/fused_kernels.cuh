@@ -335,7 +335,6 @@ __device__ __forceinline__ void kloop_asm(const CT &c, const LayerS &ly, int kb0
                     a_load_act<CT>(a2[(d & 1) ^ 1], la0, la1);
                 }
                 // blocks behind block kk that are still in flight: those issued and not yet consumed
-                // blocks behind block kk that are still in flight: those issued and not yet consumed
                 const int behind = nk - 1 - kk < RD - 1 ? nk - 1 - kk : RD - 1;
                 if (behind >= 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
                 else if (behind == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
