@@ -22,6 +22,8 @@
 // Included by tdmpc2_plan.hip inside its anonymous namespace.
 #pragma once
 
+#include "kloop_schedule.h"  // kloop_asm's schedule arithmetic (shared with tests/test_ring_schedule.py)
+
 // In-kernel phase timers (profiling builds only: -DSPLIT_TIMING, see tools/ablate.sh): wave 0 of every workgroup sums
 // the shader-clock cycles it spends in each phase class into p.timing[class].
 #ifdef SPLIT_TIMING
@@ -297,7 +299,7 @@ __device__ __forceinline__ void kloop_asm(const CT &c, const LayerS &ly, int kb0
     // weight ring of RD = 2 k-blocks (16 VGPRs each): at step k block k + 1 is in flight behind the 12 MFMAs of block k (768 cycles
     // with the partner wave's).  (A ring of 4 lost 3.3 %: the kernel fills its VGPR budget and the loop does not wait for L2
     // latency -- profiles/r4w_kloop_ring4_ab.txt.)
-    constexpr int RD = 2;
+    constexpr int RD = KL_RD;  // kloop_schedule.h: the schedule arithmetic, replayed on the CPU by tests/test_ring_schedule.py
     BFragT<2> ring[RD];
     AFragT<CT::NST> a2[2];
 #pragma unroll
@@ -308,7 +310,7 @@ __device__ __forceinline__ void kloop_asm(const CT &c, const LayerS &ly, int kb0
     const char *pn = u0 + RD * 2048;  // block k + RD
     // steady state, RD steps per trip (ring slot = step % RD, fragment set = step parity), no conditionals
 #pragma unroll 1
-    for (; k + 2 * RD - 1 < nk; k += RD) {
+    for (; kl_steady_trip(k, nk, RD); k += RD) {
 #pragma unroll
         for (int d = 0; d < RD; ++d) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -329,13 +331,13 @@ __device__ __forceinline__ void kloop_asm(const CT &c, const LayerS &ly, int kb0
             const int kk = k + d;
             if (kk < nk) {  // wave-uniform
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (kk + 1 < nk) {
+                if (kl_next_act(kk, nk)) {
                     la0 += 32;
                     la1 += 32;
                     a_load_act<CT>(a2[(d & 1) ^ 1], la0, la1);
                 }
                 // blocks behind block kk that are still in flight: those issued and not yet consumed
-                const int behind = nk - 1 - kk < RD - 1 ? nk - 1 - kk : RD - 1;
+                const int behind = kl_behind(kk, nk, RD);
                 if (behind >= 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
                 else if (behind == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 else if (behind == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -343,7 +345,7 @@ __device__ __forceinline__ void kloop_asm(const CT &c, const LayerS &ly, int kb0
                 else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 a_mfma12<CT>(acc, ring[d], a2[d & 1]);
-                if (kk + RD < nk) {
+                if (kl_issue(kk, nk, RD)) {
                     a_load_w(ring[d], voff, pn, pn + cts);
                     pn += 2048;
                 }

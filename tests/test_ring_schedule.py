@@ -1,4 +1,5 @@
-"""g_gemm_w's DMA ring (tdmpc2_amd/csrc/layered_wide.cuh), replayed on the CPU.
+"""The two hand-written rings, replayed on the CPU: g_gemm_w's DMA ring (tdmpc2_amd/csrc/layered_wide.cuh; first part) and the
+register ring of the fused family's contraction loop (fused_kernels.cuh: kloop_asm, the loop of the benched ks_rollout; second part).
 
 The kernel's main loop overlaps three things per k16-slab: the DMA request of slab s + NS into the ring slot slab s has just
 left (`global_load_lds`, counted by vmcnt), the LDS reads of slab s + 1 into the other register set, and the MFMAs of slab s.
@@ -170,3 +171,116 @@ def test_ring_of_five_slots_would_also_be_scheduled_correctly(lib):
             done.append(ss)
         ring.wait(0)
         assert done == list(range(nk))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# The fused family's hand-ordered contraction loop (fused_kernels.cuh: kloop_asm -- the loop of the benched ks_rollout): a
+# REGISTER ring of KL_RD weight blocks (4 global_load_dwordx4 each) and two activation fragment sets read from LDS a step ahead.
+KSHIM = r"""
+#include "kloop_schedule.h"
+extern "C" int rd() { return KL_RD; }
+extern "C" int w_loads() { return KL_W_LOADS; }
+extern "C" int steady_trip(int k, int nk, int r) { return kl_steady_trip(k, nk, r) ? 1 : 0; }
+extern "C" int steady_vmcnt(int r) { return kl_steady_vmcnt(r); }
+extern "C" int behind(int kk, int nk, int r) { return kl_behind(kk, nk, r); }
+extern "C" int next_act(int kk, int nk) { return kl_next_act(kk, nk) ? 1 : 0; }
+extern "C" int issue(int kk, int nk, int r) { return kl_issue(kk, nk, r) ? 1 : 0; }
+"""
+
+
+@pytest.fixture(scope="module")
+def klib(tmp_path_factory):
+    d = tmp_path_factory.mktemp("kloop")
+    (d / "shim.cpp").write_text(KSHIM)
+    so = d / "libkloop.so"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I", CSRC, str(d / "shim.cpp"), "-o", str(so)], check=True)
+    return ctypes.CDLL(str(so))
+
+
+def test_the_kernel_calls_the_schedule_functions_this_file_replays(klib):
+    src = open(os.path.join(CSRC, "fused_kernels.cuh")).read()
+    body = src[src.index("void kloop_asm("):src.index("void kloop_s(")]
+    for name in ("constexpr int RD = KL_RD;", "kl_steady_trip(k, nk, RD)", "kl_next_act(kk, nk)", "kl_behind(kk, nk, RD)", "kl_issue(kk, nk, RD)"):
+        assert name in body, name
+    # the steady loop's literal wait is the helper's value; the ladder of the last steps is vmcnt(4 * behind)
+    steady = body[body.index("kl_steady_trip"):body.index("// the last RD")]
+    assert f's_waitcnt vmcnt({klib.steady_vmcnt(klib.rd())})' in steady
+    for b, n in ((5, 20), (4, 16), (3, 12), (2, 8), (1, 4)):
+        assert re.search(rf"behind (>=|==) {b}\) asm volatile\(\"s_waitcnt vmcnt\({n}\)\"", body), (b, n)
+    assert klib.w_loads() == 4 and body.count("global_load_dwordx4") == 0  # (a_load_w, one asm statement of 4 loads, sits above)
+    assert src.count('"global_load_dwordx4 %') == 4
+
+
+def kloop_replay(klib, nk, slack=0):
+    """one wave: -> blocks in the order their 12 MFMAs were issued"""
+    rd, wl = klib.rd(), klib.w_loads()
+    fly = []            # weight loads issued, oldest first: block ids
+    w_landed = set()
+    ring = [None] * rd  # block whose fragments (will) sit in ring slot d
+    act_req, act_ok = set(), set()  # activation fragments requested from LDS / known to have landed (lgkmcnt(0))
+    used = []
+
+    def load_w(slot, blk):
+        old = ring[slot]
+        assert old is None or old in used, f"ring slot {slot}: block {blk} loaded over block {old} before its MFMAs were issued"
+        assert old not in fly, f"ring slot {slot} reloaded while block {old} is still landing"
+        ring[slot] = blk
+        fly.extend([blk] * wl)
+
+    def vmcnt(n):
+        n += slack
+        while len(fly) > n:
+            b = fly.pop(0)
+            if b not in fly:
+                w_landed.add(b)
+
+    def mfma(slot, kk):
+        assert ring[slot] == kk, f"step {kk}: ring slot {slot} holds block {ring[slot]}"
+        assert kk in w_landed, f"step {kk}: weight fragments used before their loads have landed"
+        assert kk in act_ok, f"step {kk}: activation fragments used before lgkmcnt(0)"
+        used.append(kk)
+
+    for d in range(rd):
+        if d < nk:
+            load_w(d, d)
+    act_req.add(0)
+    k = 0
+    while klib.steady_trip(k, nk, rd):
+        for d in range(rd):
+            kk = k + d
+            act_ok |= act_req                      # s_waitcnt lgkmcnt(0)
+            act_req.add(kk + 1)                    # the other fragment set: block kk - 1's MFMAs were issued a step ago
+            assert kk + 1 < nk
+            vmcnt(klib.steady_vmcnt(rd))
+            mfma(d, kk)
+            assert kk + rd < nk
+            load_w(d, kk + rd)
+        k += rd
+    while k < nk:
+        for d in range(rd):
+            kk = k + d
+            if kk < nk:
+                act_ok |= act_req
+                if klib.next_act(kk, nk):
+                    act_req.add(kk + 1)
+                vmcnt(wl * klib.behind(kk, nk, rd))
+                mfma(d, kk)
+                if klib.issue(kk, nk, rd):
+                    load_w(d, kk + rd)
+        k += rd
+    assert not fly, "weight loads in flight when the loop ends (the compiler reuses their destination registers)"
+    assert act_req <= act_ok, "LDS reads in flight when the loop ends"
+    assert max(act_req) == nk - 1
+    return used
+
+
+@pytest.mark.parametrize("nk", list(range(1, 36)) + [48, 63, 64, 65])
+def test_kloop_every_fragment_lands_before_its_mfmas(klib, nk):
+    # (the benched layers: K = 512 + action padding -> 32 .. 36 blocks; heads 32; the t = 0 short contraction 1 .. 4)
+    assert kloop_replay(klib, nk) == list(range(nk))
+
+
+@pytest.mark.parametrize("nk", [2, 3, 4, 5, 8, 33, 36])
+def test_kloop_counted_waits_are_tight(klib, nk):
+    with pytest.raises(AssertionError, match="used before their loads have landed"):
+        kloop_replay(klib, nk, slack=1)
