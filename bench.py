@@ -81,6 +81,34 @@ def _sync(device):
         torch.cuda.synchronize(device)
 
 
+def box_under_load(queue_work, device, with_props=False):
+    """What box is this, per LEG (clocks were sampled once per run, so a slow box could not be told from slow code
+    inside the record)?  The kernels are power-managed: boxes of the same pool differ by up to 15 % in every figure.  Outside the
+    timed region: `queue_work()` enqueues about half a second of the leg's own steps, the clocks / socket power the driver
+    reports are read while they run."""
+    import subprocess
+    try:
+        queue_work()
+        smi = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower"], capture_output=True, text=True, timeout=20)
+        _sync(device)
+        keep = {}
+        for line in smi.stdout.splitlines():
+            low = line.lower()
+            for key, pat in (("sclk", "sclk"), ("mclk", "mclk"), ("fclk", "fclk"), ("power_w", "current socket"),
+                             ("power_cap_w", "max graphics package power")):
+                if pat in low and ":" in line and key not in keep:  # "GPU[0]  : sclk clock level: S: (2100Mhz)"
+                    keep[key] = line.split(":", 1)[1].strip()[:90]
+        if with_props:
+            pr = torch.cuda.get_device_properties(device)
+            for k in ("name", "gcnArchName", "multi_processor_count", "clock_rate", "memory_clock_rate", "L2_cache_size"):
+                v = getattr(pr, k, None)
+                if v is not None:
+                    keep["prop_" + k] = v if isinstance(v, (int, float)) else str(v)[:60]
+        return keep or {"raw": smi.stdout[:300]}
+    except Exception as ex:  # no rocm-smi, no permission: the line is still valid
+        return {"error": repr(ex)[:120]}
+
+
 def disc_pow_rows(cfg, n_envs, device):
     g = get_discount(cfg, cfg.episode_length)
     d, vals = 1, []
@@ -459,6 +487,9 @@ def config_leg(name, E, steps, device, rank=0, single_env=True):
     finite = bool(torch.isfinite(out).all())
     leg_faults = planner.take_fault()
     dev_mib = planner.device_bytes / 2**20
+    n_load = max(2, int(np.ceil(0.5 * steps / max(el, 1e-3))))  # about half a second of this leg's steps
+    box = box_under_load(lambda: [planner.plan(z0, disc, prev, warm, task_emb=emb, act_mask=mask, seed=500 + i, out=out)
+                                  for i in range(n_load)], device)
     planner.close()
     lat1 = None
     if single_env:  # the reference's own semantics: one environment, one plan at a time (evaluate.py:80)
@@ -483,7 +514,7 @@ def config_leg(name, E, steps, device, rank=0, single_env=True):
     ach_x = flops_rollout_executed(cfg, E, family == "fused") / launch_s / 1e12
     return {
         "value": round(steps * E / el, 2), "unit": "plans/s", "steps": steps, "ms_per_step": round(1e3 * el / steps, 3), "finite": finite,
-        "bounded_wait_faults": leg_faults,
+        "bounded_wait_faults": leg_faults, "box_under_load": box,
         **({"latency_ms_single_env": round(lat1, 3)} if lat1 is not None else {}),
         "config": {"workload": f"{name}: {cfg.task} world model (L{cfg.latent_dim} M{cfg.mlp_dim} A{cfg.action_dim} nq{cfg.num_q} "
                                f"T{cfg.task_dim}), plan() H={cfg.horizon} N={cfg.num_samples} K={cfg.num_elites} P={cfg.num_pi_trajs} "
@@ -540,7 +571,9 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the planner has no CPU path")
-        device = torch.device("cuda", local_rank)
+        # TDMPC2_BENCH_ONE_GPU=1: every rank on cuda:0 -- two PROCESSES on the builder's single GPU, to run the N > 1 job logic over RCCL
+        # itself (init, broadcast, all_reduce(MAX)) where no second GPU exists; a dry run of the collectives, never a measurement
+        device = torch.device("cuda", 0 if os.environ.get("TDMPC2_BENCH_ONE_GPU") else local_rank)
         torch.cuda.set_device(device)
     import torch.distributed as dist
     # under torch.distributed.run (RANK set) the RCCL group is always initialised, also for one rank, so that the same
@@ -666,30 +699,8 @@ def main():
     if long_region is not None:
         extra["long_region"] = long_region
     if rank == 0 and world == 1 and not STUB:
-        # What box is this?  The fused kernels are power-managed (profiles/README.md): boxes of the same pool differ by up to 15 %
-        # in EVERY figure of this line.  Outside the timed region: queue half a second of the same steps and read the
-        # clocks / socket power the driver reports while they run.
-        try:
-            import subprocess
-            for i in range(15):
-                step(500 + i, warm)
-            smi = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower"], capture_output=True, text=True, timeout=20)
-            _sync(device)
-            keep = {}
-            for line in smi.stdout.splitlines():
-                low = line.lower()
-                for key, pat in (("sclk", "sclk"), ("mclk", "mclk"), ("fclk", "fclk"), ("power_w", "current socket"),
-                                 ("power_cap_w", "max graphics package power")):
-                    if pat in low and ":" in line and key not in keep:  # "GPU[0]  : sclk clock level: S: (2100Mhz)"
-                        keep[key] = line.split(":", 1)[1].strip()[:90]
-            pr = torch.cuda.get_device_properties(device)
-            for k in ("name", "gcnArchName", "multi_processor_count", "clock_rate", "memory_clock_rate", "L2_cache_size"):
-                v = getattr(pr, k, None)
-                if v is not None:
-                    keep["prop_" + k] = v if isinstance(v, (int, float)) else str(v)[:60]
-            extra["box_under_load"] = keep or {"raw": smi.stdout[:300]}
-        except Exception as ex:  # no rocm-smi, no permission: the line is still valid
-            extra["box_under_load"] = {"error": repr(ex)[:120]}
+        # per-leg clocks / socket power under the leg's own load (box_under_load)
+        extra["box_under_load"] = box_under_load(lambda: [step(500 + i, warm) for i in range(15)], device, with_props=True)
     if rank == 0 and not STUB:
         # single-environment latency (the reference's E = 1 semantics), reported beside the throughput
         one = NativePlanner(cfg, I, device, max_envs=1, path=path, precision=prec)
@@ -783,10 +794,16 @@ def main():
             pe = torch.zeros_like(prev)
             for i in range(2):
                 ex.plan(z0, disc, pe, warm, task_emb=emb, act_mask=mask, seed=900 + i, out=out)
-            ex.set_profiling(3 * I)
+            # a timed region of >= 1 s (3 steps were 0.23 s): calibrate on one step, then time n_ex
             _sync(device)
             t1 = time.perf_counter()
-            for i in range(3):
+            ex.plan(z0, disc, pe, warm, task_emb=emb, act_mask=mask, seed=902, out=out)
+            _sync(device)
+            n_ex = max(3, int(np.ceil(1.1 / max(time.perf_counter() - t1, 1e-3))))
+            ex.set_profiling(n_ex * I)
+            _sync(device)
+            t1 = time.perf_counter()
+            for i in range(n_ex):
                 ex.plan(z0, disc, pe, warm, task_emb=emb, act_mask=mask, seed=910 + i, out=out)
             _sync(device)
             el = time.perf_counter() - t1
@@ -794,7 +811,7 @@ def main():
             ach = flops_rollout_launch(cfg, E) / (ms / 1e3 / max(n, 1)) / 1e12
             ach_x = flops_rollout_executed(cfg, E, family == "fused") / (ms / 1e3 / max(n, 1)) / 1e12
             extra["exact_fp32_mode"] = {
-                "value": round(3 * E / el, 2), "unit": "plans/s (this rank)", "steps": 3,
+                "value": round(n_ex * E / el, 2), "unit": "plans/s (this rank)", "steps": n_ex, "seconds": round(el, 3),
                 "arithmetic": "fp32 MFMA (v_mfma_f32_32x32x2_f32): bitwise an fmaf chain",
                 "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                              # `frac` prices what the kernel EXECUTES (2 of num_q heads, shared z0 products): <= 1 by construction;
@@ -809,7 +826,10 @@ def main():
             extra["configs"] = {}
             # timed regions of >= 1 s each.  c2_i8: the headline model at the reference's OWN iteration count (tdmpc2.py:34: + 2 for
             # action_dim >= 20); c4_l1024: BASELINE configs[3] as literally written (latent_dim 1024; the reference's 317M has 1376 = c4)
-            for key, name, e_leg, k_leg in (("c3", "c3", 30, 44), ("c4", "c4", 8, 13), ("c2_i8", "c2", 256, 32), ("c4_l1024", "c4_l1024", 8, 13)):
+            # c5_share: BASELINE configs[4]'s PER-GPU share (64 of the 512 envs of the 317M model) on this one GPU -- the N = 1 point the
+            # first SCALE record's c5 leg (c5_leg, N > 1 only) divides by
+            for key, name, e_leg, k_leg in (("c3", "c3", 30, 44), ("c4", "c4", 8, 13), ("c2_i8", "c2", 256, 32), ("c4_l1024", "c4_l1024", 8, 13),
+                                            ("c5_share", "c4", 64, 2)):
                 try:
                     extra["configs"][key] = config_leg(name, e_leg, k_leg, device, rank, single_env=key in ("c3", "c4"))
                     log(f"extra config {key}: {extra['configs'][key]['value']} plans/s")

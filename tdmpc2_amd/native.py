@@ -658,6 +658,8 @@ class NativePlanner:
                                                          _ptr(action), dbg_p, self._stream()))
 
     def debug_buffers(self, E: int):
+        """Stage buffers for the stage-wise entry points (shard_refit): sized to the handle's sample count, so whole tiles only."""
+        self._whole_tiles_only("debug_buffers")
         cfg, dev, I = self.cfg, self.device, self.iterations
         H, N, K, A = cfg.horizon, cfg.num_samples, cfg.num_elites, cfg.action_dim
         return {"value": torch.empty(E, I, N, device=dev), "elite_idx": torch.empty(E, I, K, device=dev, dtype=torch.int32),
@@ -667,7 +669,6 @@ class NativePlanner:
     # ------------------------------------------------------------------ tuning / profiling
     def set_rows_per_workgroup(self, rows: int):
         """0 = automatic (32-row workgroups for calls with few plans: latency), or force 32 / 64 sample rows."""
-        self._whole_tiles_only("debug_buffers")
         self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 0, int(rows)))
 
     def set_fold_refit(self, mode):
