@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define TDMPC2_PLAN_ABI_VERSION 8
+#define TDMPC2_PLAN_ABI_VERSION 9
 
 typedef struct tdmpc2_plan tdmpc2_plan_t;
 
@@ -350,9 +350,20 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
  * plan then computes the same bits alone, in any batch and with its rows split over ranks; 1 = whenever the round arithmetic
  * says so (measured: slower on launches that fill the chip -- the partial sums' traffic); 2 (default) = only for launches of
  * 16 .. 128 tiles, which leave most of the chip idle (one or two plans of the 317M model: single-plan latency -9 %).  Same values
- * to fp32 round-off (1e-5 of the trajectory values); the bits of a plan then depend on how many plans share the call. */
+ * to fp32 round-off (1e-5 of the trajectory values); the bits of a plan then depend on how many plans share the call.
+ * key TDMPC2_TUNE_FEWROW (ABI 9; layered family, f16x2-split arithmetic): 1 (default) = calls with so few sample rows that one round
+ * of 64 x 256 output tiles does not fill the chip -- single plans, the reference's own call pattern (evaluate.py:80): the 48M
+ * model up to 4 plans, the 317M model 1 -- run every nn.Linear as K-PARTS of such tiles (tdmpc2_amd/csrc/layered_mid.cuh: an 8-wave
+ * LDS-DMA ring GEMM writing raw partial sums) followed by a row kernel that adds the parts in a fixed order and applies the
+ * NormedLinear / two-hot / policy-head math; two chains per launch, one stream, no workgroup ever waits for another one (no fault
+ * path).  Same values to fp32 round-off; needs TDMPC2_TUNE_KSPLIT != 0 (with KSPLIT = 0 a plan keeps computing the same bits alone and
+ * in any batch).  0 = the per-layer tiles of the batch path for every call size.
+ * key TDMPC2_TUNE_WAIT_US (ABI 9): the wall-clock bound of the inter-workgroup waits in microseconds (default 5000; 100 .. 10 000 000).
+ * A handle that shares its GPU with another process's multi-millisecond kernels may want more; the hot path never reads it (the
+ * clock is only consulted from the 256th poll of a wait on). */
 enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0, TDMPC2_TUNE_FOLD_REFIT = 1, TDMPC2_TUNE_CLUSTER = 2, TDMPC2_TUNE_FUSE_LN = 3,
-                     TDMPC2_TUNE_REARM_AFTER = 4, TDMPC2_TUNE_SAFE_ONCE = 5, TDMPC2_TUNE_KSPLIT = 6 };
+                     TDMPC2_TUNE_REARM_AFTER = 4, TDMPC2_TUNE_SAFE_ONCE = 5, TDMPC2_TUNE_KSPLIT = 6, TDMPC2_TUNE_FEWROW = 7,
+                     TDMPC2_TUNE_WAIT_US = 8 };
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
 
 /* Fault report of the paths whose workgroups wait for each other: the cluster path (TDMPC2_TUNE_CLUSTER) and the NormedLinear

@@ -31,7 +31,7 @@ __device__ __forceinline__ void cl2_wait_peer(const CT &c, ClState &x, const uns
     if (c.tid < CL && !*x.dead) {
         WaitClock wc;
         while ((__hip_atomic_load(pflags + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffffu) < phase) {
-            if (wc.expired()) {
+            if (wc.expired(x.err)) {
                 raise_fault(x.err, 1u);
                 *x.dead = 1;
                 break;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl2(RolloutParamsT<Net
         if (tid < nct && !*x.dead) {
             WaitClock wc;
             while (__hip_atomic_load(hflags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < hphase) {
-                if (wc.expired()) {
+                if (wc.expired(x.err)) {
                     raise_fault(x.err, 1u);
                     *x.dead = 1;
                     break;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void ks_rollout_cl2(RolloutParamsT<Net
         if (tid == 0 && !*x.dead) {
             WaitClock wc;
             while (__hip_atomic_load(peer_flags + CL2_MAIL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(p.iter + 1)) {
-                if (wc.expired()) {
+                if (wc.expired(x.err)) {
                     raise_fault(x.err, 1u);
                     *x.dead = 1;
                     break;

@@ -203,7 +203,7 @@ __device__ __forceinline__ void cl_barrier(const CT &c, ClState &x, bool learn) 
         WaitClock wc;
         unsigned v;
         while (((v = __hip_atomic_load(x.flags + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffffffu) < x.phase) {
-            if (wc.expired()) {  // host-mapped word: a plain system-scope store
+            if (wc.expired(x.err)) {  // host-mapped word: a plain system-scope store
                 raise_fault(x.err, 1u);
                 *x.dead = 1;
                 v = 0xff000000u;
@@ -382,7 +382,7 @@ __device__ __forceinline__ void cl_head_logits(const CT &c, ClState &x, const La
     if (c.tid < ly.CT && !*x.dead) {
         WaitClock wc;
         while (__hip_atomic_load(hflags + c.tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < x.hphase) {
-            if (wc.expired()) {
+            if (wc.expired(x.err)) {
                 raise_fault(x.err, 1u);
                 *x.dead = 1;
                 break;

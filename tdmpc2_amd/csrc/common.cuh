@@ -75,17 +75,24 @@ struct NetS {
 // limit, a tile whose last K-part is still queued -- one tile's run time (< 0.5 ms for the 317M model's K = 4096).  The clock is
 // only read from the 256th poll on (and then every 64th), so that a hand-over on the latency path never pays for it.
 constexpr unsigned long long WAIT_TICKS = 500000ull;
+// The bound is the handle's to choose (TDMPC2_TUNE_WAIT_US, ABI 9): word ERR_WAIT_TICKS of its host-mapped error line holds it in
+// clock ticks (0: the default above).  Read ONCE per slow wait, when the clock is first consulted.
+constexpr int ERR_WAIT_TICKS = 12;
 struct WaitClock {
     int spin = 0;
-    unsigned long long t0 = 0;
-    __device__ __forceinline__ bool expired() {
+    unsigned long long t0 = 0, limit = WAIT_TICKS;
+    __device__ __forceinline__ bool expired(const unsigned int *err = nullptr) {
         if (++spin < 256 || (spin & 63) != 0) return false;
         const unsigned long long now = __builtin_amdgcn_s_memrealtime();
         if (t0 == 0) {
             t0 = now;
+            if (err) {
+                const unsigned int w = __hip_atomic_load(err + ERR_WAIT_TICKS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (w) limit = w;
+            }
             return false;
         }
-        return now - t0 > WAIT_TICKS;
+        return now - t0 > limit;
     }
 };
 __device__ __forceinline__ void raise_fault(unsigned int *err, unsigned int code) {

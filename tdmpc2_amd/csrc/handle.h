@@ -79,7 +79,12 @@ struct Layered {
     // g_gemm_w's K-split tail (layered_wide.cuh): partial accumulators of the split tiles, one workspace per chain
     float *ksws = nullptr, *ksws2 = nullptr;
     size_t ksws_slots = 0;                  // 256 KiB slots (split tile x part) per workspace
+    size_t ks_tiles = 0;                    // 256 x 256 tiles of the handle's largest call (0: the wide tile never applies)
     int ksplit = 2;                         // TDMPC2_TUNE_KSPLIT: 0 never, 1 whenever the rule says so, 2 few-tile launches only (layered_host.cuh)
+    // the few-row path (layered_mid.cuh): K-part tiles + row kernels for single plans; partial-sum workspaces of a launch's two problems
+    bool mid = true;                        // TDMPC2_TUNE_FEWROW (and TDMPC2_TUNE_KSPLIT != 0)
+    float *mws[2] = {nullptr, nullptr};
+    size_t mws_cap = 0;                     // floats per workspace
 };
 
 struct tdmpc2_plan {

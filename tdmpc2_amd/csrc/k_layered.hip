@@ -9,6 +9,7 @@ namespace {
 #include "layered_kernels.cuh"
 #include "layered_split.cuh"
 #include "layered_wide.cuh"
+#include "layered_mid.cuh"
 }  // namespace
 
 namespace tdk {

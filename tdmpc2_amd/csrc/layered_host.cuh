@@ -416,6 +416,209 @@ int lay_cvec(tdmpc2_plan *h, hipStream_t st, int E, const float *z0) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The few-row path (layered_mid.cuh): every nn.Linear = one g_gemm_m problem (K-parts of 64 x 256 tiles, raw fp32 partial sums) +
+// one m_rows problem (sum the parts, scale, bias, then LayerNorm + Mish / SimNorm + split, two-hot, policy head or termination);
+// a launch of either kernel carries up to two problems -- the two chains of a step, the two Q heads -- on ONE stream.
+struct MidOp {
+    // the nn.Linear
+    const float *A;          // fragment-packed operand buffer
+    int lda;
+    const HostLayer *ly;
+    int slot;                // index of the net in beff (multitask first layers), -1 otherwise
+    const int *sel;          // Q head of each plan, or null
+    bool is_q;
+    int layer;               // 0, 1, 2 (strides of the Q ensemble)
+    const GemmRange *range;  // a k-range with a per-environment bias (t = 0: the action columns, lay_cvec), or null
+    // what follows it
+    int kind;                // MR_*
+    float *out;              // MR_LN_*: packed operand buffer of ldo columns
+    int ldo, width;
+    const float *actions;    // MR_LN_SIMNORM into X: also write the action columns of step act_t (null: no)
+    int act_t, act_nsub, act_noff;
+    TwoHotParams th;
+    PiHeadParams pi;
+};
+
+inline bool mid_ok(const tdmpc2_plan *h, size_t rows_p) {
+    const Layered &L = h->lay;
+    if (!h->split || !L.mid || L.ksplit == 0 || !L.mws[0] || !L.HA2 || L.row_env) return false;
+    const long cus = h->num_cus > 0 ? h->num_cus : 256;
+    const long maxct = (std::max(h->cfg.mlp_dim, h->cfg.latent_dim) + 31) / 32;
+    return 2 * (long)(rows_p / GM_TM) * ((maxct + 7) / 8) <= cus;  // a launch's two widest problems fill at most one round of the chip
+}
+
+// one launch of g_gemm_m + one of m_rows for n (1 or 2) layers over the same `rows` sample rows
+int mid_stage(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rpe, const MidOp *ops, int n, bool rows_one_by_one = false) {
+    Layered &L = h->lay;
+    const long cus = h->num_cus > 0 ? h->num_cus : 256;
+    GemmMParams G{};
+    MRowParams R{};
+    G.nprob = R.nprob = n;
+    long tiles = 0;
+    for (int i = 0; i < n; ++i) tiles += (long)(rows_p / GM_TM) * ((ops[i].ly->CT + 7) / 8);
+    static const int pmax = getenv("TDMPC2_MID_PARTS_MAX") ? atoi(getenv("TDMPC2_MID_PARTS_MAX")) : 16;
+    const int pall = (int)std::max<long>(1, std::min<long>(pmax, cus / std::max<long>(tiles, 1)));
+    unsigned gblk = 0, rblk = 0;
+    for (int i = 0; i < n; ++i) {
+        const MidOp &o = ops[i];
+        const HostLayer &ly = *o.ly;
+        const bool sel = o.sel != nullptr;
+        GemmMProb &g = G.pr[i];
+        g.A = reinterpret_cast<const _Float16 *>(o.A); g.KBa = o.lda / 16;
+        g.a_kb0 = o.range ? o.range->col_off / 16 : 0;
+        g.nk = o.range ? o.range->kblocks : ly.KB;
+        g.kb0 = o.range ? o.range->kb0 : 0; g.kbs = ly.KB;
+        g.wp = ly.wps; g.w_sel_stride = sel && o.is_q ? q_wstride(h, o.layer) : 0;
+        g.CT = ly.CT; g.ncolblk = (ly.CT + 7) / 8; g.nrowblk = (int)(rows_p / GM_TM);
+        g.parts = std::max(1, std::min(pall, g.nk / 4));
+        g.sel = o.sel; g.sel_stride = 2; g.rows_per_env = rpe;
+        g.ldw = g.ncolblk * 256; g.part_stride = (long)rows_p * g.ldw;
+        if ((size_t)g.parts * g.part_stride > L.mws_cap) return fail(TDMPC2_ERR_STATE, "few-row path: partial-sum workspace too small");
+        g.ws = L.mws[i];
+        g.nblk = 8 * ((g.ncolblk * g.parts + 7) / 8) * g.nrowblk;
+        gblk += (unsigned)g.nblk;
+        MRowProb &r = R.pr[i];
+        r.kind = o.kind; r.rows = (int)rows; r.rows_per_env = rpe;
+        if ((int)rows < MR_WIDE_MIN) r.nwg = (o.kind == MR_LN_MISH || o.kind == MR_LN_SIMNORM) ? (int)rows : (int)((rows + 3) / 4);  // m_rows<256>
+        else r.nwg = (int)((rows + MR_R - 1) / MR_R);                                                                            // m_rows<512>
+        r.ws = g.ws; r.part_stride = g.part_stride; r.ldw = g.ldw; r.parts = g.parts;
+        r.oscale = ly.oscale; r.osc_sel_stride = sel ? (long)(3 * sizeof(LayerScal) / sizeof(float)) : 0;
+        if (o.slot >= 0 && h->cfg.multitask) {
+            r.bias = L.bias_tab + (size_t)o.slot * L.Mp; r.bias_env_stride = (long)h->nnets * L.Mp; r.bias_sel_stride = sel ? L.Mp : 0;
+        } else {
+            r.bias = ly.bias; r.bias_env_stride = 0; r.bias_sel_stride = sel && o.is_q ? q_bstride(h, o.layer) : 0;
+        }
+        if (o.range && o.range->bias_env) { r.bias = o.range->bias_env; r.bias_env_stride = o.range->bias_env_stride; r.bias_sel_stride = 0; }
+        r.sel = o.sel; r.sel_stride = 2; r.row_env = nullptr;
+        if (o.kind == MR_LN_MISH || o.kind == MR_LN_SIMNORM) {
+            r.width = o.width; r.g = ly.g; r.b = ly.b; r.gb_sel_stride = sel && o.is_q ? q_gstride(h, o.layer) : 0;
+            r.ascale = ly.ascale; r.asc_sel_stride = sel ? (long)(3 * sizeof(LayerScal) / sizeof(float)) : 0;
+            r.out = reinterpret_cast<char *>(o.out); r.KBo = o.ldo / 16;
+            r.actions = o.actions; r.act_t = o.act_t; r.act_A = h->cfg.action_dim; r.act_L = h->cfg.latent_dim; r.act_ldx = L.Kin;
+            r.act_N = h->cfg.num_samples; r.act_H = h->cfg.horizon; r.act_nsub = o.act_nsub; r.act_noff = o.act_noff;
+        }
+        r.term = L.TERM;
+        r.th = o.th; r.pi = o.pi;
+        rblk += (unsigned)r.nwg;
+    }
+    hipLaunchKernelGGL(g_gemm_m, dim3(gblk), dim3(512), 0, st, G);
+    LAUNCH_CHECK();
+    const bool small = (int)rows < MR_WIDE_MIN;
+    if (rows_one_by_one && n == 2) {  // the second problem's rows read what the first one's write (the two Q heads' two-hots)
+        MRowParams R1{};
+        R1.nprob = 1;
+        R1.pr[0] = R.pr[0];
+        for (int i = 0; i < 2; ++i) {
+            R1.pr[0] = R.pr[i];
+            if (small) hipLaunchKernelGGL(m_rows<256>, dim3((unsigned)R1.pr[0].nwg), dim3(256), 0, st, R1);
+            else hipLaunchKernelGGL(m_rows<512>, dim3((unsigned)R1.pr[0].nwg), dim3(512), 0, st, R1);
+            LAUNCH_CHECK();
+        }
+        return 0;
+    }
+    if (small) hipLaunchKernelGGL(m_rows<256>, dim3(rblk), dim3(256), 0, st, R);
+    else hipLaunchKernelGGL(m_rows<512>, dim3(rblk), dim3(512), 0, st, R);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+inline MidOp mid_hidden(const Layered &L, const float *A, int lda, const HostNet &net, int layer, int slot, const int *sel, bool is_q,
+                        float *out, int mlp_dim, const GemmRange *range = nullptr) {
+    MidOp o{};
+    o.A = A; o.lda = lda; o.ly = &net.l[layer]; o.slot = slot; o.sel = sel; o.is_q = is_q; o.layer = layer; o.range = range;
+    o.kind = MR_LN_MISH; o.out = out; o.ldo = L.Mp; o.width = mlp_dim;
+    return o;
+}
+inline MidOp mid_head(const Layered &L, const float *A, const HostNet &net, const int *sel, bool is_q, int kind) {
+    MidOp o{};
+    o.A = A; o.lda = L.Mp; o.ly = &net.l[2]; o.slot = -1; o.sel = sel; o.is_q = is_q; o.layer = 2; o.kind = kind;
+    return o;
+}
+
+int lay_estimate_value_m(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float *act_mask, const float *disc_pow,
+                         const float *actions, const float *pi_eps, long pi_eps_estride, const int *qidx, unsigned long long seed,
+                         unsigned call, int iter, float *value, float *trace, int n_off, int n_sub) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    const Layered &L = h->lay;
+    const int NF = c.num_samples, H = c.horizon, A = c.action_dim;
+    const int N = n_sub > 0 ? n_sub : NF;
+    const bool ranged = N != NF;
+    const size_t rows = (size_t)E * N, rows_p = round_up(rows, GBM);
+    int rc;
+    if (L.cvec_ready) {
+        if (c.episodic) HIP_TRY(hipMemsetAsync(L.TERM, 0, rows * sizeof(float), st));
+    } else {
+        hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM, (int)rows);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(l_set_action_s, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, A, NF, H, 0, (int)rows, actions, N, n_off);
+    LAUNCH_CHECK();
+    for (int t = 0; t < H; ++t) {
+        GemmRange r_rew{c.latent_dim / 16, (L.Kin - c.latent_dim) / 16, L.cvec, (long)L.Mp, c.latent_dim};
+        GemmRange r_dyn = r_rew;
+        r_dyn.bias_env = L.cvec + (size_t)L.cvec_rows * L.Mp;
+        const bool shortk = t == 0 && L.cvec_ready;
+        {   // [dynamics.l0 | reward.l0]: X -> HA, HA2
+            MidOp ops[2] = {mid_hidden(L, L.X, L.Kin, h->dyn, 0, BE_DYN, nullptr, false, L.HA, c.mlp_dim, shortk ? &r_dyn : nullptr),
+                            mid_hidden(L, L.X, L.Kin, h->rew, 0, BE_REW, nullptr, false, L.HA2, c.mlp_dim, shortk ? &r_rew : nullptr)};
+            if ((rc = mid_stage(h, st, rows, rows_p, N, ops, 2))) return rc;
+        }
+        {   // [dynamics.l1 | reward.l1]
+            MidOp ops[2] = {mid_hidden(L, L.HA, L.Mp, h->dyn, 1, -1, nullptr, false, L.HB, c.mlp_dim),
+                            mid_hidden(L, L.HA2, L.Mp, h->rew, 1, -1, nullptr, false, L.HB2, c.mlp_dim)};
+            if ((rc = mid_stage(h, st, rows, rows_p, N, ops, 2))) return rc;
+        }
+        {   // [dynamics.l2 -> SimNorm -> z_{t+1} into X (+ a_{t+1}) | reward head -> two_hot_inv -> G += disc (1 - term) r]
+            MidOp ops[2] = {mid_head(L, L.HB, h->dyn, nullptr, false, MR_LN_SIMNORM), mid_head(L, L.HB2, h->rew, nullptr, false, MR_TWOHOT)};
+            ops[0].out = L.X; ops[0].ldo = L.Kin; ops[0].width = c.latent_dim;
+            if (t + 1 < H) { ops[0].actions = actions; ops[0].act_t = t + 1; ops[0].act_nsub = N; ops[0].act_noff = n_off; }
+            ops[1].th = lay_twohot_params(h, rows, N, 0, t, disc_pow, value, trace, 0, 0, nullptr);
+            if ((rc = mid_stage(h, st, rows, rows_p, N, ops, 2))) return rc;
+        }
+        if (c.episodic) {  // termination head on the new latent (tdmpc2.py:133-134)
+            MidOp o0 = mid_hidden(L, L.X, L.Kin, h->term, 0, -1, nullptr, false, L.HA, c.mlp_dim);
+            if ((rc = mid_stage(h, st, rows, rows_p, N, &o0, 1))) return rc;
+            MidOp o1 = mid_hidden(L, L.HA, L.Mp, h->term, 1, -1, nullptr, false, L.HB, c.mlp_dim);
+            if ((rc = mid_stage(h, st, rows, rows_p, N, &o1, 1))) return rc;
+            MidOp o2 = mid_head(L, L.HB, h->term, nullptr, false, MR_TERM);
+            if ((rc = mid_stage(h, st, rows, rows_p, N, &o2, 1))) return rc;
+        }
+    }
+    // a_H = pi(z_H)
+    {
+        MidOp o0 = mid_hidden(L, L.X, L.Kin, h->pi, 0, BE_PI, nullptr, false, L.HA, c.mlp_dim);
+        if ((rc = mid_stage(h, st, rows, rows_p, N, &o0, 1))) return rc;
+        MidOp o1 = mid_hidden(L, L.HA, L.Mp, h->pi, 1, -1, nullptr, false, L.HB, c.mlp_dim);
+        if ((rc = mid_stage(h, st, rows, rows_p, N, &o1, 1))) return rc;
+        MidOp o2 = mid_head(L, L.HB, h->pi, nullptr, false, MR_PI);
+        PiHeadParams &p = o2.pi;
+        p.rows = (int)rows; p.rows_per_env = N; p.nvalid = N; p.A = A; p.L = c.latent_dim; p.ldx = L.Kin;
+        p.lsmin = c.log_std_min; p.lsdif = c.log_std_dif; p.mask = act_mask; p.eps = pi_eps; p.eps_estride = pi_eps_estride;
+        p.seed = seed; p.call = call; p.site = SITE_PI; p.iter = iter; p.X = L.X; p.actions = nullptr; p.t = 0; p.H = H; p.N = NF;
+        p.trace = trace; p.row_env = nullptr; p.n_off = n_off;
+        if ((rc = mid_stage(h, st, rows, rows_p, N, &o2, 1))) return rc;
+    }
+    // value = G + disc^H (1 - term) avg of the two selected Q heads
+    {
+        MidOp ops[2] = {mid_hidden(L, L.X, L.Kin, h->q[0], 0, BE_Q0, qidx, true, L.HA, c.mlp_dim),
+                        mid_hidden(L, L.X, L.Kin, h->q[0], 0, BE_Q0, qidx + 1, true, L.HA2, c.mlp_dim)};
+        if ((rc = mid_stage(h, st, rows, rows_p, N, ops, 2))) return rc;
+    }
+    {
+        MidOp ops[2] = {mid_hidden(L, L.HA, L.Mp, h->q[0], 1, -1, qidx, true, L.HB, c.mlp_dim),
+                        mid_hidden(L, L.HA2, L.Mp, h->q[0], 1, -1, qidx + 1, true, L.HB2, c.mlp_dim)};
+        if ((rc = mid_stage(h, st, rows, rows_p, N, ops, 2))) return rc;
+    }
+    {   // the heads' GEMMs as one launch; their two-hots one behind the other (the second reads the first's value)
+        MidOp ops[2] = {mid_head(L, L.HB, h->q[0], qidx, true, MR_TWOHOT), mid_head(L, L.HB2, h->q[0], qidx + 1, true, MR_TWOHOT)};
+        ops[0].th = lay_twohot_params(h, rows, N, 1, 0, disc_pow, value, trace, ranged ? NF : 0, n_off, nullptr);
+        ops[1].th = lay_twohot_params(h, rows, N, 2, 0, disc_pow, value, trace, ranged ? NF : 0, n_off, nullptr);
+        if ((rc = mid_stage(h, st, rows, rows_p, N, ops, 2, /*rows_one_by_one=*/true))) return rc;
+    }
+    return 0;
+}
+
 // TDMPC2._estimate_value (tdmpc2/tdmpc2.py:122-136) for E plans with the step actions in `actions` [E,H,N,A].
 int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float *act_mask, const float *disc_pow,
                        const float *actions, const float *pi_eps, long pi_eps_estride, const int *qidx /* dense [E,2] */,
@@ -429,6 +632,8 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
     const bool ranged = N != NF;
     const size_t rows = (size_t)E * N, rows_p = round_up(rows, GBM);
     int rc;
+    if (mid_ok(h, rows_p))  // few rows (single plans): K-part tiles + row kernels on one stream (layered_mid.cuh)
+        return lay_estimate_value_m(h, st, E, z0, act_mask, disc_pow, actions, pi_eps, pi_eps_estride, qidx, seed, call, iter, value, trace, n_off, n_sub);
     if ((rc = lay_arrive_reset(h, st))) return rc;
     // X <- [z0 | .] for every sample row, G <- 0, TERM <- 0.  With the shared z0 products (lay_cvec) nothing reads the z columns
     // before the first dynamics step has written z_1 there (the t = 0 GEMMs contract the action columns only), G is
@@ -501,6 +706,42 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
     return lay_twohot(h, st, rows, N, 2, 0, disc_pow, value, trace, ranged ? NF : 0, n_off, b2.LG);
 }
 
+// The P policy-prior trajectories on the few-row path: H x pi (3 layers) and (H - 1) x dynamics, one problem per launch.
+int lay_pitraj_m(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float *act_mask, const float *tape_eps,
+                 unsigned long long seed, unsigned call) {
+    const tdmpc2_plan_cfg &c = h->cfg;
+    const Layered &L = h->lay;
+    const int P = c.num_pi_trajs, H = c.horizon, A = c.action_dim, rpe = L.Ppad;
+    const size_t rows = (size_t)E * rpe, rows_p = round_up(rows, GBM);
+    int rc;
+    hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, rpe, z0, (float *)nullptr,
+                       (float *)nullptr, (int)rows);
+    LAUNCH_CHECK();
+    for (int t = 0; t < H; ++t) {
+        MidOp o0 = mid_hidden(L, L.X, L.Kin, h->pi, 0, BE_PI, nullptr, false, L.HA, c.mlp_dim);
+        if ((rc = mid_stage(h, st, rows, rows_p, rpe, &o0, 1))) return rc;
+        MidOp o1 = mid_hidden(L, L.HA, L.Mp, h->pi, 1, -1, nullptr, false, L.HB, c.mlp_dim);
+        if ((rc = mid_stage(h, st, rows, rows_p, rpe, &o1, 1))) return rc;
+        MidOp o2 = mid_head(L, L.HB, h->pi, nullptr, false, MR_PI);
+        PiHeadParams &p = o2.pi;
+        p.rows = (int)rows; p.rows_per_env = rpe; p.nvalid = P; p.A = A; p.L = c.latent_dim; p.ldx = L.Kin;
+        p.lsmin = c.log_std_min; p.lsdif = c.log_std_dif; p.mask = act_mask;
+        p.eps = tape_eps ? tape_eps + (size_t)t * P * A : nullptr; p.eps_estride = (long)H * P * A;  // tape layout [E, H, P, A]
+        p.seed = seed; p.call = call; p.site = SITE_PITRAJ; p.iter = t; p.X = L.X; p.actions = h->actions; p.t = t; p.H = H;
+        p.N = c.num_samples; p.trace = nullptr; p.row_env = nullptr; p.n_off = 0;
+        if ((rc = mid_stage(h, st, rows, rows_p, rpe, &o2, 1))) return rc;
+        if (t == H - 1) break;
+        MidOp d0 = mid_hidden(L, L.X, L.Kin, h->dyn, 0, BE_DYN, nullptr, false, L.HA, c.mlp_dim);
+        if ((rc = mid_stage(h, st, rows, rows_p, rpe, &d0, 1))) return rc;
+        MidOp d1 = mid_hidden(L, L.HA, L.Mp, h->dyn, 1, -1, nullptr, false, L.HB, c.mlp_dim);
+        if ((rc = mid_stage(h, st, rows, rows_p, rpe, &d1, 1))) return rc;
+        MidOp d2 = mid_head(L, L.HB, h->dyn, nullptr, false, MR_LN_SIMNORM);
+        d2.out = L.X; d2.ldo = L.Kin; d2.width = c.latent_dim;
+        if ((rc = mid_stage(h, st, rows, rows_p, rpe, &d2, 1))) return rc;
+    }
+    return 0;
+}
+
 // The P policy-prior trajectories (tdmpc2/tdmpc2.py:154-160): rows n < P of actions[E, H, N, A].
 int lay_pitraj(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float *act_mask, const float *tape_eps,
                unsigned long long seed, unsigned call) {
@@ -509,6 +750,7 @@ int lay_pitraj(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const flo
     const int P = c.num_pi_trajs, H = c.horizon, A = c.action_dim, rpe = L.Ppad;
     const size_t rows = (size_t)E * rpe, rows_p = round_up(rows, GBM);
     int rc;
+    if (mid_ok(h, rows_p)) return lay_pitraj_m(h, st, E, z0, act_mask, tape_eps, seed, call);
     if ((rc = lay_arrive_reset(h, st))) return rc;
     if (h->split)
         hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, rpe, z0, (float *)nullptr,

@@ -456,7 +456,7 @@ __global__ __launch_bounds__(512) void g_gemm_w(GemmSParams p) {
         if (!(p.fault && rb == 0 && cb == 0)) __hip_atomic_fetch_add(p.arrive + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         WaitClock wc;
         while (__hip_atomic_load(p.arrive + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.ncolblk) {
-            if (wc.expired()) {
+            if (wc.expired(p.err)) {
                 // code: 2 | row block << 4 | column block << 16 | arrivals seen << 24 (TDMPC2_DEBUG_FAULT=1 prints it)
                 if (p.err) raise_fault(p.err, 2u | ((unsigned)rb << 4) | ((unsigned)cb << 16) |
                                                   (__hip_atomic_load(p.arrive + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 24));

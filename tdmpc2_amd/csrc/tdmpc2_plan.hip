@@ -289,6 +289,25 @@ int dev_alloc(tdmpc2_plan *h, void **p, size_t bytes) {
     return 0;
 }
 
+// g_gemm_w's K-split workspaces (256 KiB per split tile and part, one workspace per chain), sized for what the handle's mode can
+// use (every layered handle used to pay for 1 024 slots per chain -- 0.5 GiB -- whatever its mode): mode 0 none; mode 2
+// (the default) only splits launches of at most cus / 2 tiles = at most cus / 16 tail tiles per XCD; mode 1 the last round of any
+// launch = 32 tail tiles per XCD.  Called at create and when tdmpc2_plan_set_tuning raises the mode (grows, never shrinks; the
+// smaller buffers stay with the handle until destroy).
+int ksws_ensure(tdmpc2_plan *h) {
+    Layered &L = h->lay;
+    if (!L.ks_tiles || L.ksplit == 0) return 0;
+    const size_t cus = (size_t)(h->num_cus > 0 ? h->num_cus : 256);
+    const size_t cap_slots = L.ksplit == 2 ? 8 * ((cus / 16 + 3) / 4 * 4) * 4 : 8 * 32 * 4;
+    const size_t want = std::min<size_t>(cap_slots, L.ks_tiles * 4);
+    if (want <= L.ksws_slots) return 0;
+    float *a = nullptr, *b = nullptr;
+    int rc;
+    if ((rc = dev_alloc(h, (void **)&a, want * 65536 * 4)) || (L.side && (rc = dev_alloc(h, (void **)&b, want * 65536 * 4)))) return rc;
+    L.ksws = a; L.ksws2 = b; L.ksws_slots = want;
+    return 0;
+}
+
 void dev_release(tdmpc2_plan *h, void *p) {  // free one allocation made with dev_alloc (tables that are re-grown)
     if (!p) return;
     for (size_t i = 0; i < h->allocs.size(); ++i)
@@ -880,14 +899,23 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             // g_gemm_w's K-split tail: 256 KiB per (split tile, part); at most 32 tail tiles per XCD x 4 parts, or all the tiles
             // of the handle's largest call (one workspace per chain)
             if (const char *ks = getenv("TDMPC2_KSPLIT")) L.ksplit = std::min(2, std::max(0, atoi(ks)));
-            if (Rp % 256 == 0 && maxct >= 8) {
-                const size_t tiles = (Rp / 256) * ((maxct + 7) / 8);
-                L.ksws_slots = std::min<size_t>(8 * 32 * 4, tiles * 4);
-                if ((rc = dev_alloc(h, (void **)&L.ksws, L.ksws_slots * 65536 * 4)) ||
-                    (L.side && (rc = dev_alloc(h, (void **)&L.ksws2, L.ksws_slots * 65536 * 4)))) {
-                    tdmpc2_plan_destroy(h);
-                    return rc;
+            L.ks_tiles = (Rp % 256 == 0 && maxct >= 8) ? (Rp / 256) * ((maxct + 7) / 8) : 0;
+            if ((rc = ksws_ensure(h))) {
+                tdmpc2_plan_destroy(h);
+                return rc;
+            }
+            // the few-row path (layered_mid.cuh): partial sums of a launch's two problems -- parts x tiles <= #CUs tiles of 64 x 256
+            // (128 x 256) floats each.  Only where a single plan fits the chip in one round of such tiles, and the second buffer set exists.
+            {
+                const size_t cus = (size_t)(h->num_cus > 0 ? h->num_cus : 256);
+                if (L.HA2 && ((size_t)N + 127) / 128 * ((maxct + 7) / 8) <= cus) {
+                    L.mws_cap = cus * 128 * 256;
+                    if ((rc = dev_alloc(h, (void **)&L.mws[0], L.mws_cap * 4)) || (rc = dev_alloc(h, (void **)&L.mws[1], L.mws_cap * 4))) {
+                        tdmpc2_plan_destroy(h);
+                        return rc;
+                    }
                 }
+                if (const char *fr = getenv("TDMPC2_FEWROW")) L.mid = atoi(fr) != 0;
             }
             // fp32 pre-activations of the NormedLinear layers whose epilogue is not fused (the fallback after a reported wait,
             // TDMPC2_TUNE_FUSE_LN = 0, tiles the fused path does not take): one buffer per chain
@@ -981,6 +1009,7 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
     h->user_cluster_mode = h->cluster_mode;  // what was asked for (environment or default); set_tuning / fault recovery go through apply_modes
     h->user_fuse_ln = h->lay.fuse_ln;
     if (const char *cf = getenv("TDMPC2_CLUSTER_FAULT")) h->cl_fault = atoi(cf);
+    if (h->cl_fault) h->lay.mid = false;  // the hook mutes a workgroup of the WAITING paths: the handle runs them (the few-row path has no waits)
     if (getenv("TDMPC2_TIMING")) {
         if (dev_alloc(h, (void **)&h->timing, 16 * 8) == 0) (void)hipMemset(h->timing, 0, 16 * 8);
     }
@@ -1833,6 +1862,21 @@ int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value) {
     if (key == TDMPC2_TUNE_KSPLIT) {
         if (value < 0 || value > 2) return fail(TDMPC2_ERR_INVALID, "ksplit must be 0 (never), 1 (always) or 2 (few-tile launches)");
         h->lay.ksplit = value;
+        {
+            DevGuard dev_(h->cfg.device);
+            return ksws_ensure(h);  // (a bigger workspace when the mode needs one)
+        }
+    }
+    if (key == TDMPC2_TUNE_WAIT_US) {
+        if (value < 100 || value > 10000000) return fail(TDMPC2_ERR_INVALID, "wait_us must be 100 .. 10 000 000");
+        if (!h->cl_err_host) return fail(TDMPC2_ERR_STATE, "this handle has no path with inter-workgroup waits");
+        // 100 MHz constant clock (s_memrealtime): 100 ticks per microsecond; word 12 of the host-mapped error line (WaitClock)
+        __atomic_store_n(h->cl_err_host + ERR_WAIT_TICKS, (unsigned int)std::min<long long>(100LL * value, 0xffffffffLL), __ATOMIC_RELAXED);
+        return TDMPC2_OK;
+    }
+    if (key == TDMPC2_TUNE_FEWROW) {
+        if (value < 0 || value > 1) return fail(TDMPC2_ERR_INVALID, "fewrow must be 0 or 1");
+        h->lay.mid = value != 0;
         return TDMPC2_OK;
     }
     if (key == TDMPC2_TUNE_FOLD_REFIT) {

@@ -78,6 +78,7 @@ __host__ __device__ inline bool gemm_s_tile(int b, int nrowblk, int ncolblk, int
 // ONE engine and spreads the tiles -- and so the waiters -- over all four, as the whole tiles are.
 #ifndef GW_SE
 #define GW_SE 4
+#endif
 // ---------------------------------------------------------------------------------------------------------------------------
 // g_gemm_w's DMA ring (layered_wide.cuh): the schedule arithmetic -- which slabs a phase requests, reads, and how many DMA
 // requests it may leave in flight -- in one place, shared by the kernel and by tests/test_ring_schedule.py, which replays the
@@ -105,7 +106,24 @@ __host__ __device__ inline int gw_phase_vmcnt(bool steady, int vmc, int ns) {
     return vmc == 8 ? 8 : vmc == 4 ? 4 : 0;
 }
 
-#endif
+// ---------------------------------------------------------------------------------------------------------------------------
+// g_gemm_m's DMA ring (layered_mid.cuh): the same schedule with GM_REQ = 3 requests per wave and k16-slab and a ring of 6.
+constexpr int GM_REQ = 3;
+struct GmTailStep {
+    bool issue;  // slab ss + ns exists: request it into the slot slab ss has just left
+    bool next;   // slab ss + 1 exists: read it from LDS during this phase's MFMAs
+    int vmc;     // requests that may stay in flight at the top of the phase (slab ss + 1 must have landed)
+};
+__host__ __device__ inline int gm_prologue_slabs(int nk, int ns) { return nk < ns ? nk : ns; }
+__host__ __device__ inline int gm_prologue_vmcnt(int npro) { return npro > 1 ? GM_REQ * (npro - 1) : 0; }
+__host__ __device__ inline bool gm_steady_trip(int s, int nk, int ns, int u) { return s + u - 1 + ns < nk; }
+__host__ __device__ inline int gm_steady_vmcnt(int ns) { return GM_REQ * (ns - 2); }
+__host__ __device__ inline GmTailStep gm_tail_step(int ss, int nk, int ns) {
+    const int last_req = ss + ns - 1 < nk - 1 ? ss + ns - 1 : nk - 1;
+    const int inflight = last_req - (ss + 1);
+    return GmTailStep{ss + ns < nk, ss + 1 < nk, inflight > 0 ? GM_REQ * inflight : 0};
+}
+
 struct GemmWOrder {
     int parts;     // K-parts of a tail tile (1: nothing is split -- the caller then keeps the order of gemm_s_order)
     int full;      // per XCD: tiles [0, full) of its list are whole

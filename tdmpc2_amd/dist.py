@@ -161,6 +161,11 @@ def sharded_plan(backend, z0, disc_pow, prev_mean, t0, eval_mode: bool = False, 
             mh = metas.cpu()  # [world, 4]
             if tape is None:
                 if not bool((mh[:, :2] == mh[0, :2]).all()):
+                    # the plan that has just been enqueued is void: give the caller back the warm start and the Philox call counter
+                    # it came in with (the error used to leave prev_mean shifted + refitted and the counter advanced)
+                    prev_mean.copy_(prev_in)
+                    if has_counter:
+                        backend.set_call_counter(call0)
                     raise ValueError("sharded_plan: the Philox seed differs between ranks (it must not depend on the rank: every rank "
                                      f"has to sample the same actions); this rank passed {seed:#x}")
                 realign = has_counter and not bool((mh[:, 2] == mh[0, 2]).all())

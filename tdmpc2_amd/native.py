@@ -17,7 +17,7 @@ import torch
 _LIB_PATH = os.environ.get("TDMPC2_PLAN_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtdmpc2_plan.so")
 _lib = None
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # every symbol include/tdmpc2_plan.h declares (tests check the .so exports all of them)
 ABI_SYMBOLS = [
@@ -413,6 +413,14 @@ class NativePlanner:
         fi = FaultInfo()
         self._check(self.lib.tdmpc2_plan_fault_info(self._h, C.byref(fi)))
         return {k: getattr(fi, k) for k, _ in FaultInfo._fields_ if k != "reserved"}
+
+    def set_fewrow(self, on):
+        """Layered family (TDMPC2_TUNE_FEWROW): K-part tiles + row kernels for calls with few sample rows (single plans)."""
+        self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 7, int(bool(on))))
+
+    def set_wait_us(self, us):
+        """Wall-clock bound of the inter-workgroup waits in microseconds (TDMPC2_TUNE_WAIT_US; default 5000)."""
+        self._check(self.lib.tdmpc2_plan_set_tuning(self._h, 8, int(us)))
 
     def set_ksplit(self, mode):
         """TDMPC2_TUNE_KSPLIT: layered family -- split 256 x 256 GEMM tiles along K over 2-4 workgroups: 0 never (a plan's bits do

@@ -40,7 +40,7 @@ def pytest_sessionfinish(session, exitstatus):
         return
     import json
 
-    out = os.environ.get("TDMPC2_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "parity_r05.json"))
+    out = os.environ.get("TDMPC2_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "parity_r06.json"))
     try:
         os.makedirs(os.path.dirname(out), exist_ok=True)
         with open(out, "w") as f:

@@ -37,6 +37,32 @@ def test_layered_plan_matches_reference_golden(name, prec):
     _compare_stages(name, c, got, g, g["action"], g["prev_mean_out"], tag=f"/layered/{_PN[prec]}/golden")
 
 
+@pytest.mark.parametrize("name", ["small", "small_ep_fire", "small_mt", "c3", "c4", "c3_x4", "m19_mt80", "m1_mt30", "small_nb1_ep"])
+def test_few_row_path_and_per_layer_tiles_both_reproduce_the_golden(name):
+    """Single plans (and calls of a few) take the FEW-ROW path by default since round 6 (layered_mid.cuh: K-parts of 128 x 256
+    tiles + row kernels, two chains per launch, no inter-workgroup waits) -- that is what test_layered_plan_matches_reference_golden
+    runs for these cases.  TDMPC2_TUNE_FEWROW = 0 keeps the per-layer tiles of the batch path for every call size: they must still
+    reproduce the golden, the two paths agree to fp32 round-off, the few-row path is deterministic and cannot fault."""
+    from tests.gpu_common import case_on_gpu
+
+    c, model, planner = case_on_gpu(name, PATH_LAYERED, 2)
+    g = load_golden(name)
+    few = _run_native(c, model, planner)
+    again = _run_native(c, model, planner)
+    planner.set_fewrow(0)
+    try:
+        tiles = _run_native(c, model, planner)
+    finally:
+        planner.set_fewrow(1)
+    for k in few:
+        assert np.array_equal(few[k], again[k]), (name, k)  # parts are added in part order
+    _compare_stages(name, c, few, g, g["action"], g["prev_mean_out"], tag="/layered/split/golden/few_row")
+    _compare_stages(name, c, tiles, g, g["action"], g["prev_mean_out"], tag="/layered/split/golden/per_layer_tiles")
+    err = value_err(few["value"][:, 0], tiles["value"][:, 0])
+    print(f"[{name}] few-row path vs per-layer tiles, iteration-0 values: rel err {err:.2e}")
+    assert err < 5e-5 and planner.take_fault() == 0
+
+
 @PRECS
 @pytest.mark.parametrize("name", ["c1", "mt5", "c2"])
 def test_layered_family_on_fused_size_class(name, prec):
@@ -176,13 +202,17 @@ def test_normed_linear_epilogue_inside_the_gemm_agrees_with_the_row_kernel(name)
 
     c, model, planner = case_on_gpu(name, PATH_LAYERED, 2)
     g = load_golden(name)
-    fused = _run_native(c, model, planner)
-    again = _run_native(c, model, planner)
-    planner.set_fuse_ln(0)
+    planner.set_fewrow(0)  # the per-layer tiles (calls this small take the few-row path by default: layered_mid.cuh, tested below)
     try:
-        plain = _run_native(c, model, planner)
+        fused = _run_native(c, model, planner)
+        again = _run_native(c, model, planner)
+        planner.set_fuse_ln(0)
+        try:
+            plain = _run_native(c, model, planner)
+        finally:
+            planner.set_fuse_ln(1)
     finally:
-        planner.set_fuse_ln(1)
+        planner.set_fewrow(1)
     for k in fused:
         assert np.array_equal(fused[k], again[k]), (name, k)  # the exchange is deterministic
     _compare_stages(name, c, plain, g, g["action"], g["prev_mean_out"], tag="/layered/split/golden/ln_row_kernel")
@@ -222,10 +252,12 @@ def test_fused_epilogue_wait_that_never_completes_is_reported_not_hung(monkeypat
     pm_a, pm_b = inp["prev_mean"].clone(), inp["prev_mean"].clone()
     a = planner.plan(inp["z0"], inp["disc_pow"], pm_a, inp["t0"], **kw).clone()
     ref.set_fuse_ln(0)
+    ref.set_fewrow(0)  # (the handle with the muted workgroup runs the per-layer tiles: the hook belongs to their waits)
     try:
         b = ref.plan(inp["z0"], inp["disc_pow"], pm_b, inp["t0"], **kw).clone()
     finally:
         ref.set_fuse_ln(1)
+        ref.set_fewrow(1)
     torch.cuda.synchronize()
     assert torch.equal(a, b) and torch.equal(pm_a, pm_b) and planner.take_fault() == 0
     planner.close()
@@ -276,10 +308,12 @@ def test_sharded_plan_reports_a_wait_that_gave_up_in_an_earlier_iteration(monkey
     a = sharded_plan(planner, inp["z0"], inp["disc_pow"], pm_a, inp["t0"], eval_mode=c["eval_mode"], tape=inp["tape"], **kw).clone()
     assert planner.last_shard_retries == 1 and planner.take_fault() == 0
     ref.set_fuse_ln(0)
+    ref.set_fewrow(0)
     try:
         b = ref.plan(inp["z0"], inp["disc_pow"], pm_b, inp["t0"], eval_mode=c["eval_mode"], tape=inp["tape"], **kw).clone()
     finally:
         ref.set_fuse_ln(1)
+        ref.set_fewrow(1)
     torch.cuda.synchronize()
     assert torch.isfinite(a).all() and torch.allclose(a, b, atol=1e-6) and torch.allclose(pm_a, pm_b, atol=1e-6)
     planner.close()
@@ -684,11 +718,13 @@ def test_safe_once_covers_one_plan_and_the_verdict_word_is_readable_on_the_devic
     fi1 = planner.fault_info()
     assert (fi1["degraded"], fi1["rearms"], fi1["rearm_after"]) == (fi0["degraded"], fi0["rearms"], fi0["rearm_after"])
     ref.set_fuse_ln(0)
+    ref.set_fewrow(0)
     try:
         pm_ref = inp["prev_mean"].clone()
         want = ref.plan(inp["z0"], inp["disc_pow"], pm_ref, inp["t0"], **kw).clone()
     finally:
         ref.set_fuse_ln(1)
+        ref.set_fewrow(1)
     torch.cuda.synchronize()
     assert torch.equal(good, want) and torch.equal(pm_good, pm_ref)
     bad3, _ = plan()  # the flag covered exactly one plan

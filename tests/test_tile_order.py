@@ -192,3 +192,184 @@ def test_k_split_rule_picks_what_the_round_arithmetic_says(lib):
     assert o["parts"] == 1
     o = w_order(lib, 60, 7, nk=2, ovh=400)  # the t = 0 first layers contract the action columns only: K = 32
     assert o["parts"] == 1
+
+
+# ---------------------------------------------------------------- a CPU model of the dispatcher (round 6)
+# DESIGN 8 argues deadlock-freedom of the launches whose workgroups wait for each other (the NormedLinear epilogue inside the
+# GEMM: the column blocks of a row block; with a K-split tail the last arriver of every tile) from how the hardware was SEEN to
+# place workgroups: 8 XCDs, block b on XCD b % 8; an XCD hands the workgroups of its share of a grid, in order, round-robin to
+# its 4 shader engines of 8 CUs; a workgroup only ever runs on its engine; a waiting workgroup keeps its CU.  This is that
+# model, and the invariant every order the library can pick has to satisfy in it -- so that a new order is judged here, on the
+# CPU, and not by thousands of stress stages on a GPU.
+#
+# Per XCD and launch: the ordered list of its workgroups (slot t -> engine t % 4; a padding block takes a slot and leaves at
+# once).  After a prefix of p slots has been dispatched, a workgroup can be HELD -- waiting, possibly for ever -- only if its row
+# block is not completely inside the prefix; a tile in K-parts holds at most ONE workgroup (its last arriver; the other parts
+# leave), and only once all its parts are inside the prefix -- on whichever of its parts' engines the adversary likes.
+# H[p][e] = the most workgroups the launch can hold on engine e after prefix p.  The launch's next workgroup needs engine p % 4.
+# One launch alone deadlocks if H[p][p % 4] >= capacity for some p < n; two launches A, B in flight (the two chains of a stage,
+# dispatched in ANY interleaving) deadlock if there are prefixes pa, pb with BOTH next workgroups' engines full of held
+# workgroups: H_A[pa][ea] + H_B[pb][ea] >= cap and H_A[pa][eb] + H_B[pb][eb] >= cap.  (Sufficient for safety: everything that is
+# not held finishes by itself and frees its CU.)  Row blocks that span XCDs (the row-major orders of few-row launches) are
+# outside this per-XCD argument: for those the test asks for plain co-residency of both launches.
+import numpy as np
+
+SE, CUS_PER_SE = 4, 8
+
+
+def _xcd_lists(entries, nblk):
+    """entries: {block id: (rb, tile key, n_parts)}; -> per XCD the slot list [(rb, tile, n_parts) or None (padding)]"""
+    out = [[] for _ in range(8)]
+    for b in range(nblk):
+        out[b % 8].append(entries.get(b))
+    return out
+
+
+def _held_bound(slots, rb_sizes):
+    """H[p][e] for p = 0 .. n (see above).  rb_sizes: workgroups of each row block in the WHOLE launch (all XCDs)."""
+    n = len(slots)
+    H = np.zeros((n + 1, SE), dtype=np.int32)
+    seen_rb, seen_tile, tile_engines = {}, {}, {}
+    for p in range(1, n + 1):
+        s = slots[p - 1]
+        if s is not None:
+            rb, tile, parts = s
+            seen_rb[rb] = seen_rb.get(rb, 0) + 1
+            seen_tile[tile] = seen_tile.get(tile, 0) + 1
+            tile_engines.setdefault(tile, set()).add((p - 1) % SE)
+        h = np.zeros(SE, dtype=np.int32)
+        for tile, cnt in seen_tile.items():
+            rb, parts = tile[0], tile[2]
+            if cnt == parts and seen_rb[rb] < rb_sizes[rb]:  # a complete tile of an incomplete row block: one held workgroup
+                for e in tile_engines[tile]:
+                    h[e] += 1
+        H[p] = h
+    return H
+
+
+def _deadlock_alone(H, cap):
+    n = H.shape[0] - 1
+    return any(H[p][p % SE] >= cap for p in range(n))
+
+
+def _deadlock_pair(HA, HB, cap):
+    nA, nB = HA.shape[0] - 1, HB.shape[0] - 1
+    for ea in range(SE):
+        pa = np.arange(ea, nA, SE)
+        if pa.size == 0:
+            continue
+        for eb in range(SE):
+            pb = np.arange(eb, nB, SE)
+            if pb.size == 0:
+                continue
+            blocked_a = (HA[pa][:, ea][:, None] + HB[pb][:, ea][None, :]) >= cap
+            blocked_b = (HA[pa][:, eb][:, None] + HB[pb][:, eb][None, :]) >= cap
+            if (blocked_a & blocked_b).any():
+                return True
+    return False
+
+
+def _launch_model(lib, nrowblk, ncolblk, nk, ksplit, tile_fn=None):
+    """Per-XCD held bounds of one fused-epilogue launch of the wide tile (one workgroup per CU) as the host would order it:
+    K-split tail when `ksplit` and the rule says so, else XCD-local row blocks (>= 16 row blocks) or row-major."""
+    entries, nblk, spans = {}, 0, False
+    o = w_order(lib, nrowblk, ncolblk, nk=nk, ovh=12000 // (nk + 25)) if ksplit else {"parts": 1}
+    if o["parts"] > 1:
+        nblk = o["nblk"]
+        rb, cb, part, slot = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        for b in range(nblk):
+            got = (tile_fn or _w_tile)(lib, b, nrowblk, ncolblk, o)
+            if got:
+                r, c, _, sl = got
+                entries[b] = (r, (r, c, o["parts"] if sl >= 0 else 1), o["parts"] if sl >= 0 else 1)
+    else:
+        so = order(lib, nrowblk, ncolblk, 1 if nrowblk >= 16 else 0, 1)
+        nblk, spans = so["nblk"], so["xcd_rows"] == 0
+        for b, r, c in tiles(lib, nrowblk, ncolblk, so):
+            entries[b] = (r, (r, c, 1), 1)
+    rb_sizes = {}
+    for r, tile, parts in entries.values():
+        rb_sizes[r] = rb_sizes.get(r, 0) + 1
+    lists = _xcd_lists(entries, nblk)
+    return [(_held_bound(l, rb_sizes), sum(s is not None for s in l)) for l in lists], spans
+
+
+def _w_tile(lib, b, nrowblk, ncolblk, o):
+    rb, cb, part, slot = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    if lib.w_tile(b, nrowblk, ncolblk, o["full"], o["parts"], o["max_tail"], ctypes.byref(rb), ctypes.byref(cb), ctypes.byref(part), ctypes.byref(slot)):
+        return rb.value, cb.value, part.value, slot.value
+    return None
+
+
+def _w_tile_tile_major(lib, b, nrowblk, ncolblk, o):
+    """Round 5's FIRST tail order (r5c): the K-parts of a tile on consecutive slots -- part p of every tile on engine p."""
+    x, t = b & 7, b >> 3
+    if t < o["full"]:
+        return _w_tile(lib, b, nrowblk, ncolblk, o)
+    u = t - o["full"]
+    i, part = o["full"] + u // o["parts"], u % o["parts"]
+    # the shipped map, asked for tile i's FIRST part, tells which tile that is
+    g, r = (i - o["full"]) // 4, (i - o["full"]) % 4
+    got = _w_tile(lib, 8 * (o["full"] + g * 4 * o["parts"] + r) + x, nrowblk, ncolblk, o)
+    return None if got is None else (got[0], got[1], part, got[3])
+
+
+# the GEMM shapes of a stage: (column blocks of 256, k16-slabs) of the hidden layers / the SimNorm output layer
+C3 = [(7, 112), (7, 50), (3, 112)]
+C4 = [(16, 256), (16, 88), (6, 256)]
+
+
+@pytest.mark.parametrize("model,shapes,rows_per_plan", [("c3", C3, 512), ("c4", C4, 1024)])
+def test_no_order_the_library_picks_can_deadlock_in_the_dispatcher_model(lib, model, shapes, rows_per_plan):
+    cap = CUS_PER_SE  # the wide tile: one workgroup per CU
+    proven, coresident = 0, 0
+    for E in range(1, 65):
+        if (E * rows_per_plan) % 256:
+            continue  # the wide tile takes whole 256-row blocks
+        nrowblk = E * rows_per_plan // 256
+        for ksplit in (False, True):
+            launches = [_launch_model(lib, nrowblk, nc, nk, ksplit) for nc, nk in shapes]
+            for i, (la, spans_a) in enumerate(launches):
+                for x in range(8):
+                    assert not _deadlock_alone(la[x][0], cap), (model, E, ksplit, shapes[i], x)
+                for j, (lb, spans_b) in enumerate(launches):
+                    if spans_a or spans_b:
+                        # row blocks on several XCDs (row-major orders of launches with < 16 row blocks): the per-XCD argument does
+                        # not apply; such a pair is only claimed safe when both launches fit the chip together
+                        if all(la[x][1] + lb[x][1] <= SE * cap for x in range(8)):
+                            coresident += 1
+                        continue
+                    for x in range(8):
+                        assert not _deadlock_pair(la[x][0], lb[x][0], cap), (model, E, ksplit, shapes[i], shapes[j], x)
+                    proven += 1
+    assert proven > 100
+    print(f"[{model}] dispatcher model: {proven} launch pairs proven per XCD, {coresident} row-major pairs co-resident")
+
+
+def test_the_dispatcher_model_reports_the_orders_that_deadlocked_on_the_gpu(lib):
+    """Negative controls.  (i) r5c: the K-parts of a tile on consecutive slots -- the 317M model (16 column blocks in 4 parts = 64
+    workgroups per row block and XCD; two plans: one row block per XCD) stopped at 8 or 15 of 16 arrivals with ONE stream, on every
+    launch with more than 32 workgroups per XCD.  (ii) r5g: all column blocks of a row block
+    on one engine (four row blocks of an XCD slot-interleaved) -- the 48M model's two chains deadlocked on every stage."""
+    cap = CUS_PER_SE
+    # (i)
+    good, _ = _launch_model(lib, 12, 16, 256, True)  # three plans: 24 tiles x 4 parts on every XCD
+    bad, _ = _launch_model(lib, 12, 16, 256, True, tile_fn=_w_tile_tile_major)
+    assert good[0][1] == 96
+    assert not any(_deadlock_alone(good[x][0], cap) for x in range(8))
+    assert any(_deadlock_alone(bad[x][0], cap) for x in range(8))
+    # (ii) 60 row blocks x 7 column blocks, XCD-local; engine-local variant: slot t of an XCD -> row block 4 (t // 28) + t % 4, column t // 4 % 7
+    nrowblk, ncolblk = 60, 7
+    entries = {}
+    for x in range(8):
+        rbs = list(range(x, nrowblk, 8))
+        for t in range(-(-len(rbs) // 4) * 4 * ncolblk):
+            k = 4 * (t // (4 * ncolblk)) + t % 4
+            if k < len(rbs):
+                entries[8 * t + x] = (rbs[k], (rbs[k], (t // 4) % ncolblk, 1), 1)
+    rb_sizes = {r: ncolblk for r in range(nrowblk)}
+    nblk = 8 * (max(entries) // 8 + 1)
+    se_local = [_held_bound(l, rb_sizes) for l in _xcd_lists(entries, nblk)]
+    shipped, _ = _launch_model(lib, nrowblk, ncolblk, 112, False)
+    assert not any(_deadlock_pair(shipped[x][0], shipped[x][0], cap) for x in range(8))
+    assert any(_deadlock_pair(se_local[x], se_local[x], cap) for x in range(8))

@@ -18,7 +18,9 @@ for step in "$@"; do
   echo "=== [$TAG] $step  ($(date +%T))"
   case $kind in
     pytest)
-      timeout ${PYTEST_TIMEOUT:-900} python -m pytest tests -q -m gpu ${rest:--x} 2>&1 | tail -${PYTEST_TAIL:-60} > gpurun_out/${TAG}_pytest.log; tail -25 gpurun_out/${TAG}_pytest.log ;;
+      timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -q -m gpu ${rest:--x} > /tmp/${TAG}_pytest_full.log 2>&1
+      { grep -E "^(FAILED|ERROR)|^E  |passed|failed| error" /tmp/${TAG}_pytest_full.log | head -80; echo "-----"; tail -${PYTEST_TAIL:-60} /tmp/${TAG}_pytest_full.log; } > gpurun_out/${TAG}_pytest.log
+      head -40 gpurun_out/${TAG}_pytest.log ;;
     envab)
       specs=${rest%%:*}; sets=${rest#*:}
       IFS='|' read -r -a ES <<< "$sets"
