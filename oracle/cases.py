@@ -52,6 +52,12 @@ CASES = {
     # symexp at 1) through the reference's own planner -- its parser.py:59 divides by num_bins - 1, the code behind it does not
     "c1_nb0": ("c1", dict(num_bins=0, iterations=3), 2, False, 0.06),
     "small_nb1_ep": ("small", dict(num_bins=1, episodic=True), 2, False, 0.06),
+    # TRAINED-LIKE weight statistics (synth.trained_like: LayerNorm gains in [0.2, 5], biases N(0, 0.3), 0.1 % of every matrix at
+    # 20 sigma) and head weights scaled for trajectory values of a few hundred (+- 300 .. 1000) -- the benched model and the two large ones
+    # (VERDICT r5 next #4a: the split arithmetic's margin had only been shown on kind synthetic weights)
+    "c2_tl": ("c2", dict(iterations=4), 2, False, 0.015),     # dog-run 5M at the benched I = 6
+    "c3_tl": ("c3", {}, 2, False, 0.02),                    # mt30 48M
+    "c4_tl": ("c4", dict(iterations=2), 1, False, 0.012),    # mt80 317M, H5 N1024, 2 iterations
 }
 
 
@@ -62,7 +68,7 @@ def build_case(name: str):
 
 def build_custom(cfg, E: int, eval_mode: bool = False, head_std: float = 0.06, name: str = "", t0=None):
     """A case from an arbitrary config (edge-case tests build these on the fly; no golden fixture)."""
-    if cfg.multitask and name in ("tiny_mt", "small_mt", "c3", "c4", "c4_l1024", "c3_x4", "c4_x2", "m19_mt80", "m19_mt30", "m1_mt30"):
+    if cfg.multitask and name in ("tiny_mt", "small_mt", "c3", "c4", "c4_l1024", "c3_x4", "c4_x2", "m19_mt80", "m19_mt30", "m1_mt30", "c3_tl", "c4_tl"):
         # heterogeneous action dims / episode lengths to exercise masks and per-task discounts
         n = len(cfg.tasks)
         cfg.action_dims = [cfg.action_dim - (i % 3) for i in range(n)]
@@ -73,6 +79,8 @@ def build_custom(cfg, E: int, eval_mode: bool = False, head_std: float = 0.06, n
         cfg.episode_lengths = [500 if i % 2 == 0 else 1000 for i in range(n)]
     I = planner_iterations(cfg)
     sd = synth.make_state_dict(cfg, seed=0, head_std=head_std)
+    if name.endswith("_tl"):
+        sd = synth.trained_like(sd, seed=0)
     if name == "small_ep_fire":  # spread the termination logits around 0 (world_model.py:132-141: sigmoid(.) > 0.5 terminates)
         sd["_termination.2.weight"] = sd["_termination.2.weight"] * 12.0
         sd["_termination.2.bias"] = sd["_termination.2.bias"] * 0.0 + 3.3
