@@ -368,9 +368,20 @@ def cpu_baseline(cfg, iterations, sd_np, budget_s=12.0):
             if (el >= budget_s and n >= (3 if el < 4 * budget_s else 1)) or n >= 64:
                 break
     # time per plan of this restatement / of the reference's own TDMPC2._plan run verbatim (oracle/ref_runner.py): MEASURED here
-    # when the reference tree is on this machine (the build container), else the constant last measured there, labelled as such
-    pvr = {"value": 1.0, "source": "constant, NOT measured in this run (/root/reference is not on this machine): in the build container "
-                                    "the ratio came out 0.92 (round 2, c2) and 1.11 (round 5, c1) on 8 threads -- the two are the same speed to +-10 %"}
+    # when the reference tree is on this machine (the build container).  The reference is Python and may not travel to the GPU box
+    # in any form, so there the ratio comes from the committed record of the one place where both exist
+    # (profiles/port_vs_reference.json, made by oracle/time_port_vs_reference.py: same inputs, same thread count, interleaved)
+    pvr = {"value": 1.0, "source": "constant (no record for this configuration)"}
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "port_vs_reference.json")))
+        key = "c1" if cfg.action_dim < 20 and not cfg.multitask else "c2"
+        if not cfg.multitask and cfg.latent_dim == 512 and key in rec["cases"]:
+            r = rec["cases"][key]
+            pvr = {"value": r["port_vs_reference"],
+                   "source": f"profiles/port_vs_reference.json ({key}: port {r['port_ms_per_plan']} ms, the reference's own _plan {r['reference_ms_per_plan']} ms "
+                             f"per plan on {rec['threads']} threads of the build container) -- NOT measured on this machine: /root/reference is not here"}
+    except Exception:
+        pass
     if os.path.isdir("/root/reference/tdmpc2"):
         try:
             from oracle import ref_runner
@@ -384,6 +395,7 @@ def cpu_baseline(cfg, iterations, sd_np, budget_s=12.0):
         except Exception as ex:
             pvr["error"] = repr(ex)[:160]
     return {"value": round(n / el, 3), "unit": "plans/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "reference_estimate": round(n / el * pvr["value"], 3),  # what the reference's own _plan would do here, by that ratio
             "port_vs_reference": pvr["value"], "port_vs_reference_source": pvr["source"], **({"port_vs_reference_error": pvr["error"]} if "error" in pvr else {}),
             "sample": f"{n} sequential plan() calls of the same workload (1 env, recorded noise tape) after 1 warm-up, "
                       f"{el:.1f} s wall, torch {torch.__version__} CPU fp32",

@@ -360,10 +360,19 @@ int tdmpc2_plan_shard_refit(tdmpc2_plan_t *h, int n_envs, int iter, float *value
  * in any batch).  0 = the per-layer tiles of the batch path for every call size.
  * key TDMPC2_TUNE_WAIT_US (ABI 9): the wall-clock bound of the inter-workgroup waits in microseconds (default 5000; 100 .. 10 000 000).
  * A handle that shares its GPU with another process's multi-millisecond kernels may want more; the hot path never reads it (the
- * clock is only consulted from the 256th poll of a wait on). */
+ * clock is only consulted from the 256th poll of a wait on).
+ * keys TDMPC2_TUNE_EXPERT + tdmpc2_expert_knob (ABI 9): the measurement knobs of the layered family's tile choice -- thresholds between
+ * kernels that compute the same values to fp32 round-off.  They were environment variables of the library until ABI 8; the library
+ * now reads exactly the environment variables listed in INTEGRATION.md section C and nothing else.  value INT32_MIN = the default. */
 enum tdmpc2_tuning { TDMPC2_TUNE_ROWS_PER_WORKGROUP = 0, TDMPC2_TUNE_FOLD_REFIT = 1, TDMPC2_TUNE_CLUSTER = 2, TDMPC2_TUNE_FUSE_LN = 3,
                      TDMPC2_TUNE_REARM_AFTER = 4, TDMPC2_TUNE_SAFE_ONCE = 5, TDMPC2_TUNE_KSPLIT = 6, TDMPC2_TUNE_FEWROW = 7,
-                     TDMPC2_TUNE_WAIT_US = 8 };
+                     TDMPC2_TUNE_WAIT_US = 8, TDMPC2_TUNE_EXPERT = 100 };
+/* (what each knob decides: tdmpc2_amd/csrc/layered_host.cuh; defaults in tdmpc2_amd/csrc/handle.h) */
+enum tdmpc2_expert_knob { TDMPC2_X_GEMM_W256_MIN = 0, TDMPC2_X_GEMM_W_SPLIT_MIN, TDMPC2_X_GEMM_W_SPLIT_MAX, TDMPC2_X_GEMM_W_SPLIT_OVH,
+                          TDMPC2_X_KSPLIT_AUTO_LO, TDMPC2_X_KSPLIT_AUTO_MIN, TDMPC2_X_GEMM_W_XCD_ROWS, TDMPC2_X_GEMM_NCT1,
+                          TDMPC2_X_GEMM_WIDE_MIN, TDMPC2_X_GEMM_RT4, TDMPC2_X_GEMM_FILL_PERMILLE, TDMPC2_X_GEMM_FILL_HEAD_PERMILLE,
+                          TDMPC2_X_GEMM_SD1, TDMPC2_X_GEMM_XCD_ROWS, TDMPC2_X_GEMM_COL_PAD, TDMPC2_X_TWOHOT_UNFUSED, TDMPC2_X_Z0_SHARED_OFF,
+                          TDMPC2_X_MID_PARTS_MAX, TDMPC2_X_COUNT };
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
 
 /* Fault report of the paths whose workgroups wait for each other: the cluster path (TDMPC2_TUNE_CLUSTER) and the NormedLinear

@@ -24,6 +24,9 @@ ONLY=""
 # unit name | source | extra flags
 UNITS=()
 UNITS+=("main|tdmpc2_plan.hip|${ONLY} ${TDMPC2_FLAGS_main:-}")
+# the C-ABI unit once more with the test hooks compiled in (TDMPC2_CLUSTER_FAULT, TDMPC2_DEBUG_NO_TURN, TDMPC2_POISON): linked with the
+# SAME kernel objects into libtdmpc2_plan_hooks.so, which only the GPU tests of the fault paths load (tdmpc2_amd/native.py)
+[ -z "${TDMPC2_NO_HOOKS_LIB:-}" ] && UNITS+=("main_hooks|tdmpc2_plan.hip|${ONLY} -DTDMPC2_TEST_HOOKS ${TDMPC2_FLAGS_main:-}")
 UNITS+=("layered|k_layered.hip|${TDMPC2_FLAGS_layered:-}")
 for ap in ${APADS}; do
     UNITS+=("fused${ap}|k_fused.hip|-DTU_APAD=${ap} ${TDMPC2_FLAGS_fused:-}")
@@ -61,7 +64,16 @@ export -f compile_unit unit_deps
 export HERE BUILD HIPCC COMMON
 
 printf '%s\n' "${UNITS[@]}" | xargs -P "${JOBS}" -I{} bash -c 'IFS="|" read -r n s f <<< "{}"; compile_unit "$n" "$s" "$f"'
-OBJS=()
-for u in "${UNITS[@]}"; do OBJS+=("${BUILD}/${u%%|*}.o"); done
+OBJS=(); HOBJS=()
+for u in "${UNITS[@]}"; do
+    n="${u%%|*}"
+    [ "$n" == "main_hooks" ] && { HOBJS+=("${BUILD}/$n.o"); continue; }
+    OBJS+=("${BUILD}/$n.o")
+    [ "$n" != "main" ] && HOBJS+=("${BUILD}/$n.o")
+done
 "${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT}" "${OBJS[@]}"
 echo "built ${OUT}"
+if [ -z "${TDMPC2_NO_HOOKS_LIB:-}" ]; then
+    "${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT%.so}_hooks.so" "${HOBJS[@]}"
+    echo "built ${OUT%.so}_hooks.so"
+fi

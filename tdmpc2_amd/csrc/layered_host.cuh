@@ -105,7 +105,7 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         // combination order is tile-independent, so a plan's bits do not depend on the size of the call it is part of)
         const bool can_fuse = ln && L.fuse_ln && L.arrive && bufs->stats && rows_p * ((ly.CT + 3) / 4) * 2 <= L.stats_cap;
         // ---- the 256 x 256 tile (g_gemm_w): fused NormedLinear layers of calls that fill the chip with one workgroup per CU
-        static const long w256_min = getenv("TDMPC2_GEMM_W256_MIN") ? atol(getenv("TDMPC2_GEMM_W256_MIN")) : 192;
+        const long w256_min = L.knob[LK_W256_MIN];
         // (Measured and rejected, profiles/README.md r4f: 256 x 224 / 192 tiles -- 8 x 1 wave layout, one W fragment set -- for widths
         // like the 48M model's 1792 = 8 x 224, which would fill 1.875 rounds of the chip instead of 1.64: the layout reads every W
         // fragment eight times from LDS (128 KiB per slab) and lost 4.5 % in spite of the better fill.)
@@ -116,9 +116,9 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         // workgroups each.  That makes the wide tile worth taking from fewer tiles on (a 180-tile SimNorm layer: 720 workgroups)
         const int nrowblk_w = (int)(rows_p / 256);
         const long cus_x = cus >= 8 ? cus / 8 : 1;
-        static const long ks_min = getenv("TDMPC2_GEMM_W_SPLIT_MIN") ? atol(getenv("TDMPC2_GEMM_W_SPLIT_MIN")) : 192;
-        static const int ks_maxp = getenv("TDMPC2_GEMM_W_SPLIT_MAX") ? atoi(getenv("TDMPC2_GEMM_W_SPLIT_MAX")) : 4;
-        static const int ks_ovh = getenv("TDMPC2_GEMM_W_SPLIT_OVH") ? atoi(getenv("TDMPC2_GEMM_W_SPLIT_OVH")) : 12000;
+        const long ks_min = L.knob[LK_W_SPLIT_MIN];
+        const int ks_maxp = L.knob[LK_W_SPLIT_MAX];
+        const int ks_ovh = L.knob[LK_W_SPLIT_OVH];
         GemmWOrder wo{};
         wo.parts = 1;
         const bool w_shape = can_fuse && ly.CT >= 8 && rows_p % 256 == 0 && rows_per_env % 256 == 0 && ncb256 <= 32 && !L.row_env &&
@@ -129,8 +129,8 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         // through the fabric, +210 MB per hidden GEMM of the 48M model at E = 30) costs more than the better fill buys: c3 -10 ... -13 %,
         // c4 -2.7 % (profiles/README.md r5d).
         const long tiles_w = (long)nrowblk_w * ncb256;
-        static const long ks_auto_lo = getenv("TDMPC2_KSPLIT_AUTO_LO") ? atol(getenv("TDMPC2_KSPLIT_AUTO_LO")) : 16;
-        static const long ks_auto_min = getenv("TDMPC2_KSPLIT_AUTO_MIN") ? atol(getenv("TDMPC2_KSPLIT_AUTO_MIN")) : cus / 4;
+        const long ks_auto_lo = L.knob[LK_KSPLIT_AUTO_LO];
+        const long ks_auto_min = L.knob[LK_KSPLIT_AUTO_MIN] >= 0 ? L.knob[LK_KSPLIT_AUTO_MIN] : cus / 4;
         const bool ks_want = L.ksplit == 1 || (L.ksplit == 2 && tiles_w >= ks_auto_lo && tiles_w <= cus / 2);
         if (w_shape && ks_want && bufs->ksws && ks_maxp > 1) {
             const int nk = q.K / 16;
@@ -151,7 +151,7 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             // tile order: XCD-local row blocks keep the column blocks of a row block -- which wait for each other -- on consecutive
             // slots of ONE XCD (with one workgroup per CU and <= 16 column blocks two launches in flight cannot starve each other:
             // 2 x 15 waiting workgroups < 32 CUs), and read every A row through one L2
-            static const int xr_env = getenv("TDMPC2_GEMM_W_XCD_ROWS") ? atoi(getenv("TDMPC2_GEMM_W_XCD_ROWS")) : -1;
+            const int xr_env = L.knob[LK_W_XCD_ROWS];
             // TDMPC2_GEMM_W_XCD_ROWS=2: XCD rectangles, a row block on 2 XCDs -- per XCD and launch A/4 + W/2 instead of A/8 + W
             // through the L2.  At 16 column blocks (317M model): c4 +1 %, fabric-side reads of the launch 881 -> 654 MB, of a stage
             // 27.3 -> 20.6 GB (profiles/README.md r4s, r4t) -- but NOT the default: with a row block on two XCDs two launches in
@@ -175,23 +175,23 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
         // wide outputs (>= 256 columns) take the 128 x 256 tile from 128 such workgroups on: with a second chain in flight
         // (lay_estimate_value) a partly filled round is not idle (A/B r3n: threshold 512 -> 256: c3 +2.0 %, c4 +2.3 %; 128: single
         // plans of the 317M model 20.8 -> 18.7 ms; below that single plans of the 48M model lose)
-        static const size_t wide_min = getenv("TDMPC2_GEMM_NCT1") ? (size_t)1 << 30 : getenv("TDMPC2_GEMM_WIDE_MIN") ? (size_t)atoi(getenv("TDMPC2_GEMM_WIDE_MIN")) : 128;
+        const size_t wide_min = L.knob[LK_NCT1] ? (size_t)1 << 30 : (size_t)L.knob[LK_WIDE_MIN];
         const bool wide = ly.CT >= 8 && (rows_p / GBM) * ((ly.CT + 7) / 8) >= wide_min;
         q.ncolblk = wide ? (ly.CT + 7) / 8 : (ly.CT + 3) / 4;
         // rows per workgroup tile: 128 when that fills the chip (two workgroups per CU), else 64 or 32 -- few rows mean
         // single-plan latency, where occupancy beats operand reuse (TDMPC2_GEMM_RT=4 forces the 128-row tile)
         const long slots = 2L * cus;
         int rt = 4;
-        if (!wide && !getenv("TDMPC2_GEMM_RT4")) {
-            static const double fill = getenv("TDMPC2_GEMM_FILL") ? atof(getenv("TDMPC2_GEMM_FILL")) : 0.75;
-            static const double fill_head = getenv("TDMPC2_GEMM_FILL_HEAD") ? atof(getenv("TDMPC2_GEMM_FILL_HEAD")) : 0.75;
+        if (!wide && !L.knob[LK_RT4]) {
+            const double fill = L.knob[LK_FILL_PERMILLE] / 1000.0;
+            const double fill_head = L.knob[LK_FILL_HEAD_PERMILLE] / 1000.0;
             const double f = ly.CT <= 4 ? fill_head : fill;  // narrow outputs (two-hot / policy heads): one column block
             while (rt > 1 && (double)((long)(rows_p / (32 * rt)) * q.ncolblk) < (double)slots * f) rt >>= 1;
         }
         const int nrowblk = (int)(rows_p / (32 * rt));
         int nblk = nrowblk * q.ncolblk;
         // few workgroups per CU: row operand staged four chunks deep, weight ring of 8 / 16 blocks (g_gemm_s<.., .., 4>)
-        const bool deep = !wide && (long)nblk < 2 * slots && !getenv("TDMPC2_GEMM_SD1");
+        const bool deep = !wide && (long)nblk < 2 * slots && !L.knob[LK_SD1];
         int epi = 0;
         const bool fuse = can_fuse && L.arrive_off + (size_t)nrowblk <= L.arrive_cap;
         if (fuse) {
@@ -203,15 +203,15 @@ int lay_gemm(tdmpc2_plan *h, hipStream_t st, const float *A, int lda, size_t row
             q.out = out; q.KBo = ldo / 16;
             // tile order (tile_order.h); TDMPC2_GEMM_XCD_ROWS = 0 / 1: never / always XCD-local row blocks, TDMPC2_GEMM_COL_PAD = 0:
             // no padding of the row-major order
-            static const int xcd_rows_env = getenv("TDMPC2_GEMM_XCD_ROWS") ? atoi(getenv("TDMPC2_GEMM_XCD_ROWS")) : -1;
-            static const int col_pad_env = getenv("TDMPC2_GEMM_COL_PAD") ? atoi(getenv("TDMPC2_GEMM_COL_PAD")) : 1;
+            const int xcd_rows_env = L.knob[LK_XCD_ROWS];
+            const int col_pad_env = L.knob[LK_COL_PAD];
             const GemmSOrder ord = gemm_s_order(nrowblk, q.ncolblk, xcd_rows_env, col_pad_env);
             q.xcd_rows = ord.xcd_rows; q.ncol_grid = ord.ncol_grid; q.nrowblk = nrowblk;
             nblk = ord.nblk;
         } else if (ln) {  // pre-activations -> PRE, the LayerNorm kernel writes the packed operand
             if (!bufs->PRE) return fail(TDMPC2_ERR_STATE, "no pre-activation buffer on this handle");
             q.out = bufs->PRE; q.ldo = L.ldpre;
-        } else if (th && !wide && rt <= 2 && ly.CT <= 4 && (long)nblk >= cus && !getenv("TDMPC2_TWOHOT_UNFUSED")) {
+        } else if (th && !wide && rt <= 2 && ly.CT <= 4 && (long)nblk >= cus && !L.knob[LK_TWOHOT_UNFUSED]) {
             // two-hot head: the row routine in the epilogue -- from one workgroup per CU on (c3 E = 30: +1.4 %; a single plan's 16-32
             // workgroups are better served by l_twohot's one wavefront per row across the chip: 3.33 vs 3.44 ms, profiles r4i)
             epi = 3;
@@ -399,7 +399,7 @@ int lay_setup(tdmpc2_plan *h, hipStream_t st, int E, const float *task_emb, cons
 int lay_cvec(tdmpc2_plan *h, hipStream_t st, int E, const float *z0) {
     Layered &L = h->lay;
     L.cvec_ready = false;
-    if (!h->split || !L.Z0X || getenv("TDMPC2_Z0_SHARED_OFF")) return 0;
+    if (!h->split || !L.Z0X || L.knob[LK_Z0_SHARED_OFF]) return 0;
     const tdmpc2_plan_cfg &c = h->cfg;
     const size_t rows_p = round_up((size_t)E, GBM);
     hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)((E + 31) / 32)), dim3(256), 0, st, L.Z0X, L.Kin, c.latent_dim, 1, z0, (float *)nullptr, (float *)nullptr, E);
@@ -457,7 +457,7 @@ int mid_stage(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rp
     G.nprob = R.nprob = n;
     long tiles = 0;
     for (int i = 0; i < n; ++i) tiles += (long)(rows_p / GM_TM) * ((ops[i].ly->CT + 7) / 8);
-    static const int pmax = getenv("TDMPC2_MID_PARTS_MAX") ? atoi(getenv("TDMPC2_MID_PARTS_MAX")) : 16;
+    const int pmax = L.knob[LK_MID_PARTS_MAX];
     const int pall = (int)std::max<long>(1, std::min<long>(pmax, cus / std::max<long>(tiles, 1)));
     unsigned gblk = 0, rblk = 0;
     for (int i = 0; i < n; ++i) {
@@ -649,7 +649,7 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
     // dynamics chain, the second Q head beside the first.  Hazards: reward.l0 is the side chain's only reader of X -- the
     // dynamics' last layer (the writer of z_{t+1}) waits for it; the termination update waits for the reward's two-hot (which
     // reads TERM); everything is joined before the value is formed, i.e. inside the stage.
-    const bool two = L.side != nullptr && !getenv("TDMPC2_ONE_STREAM");
+    const bool two = L.side != nullptr;  // (TDMPC2_ONE_STREAM at create: no side stream on the handle)
     hipStream_t sd = two ? L.side : st;
     const LayBufs b2 = lay_bufs(h, two ? 1 : 0);
     for (int t = 0; t < H; ++t) {

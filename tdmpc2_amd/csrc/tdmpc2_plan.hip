@@ -253,7 +253,11 @@ struct StreamTurn {
     hipError_t err;
     StreamTurn(tdmpc2_plan *hh, hipStream_t s) : h(hh), st(s), live(false), err(hipSuccess) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        static const bool off = getenv("TDMPC2_DEBUG_NO_TURN") != nullptr;  // negative control of the test that pins this (tools/gpu_r4r.sh)
+#ifdef TDMPC2_TEST_HOOKS
+        static const bool off = getenv("TDMPC2_DEBUG_NO_TURN") != nullptr;  // negative control of the test that pins this (hooks build only)
+#else
+        constexpr bool off = false;
+#endif
         if (!h->turn_ev || off) return;
         if (hipStreamIsCapturing(st, &cap) != hipSuccess) {
             (void)hipGetLastError();
@@ -284,8 +288,10 @@ int dev_alloc(tdmpc2_plan *h, void **p, size_t bytes) {
     h->bytes += bytes;
     // TDMPC2_POISON=1 (tests): every allocation starts as NaN bit patterns instead of whatever the allocator hands out
     // (fresh pages read as zero and hide a read of memory that was never written; recycled memory does not)
+#ifdef TDMPC2_TEST_HOOKS
     static const bool poison = getenv("TDMPC2_POISON") != nullptr;
     if (poison) HIP_TRY(hipMemset(*p, 0xFF, bytes ? bytes : 16));
+#endif
     return 0;
 }
 
@@ -919,12 +925,14 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
             }
             // fp32 pre-activations of the NormedLinear layers whose epilogue is not fused (the fallback after a reported wait,
             // TDMPC2_TUNE_FUSE_LN = 0, tiles the fused path does not take): one buffer per chain
+#ifdef GW_TIMING
             if (getenv("TDMPC2_GW_TIMING")) {
                 if ((rc = dev_alloc(h, (void **)&L.gw_timing, 32 * 8)) || hipMemset(L.gw_timing, 0, 32 * 8) != hipSuccess) {
                     tdmpc2_plan_destroy(h);
                     return rc ? rc : fail(TDMPC2_ERR_HIP, "hipMemset failed");
                 }
             }
+#endif
             L.ldpre = std::max(L.Mp, (int)round_up((size_t)c.latent_dim, 32));
             if ((rc = dev_alloc(h, (void **)&L.PRE, Rp * L.ldpre * 4)) || (L.side && (rc = dev_alloc(h, (void **)&L.PRE2, Rp * L.ldpre * 4)))) {
                 tdmpc2_plan_destroy(h);
@@ -1001,18 +1009,21 @@ int tdmpc2_plan_create(const tdmpc2_plan_cfg *cfg, tdmpc2_plan_t **out) {
                     tdmpc2_plan_destroy(h);
                     return fail(TDMPC2_ERR_HIP, "hipMemset(cl2 flags) failed");
                 }
-                if (const char *c2 = getenv("TDMPC2_CLUSTER2")) h->cl2_mode = atoi(c2);
             }
         }
     }
     if (const char *cm = getenv("TDMPC2_CLUSTER")) h->cluster_mode = atoi(cm);
     h->user_cluster_mode = h->cluster_mode;  // what was asked for (environment or default); set_tuning / fault recovery go through apply_modes
     h->user_fuse_ln = h->lay.fuse_ln;
+#ifdef TDMPC2_TEST_HOOKS  // libtdmpc2_plan_hooks.so (built beside the product library, loaded by the GPU tests of the fault paths only)
     if (const char *cf = getenv("TDMPC2_CLUSTER_FAULT")) h->cl_fault = atoi(cf);
+#endif
     if (h->cl_fault) h->lay.mid = false;  // the hook mutes a workgroup of the WAITING paths: the handle runs them (the few-row path has no waits)
+#ifdef SPLIT_TIMING  // in-kernel phase timers exist in -DSPLIT_TIMING builds only (tools/ablate.sh)
     if (getenv("TDMPC2_TIMING")) {
         if (dev_alloc(h, (void **)&h->timing, 16 * 8) == 0) (void)hipMemset(h->timing, 0, 16 * 8);
     }
+#endif
     *out = h;
     return TDMPC2_OK;
 }
@@ -1866,6 +1877,12 @@ int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value) {
             DevGuard dev_(h->cfg.device);
             return ksws_ensure(h);  // (a bigger workspace when the mode needs one)
         }
+    }
+    if (key >= TDMPC2_TUNE_EXPERT && key < TDMPC2_TUNE_EXPERT + LK_COUNT) {
+        // measurement knobs of the layered family's tile choice (handle.h: LayKnob; include/tdmpc2_plan.h: tdmpc2_expert_knob).
+        // INT32_MIN restores the default.  They move work between kernels that compute the same values to fp32 round-off.
+        h->lay.knob[key - TDMPC2_TUNE_EXPERT] = value == INT32_MIN ? LAY_KNOB_DEFAULTS[key - TDMPC2_TUNE_EXPERT] : value;
+        return TDMPC2_OK;
     }
     if (key == TDMPC2_TUNE_WAIT_US) {
         if (value < 100 || value > 10000000) return fail(TDMPC2_ERR_INVALID, "wait_us must be 100 .. 10 000 000");

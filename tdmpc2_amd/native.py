@@ -75,15 +75,35 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
-def load_library():
-    """dlopen the planner library and declare its prototypes.  Raises if absent."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(_LIB_PATH):
-        raise NativeError(f"{_LIB_PATH} not found: build it with tdmpc2_amd/csrc/build.sh "
+# Environment variables that are TEST HOOKS of the bounded-wait / stream-order machinery.  The shipped library does not read them
+# (ABI 9); `libtdmpc2_plan_hooks.so` -- the same objects with the C-ABI unit compiled -DTDMPC2_TEST_HOOKS, built beside the product
+# library -- does, and a planner created while one of them is set is created on that library (the GPU tests of the fault paths).
+TEST_HOOK_ENVS = ("TDMPC2_CLUSTER_FAULT", "TDMPC2_DEBUG_NO_TURN", "TDMPC2_POISON")
+_HOOKS_LIB_PATH = os.path.join(os.path.dirname(_LIB_PATH), "libtdmpc2_plan_hooks.so")
+_lib_hooks = None
+
+
+def hooks_lib_path() -> str:
+    return _HOOKS_LIB_PATH
+
+
+def load_library(hooks: bool = False):
+    """dlopen the planner library (hooks = True: its test-hooks flavour) and declare its prototypes.  Raises if absent."""
+    global _lib, _lib_hooks
+    if hooks and "TDMPC2_PLAN_LIB" not in os.environ:
+        if _lib_hooks is None:
+            _lib_hooks = _open(_HOOKS_LIB_PATH)
+        return _lib_hooks
+    if _lib is None:
+        _lib = _open(_LIB_PATH)
+    return _lib
+
+
+def _open(path):
+    if not os.path.exists(path):
+        raise NativeError(f"{path} not found: build it with tdmpc2_amd/csrc/build.sh "
                           "(or __graft_entry__.build()); there is no CPU fallback for the planner")
-    lib = C.CDLL(_LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
     lib.tdmpc2_plan_abi_version.restype = i32
     lib.tdmpc2_last_error.restype = C.c_char_p
@@ -154,8 +174,15 @@ def load_library():
     lib.tdmpc2_plan_profile_read.restype = i32
     if lib.tdmpc2_plan_abi_version() != ABI_VERSION:
         raise NativeError(f"ABI version mismatch: library {lib.tdmpc2_plan_abi_version()}, binding {ABI_VERSION}")
-    _lib = lib
     return lib
+
+
+# include/tdmpc2_plan.h: enum tdmpc2_expert_knob, in order.  TDMPC2_X_<NAME> in the environment OF THE PYTHON PROCESS is applied to every
+# planner at creation (the A/B tools: tools/gpu_env_ab.sh); the library itself reads none of these.
+EXPERT_KNOBS = ("GEMM_W256_MIN", "GEMM_W_SPLIT_MIN", "GEMM_W_SPLIT_MAX", "GEMM_W_SPLIT_OVH", "KSPLIT_AUTO_LO", "KSPLIT_AUTO_MIN",
+                "GEMM_W_XCD_ROWS", "GEMM_NCT1", "GEMM_WIDE_MIN", "GEMM_RT4", "GEMM_FILL_PERMILLE", "GEMM_FILL_HEAD_PERMILLE", "GEMM_SD1",
+                "GEMM_XCD_ROWS", "GEMM_COL_PAD", "TWOHOT_UNFUSED", "Z0_SHARED_OFF", "MID_PARTS_MAX")
+TUNE_EXPERT = 100
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -190,7 +217,7 @@ class NativePlanner:
             raise NativeError(f"the planner runs on an MI355X only (device {device}); there is no CPU fallback")
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        self.lib = load_library()
+        self.lib = load_library(hooks=any(k in os.environ for k in TEST_HOOK_ENVS))
         self.cfg = cfg
         self.device = device
         self.iterations = int(iterations)
@@ -218,6 +245,9 @@ class NativePlanner:
         self._h = h
         self.path = int(self.lib.tdmpc2_plan_path(h))  # PATH_FUSED or PATH_LAYERED
         self.precision = int(self.lib.tdmpc2_plan_precision(h))  # PREC_FP32 or PREC_SPLIT_F16
+        for name in EXPERT_KNOBS:  # measurement knobs from THIS process's environment (see EXPERT_KNOBS)
+            if f"TDMPC2_X_{name}" in os.environ:
+                self.set_expert(name, int(os.environ[f"TDMPC2_X_{name}"]))
         self._seed_calls = 0
         self._shard_noise = None  # struct tdmpc2_noise of the sharded plan in progress (shard_begin .. shard_refit)
         self.encoder_layers = 0
@@ -413,6 +443,11 @@ class NativePlanner:
         fi = FaultInfo()
         self._check(self.lib.tdmpc2_plan_fault_info(self._h, C.byref(fi)))
         return {k: getattr(fi, k) for k, _ in FaultInfo._fields_ if k != "reserved"}
+
+    def set_expert(self, name: str, value: Optional[int]):
+        """A measurement knob of the layered family's tile choice (TDMPC2_TUNE_EXPERT + tdmpc2_expert_knob); None = the default."""
+        v = -2**31 if value is None else int(value)
+        self._check(self.lib.tdmpc2_plan_set_tuning(self._h, TUNE_EXPERT + EXPERT_KNOBS.index(name), v))
 
     def set_fewrow(self, on):
         """Layered family (TDMPC2_TUNE_FEWROW): K-part tiles + row kernels for calls with few sample rows (single plans)."""

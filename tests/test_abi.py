@@ -130,3 +130,28 @@ def test_create_validates_the_configuration_before_touching_the_device(lib):
     assert rc == INVALID and "precision" in msg
     rc, msg = make(path=9)
     assert rc == INVALID and "path" in msg
+
+
+def test_the_shipped_library_reads_six_environment_variables():
+    """the product library's environment surface is six names, listed in INTEGRATION.md section C; the test
+    hooks live in libtdmpc2_plan_hooks.so only, the measurement knobs behind tdmpc2_plan_set_tuning (TDMPC2_TUNE_EXPERT)."""
+    import re
+    import subprocess
+
+    from tdmpc2_amd import native
+
+    if not os.path.exists(native.lib_path()):
+        pytest.skip("library not built")
+    names = lambda p: sorted(set(re.findall(r"^TDMPC2_[A-Z0-9_]+$", subprocess.run(["strings", p], capture_output=True, text=True).stdout, re.M)))  # noqa: E731
+    shipped = names(native.lib_path())
+    assert shipped == ["TDMPC2_CLUSTER", "TDMPC2_DEBUG_FAULT", "TDMPC2_FEWROW", "TDMPC2_FUSE_LN", "TDMPC2_KSPLIT", "TDMPC2_ONE_STREAM"], shipped
+    doc = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "INTEGRATION.md")).read()
+    for n in shipped:
+        assert f"`{n}" in doc, n
+    if os.path.exists(native.hooks_lib_path()):
+        assert set(names(native.hooks_lib_path())) - set(shipped) == set(native.TEST_HOOK_ENVS)
+    # every expert knob of the header has a name in the binding, in order
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "tdmpc2_plan.h")).read()
+    enum = hdr[hdr.index("enum tdmpc2_expert_knob"):]
+    enum = enum[:enum.index("};")]
+    assert tuple(re.findall(r"TDMPC2_X_([A-Z0-9_]+)", enum))[:-1] == native.EXPERT_KNOBS

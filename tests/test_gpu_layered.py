@@ -528,7 +528,7 @@ def test_two_chains_in_flight_never_starve_each_other(name, E, default_stages, k
     streams and a foreign kernel stream in the background: no bounded wait may give up (the XCD-local tile order keeps a row
     block's peers on consecutive slots of one XCD; 2 x (column blocks - 1) waiting workgroups never fill an XCD's 32 CUs).
     c4: 16 column blocks, the limit of that argument (2 x 15 = 30 < 32).  (XCD rectangles -- a row block on TWO XCDs,
-    TDMPC2_GEMM_W_XCD_ROWS=2, 1 % faster on c4 -- lost 3 waits in 6 300 stages of this test and are therefore not the default:
+    TDMPC2_X_GEMM_W_XCD_ROWS=2, 1 % faster on c4 -- lost 3 waits in 6 300 stages of this test and are therefore not the default:
     profiles/README.md r4za.)  Round 5 adds the K-split tail (TDMPC2_TUNE_KSPLIT; 2 = the default, 1 = wherever the rule says so):
     c3 at E = 30 -- 3 parts per tile of the last round, whose last arriver joins the row block's wait --, a single 317M plan (the
     default's case: 64 tiles x 4 parts per launch, two launches in flight) and three 317M plans (16 peers per row block, 96

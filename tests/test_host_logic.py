@@ -238,10 +238,10 @@ def test_every_tuning_key_of_the_header_has_a_binding():
     keys = dict((k, int(v)) for k, v in re.findall(r"(TDMPC2_TUNE_[A-Z_]+) = (\d+)", hdr))
     assert keys == {"TDMPC2_TUNE_ROWS_PER_WORKGROUP": 0, "TDMPC2_TUNE_FOLD_REFIT": 1, "TDMPC2_TUNE_CLUSTER": 2, "TDMPC2_TUNE_FUSE_LN": 3,
                     "TDMPC2_TUNE_REARM_AFTER": 4, "TDMPC2_TUNE_SAFE_ONCE": 5, "TDMPC2_TUNE_KSPLIT": 6, "TDMPC2_TUNE_FEWROW": 7,
-                    "TDMPC2_TUNE_WAIT_US": 8}
+                    "TDMPC2_TUNE_WAIT_US": 8, "TDMPC2_TUNE_EXPERT": 100}
     src = open(native.__file__).read()
     for key_id, method in [(1, "set_fold_refit"), (2, "set_cluster"), (3, "set_fuse_ln"), (4, "set_rearm_after"), (5, "plan_safely_once"), (6, "set_ksplit"),
-                           (7, "set_fewrow"), (8, "set_wait_us")]:
+                           (7, "set_fewrow"), (8, "set_wait_us")]:  # (TDMPC2_TUNE_EXPERT: set_expert, tests/test_abi.py)
         body = src[src.index(f"def {method}("):]
         body = body[:body.index("\n    def ", 10)]
         assert f"tdmpc2_plan_set_tuning(self._h, {key_id}," in body, method

@@ -114,7 +114,7 @@ def test_the_rule_is_the_measured_one(lib):
     assert order(lib, 16, 14) == {"xcd_rows": 0, "ncol_grid": 16, "nblk": 256}
     # ... never padded when that would leave an XCD without work (7 -> 8), nor with the switch off
     assert order(lib, 24, 7)["ncol_grid"] == 7 and order(lib, 16, 14, col_pad=0)["ncol_grid"] == 14
-    # XCD rectangles are asked for by the caller (TDMPC2_GEMM_W_XCD_ROWS=2; measured, not the default: profiles/README.md r4s, r4t, r4za)
+    # XCD rectangles are asked for by the caller (TDMPC2_X_GEMM_W_XCD_ROWS=2; measured, not the default: profiles/README.md r4s, r4t, r4za)
     assert order(lib, 32, 16, force=2) == {"xcd_rows": 2, "ncol_grid": 0, "nblk": 512}
     assert order(lib, 60, 7, force=2)["xcd_rows"] == 1  # 7 column blocks do not split over 2 XCDs
     # the switches

@@ -43,7 +43,7 @@ if has pmc_layered; then  # the layered family's GEMMs at the c3 / c4 geometry o
   grep -A16 "g_gemm_w<1, 0>  workgroups=448\|g_gemm_w<1, 0>  workgroups=512" gpurun_out/${TAG}_c3_pmc.txt gpurun_out/${TAG}_c4_pmc.txt | grep -E "g_gemm_w|pipe|clock|HBM" | head -20
   rm -rf gpurun_out/pmc_${TAG}_c3/*/ gpurun_out/pmc_${TAG}_c4/*/ 2>/dev/null
 fi
-if has ab; then  # environment-switch A/B of the in-tree library (interleaved twice), e.g. AB_SPEC="c3 30 8" AB_ENVS="A=0|TDMPC2_GEMM_XCD_ROWS=0"
+if has ab; then  # environment-switch A/B of the in-tree library (interleaved twice), e.g. AB_SPEC="c3 30 8" AB_ENVS="A=0|TDMPC2_X_GEMM_XCD_ROWS=0"
   IFS='|' read -r -a ABE <<< "${AB_ENVS:-A=0}"
   bash tools/gpu_env_ab.sh ${TAG} "${AB_SPEC:-c3 30 8}" "${ABE[@]}" > /dev/null
   cat gpurun_out/${TAG}_ab.txt

@@ -15,4 +15,4 @@ for spec in "$@"; do
   unit="${spec%%:*}"; flags="${spec#*:}"
   ENVS+=("TDMPC2_FLAGS_${unit}=${flags}")
 done
-env "${ENVS[@]}" TDMPC2_BUILD_DIR="$VB" TDMPC2_OUT="$R/build/ablate/lib_${NAME}.so" ${TDMPC2_ONLY_APAD:+TDMPC2_ONLY_APAD=$TDMPC2_ONLY_APAD} "$SRC/build.sh"
+env "${ENVS[@]}" TDMPC2_NO_HOOKS_LIB=1 TDMPC2_BUILD_DIR="$VB" TDMPC2_OUT="$R/build/ablate/lib_${NAME}.so" ${TDMPC2_ONLY_APAD:+TDMPC2_ONLY_APAD=$TDMPC2_ONLY_APAD} "$SRC/build.sh"
