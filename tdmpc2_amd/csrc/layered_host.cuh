@@ -460,6 +460,7 @@ int mid_stage(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rp
     const int pmax = L.knob[LK_MID_PARTS_MAX];
     const int pall = (int)std::max<long>(1, std::min<long>(pmax, cus / std::max<long>(tiles, 1)));
     unsigned gblk = 0, rblk = 0;
+    int nrow = 0;
     for (int i = 0; i < n; ++i) {
         const MidOp &o = ops[i];
         const HostLayer &ly = *o.ly;
@@ -478,7 +479,8 @@ int mid_stage(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rp
         g.ws = L.mws[i];
         g.nblk = 8 * ((g.ncolblk * g.parts + 7) / 8) * g.nrowblk;
         gblk += (unsigned)g.nblk;
-        MRowProb &r = R.pr[i];
+        // the row-side description of the layer (m_rows, or the GEMM's own epilogue when the tile is whole: parts == 1)
+        MRowProb r{};
         r.kind = o.kind; r.rows = (int)rows; r.rows_per_env = rpe;
         if ((int)rows < MR_WIDE_MIN) r.nwg = (o.kind == MR_LN_MISH || o.kind == MR_LN_SIMNORM) ? (int)rows : (int)((rows + 3) / 4);  // m_rows<256>
         else r.nwg = (int)((rows + MR_R - 1) / MR_R);                                                                            // m_rows<512>
@@ -491,7 +493,8 @@ int mid_stage(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rp
         }
         if (o.range && o.range->bias_env) { r.bias = o.range->bias_env; r.bias_env_stride = o.range->bias_env_stride; r.bias_sel_stride = 0; }
         r.sel = o.sel; r.sel_stride = 2; r.row_env = nullptr;
-        if (o.kind == MR_LN_MISH || o.kind == MR_LN_SIMNORM) {
+        const bool ln = o.kind == MR_LN_MISH || o.kind == MR_LN_SIMNORM;
+        if (ln) {
             r.width = o.width; r.g = ly.g; r.b = ly.b; r.gb_sel_stride = sel && o.is_q ? q_gstride(h, o.layer) : 0;
             r.ascale = ly.ascale; r.asc_sel_stride = sel ? (long)(3 * sizeof(LayerScal) / sizeof(float)) : 0;
             r.out = reinterpret_cast<char *>(o.out); r.KBo = o.ldo / 16;
@@ -500,12 +503,31 @@ int mid_stage(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rp
         }
         r.term = L.TERM;
         r.th = o.th; r.pi = o.pi;
-        rblk += (unsigned)r.nwg;
+        // whole-K tiles of a NormedLinear: LayerNorm + activation + split in the GEMM's own epilogue (no partial sums, no m_rows) -- the
+        // 317M model's hidden layers (2 x 128 tiles = the chip), the 48M model from four plans on.  Needs the exchange buffers and the
+        // handle's consent (L.fuse_ln: off after a reported wait, apply_modes).  Rows that also carry the next step's actions stay with m_rows.
+        float *stats = i == 0 ? L.stats : L.stats2;
+        const size_t stats_need = rows_p * ((ly.CT + 3) / 4) * 2;
+        if (ln && g.parts == 1 && L.fuse_ln && L.knob[LK_MID_FUSE_LN] && !o.actions && stats && L.arrive && stats_need <= L.stats_cap &&
+            L.arrive_off + (size_t)g.nrowblk <= L.arrive_cap && rpe % GM_TM == 0) {
+            g.epi = o.kind == MR_LN_MISH ? 1 : 2;
+            g.oscale = r.oscale; g.osc_sel_stride = r.osc_sel_stride;
+            g.bias = r.bias; g.bias_env_stride = r.bias_env_stride; g.bias_sel_stride = r.bias_sel_stride;
+            g.ln_g = r.g; g.ln_b = r.b; g.gb_sel_stride = r.gb_sel_stride; g.ascale = r.ascale; g.asc_sel_stride = r.asc_sel_stride;
+            g.width = o.width; g.stats = stats; g.arrive = L.arrive + L.arrive_off; g.err = h->cl_err_dev; g.fault = h->cl_fault;
+            g.out = o.out; g.KBo = o.ldo / 16;
+            L.arrive_off += (size_t)g.nrowblk;
+        } else {
+            R.pr[nrow++] = r;
+            rblk += (unsigned)r.nwg;
+        }
     }
+    R.nprob = nrow;
     hipLaunchKernelGGL(g_gemm_m, dim3(gblk), dim3(512), 0, st, G);
     LAUNCH_CHECK();
     const bool small = (int)rows < MR_WIDE_MIN;
-    if (rows_one_by_one && n == 2) {  // the second problem's rows read what the first one's write (the two Q heads' two-hots)
+    if (nrow == 0) return 0;  // both layers' epilogues ran inside the GEMM
+    if (rows_one_by_one && nrow == 2) {  // the second problem's rows read what the first one's write (the two Q heads' two-hots)
         MRowParams R1{};
         R1.nprob = 1;
         R1.pr[0] = R.pr[0];
@@ -546,6 +568,7 @@ int lay_estimate_value_m(tdmpc2_plan *h, hipStream_t st, int E, const float *z0,
     const bool ranged = N != NF;
     const size_t rows = (size_t)E * N, rows_p = round_up(rows, GBM);
     int rc;
+    if (L.fuse_ln && (rc = lay_arrive_reset(h, st))) return rc;  // (whole-K tiles run the NormedLinear epilogue inside g_gemm_m: mid_stage)
     if (L.cvec_ready) {
         if (c.episodic) HIP_TRY(hipMemsetAsync(L.TERM, 0, rows * sizeof(float), st));
     } else {

@@ -58,6 +58,22 @@ struct GemmMProb {
     long part_stride;
     int ldw;
     int nblk;            // workgroups of this problem: 8 * ceil(ncolblk * parts / 8) * nrowblk
+    // epi != 0 (parts == 1 only): the NormedLinear epilogue INSIDE this launch -- g_gemm_w's protocol on 128-row tiles (the column blocks
+    // of a row block exchange per-row (mean, M2) partials, canonical combination order: the same bits as every other fused tile) --
+    // instead of partial sums + m_rows.  1: Mish, 2: SimNorm.  Every workgroup of a few-row launch is resident (grid <= #CUs, one
+    // stream), so the wait is for running peers; it is bounded all the same (WaitClock) and reports like the other fused epilogues.
+    int epi;
+    const float *oscale; long osc_sel_stride;
+    const float *bias; long bias_env_stride, bias_sel_stride;
+    const float *ln_g, *ln_b; long gb_sel_stride;
+    const float *ascale; long asc_sel_stride;
+    int width;
+    float *stats;        // [row block][128-column group][128 rows][2]
+    unsigned int *arrive;  // [row block] (zero on entry)
+    unsigned int *err;
+    int fault;
+    float *out;          // fragment-packed operand buffer, KBo k16-blocks per row
+    int KBo;
 };
 struct GemmMParams {
     GemmMProb pr[2];
@@ -145,6 +161,178 @@ __device__ __forceinline__ void gm_phase(f32x16 (&acc)[2][2], GmFrags (&fr)[2], 
     GW_MFMA(acc[1][1], c.wh[1], c.al[1]);
 }
 
+// The NormedLinear epilogue of a whole-K tile (GemmMProb::epi): g_gemm_w's, on 128 rows -- see layered_wide.cuh / layered_split.cuh
+// for the protocol and for why the combination order is what it is.
+__device__ __forceinline__ void gm_epilogue_ln(const GemmMProb &p, f32x16 (&acc)[2][2], float *lds, int rb, int cb, int row0, int sel, int wr, int wc,
+                                               float vb, float vg, float vbe) {
+    constexpr int TM = GM_TM;
+    const int tid = threadIdx.x, lane = tid & 63, i32 = lane & 31, hh = lane >> 5;
+    const int ct0 = cb * 8 + wc * 2;
+    const float osc = p.oscale[(size_t)sel * p.osc_sel_stride];
+    __syncthreads();  // every wave is done with the ring
+    float *red = lds;                 // [8 column tiles of the block][TM][2]
+    float *rs = red + 8 * TM * 2;     // [TM][2]
+    float *vecs = rs + TM * 2;        // [bias | g | b][256]
+    if (tid < 256) {
+        vecs[tid] = vb;
+        vecs[256 + tid] = vg;
+        vecs[512 + tid] = vbe;
+    }
+    __syncthreads();
+    // (1) v = acc * oscale + bias, in place
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4 *>(vecs + (wc * 2 + n) * 32 + 8 * j + 4 * hh);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[n][i][4 * j + r] = fmaf(acc[n][i][4 * j + r], osc, b4[r]);
+        }
+    // (2) (mean, M2) of every row over each 32-column tile: 16 thread-local values + the lane ^ 32 half
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s1 += acc[n][i][e];
+            s1 += __shfl_xor(s1, 32);
+            const float mw = s1 * (1.f / 32.f);
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float d = acc[n][i][e] - mw;
+                q = fmaf(d, d, q);
+            }
+            q += __shfl_xor(q, 32);
+            if (hh == 0) {
+                red[((wc * 2 + n) * TM + (2 * wr + i) * 32 + i32) * 2 + 0] = mw;
+                red[((wc * 2 + n) * TM + (2 * wr + i) * 32 + i32) * 2 + 1] = q;
+            }
+        }
+    __syncthreads();
+    // (3) fold the tiles of each 128-column group left to right -> stats[row block][group][row]: 2 groups x 128 rows
+    const int NG = (p.CT + 3) / 4;
+    if (tid < 2 * TM) {
+        const int g = tid / TM, r = tid - g * TM, G = cb * 2 + g;
+        if (G < NG) {
+            float n_acc = 0.f, m_acc = 0.f, q_acc = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (G * 4 + t >= p.CT) break;
+                chan_fold(n_acc, m_acc, q_acc, 32.f, red[((g * 4 + t) * TM + r) * 2], red[((g * 4 + t) * TM + r) * 2 + 1]);
+            }
+            float *slot = p.stats + (((size_t)rb * NG + G) * TM + r) * 2;
+            __hip_atomic_store(slot, m_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + 1, q_acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // (4) arrive (stores acknowledged first), wait for the row block's other column blocks -- bounded
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        if (!(p.fault && rb == 0 && cb == 0)) __hip_atomic_fetch_add(p.arrive + rb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        WaitClock wck;
+        while (__hip_atomic_load(p.arrive + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.ncolblk) {
+            if (wck.expired(p.err)) {
+                if (p.err) raise_fault(p.err, 3u | ((unsigned)rb << 4) | ((unsigned)cb << 16) |
+                                                  (__hip_atomic_load(p.arrive + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 24));
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    // (5) the row's statistics: the groups folded left to right
+    if (tid < TM) {
+        float n_acc = 0.f, m_acc = 0.f, q_acc = 0.f;
+        const float *all = p.stats + ((size_t)rb * NG * TM + tid) * 2;
+        for (int g0 = 0; g0 < NG; g0 += 8) {
+            float mb[8], qb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int G = g0 + u < NG ? g0 + u : NG - 1;
+                mb[u] = __hip_atomic_load(all + (size_t)G * TM * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                qb[u] = __hip_atomic_load(all + (size_t)G * TM * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (g0 + u >= NG) break;
+                int nt4 = p.CT - (g0 + u) * 4;
+                nt4 = nt4 > 4 ? 4 : nt4;
+                chan_fold(n_acc, m_acc, q_acc, 32.f * (float)nt4, mb[u], qb[u]);
+            }
+        }
+        rs[2 * tid] = m_acc;
+        rs[2 * tid + 1] = 1.0f / sqrtf(q_acc / n_acc + LN_EPS);
+    }
+    __syncthreads();
+    // (6) normalise, activate, split -> the fragment-packed output: v_permlane32_swap pairs the two k-halves of a row so that one
+    // 16-byte store per lane writes a whole 1 KiB fragment plane (see g_gemm_w)
+    const bool mish = p.epi == 1;
+    const float oscl = mish ? p.ascale[(size_t)sel * p.asc_sel_stride] : ACT_SCALE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rloc = (2 * wr + i) * 32 + i32;
+        const float rmean = rs[2 * rloc], rrstd = rs[2 * rloc + 1];
+        char *otile = reinterpret_cast<char *>(p.out) + (size_t)((row0 >> 5) + 2 * wr + i) * p.KBo * 2048 + lane * 16;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            if (ct0 + n >= p.CT) continue;
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+                unsigned hw[2][2], lw2[2][2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * jp + jj;
+                    const f32x4 g4 = *reinterpret_cast<const f32x4 *>(vecs + 256 + (wc * 2 + n) * 32 + 8 * j + 4 * hh);
+                    const f32x4 be4 = *reinterpret_cast<const f32x4 *>(vecs + 512 + (wc * 2 + n) * 32 + 8 * j + 4 * hh);
+                    f32x4 y;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[r] = fmaf((acc[n][i][4 * j + r] - rmean) * rrstd, g4[r], be4[r]);
+                    if (mish) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = mish_fast(y[r]);
+                    } else {  // SimNorm: groups of 8 consecutive features = this lane's 4 + lane ^ 32's 4
+                        float m = fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3]));
+                        m = fmaxf(m, __shfl_xor(m, 32));
+                        float es = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            y[r] = __expf(y[r] - m);
+                            es += y[r];
+                        }
+                        es += __shfl_xor(es, 32);
+                        const float inv = 1.0f / es;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] *= inv;
+                    }
+                    f16x4 hi, lo;
+                    split4(y, hi, lo, oscl);
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 hb = __builtin_bit_cast(u32x2, hi), lb = __builtin_bit_cast(u32x2, lo);
+                    hw[jj][0] = hb[0]; hw[jj][1] = hb[1];
+                    lw2[jj][0] = lb[0]; lw2[jj][1] = lb[1];
+                }
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 ho, lo4;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const auto sh = __builtin_amdgcn_permlane32_swap(hw[0][d], hw[1][d], false, false);
+                    const auto sl = __builtin_amdgcn_permlane32_swap(lw2[0][d], lw2[1][d], false, false);
+                    ho[d] = sh[0]; ho[2 + d] = sh[1];
+                    lo4[d] = sl[0]; lo4[2 + d] = sl[1];
+                }
+                char *o = otile + (size_t)((ct0 + n) * 2 + jp) * 2048;
+                *reinterpret_cast<u32x4 *>(o) = ho;
+                *reinterpret_cast<u32x4 *>(o + 1024) = lo4;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(512) void g_gemm_m(GemmMParams P) {
     __shared__ __attribute__((aligned(1024))) char ring[GM_NS * GM_SLOT];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -188,6 +376,18 @@ __global__ __launch_bounds__(512) void g_gemm_m(GemmMParams P) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[n][i][e] = 0.f;
     GmFrags fr[2];
+    // fused epilogue: the block's 256 columns of bias / LayerNorm weight / bias ride through the main loop in three registers
+    float vb = 0.f, vg = 0.f, vbe = 0.f;
+    if (p.epi && tid < 256) {
+        const int col = cb * 256 + tid;
+        if (col < p.CT * 32) {
+            const float *bp = p.bias + (size_t)sel * p.bias_sel_stride;
+            if (p.bias_env_stride != 0) bp += (size_t)(row0 / p.rows_per_env) * p.bias_env_stride;
+            vb = bp[col];
+            vg = p.ln_g[(size_t)sel * p.gb_sel_stride + col];
+            vbe = p.ln_b[(size_t)sel * p.gb_sel_stride + col];
+        }
+    }
 
     // prologue: slabs 0 .. min(nk, NS) - 1 requested; slab 0 into registers
     const int npro = gm_prologue_slabs(nk, GM_NS);
@@ -225,6 +425,10 @@ __global__ __launch_bounds__(512) void g_gemm_m(GemmMParams P) {
 #undef GM_STEADY
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // XDL write -> VALU read of the accumulators
 
+    if (p.epi) {
+        gm_epilogue_ln(p, acc, reinterpret_cast<float *>(ring), rb, cb, row0, sel, wr, wc, vb, vg, vbe);
+        return;
+    }
     // ---- the tile leaves as fp32 rows: transposed through the (idle) ring so that one store instruction of a wave covers 1 KiB
     // of one row.  C = [feature][row] (the weight fragment is the MFMA's A operand, as in the NormedLinear tiles): a lane holds
     // row (lane & 31) of a row tile and features 8 j + 4 (lane >> 5) + (0..3) of a column tile.
