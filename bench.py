@@ -503,7 +503,7 @@ def config_leg(name, E, steps, device, rank=0, single_env=True):
     box = box_under_load(lambda: [planner.plan(z0, disc, prev, warm, task_emb=emb, act_mask=mask, seed=500 + i, out=out)
                                   for i in range(n_load)], device)
     planner.close()
-    lat1 = None
+    lat1 = lat1_tiles = None
     if single_env:  # the reference's own semantics: one environment, one plan at a time (evaluate.py:80)
         one = NativePlanner(cfg, I, device, max_envs=1)
         one.bind_state_dict(sd)
@@ -519,6 +519,18 @@ def config_leg(name, E, steps, device, rank=0, single_env=True):
             one.plan(z1, d1, p1, warm[:1], seed=10 + i, out=o1, task_emb=e1, act_mask=m1)
         _sync(device)
         lat1 = (time.perf_counter() - t1) / 5 * 1e3
+        if family == "layered" and split:
+            # the same single plan on the per-layer tiles of the batch path (TDMPC2_TUNE_FEWROW = 0): what the few-row path
+            # (tdmpc2_amd/csrc/layered_mid.cuh, round 6) buys, in the same run on the same box
+            one.set_fewrow(0)
+            for i in range(2):
+                one.plan(z1, d1, p1, warm[:1], seed=i, out=o1, task_emb=e1, act_mask=m1)
+            _sync(device)
+            t1 = time.perf_counter()
+            for i in range(5):
+                one.plan(z1, d1, p1, warm[:1], seed=10 + i, out=o1, task_emb=e1, act_mask=m1)
+            _sync(device)
+            lat1_tiles = (time.perf_counter() - t1) / 5 * 1e3
         one.close()
     launch_s = (ms / 1e3) / max(n, 1)
     peak = F16_MFMA_PEAK_TFLOPS if split else FP32_MFMA_PEAK_TFLOPS
@@ -528,6 +540,7 @@ def config_leg(name, E, steps, device, rank=0, single_env=True):
         "value": round(steps * E / el, 2), "unit": "plans/s", "steps": steps, "ms_per_step": round(1e3 * el / steps, 3), "finite": finite,
         "bounded_wait_faults": leg_faults, "box_under_load": box,
         **({"latency_ms_single_env": round(lat1, 3)} if lat1 is not None else {}),
+        **({"latency_ms_single_env_per_layer_tiles": round(lat1_tiles, 3)} if lat1_tiles is not None else {}),
         "config": {"workload": f"{name}: {cfg.task} world model (L{cfg.latent_dim} M{cfg.mlp_dim} A{cfg.action_dim} nq{cfg.num_q} "
                                f"T{cfg.task_dim}), plan() H={cfg.horizon} N={cfg.num_samples} K={cfg.num_elites} P={cfg.num_pi_trajs} "
                                f"I={I}, {E} concurrent plans (one per task id, round-robin), random-init weights",

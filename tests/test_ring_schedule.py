@@ -174,6 +174,102 @@ def test_ring_of_five_slots_would_also_be_scheduled_correctly(lib):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
+# g_gemm_m's ring (layered_mid.cuh, round 6: the few-row path): the same schedule with 3 requests per wave and k16-slab and SIX slots.
+MSHIM = r"""
+#include "tile_order.h"
+extern "C" int req() { return GM_REQ; }
+extern "C" int prologue_slabs(int nk, int ns) { return gm_prologue_slabs(nk, ns); }
+extern "C" int prologue_vmcnt(int npro) { return gm_prologue_vmcnt(npro); }
+extern "C" int steady_trip(int s, int nk, int ns, int u) { return gm_steady_trip(s, nk, ns, u) ? 1 : 0; }
+extern "C" int steady_vmcnt(int ns) { return gm_steady_vmcnt(ns); }
+extern "C" void tail_step(int ss, int nk, int ns, int *out) {
+    const GmTailStep t = gm_tail_step(ss, nk, ns);
+    out[0] = t.issue; out[1] = t.next; out[2] = t.vmc;
+}
+"""
+
+
+@pytest.fixture(scope="module")
+def mlib(tmp_path_factory):
+    d = tmp_path_factory.mktemp("mring")
+    (d / "shim.cpp").write_text(MSHIM)
+    so = d / "libmring.so"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I", CSRC, str(d / "shim.cpp"), "-o", str(so)], check=True)
+    return ctypes.CDLL(str(so))
+
+
+def _m_constants(mlib):
+    src = open(os.path.join(CSRC, "layered_mid.cuh")).read()
+    ns = int(re.search(r"constexpr int GM_NS = (\d+);", src).group(1))
+    u = int(re.search(r"constexpr int GM_U = (\d+);", src).group(1))
+    assert u % ns == 0 and u % 2 == 0  # whole turns of the ring and of the two register sets per unrolled trip
+    req = mlib.req()
+    assert f"gm_wait_vm<{ns - 2} * GM_REQ>()" in src and mlib.steady_vmcnt(ns) == (ns - 2) * req  # the steady wait of gm_phase
+    for name in ("gm_prologue_slabs(nk, GM_NS)", "gm_steady_trip(s, nk, GM_NS, GM_U)", "gm_tail_step(s + PH, nk, GM_NS)"):
+        assert name in src, name
+    # the DMA requests one gm_issue makes are GM_REQ
+    body = src[src.index("__device__ __forceinline__ void gm_issue("):]
+    body = body[:body.index("\n}\n")]
+    assert body.count("gw_glds(") == req
+    return ns, u, req
+
+
+def m_replay(mlib, nk, ns, u, req, slack=0):
+    global REQ
+    keep, REQ = REQ, req  # (Ring.request counts REQ requests per slab)
+    try:
+        r = Ring(ns, slack)
+        npro = mlib.prologue_slabs(nk, ns)
+        for d in range(npro):
+            r.request(d)
+        assert mlib.prologue_vmcnt(npro) == req * (npro - 1)  # the kernel's ladder over npro = 6 .. 1: 5, 4, 3, 2, 1, 0 x GM_REQ
+        r.wait(mlib.prologue_vmcnt(npro))
+        r.lds_read(0)
+        done, s, out = [], 0, (ctypes.c_int * 3)()
+
+        def phase(ss, steady, issue, nxt, vmc):
+            # gm_phase's ladder: steady or vmc >= 4 REQ -> 4 REQ; 3 REQ; 2 REQ; REQ; else 0
+            w = 4 * req if (steady or vmc >= 4 * req) else vmc if vmc in (3 * req, 2 * req, req) else 0
+            r.wait(w)
+            if issue:
+                r.request(ss + ns)
+            if nxt:
+                r.lds_read(ss + 1)
+            assert ss in r.read
+            done.append(ss)
+
+        while mlib.steady_trip(s, nk, ns, u):
+            for ph in range(u):
+                phase(s + ph, True, True, True, mlib.steady_vmcnt(ns))
+            s += u
+        while s < nk:
+            for ph in range(u):
+                if s + ph < nk:
+                    mlib.tail_step(s + ph, nk, ns, out)
+                    phase(s + ph, False, bool(out[0]), bool(out[1]), out[2])
+            s += u
+        assert not r.fly or slack, "requests in flight at the end of the loop (the epilogue reuses the ring's LDS)"
+        r.wait(0)
+        return done
+    finally:
+        REQ = keep
+
+
+@pytest.mark.parametrize("nk", list(range(1, 45)) + [50, 88, 111, 112, 113, 256])
+def test_g_gemm_m_every_slab_lands_before_it_is_read_and_is_multiplied_once(mlib, nk):
+    """any K-part length from one k16-slab up (the t = 0 first layers contract 2 slabs; the 317M model's hidden layers 256)"""
+    ns, u, req = _m_constants(mlib)
+    assert m_replay(mlib, nk, ns, u, req) == list(range(nk))
+
+
+@pytest.mark.parametrize("nk", [2, 3, 6, 7, 8, 13, 28, 64])
+def test_g_gemm_m_counted_waits_are_tight(mlib, nk):
+    ns, u, req = _m_constants(mlib)
+    with pytest.raises(AssertionError, match="read before its requests have landed"):
+        m_replay(mlib, nk, ns, u, req, slack=1)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
 # The fused family's hand-ordered contraction loop (fused_kernels.cuh: kloop_asm -- the loop of the benched ks_rollout): a
 # REGISTER ring of KL_RD weight blocks (4 global_load_dwordx4 each) and two activation fragment sets read from LDS a step ahead.
 KSHIM = r"""
