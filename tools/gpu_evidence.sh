@@ -11,7 +11,7 @@ TAG="${1:-r3z}"; PARTS="${2:-tests bench stats pmc_layered pmc torchrun}"
 mkdir -p gpurun_out
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 if has tests; then
-  (time timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider) > gpurun_out/${TAG}_pytest_gpu.log 2>&1
+  (time timeout 2700 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider) > gpurun_out/${TAG}_pytest_gpu.log 2>&1
   tail -8 gpurun_out/${TAG}_pytest_gpu.log
 fi
 if has bench; then
