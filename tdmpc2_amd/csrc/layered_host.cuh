@@ -468,11 +468,11 @@ int mid_stage(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rp
         GemmMProb &g = G.pr[i];
         g.A = reinterpret_cast<const _Float16 *>(o.A); g.KBa = o.lda / 16;
         g.a_kb0 = o.range ? o.range->col_off / 16 : 0;
-        g.nk = o.range ? o.range->kblocks : ly.KB;
+        g.nk = (o.range ? o.range->kblocks : ly.KB) / 2;  // k32-slabs
         g.kb0 = o.range ? o.range->kb0 : 0; g.kbs = ly.KB;
         g.wp = ly.wps; g.w_sel_stride = sel && o.is_q ? q_wstride(h, o.layer) : 0;
         g.CT = ly.CT; g.ncolblk = (ly.CT + 7) / 8; g.nrowblk = (int)(rows_p / GM_TM);
-        g.parts = std::max(1, std::min(pall, g.nk / 4));
+        g.parts = std::max(1, std::min(pall, g.nk / 2));
         g.sel = o.sel; g.sel_stride = 2; g.rows_per_env = rpe;
         g.ldw = g.ncolblk * 256; g.part_stride = (long)rows_p * g.ldw;
         if ((size_t)g.parts * g.part_stride > L.mws_cap) return fail(TDMPC2_ERR_STATE, "few-row path: partial-sum workspace too small");

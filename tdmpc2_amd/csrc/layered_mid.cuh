@@ -7,13 +7,13 @@
 // layers (heads, the SimNorm output layer: 16-96 workgroups walking all of K) 18-30 us.
 //
 // g_gemm_m: one 512-thread workgroup (8 waves, one per CU) computes a 128-row x 256-column tile over ONE K-PART of the
-// contraction and writes raw fp32 partial sums.  Both operands are fragment-packed in HBM (layered_split.cuh); a k16-slab of the
-// tile is 4 row tiles x 2 KiB of A and 8 column tiles x 2 KiB of W = 24 planes of 1 KiB, each ONE wavefront-wide LDS-DMA
-// (global_load_lds_dwordx4), 3 per wave and slab; the LDS holds a ring of 6 slabs (144 KiB).  A wave owns two row tiles x two
-// column tiles: per slab 8 ds_read_b128 (conflict-free at lane * 16) and 12 MFMAs (4 accumulators x 3 products), 8 operand bytes
-// from L1 per MFMA.  Pipeline = g_gemm_w's (layered_wide.cuh): top of phase s: my fragments of slab s are in registers
-// (lgkmcnt(0)), my DMA of slab s + 1 has landed (counted vmcnt: four newer slabs stay in flight), barrier, request slab s + 6 into
-// the slot slab s has just left, 12 MFMAs on slab s with the reads of slab s + 1 between the first four.  The K-parts are what fills
+// contraction and writes raw fp32 partial sums.  Both operands are fragment-packed in HBM (layered_split.cuh); a k32-slab of the
+// tile is 4 row tiles x 4 KiB of A and 8 column tiles x 4 KiB of W = 48 planes of 1 KiB, each ONE wavefront-wide LDS-DMA
+// (global_load_lds_dwordx4), 6 per wave and slab; the LDS holds a ring of 3 slabs (144 KiB).  A wave owns two row tiles x two
+// column tiles: per slab 16 ds_read_b128 (conflict-free at lane * 16) and 24 MFMAs (4 accumulators x 3 products x 2 k16-blocks),
+// 8 operand bytes from L1 per MFMA.  Pipeline = g_gemm_w's (layered_wide.cuh): top of phase s: my fragments of slab s are in
+// registers (lgkmcnt(0)), my DMA of slab s + 1 has landed (counted vmcnt: one newer slab stays in flight), barrier, request slab
+// s + 3 into the slot slab s has just left, 24 MFMAs on slab s with the reads of slab s + 1 between the first eight.  The K-parts are what fills
 // the chip when there are few rows: `parts` is chosen per launch so that tiles x parts ~ #CUs (c3 hidden pair: 2 x 28 tiles x 4
 // parts; the 317M model's hidden pair: 2 x 128 tiles, whole K).
 // No workgroup waits for another one: partial sums leave as 1 KiB-per-instruction write-through stores (the tile is transposed
@@ -35,18 +35,19 @@
 #pragma once
 
 constexpr int GM_TM = 128;        // rows of a tile
-constexpr int GM_SLOT = 24576;    // bytes of a k16-slab in the ring: [A: 4 row tiles x (hi, lo)][W: 8 column tiles x (hi, lo)] x 1 KiB
-constexpr int GM_NS = 6;          // ring slots (144 KiB): five slabs = 120 KiB in flight per CU -- at the loop's MFMA-bound rate (24 KiB per
-                                  // 0.37 us) that tolerates 1.8 us of L2 / Infinity-Cache / HBM latency (a first version with 64-row tiles and a
-                                  // ring of three 40 KiB k32-slabs had 80 KiB in flight for 108 GB/s per CU and ran at the latency: 0.55 us per
-                                  // 12-MFMA phase on the 48M model, 0.74 us on the 317M model whose weights stream from HBM; profiles/README.md r6c)
-constexpr int GM_U = 6;           // phases per unrolled trip: whole turns of the ring (6) and of the register sets (2)
+constexpr int GM_SLOT = 49152;    // bytes of a k32-slab in the ring: [A: 4 row tiles x (kb, plane)][W: 8 column tiles x (kb, plane)] x 1 KiB
+constexpr int GM_NS = 3;          // ring slots (144 KiB): two slabs = 96 KiB in flight per CU, two phases (~1.7 us) for a slab to arrive.
+                                  // History of this loop (profiles/README.md r6c, r6d, r6v): 64-row tiles with k32-slabs ran at the L2-miss
+                                  // latency (80 KiB in flight for 108 GB/s per CU); 128-row tiles with SIX k16-slabs fixed that and ran at
+                                  // 0.64 us per 12-MFMA phase against 0.43 MFMA-bound -- one barrier, one pair of counted waits and a pipe
+                                  // drain per 12 MFMAs of a wave (g_gemm_w pays the same ~230 cycles per 24); hence k32-slabs again, on 128 rows
+constexpr int GM_U = 6;           // phases per unrolled trip: whole turns of the ring (3) and of the register sets (2)
 constexpr int GM_LDT = 260;       // floats per row of the transposed output tile in LDS (260 mod 32 = 4: conflict-free 16-byte writes)
 
 struct GemmMProb {
     const _Float16 *A;   // fragment-packed operand buffer, KBa k16-blocks per row; first block contracted a_kb0
     int KBa, a_kb0;
-    int nk;              // k16-slabs of the contraction
+    int nk;              // k32-slabs of the contraction
     const _Float16 *wp;  // split-packed [CT][kbs][2][64][8], + sel * w_sel_stride (halfs); first k16-block kb0
     long w_sel_stride;
     int kb0, kbs;
@@ -81,24 +82,37 @@ struct GemmMParams {
 };
 
 struct GmFrags {
-    f16x8 ah[2], al[2], wh[2], wl[2];  // this wave's two row tiles / two column tiles of one k16-slab
+    f16x8 ah[2][2], al[2][2], wh[2][2], wl[2][2];  // [k16-block of the slab][row tile / column tile of this wave]
 };
 
-// fragment planes of the slab whose read addresses are la / lw (this wave's first row tile / first column tile), two per step
+// fragment planes of the slab whose read addresses are la / lw (this wave's first row tile / first column tile), two per step.
+// LDS image of a row / column tile inside a slot: [kb0: hi, lo][kb1: hi, lo] x 1 KiB.
 template <int STEP>
 __device__ __forceinline__ void gm_read2(GmFrags &f, unsigned la, unsigned lw) {
     if constexpr (STEP == 0) {
-        gw_dsrd<0>(f.wh[0], lw);
-        gw_dsrd<0>(f.ah[0], la);
+        gw_dsrd<0>(f.wh[0][0], lw);
+        gw_dsrd<0>(f.ah[0][0], la);
     } else if constexpr (STEP == 1) {
-        gw_dsrd<2048>(f.wh[1], lw);
-        gw_dsrd<2048>(f.ah[1], la);
+        gw_dsrd<4096>(f.wh[0][1], lw);
+        gw_dsrd<4096>(f.ah[0][1], la);
     } else if constexpr (STEP == 2) {
-        gw_dsrd<1024>(f.wl[0], lw);
-        gw_dsrd<2048 + 1024>(f.wl[1], lw);
+        gw_dsrd<1024>(f.wl[0][0], lw);
+        gw_dsrd<4096 + 1024>(f.wl[0][1], lw);
+    } else if constexpr (STEP == 3) {
+        gw_dsrd<1024>(f.al[0][0], la);
+        gw_dsrd<4096 + 1024>(f.al[0][1], la);
+    } else if constexpr (STEP == 4) {
+        gw_dsrd<2048>(f.wh[1][0], lw);
+        gw_dsrd<2048>(f.ah[1][0], la);
+    } else if constexpr (STEP == 5) {
+        gw_dsrd<4096 + 2048>(f.wh[1][1], lw);
+        gw_dsrd<4096 + 2048>(f.ah[1][1], la);
+    } else if constexpr (STEP == 6) {
+        gw_dsrd<2048 + 1024>(f.wl[1][0], lw);
+        gw_dsrd<4096 + 2048 + 1024>(f.wl[1][1], lw);
     } else {
-        gw_dsrd<1024>(f.al[0], la);
-        gw_dsrd<2048 + 1024>(f.al[1], la);
+        gw_dsrd<2048 + 1024>(f.al[1][0], la);
+        gw_dsrd<4096 + 2048 + 1024>(f.al[1][1], la);
     }
 }
 __device__ __forceinline__ void gm_read(GmFrags &f, unsigned la, unsigned lw) {
@@ -106,16 +120,23 @@ __device__ __forceinline__ void gm_read(GmFrags &f, unsigned la, unsigned lw) {
     gm_read2<1>(f, la, lw);
     gm_read2<2>(f, la, lw);
     gm_read2<3>(f, la, lw);
+    gm_read2<4>(f, la, lw);
+    gm_read2<5>(f, la, lw);
+    gm_read2<6>(f, la, lw);
+    gm_read2<7>(f, la, lw);
 }
 
-// this wave's 3 DMA requests of one slab: its column tile of W (2 KiB contiguous: hi, lo) and one 1 KiB plane of A (wave w:
-// plane w & 1 of row tile w >> 1)
+// this wave's 6 DMA requests of one slab: its column tile of W (4 KiB contiguous: two k16-blocks x {hi, lo}) and one k16-block
+// (2 KiB: hi, lo) of A (wave w: k16-block w & 1 of row tile w >> 1)
 __device__ __forceinline__ void gm_issue(char *slot_w, char *slot_a, const char *&pw, const char *&pa, unsigned voff) {
     gw_glds(pw + voff, slot_w);
     gw_glds(pw + voff + 1024, slot_w + 1024);
+    gw_glds(pw + voff + 2048, slot_w + 2048);
+    gw_glds(pw + voff + 3072, slot_w + 3072);
     gw_glds(pa + voff, slot_a);
-    pw += 2048;
-    pa += 2048;
+    gw_glds(pa + voff + 1024, slot_a + 1024);
+    pw += 4096;
+    pa += 4096;
 }
 
 template <int N>
@@ -123,42 +144,58 @@ __device__ __forceinline__ void gm_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// One phase (tile_order.h: gm_* -- the ring's schedule arithmetic).  PH = s mod GM_U: ring slot of slab s = PH, of slab s + 1 =
-// (PH + 1) % 6; register set of slab s = PH & 1.
+// One phase (tile_order.h: gm_* -- the ring's schedule arithmetic).  PH = s mod GM_U: ring slot of slab s = PH % 3, of slab s + 1 =
+// (PH + 1) % 3; register set of slab s = PH & 1.  24 MFMAs per wave and barrier.
 template <int PH, bool STEADY>
 __device__ __forceinline__ void gm_phase(f32x16 (&acc)[2][2], GmFrags (&fr)[2], const unsigned (&la)[GM_NS], const unsigned (&lw)[GM_NS], char *ring_w,
                                          char *ring_a, const char *&pw, const char *&pa, unsigned voff, bool issue, bool next, int vmc) {
     constexpr int SL = PH % GM_NS, SN = (PH + 1) % GM_NS;
     GmFrags &c = fr[PH & 1], &n = fr[(PH + 1) & 1];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // my DMA of slab s + 1 has landed: `vmc` newer requests may stay in flight (steady: 4 slabs = 12)
-    if (STEADY || vmc >= 4 * GM_REQ) gm_wait_vm<4 * GM_REQ>();
-    else if (vmc == 3 * GM_REQ) gm_wait_vm<3 * GM_REQ>();
-    else if (vmc == 2 * GM_REQ) gm_wait_vm<2 * GM_REQ>();
-    else if (vmc == GM_REQ) gm_wait_vm<GM_REQ>();
+    // my DMA of slab s + 1 has landed: `vmc` newer requests may stay in flight (steady: one slab = GM_REQ)
+    if (STEADY || vmc >= GM_REQ) gm_wait_vm<(GM_NS - 2) * GM_REQ>();
     else gm_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     if (STEADY || issue) gm_issue(ring_w + SL * GM_SLOT, ring_a + SL * GM_SLOT, pw, pa, voff);
     __builtin_amdgcn_sched_barrier(0);
     const bool rd = STEADY || next;
-    // per accumulator: w_hi a_hi, then w_lo a_hi, then w_hi a_lo -- the order of g_gemm_s / g_gemm_w (acc[column tile][row tile])
-    GW_MFMA(acc[0][0], c.wh[0], c.ah[0]);
+    // per accumulator and k16-block: w_hi a_hi, then w_lo a_hi, then w_hi a_lo -- the order of g_gemm_s / g_gemm_w (acc[column tile][row tile])
+    GW_MFMA(acc[0][0], c.wh[0][0], c.ah[0][0]);
     if (rd) gm_read2<0>(n, la[SN], lw[SN]);
-    GW_MFMA(acc[1][0], c.wh[1], c.ah[0]);
+    GW_MFMA(acc[1][0], c.wh[0][1], c.ah[0][0]);
     if (rd) gm_read2<1>(n, la[SN], lw[SN]);
-    GW_MFMA(acc[0][1], c.wh[0], c.ah[1]);
+    GW_MFMA(acc[0][1], c.wh[0][0], c.ah[0][1]);
     if (rd) gm_read2<2>(n, la[SN], lw[SN]);
-    GW_MFMA(acc[1][1], c.wh[1], c.ah[1]);
+    GW_MFMA(acc[1][1], c.wh[0][1], c.ah[0][1]);
     if (rd) gm_read2<3>(n, la[SN], lw[SN]);
-    GW_MFMA(acc[0][0], c.wl[0], c.ah[0]);
-    GW_MFMA(acc[1][0], c.wl[1], c.ah[0]);
-    GW_MFMA(acc[0][1], c.wl[0], c.ah[1]);
-    GW_MFMA(acc[1][1], c.wl[1], c.ah[1]);
-    GW_MFMA(acc[0][0], c.wh[0], c.al[0]);
-    GW_MFMA(acc[1][0], c.wh[1], c.al[0]);
-    GW_MFMA(acc[0][1], c.wh[0], c.al[1]);
-    GW_MFMA(acc[1][1], c.wh[1], c.al[1]);
+    GW_MFMA(acc[0][0], c.wl[0][0], c.ah[0][0]);
+    if (rd) gm_read2<4>(n, la[SN], lw[SN]);
+    GW_MFMA(acc[1][0], c.wl[0][1], c.ah[0][0]);
+    if (rd) gm_read2<5>(n, la[SN], lw[SN]);
+    GW_MFMA(acc[0][1], c.wl[0][0], c.ah[0][1]);
+    if (rd) gm_read2<6>(n, la[SN], lw[SN]);
+    GW_MFMA(acc[1][1], c.wl[0][1], c.ah[0][1]);
+    if (rd) gm_read2<7>(n, la[SN], lw[SN]);
+    GW_MFMA(acc[0][0], c.wh[0][0], c.al[0][0]);
+    GW_MFMA(acc[1][0], c.wh[0][1], c.al[0][0]);
+    GW_MFMA(acc[0][1], c.wh[0][0], c.al[0][1]);
+    GW_MFMA(acc[1][1], c.wh[0][1], c.al[0][1]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        GW_MFMA(acc[0][i], c.wh[1][0], c.ah[1][i]);
+        GW_MFMA(acc[1][i], c.wh[1][1], c.ah[1][i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        GW_MFMA(acc[0][i], c.wl[1][0], c.ah[1][i]);
+        GW_MFMA(acc[1][i], c.wl[1][1], c.ah[1][i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        GW_MFMA(acc[0][i], c.wh[1][0], c.al[1][i]);
+        GW_MFMA(acc[1][i], c.wh[1][1], c.al[1][i]);
+    }
 }
 
 // The NormedLinear epilogue of a whole-K tile (GemmMProb::epi): g_gemm_w's, on 128 rows -- see layered_wide.cuh / layered_split.cuh
@@ -353,20 +390,20 @@ __global__ __launch_bounds__(512) void g_gemm_m(GemmMParams P) {
     const int s0 = (int)((long)part * p.nk / p.parts), nk = (int)((long)(part + 1) * p.nk / p.parts) - s0;
     const int wr = wave >> 2, wc = wave & 3;  // accumulators: row tiles 2 wr, 2 wr + 1; column tiles 2 wc, 2 wc + 1
     // DMA role: column tile `wave` of W (a tile past the matrix re-reads the last one: its sums land in the padding of ws), and
-    // plane (wave & 1) of row tile (wave >> 1) of A
+    // k16-block (wave & 1) of row tile (wave >> 1) of A
     const int ctl = cb * 8 + wave < p.CT ? cb * 8 + wave : p.CT - 1;
-    const char *pw = reinterpret_cast<const char *>(p.wp + (size_t)sel * p.w_sel_stride) + ((size_t)ctl * p.kbs + p.kb0 + s0) * 2048;
-    const char *pa = reinterpret_cast<const char *>(p.A) + ((size_t)((row0 >> 5) + (wave >> 1)) * p.KBa + p.a_kb0 + s0) * 2048 + (wave & 1) * 1024;
+    const char *pw = reinterpret_cast<const char *>(p.wp + (size_t)sel * p.w_sel_stride) + ((size_t)ctl * p.kbs + p.kb0 + 2 * s0) * 2048;
+    const char *pa = reinterpret_cast<const char *>(p.A) + ((size_t)((row0 >> 5) + (wave >> 1)) * p.KBa + p.a_kb0 + 2 * s0) * 2048 + (wave & 1) * 2048;
     unsigned voff = (unsigned)lane * 16u;
     asm volatile("" : "+v"(voff));
-    char *ring_w = ring + 8192 + wave * 2048;
-    char *ring_a = ring + wave * 1024;
+    char *ring_w = ring + 16384 + wave * 4096;
+    char *ring_a = ring + wave * 2048;
     const unsigned lbase = lds_addr_of(ring) + (unsigned)lane * 16u;
     unsigned la[GM_NS], lw[GM_NS];
 #pragma unroll
     for (int i = 0; i < GM_NS; ++i) {
-        la[i] = lbase + (unsigned)(i * GM_SLOT) + (unsigned)wr * 4096u;
-        lw[i] = lbase + (unsigned)(i * GM_SLOT) + 8192u + (unsigned)wc * 4096u;
+        la[i] = lbase + (unsigned)(i * GM_SLOT) + (unsigned)wr * 8192u;
+        lw[i] = lbase + (unsigned)(i * GM_SLOT) + 16384u + (unsigned)wc * 8192u;
     }
     f32x16 acc[2][2];
 #pragma unroll
@@ -395,11 +432,8 @@ __global__ __launch_bounds__(512) void g_gemm_m(GemmMParams P) {
     for (int d = 0; d < GM_NS; ++d)
         if (d < npro) gm_issue(ring_w + d * GM_SLOT, ring_a + d * GM_SLOT, pw, pa, voff);
     __builtin_amdgcn_sched_barrier(0);
-    // slab 0 has landed: gm_prologue_vmcnt(npro) = 3 (npro - 1) requests may stay in flight
-    if (npro >= 6) gm_wait_vm<5 * GM_REQ>();
-    else if (npro == 5) gm_wait_vm<4 * GM_REQ>();
-    else if (npro == 4) gm_wait_vm<3 * GM_REQ>();
-    else if (npro == 3) gm_wait_vm<2 * GM_REQ>();
+    // slab 0 has landed: gm_prologue_vmcnt(npro) = GM_REQ (npro - 1) requests may stay in flight
+    if (npro >= 3) gm_wait_vm<2 * GM_REQ>();
     else if (npro == 2) gm_wait_vm<GM_REQ>();
     else gm_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
@@ -407,7 +441,7 @@ __global__ __launch_bounds__(512) void g_gemm_m(GemmMParams P) {
     gm_read(fr[0], la[0], lw[0]);
 
     int s = 0;
-#define GM_STEADY(PH) gm_phase<PH, true>(acc, fr, la, lw, ring_w, ring_a, pw, pa, voff, true, true, 4 * GM_REQ);
+#define GM_STEADY(PH) gm_phase<PH, true>(acc, fr, la, lw, ring_w, ring_a, pw, pa, voff, true, true, GM_REQ);
 #define GM_TAIL(PH)                                                                                        \
     if (s + PH < nk) {                                                                                     \
         const GmTailStep ts = gm_tail_step(s + PH, nk, GM_NS);                                             \

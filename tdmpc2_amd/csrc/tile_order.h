@@ -107,8 +107,8 @@ __host__ __device__ inline int gw_phase_vmcnt(bool steady, int vmc, int ns) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// g_gemm_m's DMA ring (layered_mid.cuh): the same schedule with GM_REQ = 3 requests per wave and k16-slab and a ring of 6.
-constexpr int GM_REQ = 3;
+// g_gemm_m's DMA ring (layered_mid.cuh): the same schedule with GM_REQ = 6 requests per wave and k32-slab and a ring of 3.
+constexpr int GM_REQ = 6;
 struct GmTailStep {
     bool issue;  // slab ss + ns exists: request it into the slot slab ss has just left
     bool next;   // slab ss + 1 exists: read it from LDS during this phase's MFMAs

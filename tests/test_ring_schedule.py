@@ -174,7 +174,7 @@ def test_ring_of_five_slots_would_also_be_scheduled_correctly(lib):
 
 
 # ------------------------------------------------------------------------------------------------------------------------
-# g_gemm_m's ring (layered_mid.cuh, round 6: the few-row path): the same schedule with 3 requests per wave and k16-slab and SIX slots.
+# g_gemm_m's ring (layered_mid.cuh, round 6: the few-row path): the same schedule with 6 requests per wave and k32-slab and THREE slots.
 MSHIM = r"""
 #include "tile_order.h"
 extern "C" int req() { return GM_REQ; }
@@ -204,7 +204,7 @@ def _m_constants(mlib):
     u = int(re.search(r"constexpr int GM_U = (\d+);", src).group(1))
     assert u % ns == 0 and u % 2 == 0  # whole turns of the ring and of the two register sets per unrolled trip
     req = mlib.req()
-    assert f"gm_wait_vm<{ns - 2} * GM_REQ>()" in src and mlib.steady_vmcnt(ns) == (ns - 2) * req  # the steady wait of gm_phase
+    assert "gm_wait_vm<(GM_NS - 2) * GM_REQ>()" in src and mlib.steady_vmcnt(ns) == (ns - 2) * req  # the steady wait of gm_phase
     for name in ("gm_prologue_slabs(nk, GM_NS)", "gm_steady_trip(s, nk, GM_NS, GM_U)", "gm_tail_step(s + PH, nk, GM_NS)"):
         assert name in src, name
     # the DMA requests one gm_issue makes are GM_REQ
@@ -222,14 +222,15 @@ def m_replay(mlib, nk, ns, u, req, slack=0):
         npro = mlib.prologue_slabs(nk, ns)
         for d in range(npro):
             r.request(d)
-        assert mlib.prologue_vmcnt(npro) == req * (npro - 1)  # the kernel's ladder over npro = 6 .. 1: 5, 4, 3, 2, 1, 0 x GM_REQ
+        assert mlib.prologue_vmcnt(npro) == req * (npro - 1)  # the kernel's ladder over npro = 3, 2, 1: 2, 1, 0 x GM_REQ
         r.wait(mlib.prologue_vmcnt(npro))
         r.lds_read(0)
         done, s, out = [], 0, (ctypes.c_int * 3)()
 
         def phase(ss, steady, issue, nxt, vmc):
-            # gm_phase's ladder: steady or vmc >= 4 REQ -> 4 REQ; 3 REQ; 2 REQ; REQ; else 0
-            w = 4 * req if (steady or vmc >= 4 * req) else vmc if vmc in (3 * req, 2 * req, req) else 0
+            # gm_phase's ladder (a ring of three: at most one newer slab in flight): steady or vmc >= REQ -> (NS - 2) REQ; else 0
+            assert ns == 3
+            w = (ns - 2) * req if (steady or vmc >= req) else 0
             r.wait(w)
             if issue:
                 r.request(ss + ns)
@@ -257,7 +258,7 @@ def m_replay(mlib, nk, ns, u, req, slack=0):
 
 @pytest.mark.parametrize("nk", list(range(1, 45)) + [50, 88, 111, 112, 113, 256])
 def test_g_gemm_m_every_slab_lands_before_it_is_read_and_is_multiplied_once(mlib, nk):
-    """any K-part length from one k16-slab up (the t = 0 first layers contract 2 slabs; the 317M model's hidden layers 256)"""
+    """any K-part length from one k32-slab up (the t = 0 first layers contract 1 slab; the 317M model's hidden layers 128)"""
     ns, u, req = _m_constants(mlib)
     assert m_replay(mlib, nk, ns, u, req) == list(range(nk))
 
