@@ -50,12 +50,12 @@ struct HostNet {
 // Order = enum tdmpc2_expert_knob of include/tdmpc2_plan.h.
 enum LayKnob { LK_W256_MIN, LK_W_SPLIT_MIN, LK_W_SPLIT_MAX, LK_W_SPLIT_OVH, LK_KSPLIT_AUTO_LO, LK_KSPLIT_AUTO_MIN, LK_W_XCD_ROWS, LK_NCT1,
                LK_WIDE_MIN, LK_RT4, LK_FILL_PERMILLE, LK_FILL_HEAD_PERMILLE, LK_SD1, LK_XCD_ROWS, LK_COL_PAD, LK_TWOHOT_UNFUSED,
-               LK_Z0_SHARED_OFF, LK_MID_PARTS_MAX, LK_MID_FUSE_LN, LK_COUNT };
-constexpr int LAY_KNOB_DEFAULTS[LK_COUNT] = {192, 192, 4, 12000, 16, -1 /* cus / 4 */, -1, 0, 128, 0, 750, 750, 0, -1, 1, 0, 0, 16, 1};
+               LK_Z0_SHARED_OFF, LK_MID_PARTS_MAX, LK_MID_FUSE_LN, LK_MID_SPLIT_XCD, LK_COUNT };
+constexpr int LAY_KNOB_DEFAULTS[LK_COUNT] = {192, 192, 4, 12000, 16, -1 /* cus / 4 */, -1, 0, 128, 0, 750, 750, 0, -1, 1, 0, 0, 16, 1, 1};
 
 // Workspace of the layer-at-a-time path (layered_kernels.cuh): activations of all E*N sample rows in HBM.
 struct Layered {
-    int knob[LK_COUNT] = {192, 192, 4, 12000, 16, -1, -1, 0, 128, 0, 750, 750, 0, -1, 1, 0, 0, 16, 1};
+    int knob[LK_COUNT] = {192, 192, 4, 12000, 16, -1, -1, 0, 128, 0, 750, 750, 0, -1, 1, 0, 0, 16, 1, 1};
     bool on = false;
     int Kin = 0;    // row stride of X = first-layer K: round_up(L + A, 32)
     int Mp = 0;     // mlp_dim (multiple of 32)

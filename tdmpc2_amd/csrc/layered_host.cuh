@@ -523,6 +523,13 @@ int mid_stage(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rp
         }
     }
     R.nprob = nrow;
+    // two problems of one shape: one per half of the XCDs (g_gemm_m); each problem's share of the grid is 4 x ceil(jobs / 4) x row blocks
+    if (n == 2 && L.knob[LK_MID_SPLIT_XCD] && G.pr[0].ncolblk * G.pr[0].parts == G.pr[1].ncolblk * G.pr[1].parts && G.pr[0].nrowblk == G.pr[1].nrowblk) {
+        const int jobs = G.pr[0].ncolblk * G.pr[0].parts;
+        G.split_xcd = 1;
+        gblk = 8u * (unsigned)((jobs + 3) / 4) * (unsigned)G.pr[0].nrowblk;
+        G.pr[0].nblk = G.pr[1].nblk = (int)gblk / 2;
+    }
     hipLaunchKernelGGL(g_gemm_m, dim3(gblk), dim3(512), 0, st, G);
     LAUNCH_CHECK();
     const bool small = (int)rows < MR_WIDE_MIN;

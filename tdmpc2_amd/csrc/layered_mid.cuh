@@ -79,6 +79,7 @@ struct GemmMProb {
 struct GemmMParams {
     GemmMProb pr[2];
     int nprob;
+    int split_xcd;       // two problems of one shape: problem 0 on XCDs 0-3, problem 1 on XCDs 4-7 (see g_gemm_m)
 };
 
 struct GmFrags {
@@ -375,14 +376,27 @@ __global__ __launch_bounds__(512) void g_gemm_m(GemmMParams P) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int b = blockIdx.x;
-    const int pi = (P.nprob > 1 && b >= P.pr[0].nblk) ? 1 : 0;
-    if (pi) b -= P.pr[0].nblk;
+    // workgroup -> (problem, row block, column job = column block x K-part).  Block b runs on XCD b % 8.  One problem, or two of
+    // different shapes: problem 1's blocks follow problem 0's (every nblk is a multiple of 8) and XCD x runs the jobs x, x + 8, ... of
+    // either for ALL row blocks -- a job's W slice comes through ONE L2; with parts | 8 an XCD sees one K-part, i.e. 1 / parts of every
+    // A row.  Two problems of ONE shape (the two chains' hidden layers): problem 0 on XCDs 0-3, problem 1 on XCDs 4-7, jobs x, x + 4,
+    // ... -- an XCD then streams ONE problem's A rows and four (seven) W slices instead of both problems' A rows and half as many
+    // slices of each: a third less through the fabric per MFMA on the 317M model's hidden pair.
+    int pi, x, lanes;
+    if (P.split_xcd) {
+        x = b & 7;
+        pi = x >> 2;
+        x &= 3;
+        lanes = 4;
+    } else {
+        pi = (P.nprob > 1 && b >= P.pr[0].nblk) ? 1 : 0;
+        if (pi) b -= P.pr[0].nblk;
+        x = b & 7;
+        lanes = 8;
+    }
     const GemmMProb &p = P.pr[pi];
-    // workgroup -> (row block, column job = column block x K-part): XCD x (= block id % 8: every problem's nblk is a multiple of 8)
-    // runs the jobs x, x + 8, ... for ALL row blocks, so that a job's W slice comes through ONE L2; with parts | 8 an XCD sees
-    // one K-part only, i.e. 1 / parts of every A row
-    const int x = b & 7, t = b >> 3;
-    const int jj = t / p.nrowblk, rb = t - jj * p.nrowblk, job = jj * 8 + x;
+    const int t = b >> 3;
+    const int jj = t / p.nrowblk, rb = t - jj * p.nrowblk, job = jj * lanes + x;
     if (job >= p.ncolblk * p.parts) return;
     const int cb = job / p.parts, part = job - cb * p.parts;
     const int row0 = rb * GM_TM;
