@@ -509,7 +509,12 @@ int mid_stage(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rp
         float *stats = i == 0 ? L.stats : L.stats2;
         const size_t stats_need = rows_p * ((ly.CT + 3) / 4) * 2;
         if (ln && g.parts == 1 && L.fuse_ln && L.knob[LK_MID_FUSE_LN] && !o.actions && stats && L.arrive && stats_need <= L.stats_cap &&
-            L.arrive_off + (size_t)g.nrowblk <= L.arrive_cap && rpe % GM_TM == 0) {
+            (L.arrive_pending ? 0 : L.arrive_off) + (size_t)g.nrowblk <= L.arrive_cap && rpe % GM_TM == 0) {
+            if (L.arrive_pending) {
+                L.arrive_pending = false;
+                int rc0 = lay_arrive_reset(h, st);
+                if (rc0) return rc0;
+            }
             g.epi = o.kind == MR_LN_MISH ? 1 : 2;
             g.oscale = r.oscale; g.osc_sel_stride = r.osc_sel_stride;
             g.bias = r.bias; g.bias_env_stride = r.bias_env_stride; g.bias_sel_stride = r.bias_sel_stride;
@@ -575,7 +580,8 @@ int lay_estimate_value_m(tdmpc2_plan *h, hipStream_t st, int E, const float *z0,
     const bool ranged = N != NF;
     const size_t rows = (size_t)E * N, rows_p = round_up(rows, GBM);
     int rc;
-    if (L.fuse_ln && (rc = lay_arrive_reset(h, st))) return rc;  // (whole-K tiles run the NormedLinear epilogue inside g_gemm_m: mid_stage)
+    h->lay.arrive_pending = L.fuse_ln;  // (whole-K tiles run the NormedLinear epilogue inside g_gemm_m: mid_stage zeroes the stage's arrival counters
+                                   // in front of the first launch that needs them -- a single 48M plan has none and pays no memset)
     if (L.cvec_ready) {
         if (c.episodic) HIP_TRY(hipMemsetAsync(L.TERM, 0, rows * sizeof(float), st));
     } else {
@@ -810,8 +816,12 @@ int lay_sample_iteration(tdmpc2_plan *h, hipStream_t st, int E, int iter, const 
     sp.eps = tape ? tape->sample_eps + (size_t)iter * H * (N - P) * A : nullptr;
     sp.eps_estride = (long)I * H * (N - P) * A;
     sp.seed = seed; sp.call = call; sp.actions = h->actions;
+    // in-kernel Philox and at least two heads: the iteration's Q heads are drawn by l_sample's first workgroup (one launch less per iteration)
+    const bool fold_q = !tape && c.num_q >= 2;
+    sp.qidx = fold_q ? qbuf : nullptr; sp.nq = c.num_q;
     hipLaunchKernelGGL(l_sample, dim3(1024), dim3(256), 0, st, sp);
     LAUNCH_CHECK();
+    if (fold_q) return 0;
     return lay_set_qidx(h, st, E, tape ? tape->qidx + (size_t)iter * 2 : nullptr, (long)I * 2, c.num_q, iter, seed, call, qbuf);
 }
 

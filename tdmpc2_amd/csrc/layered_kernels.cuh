@@ -360,9 +360,20 @@ struct SampleParams {
     unsigned long long seed;
     unsigned int call;
     float *actions;
+    int *qidx;                // optional [E, 2]: this iteration's two Q heads drawn here as well (Philox; what l_qidx would launch for)
+    int nq;
 };
 
 __global__ void l_sample(SampleParams p) {
+    if (p.qidx && blockIdx.x == 0) {  // two distinct heads, uniform over ordered pairs (l_qidx's draw)
+        for (int e = threadIdx.x; e < p.E; e += blockDim.x) {
+            const uint4 r = rng_raw(p.seed, p.call, SITE_QIDX, p.iter, e, 0);
+            int q0 = (int)(r.x % (unsigned)p.nq), q1 = (int)(r.y % (unsigned)(p.nq - 1));
+            if (q1 >= q0) ++q1;
+            p.qidx[2 * e] = q0;
+            p.qidx[2 * e + 1] = q1;
+        }
+    }
     // one work item per PAIR of action columns: the same Philox pairs (index, Box-Muller branches) as the fused family's
     // rollout kernels draw, so that a seed means the same plan on every kernel family (tdmpc2_plan_export_noise)
     const int hp = (p.A + 15) / 16 * 8, hpa = (p.A + 1) / 2;

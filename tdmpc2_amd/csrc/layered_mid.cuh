@@ -540,6 +540,7 @@ struct MRowProb {
 struct MRowParams {
     MRowProb pr[2];
     int nprob;
+    int serial;  // two HEAD problems over the same rows, the second reading what the first wrote (Q heads: qtmp): each wavefront does both, in order
 };
 
 // A workgroup of 512 threads owns MR_R = 8 consecutive rows.
@@ -876,29 +877,10 @@ __device__ __forceinline__ void m_rows_ln1(const MRowProb &p, int row, float (*r
     }
 }
 
-// T = 512: calls with MR_WIDE_MIN rows or more (eight rows per workgroup); T = 256: fewer rows -- one row per workgroup (LN kinds) or
-// four (heads): a single 48M plan's launches are 1 024 small workgroups, and 512-thread workgroups cost them 4 us per launch (r6i)
+// ---- narrow heads: at most 128 columns, one wavefront per row, lane holds columns lane and lane + 64
 template <int T>
-__global__ __launch_bounds__(T) void m_rows(MRowParams P) {
-    __shared__ float lgs[T / 64][128];
-    __shared__ float red[2][MR_R][MR_THREADS / 64];
-    int wg = blockIdx.x;
-    const int pidx = (P.nprob > 1 && wg >= P.pr[0].nwg) ? 1 : 0;
-    if (pidx) wg -= P.pr[0].nwg;
-    const MRowProb &p = P.pr[pidx];
+__device__ __forceinline__ void m_rows_head(const MRowProb &p, int wg, float (*lgs)[128]) {
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    if (p.kind == MR_LN_MISH || p.kind == MR_LN_SIMNORM) {
-        if constexpr (T == 256) {
-            if (p.width <= 1024) m_rows_ln1<1, T>(p, wg, red);
-            else if (p.width <= 2048) m_rows_ln1<2, T>(p, wg, red);
-            else m_rows_ln1<4, T>(p, wg, red);
-        } else {
-            if (p.width <= 2048) m_rows_ln<4>(p, wg, red);
-            else m_rows_ln<8>(p, wg, red);
-        }
-        return;
-    }
-    // ---- narrow heads: at most 128 columns, one wavefront per row, lane holds columns lane and lane + 64
     const int row = wg * (T / 64) + wv;
     if (row >= p.rows) return;
     const float *wr = p.ws + (size_t)row * p.ldw;
@@ -969,4 +951,34 @@ __global__ __launch_bounds__(T) void m_rows(MRowParams P) {
         if (q.actions && n < q.nvalid) q.actions[(((size_t)env * q.H + q.t) * q.N + n) * A + a] = act;
         if (q.trace) q.trace[(size_t)row * (q.H + 2 + A) + q.H + 2 + a] = act;
     }
+}
+
+// T = 512: calls with MR_WIDE_MIN rows or more (eight rows per workgroup); T = 256: fewer rows -- one row per workgroup (LN kinds) or
+// four (heads): a single 48M plan's launches are 1 024 small workgroups, and 512-thread workgroups cost them 4 us per launch (r6i)
+template <int T>
+__global__ __launch_bounds__(T) void m_rows(MRowParams P) {
+    __shared__ float lgs[T / 64][128];
+    __shared__ float red[2][MR_R][MR_THREADS / 64];
+    int wg = blockIdx.x;
+    const int pidx = (P.nprob > 1 && wg >= P.pr[0].nwg) ? 1 : 0;
+    if (pidx) wg -= P.pr[0].nwg;
+    const MRowProb &p = P.pr[pidx];
+    if (p.kind == MR_LN_MISH || p.kind == MR_LN_SIMNORM) {
+        if constexpr (T == 256) {
+            if (p.width <= 1024) m_rows_ln1<1, T>(p, wg, red);
+            else if (p.width <= 2048) m_rows_ln1<2, T>(p, wg, red);
+            else m_rows_ln1<4, T>(p, wg, red);
+        } else {
+            if (p.width <= 2048) m_rows_ln<4>(p, wg, red);
+            else m_rows_ln<8>(p, wg, red);
+        }
+        return;
+    }
+    if (P.serial) {  // (pidx == 0: the grid covers problem 0's rows)
+        m_rows_head<T>(P.pr[0], wg, lgs);
+        __builtin_amdgcn_wave_barrier();
+        m_rows_head<T>(P.pr[1], wg, lgs);
+        return;
+    }
+    m_rows_head<T>(p, wg, lgs);
 }
