@@ -539,17 +539,9 @@ int mid_stage(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rp
     LAUNCH_CHECK();
     const bool small = (int)rows < MR_WIDE_MIN;
     if (nrow == 0) return 0;  // both layers' epilogues ran inside the GEMM
-    if (rows_one_by_one && nrow == 2) {  // the second problem's rows read what the first one's write (the two Q heads' two-hots)
-        MRowParams R1{};
-        R1.nprob = 1;
-        R1.pr[0] = R.pr[0];
-        for (int i = 0; i < 2; ++i) {
-            R1.pr[0] = R.pr[i];
-            if (small) hipLaunchKernelGGL(m_rows<256>, dim3((unsigned)R1.pr[0].nwg), dim3(256), 0, st, R1);
-            else hipLaunchKernelGGL(m_rows<512>, dim3((unsigned)R1.pr[0].nwg), dim3(512), 0, st, R1);
-            LAUNCH_CHECK();
-        }
-        return 0;
+    if (rows_one_by_one && nrow == 2) {  // the second problem's rows read what the first one's wrote (the two Q heads' two-hots, qtmp):
+        R.serial = 1;                    // one grid over problem 0's rows, every wavefront does its row of both problems in order
+        rblk = (unsigned)R.pr[0].nwg;
     }
     if (small) hipLaunchKernelGGL(m_rows<256>, dim3(rblk), dim3(256), 0, st, R);
     else hipLaunchKernelGGL(m_rows<512>, dim3(rblk), dim3(512), 0, st, R);
