@@ -140,6 +140,29 @@ __device__ __forceinline__ void gm_issue(char *slot_w, char *slot_a, const char 
     pa += 4096;
 }
 
+// Where a phase's six DMA requests are issued: behind MFMAs 12, 14, .. 22 -- one request per two MFMAs of the phase's second half -- and
+// not all six in front of the first MFMA (the 8 waves' 48 requests right behind the barrier held the MFMAs behind them back: the 317M
+// plan + 2.3 %, four 48M plans + 1.8 %, same bits; in front of the first six MFMAs, beside the LDS reads: - 2.5 %; every fourth MFMA of the
+// whole phase + 1.3 %; the last six + 1.4 %: profiles/r6zu_/r6zv_issue_placement_ab.txt).  -DGM_SPREAD_ISSUE=0: the old placement (A/B).
+#ifndef GM_SPREAD_ISSUE
+#define GM_SPREAD_ISSUE 1
+#endif
+__host__ __device__ constexpr int gm_req_at(int k) {  // the request that goes out behind MFMA k of a phase (-1: none)
+    return GM_SPREAD_ISSUE == 1 ? ((k >= 12 && k % 2 == 0) ? (k - 12) / 2 : -1) : -1;
+}
+// request I (0..3: W, 4..5: A) of the same slab on its own (GM_SPREAD_ISSUE: one request between two MFMAs of the phase's second half)
+template <int I>
+__device__ __forceinline__ void gm_issue1(char *slot_w, char *slot_a, const char *&pw, const char *&pa, unsigned voff) {
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (I < 4) gw_glds(pw + voff + I * 1024, slot_w + I * 1024);
+    else gw_glds(pa + voff + (I - 4) * 1024, slot_a + (I - 4) * 1024);
+    if constexpr (I == 5) {
+        pw += 4096;
+        pa += 4096;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int N>
 __device__ __forceinline__ void gm_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -158,45 +181,73 @@ __device__ __forceinline__ void gm_phase(f32x16 (&acc)[2][2], GmFrags (&fr)[2], 
     else gm_wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+#if GM_SPREAD_ISSUE == 0
     if (STEADY || issue) gm_issue(ring_w + SL * GM_SLOT, ring_a + SL * GM_SLOT, pw, pa, voff);
+#endif
+    // request gm_req_at(k) goes out behind MFMA k of the phase
+#define GM_AT(K)                                                                                                  \
+    if constexpr (gm_req_at(K) >= 0) {                                                                            \
+        if (STEADY || issue) gm_issue1<(gm_req_at(K) >= 0 ? gm_req_at(K) : 0)>(ring_w + SL * GM_SLOT, ring_a + SL * GM_SLOT, pw, pa, voff); \
+    }
     __builtin_amdgcn_sched_barrier(0);
     const bool rd = STEADY || next;
     // per accumulator and k16-block: w_hi a_hi, then w_lo a_hi, then w_hi a_lo -- the order of g_gemm_s / g_gemm_w (acc[column tile][row tile])
     GW_MFMA(acc[0][0], c.wh[0][0], c.ah[0][0]);
     if (rd) gm_read2<0>(n, la[SN], lw[SN]);
+    GM_AT(0)
     GW_MFMA(acc[1][0], c.wh[0][1], c.ah[0][0]);
     if (rd) gm_read2<1>(n, la[SN], lw[SN]);
+    GM_AT(1)
     GW_MFMA(acc[0][1], c.wh[0][0], c.ah[0][1]);
     if (rd) gm_read2<2>(n, la[SN], lw[SN]);
+    GM_AT(2)
     GW_MFMA(acc[1][1], c.wh[0][1], c.ah[0][1]);
     if (rd) gm_read2<3>(n, la[SN], lw[SN]);
+    GM_AT(3)
     GW_MFMA(acc[0][0], c.wl[0][0], c.ah[0][0]);
     if (rd) gm_read2<4>(n, la[SN], lw[SN]);
+    GM_AT(4)
     GW_MFMA(acc[1][0], c.wl[0][1], c.ah[0][0]);
     if (rd) gm_read2<5>(n, la[SN], lw[SN]);
+    GM_AT(5)
     GW_MFMA(acc[0][1], c.wl[0][0], c.ah[0][1]);
     if (rd) gm_read2<6>(n, la[SN], lw[SN]);
+    GM_AT(6)
     GW_MFMA(acc[1][1], c.wl[0][1], c.ah[0][1]);
     if (rd) gm_read2<7>(n, la[SN], lw[SN]);
+    GM_AT(7)
     GW_MFMA(acc[0][0], c.wh[0][0], c.al[0][0]);
+    GM_AT(8)
     GW_MFMA(acc[1][0], c.wh[0][1], c.al[0][0]);
+    GM_AT(9)
     GW_MFMA(acc[0][1], c.wh[0][0], c.al[0][1]);
+    GM_AT(10)
     GW_MFMA(acc[1][1], c.wh[0][1], c.al[0][1]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        GW_MFMA(acc[0][i], c.wh[1][0], c.ah[1][i]);
-        GW_MFMA(acc[1][i], c.wh[1][1], c.ah[1][i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        GW_MFMA(acc[0][i], c.wl[1][0], c.ah[1][i]);
-        GW_MFMA(acc[1][i], c.wl[1][1], c.ah[1][i]);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        GW_MFMA(acc[0][i], c.wh[1][0], c.al[1][i]);
-        GW_MFMA(acc[1][i], c.wh[1][1], c.al[1][i]);
-    }
+    GM_AT(11)
+    GW_MFMA(acc[0][0], c.wh[1][0], c.ah[1][0]);
+    GM_AT(12)
+    GW_MFMA(acc[1][0], c.wh[1][1], c.ah[1][0]);
+    GM_AT(13)
+    GW_MFMA(acc[0][1], c.wh[1][0], c.ah[1][1]);
+    GM_AT(14)
+    GW_MFMA(acc[1][1], c.wh[1][1], c.ah[1][1]);
+    GM_AT(15)
+    GW_MFMA(acc[0][0], c.wl[1][0], c.ah[1][0]);
+    GM_AT(16)
+    GW_MFMA(acc[1][0], c.wl[1][1], c.ah[1][0]);
+    GM_AT(17)
+    GW_MFMA(acc[0][1], c.wl[1][0], c.ah[1][1]);
+    GM_AT(18)
+    GW_MFMA(acc[1][1], c.wl[1][1], c.ah[1][1]);
+    GM_AT(19)
+    GW_MFMA(acc[0][0], c.wh[1][0], c.al[1][0]);
+    GM_AT(20)
+    GW_MFMA(acc[1][0], c.wh[1][1], c.al[1][0]);
+    GM_AT(21)
+    GW_MFMA(acc[0][1], c.wh[1][0], c.al[1][1]);
+    GM_AT(22)
+    GW_MFMA(acc[1][1], c.wh[1][1], c.al[1][1]);
+#undef GM_AT
 }
 
 // The NormedLinear epilogue of a whole-K tile (GemmMProb::epi): g_gemm_w's, on 128 rows -- see layered_wide.cuh / layered_split.cuh

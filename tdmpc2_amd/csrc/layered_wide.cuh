@@ -112,6 +112,17 @@ __device__ __forceinline__ void gw_read(GwFrags &f, const unsigned (&la)[GW_NB],
 // One phase.  PH = s mod GW_U (ring slot of slab s = PH % NS, of slab s + 1 = (PH + 1) % NS; register set of slab s = PH & 1).
 // STEADY: slab s + NS exists (its DMA is issued here) and so does slab s + 1; otherwise the flags say (vmc: requests that may
 // stay in flight at the top of the phase).
+// Where a phase's four DMA requests are issued: behind MFMAs 12, 15, 18, 21 (the phase's second half), not all four in front of the
+// first MFMA -- 8 waves x 4 requests right behind the barrier held the MFMAs behind them back.  Same bits; 48M model at 30 plans + 1.7 %,
+// 317M at 8 plans + 2.2 % (in front of the first four MFMAs, beside the LDS reads: + 1.2 / + 1.4 %; every sixth MFMA of the whole phase:
+// 0; 13, 16, 19, 22: the same as this; the last four: + 1.8 / + 1.8 %: profiles/r6zu_/r6zv_issue_placement_ab.txt).
+// -DGW_SPREAD_ISSUE=0: the old placement (A/B).
+#ifndef GW_SPREAD_ISSUE
+#define GW_SPREAD_ISSUE 1
+#endif
+__host__ __device__ constexpr int gw_req_at(int k) {  // the request that goes out behind MFMA k of a phase (-1: none)
+    return GW_SPREAD_ISSUE == 1 ? ((k >= 12 && k % 3 == 0) ? (k - 12) / 3 : -1) : -1;
+}
 template <int PH, bool STEADY>
 __device__ __forceinline__ void gw_phase(f32x16 (&acc)[2][4], GwFrags (&fr)[2], const unsigned (&la)[GW_NB], const unsigned (&lw)[GW_NB],
                                          char *ring_w, const char *&pa, const char *&pw, unsigned voff, bool issue, bool next, int vmc) {
@@ -125,6 +136,7 @@ __device__ __forceinline__ void gw_phase(f32x16 (&acc)[2][4], GwFrags (&fr)[2], 
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+#if GW_SPREAD_ISSUE == 0
     if (STEADY || issue) {  // slab s + NS -> the slot slab s has just left
         char *slot = ring_w + SL * GW_SLOT;
         gw_glds(pa + voff, slot);
@@ -134,35 +146,82 @@ __device__ __forceinline__ void gw_phase(f32x16 (&acc)[2][4], GwFrags (&fr)[2], 
         pa += 2048;
         pw += 2048;
     }
+#endif
+    // request gw_req_at(k) goes out behind MFMA k of the phase
+#define GW_AT(K)                                                                       \
+    if constexpr (gw_req_at(K) >= 0) {                                                 \
+        if (STEADY || issue) {                                                         \
+            constexpr int R_ = gw_req_at(K) >= 0 ? gw_req_at(K) : 0;                   \
+            char *slot = ring_w + SL * GW_SLOT;                                        \
+            __builtin_amdgcn_sched_barrier(0);                                         \
+            if constexpr (R_ < 2) gw_glds(pa + voff + R_ * 1024, slot + R_ * 1024);    \
+            else gw_glds(pw + voff + (R_ - 2) * 1024, slot + 16384 + (R_ - 2) * 1024); \
+            if constexpr (R_ == 3) {                                                   \
+                pa += 2048;                                                            \
+                pw += 2048;                                                            \
+            }                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                         \
+        }                                                                              \
+    }
     __builtin_amdgcn_sched_barrier(0);
     // product 1 of 3: w_hi a_hi, the reads of the next slab (two per MFMA) between the first six
     const bool rd = STEADY || next;
     GW_MFMA(acc[0][0], c.wh[0], c.ah[0]);
     if (rd) gw_read2<SN, 0>(n, la, lw);
+    GW_AT(0)
     GW_MFMA(acc[1][0], c.wh[1], c.ah[0]);
     if (rd) gw_read2<SN, 1>(n, la, lw);
+    GW_AT(1)
     GW_MFMA(acc[0][1], c.wh[0], c.ah[1]);
     if (rd) gw_read2<SN, 2>(n, la, lw);
+    GW_AT(2)
     GW_MFMA(acc[1][1], c.wh[1], c.ah[1]);
     if (rd) gw_read2<SN, 3>(n, la, lw);
+    GW_AT(3)
     GW_MFMA(acc[0][2], c.wh[0], c.ah[2]);
     if (rd) gw_read2<SN, 4>(n, la, lw);
+    GW_AT(4)
     GW_MFMA(acc[1][2], c.wh[1], c.ah[2]);
     if (rd) gw_read2<SN, 5>(n, la, lw);
+    GW_AT(5)
     GW_MFMA(acc[0][3], c.wh[0], c.ah[3]);
+    GW_AT(6)
     GW_MFMA(acc[1][3], c.wh[1], c.ah[3]);
+    GW_AT(7)
     // product 2: w_lo a_hi
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-        GW_MFMA(acc[0][rt], c.wl[0], c.ah[rt]);
-        GW_MFMA(acc[1][rt], c.wl[1], c.ah[rt]);
-    }
+    GW_MFMA(acc[0][0], c.wl[0], c.ah[0]);
+    GW_AT(8)
+    GW_MFMA(acc[1][0], c.wl[1], c.ah[0]);
+    GW_AT(9)
+    GW_MFMA(acc[0][1], c.wl[0], c.ah[1]);
+    GW_AT(10)
+    GW_MFMA(acc[1][1], c.wl[1], c.ah[1]);
+    GW_AT(11)
+    GW_MFMA(acc[0][2], c.wl[0], c.ah[2]);
+    GW_AT(12)
+    GW_MFMA(acc[1][2], c.wl[1], c.ah[2]);
+    GW_AT(13)
+    GW_MFMA(acc[0][3], c.wl[0], c.ah[3]);
+    GW_AT(14)
+    GW_MFMA(acc[1][3], c.wl[1], c.ah[3]);
+    GW_AT(15)
     // product 3: w_hi a_lo
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-        GW_MFMA(acc[0][rt], c.wh[0], c.al[rt]);
-        GW_MFMA(acc[1][rt], c.wh[1], c.al[rt]);
-    }
+    GW_MFMA(acc[0][0], c.wh[0], c.al[0]);
+    GW_AT(16)
+    GW_MFMA(acc[1][0], c.wh[1], c.al[0]);
+    GW_AT(17)
+    GW_MFMA(acc[0][1], c.wh[0], c.al[1]);
+    GW_AT(18)
+    GW_MFMA(acc[1][1], c.wh[1], c.al[1]);
+    GW_AT(19)
+    GW_MFMA(acc[0][2], c.wh[0], c.al[2]);
+    GW_AT(20)
+    GW_MFMA(acc[1][2], c.wh[1], c.al[2]);
+    GW_AT(21)
+    GW_MFMA(acc[0][3], c.wh[0], c.al[3]);
+    GW_AT(22)
+    GW_MFMA(acc[1][3], c.wh[1], c.al[3]);
+#undef GW_AT
 }
 
 // The last arriver of a K-split tile: acc <- partial 0 + partial 1 + ... in PART ORDER (its own partial, index PART, from the
