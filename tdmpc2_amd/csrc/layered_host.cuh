@@ -387,9 +387,19 @@ int lay_setup(tdmpc2_plan *h, hipStream_t st, int E, const float *task_emb, cons
     for (int i = 0; i < c.num_q; ++i) { p.bias[BE_Q0 + i] = qarr[i].l[0].bias; p.wemb[BE_Q0 + i] = qarr[i].l[0].wemb; }
     p.task_emb = task_emb; p.prev_mean = prev_mean; p.t0 = t0; p.beff = beff_out ? beff_out : h->beff;
     p.mean = init_dist ? h->mean : nullptr; p.std = h->std;
-    hipLaunchKernelGGL(l_setup, dim3(E, c.multitask ? h->nnets : 1), dim3(256), 0, st, p);
+    // few plans: one 256-column chunk per block (a single plan: nnets x Mp / 256 blocks instead of nnets); many plans already fill the chip
+    const int chunks = c.multitask ? std::max(1, std::min((h->lay.Mp + 255) / 256, 512 / std::max(1, E * h->nnets))) : 1;
+    hipLaunchKernelGGL(l_setup, dim3(E, c.multitask ? h->nnets : 1, chunks), dim3(256), 0, st, p);
     LAUNCH_CHECK();
     return 0;
+}
+
+// grid of l_init_x_s: one row of blocks per 32-row tile x column chunks, so that calls of a few tiles (single plans, the policy-prior
+// rows) are not one workgroup looping over a whole tile
+inline dim3 init_x_grid(size_t rows, int ldx) {
+    const unsigned tiles = (unsigned)((rows + 31) / 32);
+    const unsigned passes = (unsigned)((ldx / 8 * 32 + 255) / 256);
+    return dim3(tiles, std::max(1u, std::min(passes, 256u / std::max(1u, tiles))));
 }
 
 // At t = 0 every sample row of a plan starts from the same latent (z.repeat(num_samples, 1), tdmpc2.py:163): the z columns'
@@ -402,7 +412,7 @@ int lay_cvec(tdmpc2_plan *h, hipStream_t st, int E, const float *z0) {
     if (!h->split || !L.Z0X || L.knob[LK_Z0_SHARED_OFF]) return 0;
     const tdmpc2_plan_cfg &c = h->cfg;
     const size_t rows_p = round_up((size_t)E, GBM);
-    hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)((E + 31) / 32)), dim3(256), 0, st, L.Z0X, L.Kin, c.latent_dim, 1, z0, (float *)nullptr, (float *)nullptr, E);
+    hipLaunchKernelGGL(l_init_x_s, init_x_grid((size_t)E, L.Kin), dim3(256), 0, st, L.Z0X, L.Kin, c.latent_dim, 1, z0, (float *)nullptr, (float *)nullptr, E);
     LAUNCH_CHECK();
     const HostNet *nets[2] = {&h->rew, &h->dyn};
     const int slots[2] = {BE_REW, BE_DYN};
@@ -577,7 +587,7 @@ int lay_estimate_value_m(tdmpc2_plan *h, hipStream_t st, int E, const float *z0,
     if (L.cvec_ready) {
         if (c.episodic) HIP_TRY(hipMemsetAsync(L.TERM, 0, rows * sizeof(float), st));
     } else {
-        hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM, (int)rows);
+        hipLaunchKernelGGL(l_init_x_s, init_x_grid(rows, L.Kin), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM, (int)rows);
         LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(l_set_action_s, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, A, NF, H, 0, (int)rows, actions, N, n_off);
@@ -669,7 +679,7 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
     if (h->split && L.cvec_ready) {
         if (c.episodic) HIP_TRY(hipMemsetAsync(L.TERM, 0, rows * sizeof(float), st));
     } else {
-        if (h->split) hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM, (int)rows);
+        if (h->split) hipLaunchKernelGGL(l_init_x_s, init_x_grid(rows, L.Kin), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM, (int)rows);
         else hipLaunchKernelGGL(l_init_x, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM);
         LAUNCH_CHECK();
     }
@@ -742,7 +752,7 @@ int lay_pitraj_m(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const f
     const int P = c.num_pi_trajs, H = c.horizon, A = c.action_dim, rpe = L.Ppad;
     const size_t rows = (size_t)E * rpe, rows_p = round_up(rows, GBM);
     int rc;
-    hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, rpe, z0, (float *)nullptr,
+    hipLaunchKernelGGL(l_init_x_s, init_x_grid(rows, L.Kin), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, rpe, z0, (float *)nullptr,
                        (float *)nullptr, (int)rows);
     LAUNCH_CHECK();
     for (int t = 0; t < H; ++t) {
@@ -781,7 +791,7 @@ int lay_pitraj(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const flo
     if (mid_ok(h, rows_p)) return lay_pitraj_m(h, st, E, z0, act_mask, tape_eps, seed, call);
     if ((rc = lay_arrive_reset(h, st))) return rc;
     if (h->split)
-        hipLaunchKernelGGL(l_init_x_s, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, rpe, z0, (float *)nullptr,
+        hipLaunchKernelGGL(l_init_x_s, init_x_grid(rows, L.Kin), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, rpe, z0, (float *)nullptr,
                            (float *)nullptr, (int)rows);
     else
         hipLaunchKernelGGL(l_init_x, dim3((unsigned)rows), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, rpe, z0, (float *)nullptr,

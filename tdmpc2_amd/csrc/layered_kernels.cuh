@@ -424,7 +424,9 @@ struct LSetupParams {
     float *beff, *mean, *std;
 };
 
-// grid (E, nnets): block (e, net) folds one net's task-embedding columns; block (e, 0) also initialises mean / std.
+// grid (E, nnets, column chunks): block (e, net, z) folds columns z, z + gridDim.z, ... x 256 of one net's task-embedding columns
+// (one chunk per block when the grid is made that way: a single plan of the 317M model spent 240 us here with 13 blocks of 16 columns
+// per thread, r6zw); block (e, 0, 0) also initialises mean / std.  One fmaf chain over the task dimension per column, whatever the grid.
 __global__ void l_setup(LSetupParams p) {
     const int e = blockIdx.x, tid = threadIdx.x;
     if (p.multitask) {
@@ -432,7 +434,7 @@ __global__ void l_setup(LSetupParams p) {
         {
             const int net = blockIdx.y;
             if (p.wemb[net])
-            for (int c = tid; c < p.Mp; c += blockDim.x) {
+            for (int c = blockIdx.z * blockDim.x + tid; c < p.Mp; c += blockDim.x * gridDim.z) {
                 float s = 0.f;
                 if (c < p.M) {
                     const float *w = p.wemb[net] + (size_t)c * p.T;
@@ -442,7 +444,7 @@ __global__ void l_setup(LSetupParams p) {
             }
         }
     }
-    if (p.mean && blockIdx.y == 0) {
+    if (p.mean && blockIdx.y == 0 && blockIdx.z == 0) {
         for (int idx = tid; idx < p.H * p.A; idx += blockDim.x) {
             const int t = idx / p.A;
             float m = 0.f;

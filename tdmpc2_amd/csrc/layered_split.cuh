@@ -534,10 +534,11 @@ __global__ __launch_bounds__(RW_THREADS) void l_ln_act_s(LnActParams p) {
 // Columns [c0, c1) (multiples of 8) of every row of the packed buffer X (KB k16-blocks per row) <- split(src(row, col)).
 // One workgroup per 32-row tile; a thread writes the 8 halfs (16 bytes per plane) of one (row, 8-column group): a wavefront's
 // store covers two runs of 512 contiguous bytes.
+// gridDim.y > 1: the tile's (row, column group) items are dealt over the blocks of a column of the grid.
 template <class SRC>
 __device__ __forceinline__ void fill_packed_tile(char *X, int KB, int c0, int c1, SRC src) {
     const int ng = (c1 - c0) >> 3;  // 8-column groups
-    for (int idx = threadIdx.x; idx < ng * 32; idx += blockDim.x) {
+    for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < ng * 32; idx += blockDim.x * gridDim.y) {
         const int r = idx & 31, gq = idx >> 5, col = c0 + 8 * gq;
         const size_t row = (size_t)blockIdx.x * 32 + r;
         f16x8 hi, lo;
@@ -555,11 +556,12 @@ __device__ __forceinline__ void fill_packed_tile(char *X, int KB, int c0, int c1
 }
 
 // X[row] <- operand form of [z0[env] | zeros]; G, term <- 0.  One workgroup per 32-row tile (rows past `rows`: zeros).
+// (gridDim.y: column chunks -- a single plan has ONE tile, and one workgroup took 40 us over its ldx / 8 x 32 items, r6zw)
 __global__ void l_init_x_s(float *X, int ldx, int L, int rows_per_env, const float *z0, float *G, float *term, int rows) {
     fill_packed_tile(reinterpret_cast<char *>(X), ldx / 16, 0, ldx, [&](size_t row, int c) {
         return (c < L && row < (size_t)rows) ? z0[(row / rows_per_env) * L + c] : 0.f;
     });
-    if (threadIdx.x < 32) {
+    if (threadIdx.x < 32 && blockIdx.y == 0) {
         const size_t row = (size_t)blockIdx.x * 32 + threadIdx.x;
         if (row < (size_t)rows) {
             if (G) G[row] = 0.f;
