@@ -87,6 +87,7 @@ struct Layered {
     size_t arrive_cap = 0, arrive_off = 0;  // counters; the next free one (zeroed at the start of every stage)
     unsigned long long *gw_timing = nullptr;  // TDMPC2_GW_TIMING=1 with a -DGW_TIMING build: phase clocks of g_gemm_w, 4 classes x 8 words
     size_t arrive_high = 0;                 // most counters any stage of this handle has used (the extent of that memset)
+    bool arrive_clean = false;              // l_sample has just zeroed the counters (lay_arrive_reset then has nothing to do)
     bool arrive_pending = false;            // few-row stage: the counters have not been zeroed yet (done in front of the first launch that waits)
     // g_gemm_w's K-split tail (layered_wide.cuh): partial accumulators of the split tiles, one workspace per chain
     float *ksws = nullptr, *ksws2 = nullptr;

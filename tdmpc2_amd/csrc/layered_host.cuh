@@ -33,6 +33,10 @@ inline LayBufs lay_bufs(const tdmpc2_plan *h, int set) {
 int lay_arrive_reset(tdmpc2_plan *h, hipStream_t st) {
     Layered &L = h->lay;
     if (!L.arrive) return 0;
+    // the iteration's l_sample has zeroed them (lay_sample_iteration) and nothing has taken a counter since: no memset
+    const bool clean = L.arrive_clean && L.arrive_off == 0;
+    L.arrive_clean = false;
+    if (clean) return 0;
     if (L.arrive_off > L.arrive_high) L.arrive_high = L.arrive_off;
     if (L.arrive_high) HIP_TRY(hipMemsetAsync(L.arrive, 0, L.arrive_high * sizeof(unsigned int), st));
     L.arrive_off = 0;
@@ -488,6 +492,7 @@ int mid_stage(tdmpc2_plan *h, hipStream_t st, size_t rows, size_t rows_p, int rp
         if ((size_t)g.parts * g.part_stride > L.mws_cap) return fail(TDMPC2_ERR_STATE, "few-row path: partial-sum workspace too small");
         g.ws = L.mws[i];
         g.nblk = 8 * ((g.ncolblk * g.parts + 7) / 8) * g.nrowblk;
+        g.rows = (int)rows;
         gblk += (unsigned)g.nblk;
         // the row-side description of the layer (m_rows, or the GEMM's own epilogue when the tile is whole: parts == 1)
         MRowProb r{};
@@ -821,6 +826,15 @@ int lay_sample_iteration(tdmpc2_plan *h, hipStream_t st, int E, int iter, const 
     // in-kernel Philox and at least two heads: the iteration's Q heads are drawn by l_sample's first workgroup (one launch less per iteration)
     const bool fold_q = !tape && c.num_q >= 2;
     sp.qidx = fold_q ? qbuf : nullptr; sp.nq = c.num_q;
+    {   // ... and the arrival counters of the stage that follows are zeroed by the same launch (stream order: the previous stage is done)
+        Layered &L = h->lay;
+        if (L.arrive) {
+            if (L.arrive_off > L.arrive_high) L.arrive_high = L.arrive_off;
+            sp.arrive = L.arrive; sp.arrive_n = (int)L.arrive_high;
+            L.arrive_off = 0;
+            L.arrive_clean = true;
+        }
+    }
     hipLaunchKernelGGL(l_sample, dim3(1024), dim3(256), 0, st, sp);
     LAUNCH_CHECK();
     if (fold_q) return 0;

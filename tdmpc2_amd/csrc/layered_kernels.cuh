@@ -362,9 +362,12 @@ struct SampleParams {
     float *actions;
     int *qidx;                // optional [E, 2]: this iteration's two Q heads drawn here as well (Philox; what l_qidx would launch for)
     int nq;
+    unsigned int *arrive;     // optional: the stage's arrival counters [arrive_n], zeroed here (what lay_arrive_reset's memset would launch for)
+    int arrive_n;
 };
 
 __global__ void l_sample(SampleParams p) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < p.arrive_n; i += gridDim.x * blockDim.x) p.arrive[i] = 0u;
     if (p.qidx && blockIdx.x == 0) {  // two distinct heads, uniform over ordered pairs (l_qidx's draw)
         for (int e = threadIdx.x; e < p.E; e += blockDim.x) {
             const uint4 r = rng_raw(p.seed, p.call, SITE_QIDX, p.iter, e, 0);

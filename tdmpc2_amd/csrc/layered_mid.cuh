@@ -59,6 +59,7 @@ struct GemmMProb {
     long part_stride;
     int ldw;
     int nblk;            // workgroups of this problem: 8 * ceil(ncolblk * parts / 8) * nrowblk
+    int rows;            // rows that exist (the rest of the last row block is padding: computed, never stored)
     // epi != 0 (parts == 1 only): the NormedLinear epilogue INSIDE this launch -- g_gemm_w's protocol on 128-row tiles (the column blocks
     // of a row block exchange per-row (mean, M2) partials, canonical combination order: the same bits as every other fused tile) --
     // instead of partial sums + m_rows.  1: Mish, 2: SimNorm.  Every workgroup of a few-row launch is resident (grid <= #CUs, one
@@ -554,6 +555,7 @@ __global__ __launch_bounds__(512) void g_gemm_m(GemmMParams P) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = wave * 16 + r;
+        if (row0 + row >= p.rows) break;  // wave-uniform: padding rows of the last row block (the policy-prior rows: 24-32 of 128) -- m_rows never reads them
         const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + row * GM_LDT + lane * 4);
         gw_st_sc1(out + (size_t)row * p.ldw, v);
     }
@@ -787,7 +789,10 @@ __device__ __forceinline__ void m_rows_ln(const MRowProb &p, int wg, float (*red
 // row, thread t holds columns 4 (t + T q) .. + 3 -- more workgroups in flight than eight rows per workgroup would give (128 workgroups for a
 // 48M plan's two chains: 3.84 ms per plan against 3.29, r6h); the 8-byte stores of this mapping assemble every output line from
 // eight rows' writes, which is what the eight-row mapping above avoids where there are rows enough.
-constexpr int MR_WIDE_MIN = 1024;
+#ifndef MR_WIDE_MIN_ROWS
+#define MR_WIDE_MIN_ROWS 1024
+#endif
+constexpr int MR_WIDE_MIN = MR_WIDE_MIN_ROWS;
 template <int QN, int T>
 __device__ __forceinline__ void m_rows_ln1(const MRowProb &p, int row, float (*red)[MR_R][MR_THREADS / 64]) {
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
