@@ -557,7 +557,7 @@ __global__ __launch_bounds__(512) void g_gemm_m(GemmMParams P) {
         const int row = wave * 16 + r;
         if (row0 + row >= p.rows) break;  // wave-uniform: padding rows of the last row block (the policy-prior rows: 24-32 of 128) -- m_rows never reads them
         const f32x4 v = *reinterpret_cast<const f32x4 *>(tile + row * GM_LDT + lane * 4);
-        gw_st_sc1(out + (size_t)row * p.ldw, v);
+        gw_st_sc1(out + (size_t)row * p.ldw, v);  // (write-through: plain stores, left to the end-of-kernel write-back, cost the 48M plan 2.5-3 %, r6zzb)
     }
 }
 
