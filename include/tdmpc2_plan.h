@@ -372,7 +372,7 @@ enum tdmpc2_expert_knob { TDMPC2_X_GEMM_W256_MIN = 0, TDMPC2_X_GEMM_W_SPLIT_MIN,
                           TDMPC2_X_KSPLIT_AUTO_LO, TDMPC2_X_KSPLIT_AUTO_MIN, TDMPC2_X_GEMM_W_XCD_ROWS, TDMPC2_X_GEMM_NCT1,
                           TDMPC2_X_GEMM_WIDE_MIN, TDMPC2_X_GEMM_RT4, TDMPC2_X_GEMM_FILL_PERMILLE, TDMPC2_X_GEMM_FILL_HEAD_PERMILLE,
                           TDMPC2_X_GEMM_SD1, TDMPC2_X_GEMM_XCD_ROWS, TDMPC2_X_GEMM_COL_PAD, TDMPC2_X_TWOHOT_UNFUSED, TDMPC2_X_Z0_SHARED_OFF,
-                          TDMPC2_X_MID_PARTS_MAX, TDMPC2_X_MID_FUSE_LN, TDMPC2_X_MID_SPLIT_XCD, TDMPC2_X_COUNT };
+                          TDMPC2_X_MID_PARTS_MAX, TDMPC2_X_MID_FUSE_LN, TDMPC2_X_MID_SPLIT_XCD, TDMPC2_X_MID_PIFOLD, TDMPC2_X_COUNT };
 int tdmpc2_plan_set_tuning(tdmpc2_plan_t *h, int key, int value);
 
 /* Fault report of the paths whose workgroups wait for each other: the cluster path (TDMPC2_TUNE_CLUSTER) and the NormedLinear

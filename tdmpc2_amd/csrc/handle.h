@@ -50,12 +50,12 @@ struct HostNet {
 // Order = enum tdmpc2_expert_knob of include/tdmpc2_plan.h.
 enum LayKnob { LK_W256_MIN, LK_W_SPLIT_MIN, LK_W_SPLIT_MAX, LK_W_SPLIT_OVH, LK_KSPLIT_AUTO_LO, LK_KSPLIT_AUTO_MIN, LK_W_XCD_ROWS, LK_NCT1,
                LK_WIDE_MIN, LK_RT4, LK_FILL_PERMILLE, LK_FILL_HEAD_PERMILLE, LK_SD1, LK_XCD_ROWS, LK_COL_PAD, LK_TWOHOT_UNFUSED,
-               LK_Z0_SHARED_OFF, LK_MID_PARTS_MAX, LK_MID_FUSE_LN, LK_MID_SPLIT_XCD, LK_COUNT };
-constexpr int LAY_KNOB_DEFAULTS[LK_COUNT] = {192, 192, 4, 12000, 16, -1 /* cus / 4 */, -1, 0, 128, 0, 750, 750, 0, -1, 1, 0, 0, 16, 1, 1};
+               LK_Z0_SHARED_OFF, LK_MID_PARTS_MAX, LK_MID_FUSE_LN, LK_MID_SPLIT_XCD, LK_MID_PIFOLD, LK_COUNT };
+constexpr int LAY_KNOB_DEFAULTS[LK_COUNT] = {192, 192, 4, 12000, 16, -1 /* cus / 4 */, -1, 0, 128, 0, 750, 750, 0, -1, 1, 0, 0, 16, 1, 1, 1};
 
 // Workspace of the layer-at-a-time path (layered_kernels.cuh): activations of all E*N sample rows in HBM.
 struct Layered {
-    int knob[LK_COUNT] = {192, 192, 4, 12000, 16, -1, -1, 0, 128, 0, 750, 750, 0, -1, 1, 0, 0, 16, 1, 1};
+    int knob[LK_COUNT] = {192, 192, 4, 12000, 16, -1, -1, 0, 128, 0, 750, 750, 0, -1, 1, 0, 0, 16, 1, 1, 1};
     bool on = false;
     int Kin = 0;    // row stride of X = first-layer K: round_up(L + A, 32)
     int Mp = 0;     // mlp_dim (multiple of 32)
@@ -87,6 +87,10 @@ struct Layered {
     size_t arrive_cap = 0, arrive_off = 0;  // counters; the next free one (zeroed at the start of every stage)
     unsigned long long *gw_timing = nullptr;  // TDMPC2_GW_TIMING=1 with a -DGW_TIMING build: phase clocks of g_gemm_w, 4 classes x 8 words
     size_t arrive_high = 0;                 // most counters any stage of this handle has used (the extent of that memset)
+    // lay_run -> lay_estimate_value_m, iteration 0 of a single few-row plan: the policy-prior rows' actions a_t = pi(z_t) are computed at
+    // the top of step t of the stage itself (their latents ARE rows of the stage), instead of a pass of their own in front (lay_pitraj)
+    bool pifold = false;
+    const float *pifold_eps = nullptr;      // the tape's pi_traj_eps [E, H, P, A], or null (Philox)
     bool arrive_clean = false;              // l_sample has just zeroed the counters (lay_arrive_reset then has nothing to do)
     bool arrive_pending = false;            // few-row stage: the counters have not been zeroed yet (done in front of the first launch that waits)
     // g_gemm_w's K-split tail (layered_wide.cuh): partial accumulators of the split tiles, one workspace per chain

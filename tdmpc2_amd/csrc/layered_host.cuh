@@ -589,8 +589,14 @@ int lay_estimate_value_m(tdmpc2_plan *h, hipStream_t st, int E, const float *z0,
     int rc;
     h->lay.arrive_pending = L.fuse_ln;  // (whole-K tiles run the NormedLinear epilogue inside g_gemm_m: mid_stage zeroes the stage's arrival counters
                                    // in front of the first launch that needs them -- a single 48M plan has none and pays no memset)
+    const bool pifold = L.pifold && E == 1 && !ranged && c.num_pi_trajs > 0;
     if (L.cvec_ready) {
         if (c.episodic) HIP_TRY(hipMemsetAsync(L.TERM, 0, rows * sizeof(float), st));
+        if (pifold) {  // the policy head of step 0 reads z_0 from the z columns of its rows (nothing else of this stage reads them: lay_cvec)
+            hipLaunchKernelGGL(l_init_x_s, init_x_grid((size_t)L.Ppad, L.Kin), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, L.Ppad, z0, (float *)nullptr,
+                               (float *)nullptr, L.Ppad);
+            LAUNCH_CHECK();
+        }
     } else {
         hipLaunchKernelGGL(l_init_x_s, init_x_grid(rows, L.Kin), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, N, z0, L.G, L.TERM, (int)rows);
         LAUNCH_CHECK();
@@ -598,6 +604,22 @@ int lay_estimate_value_m(tdmpc2_plan *h, hipStream_t st, int E, const float *z0,
     hipLaunchKernelGGL(l_set_action_s, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, st, L.X, L.Kin, c.latent_dim, A, NF, H, 0, (int)rows, actions, N, n_off);
     LAUNCH_CHECK();
     for (int t = 0; t < H; ++t) {
+        if (pifold) {  // a_t = pi(z_t) for the P policy-prior rows (tdmpc2.py:156-158): rows [0, P) of X, into their action columns and `actions`
+            const int P = c.num_pi_trajs;
+            const size_t prow = (size_t)P, prow_p = round_up(prow, GBM);
+            MidOp o0 = mid_hidden(L, L.X, L.Kin, h->pi, 0, BE_PI, nullptr, false, L.HA, c.mlp_dim);
+            if ((rc = mid_stage(h, st, prow, prow_p, L.Ppad, &o0, 1))) return rc;
+            MidOp o1 = mid_hidden(L, L.HA, L.Mp, h->pi, 1, -1, nullptr, false, L.HB, c.mlp_dim);
+            if ((rc = mid_stage(h, st, prow, prow_p, L.Ppad, &o1, 1))) return rc;
+            MidOp o2 = mid_head(L, L.HB, h->pi, nullptr, false, MR_PI);
+            PiHeadParams &p = o2.pi;
+            p.rows = P; p.rows_per_env = L.Ppad; p.nvalid = P; p.A = A; p.L = c.latent_dim; p.ldx = L.Kin;
+            p.lsmin = c.log_std_min; p.lsdif = c.log_std_dif; p.mask = act_mask;
+            p.eps = L.pifold_eps ? L.pifold_eps + (size_t)t * P * A : nullptr; p.eps_estride = (long)H * P * A;  // tape layout [E, H, P, A]
+            p.seed = seed; p.call = call; p.site = SITE_PITRAJ; p.iter = t; p.X = L.X; p.actions = h->actions; p.t = t; p.H = H;
+            p.N = c.num_samples; p.trace = nullptr; p.row_env = nullptr; p.n_off = 0;
+            if ((rc = mid_stage(h, st, prow, prow_p, L.Ppad, &o2, 1))) return rc;
+        }
         GemmRange r_rew{c.latent_dim / 16, (L.Kin - c.latent_dim) / 16, L.cvec, (long)L.Mp, c.latent_dim};
         GemmRange r_dyn = r_rew;
         r_dyn.bias_env = L.cvec + (size_t)L.cvec_rows * L.Mp;
@@ -859,15 +881,21 @@ int lay_run(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, const float 
     int rc;
     if ((rc = lay_setup(h, st, E, task_emb, prev_mean, t0, true))) return rc;
     if ((rc = lay_cvec(h, st, E, z0))) return rc;
-    if (P > 0 && (rc = lay_pitraj(h, st, E, z0, act_mask, tape ? tape->pi_traj_eps : nullptr, seed, call))) return rc;
+    // one plan on the few-row path: the policy-prior trajectories ride along in iteration 0's stage (lay_estimate_value_m) -- their own
+    // pass would repeat the dynamics of rows the stage rolls out anyway (12 of its 27 layer launches on the 317M model)
+    const bool pifold = P > 0 && E == 1 && h->lay.knob[LK_MID_PIFOLD] && mid_ok(h, round_up((size_t)E * N, GBM));
+    if (P > 0 && !pifold && (rc = lay_pitraj(h, st, E, z0, act_mask, tape ? tape->pi_traj_eps : nullptr, seed, call))) return rc;
     int refit_stage = 0;
     const size_t refit_lds = refit_lds_bytes(N, K, H, A, &refit_stage);
     for (int it = 0; it < I; ++it) {
         if ((rc = lay_sample_iteration(h, st, E, it, act_mask, tape, seed, call, h->lay.qidx))) return rc;
         if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) HIP_TRY(hipEventRecord(h->ev[h->ev_used], st));
-        if ((rc = lay_estimate_value(h, st, E, z0, act_mask, disc_pow, h->actions,
-                                     tape ? tape->pi_eps + (size_t)it * N * A : nullptr, (long)I * N * A, h->lay.qidx, seed, call,
-                                     it, h->value, nullptr))) return rc;
+        h->lay.pifold = pifold && it == 0;
+        h->lay.pifold_eps = tape ? tape->pi_traj_eps : nullptr;
+        rc = lay_estimate_value(h, st, E, z0, act_mask, disc_pow, h->actions, tape ? tape->pi_eps + (size_t)it * N * A : nullptr,
+                                (long)I * N * A, h->lay.qidx, seed, call, it, h->value, nullptr);
+        h->lay.pifold = false;
+        if (rc) return rc;
         if (h->profiling && h->ev_used + 2 <= (int)h->ev.size()) {
             HIP_TRY(hipEventRecord(h->ev[h->ev_used + 1], st));
             h->ev_used += 2;

@@ -181,7 +181,7 @@ def _open(path):
 # planner at creation (the A/B tools: tools/gpu_env_ab.sh); the library itself reads none of these.
 EXPERT_KNOBS = ("GEMM_W256_MIN", "GEMM_W_SPLIT_MIN", "GEMM_W_SPLIT_MAX", "GEMM_W_SPLIT_OVH", "KSPLIT_AUTO_LO", "KSPLIT_AUTO_MIN",
                 "GEMM_W_XCD_ROWS", "GEMM_NCT1", "GEMM_WIDE_MIN", "GEMM_RT4", "GEMM_FILL_PERMILLE", "GEMM_FILL_HEAD_PERMILLE", "GEMM_SD1",
-                "GEMM_XCD_ROWS", "GEMM_COL_PAD", "TWOHOT_UNFUSED", "Z0_SHARED_OFF", "MID_PARTS_MAX", "MID_FUSE_LN", "MID_SPLIT_XCD")
+                "GEMM_XCD_ROWS", "GEMM_COL_PAD", "TWOHOT_UNFUSED", "Z0_SHARED_OFF", "MID_PARTS_MAX", "MID_FUSE_LN", "MID_SPLIT_XCD", "MID_PIFOLD")
 TUNE_EXPERT = 100
 
 

@@ -63,6 +63,36 @@ def test_few_row_path_and_per_layer_tiles_both_reproduce_the_golden(name):
     assert err < 5e-5 and planner.take_fault() == 0
 
 
+@pytest.mark.parametrize("name", ["small", "small_mt", "c3", "m1_mt30", "c4_x2"])
+def test_single_plans_fold_the_policy_prior_rows_into_iteration_0(name):
+    """ONE plan per call on the few-row path (what evaluate.py:80 does): the policy-prior trajectories (tdmpc2.py:154-160) are not a pass
+    of their own -- a_t = pi(z_t) of the P rows is computed at the top of step t of iteration 0's stage, whose rows they are
+    (lay_estimate_value_m; TDMPC2_X_MID_PIFOLD = 0: the separate pass).  Every environment of a multi-plan golden, planned ALONE with its
+    slice of the noise tape, must reproduce its slice of the golden on both routes; the two routes agree to fp32 round-off (the
+    K-parts of a policy-prior row's dynamics differ: 16 in the separate pass, the stage's 1-4 here)."""
+    from tests.gpu_common import case_on_gpu
+
+    c, model, planner = case_on_gpu(name, PATH_LAYERED, 2)
+    g = load_golden(name)
+    for e in range(c["n_envs"]):
+        c1 = dict(c, n_envs=1, z0=c["z0"][e:e + 1], prev_mean=c["prev_mean"][e:e + 1], t0=c["t0"][e:e + 1],
+                  tape={k: v[e:e + 1] for k, v in c["tape"].items()}, discounts=c["discounts"][e:e + 1],
+                  tasks=None if c["tasks"] is None else c["tasks"][e:e + 1])
+        g1 = {k: g[k][e:e + 1] for k in ("value", "elite_idx", "score", "mean", "std", "action", "prev_mean_out")}
+        fold = _run_native(c1, model, planner)
+        planner.set_expert("MID_PIFOLD", 0)
+        try:
+            apart = _run_native(c1, model, planner)
+        finally:
+            planner.set_expert("MID_PIFOLD", None)
+        _compare_stages(name, c1, fold, g1, g1["action"], g1["prev_mean_out"], tag=f"/layered/split/golden/single_plan_env{e}/pi_rows_in_stage")
+        _compare_stages(name, c1, apart, g1, g1["action"], g1["prev_mean_out"], tag=f"/layered/split/golden/single_plan_env{e}/pi_rows_apart")
+        err = value_err(fold["value"][:, 0], apart["value"][:, 0])
+        da = float(np.abs(fold["action"] - apart["action"]).max())
+        print(f"[{name} env {e}] policy-prior rows in the stage vs apart: iteration-0 values rel err {err:.2e}, action {da:.2e}")
+        assert err < 5e-5 and planner.take_fault() == 0
+
+
 @PRECS
 @pytest.mark.parametrize("name", ["c1", "mt5", "c2"])
 def test_layered_family_on_fused_size_class(name, prec):
