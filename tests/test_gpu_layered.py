@@ -63,7 +63,7 @@ def test_few_row_path_and_per_layer_tiles_both_reproduce_the_golden(name):
     assert err < 5e-5 and planner.take_fault() == 0
 
 
-@pytest.mark.parametrize("name", ["small", "small_mt", "c3", "m1_mt30", "c4_x2"])
+@pytest.mark.parametrize("name", ["small", "small_mt", "small_ep_fire", "c3", "m1_mt30", "c4_x2"])
 def test_single_plans_fold_the_policy_prior_rows_into_iteration_0(name):
     """ONE plan per call on the few-row path (what evaluate.py:80 does): the policy-prior trajectories (tdmpc2.py:154-160) are not a pass
     of their own -- a_t = pi(z_t) of the P rows is computed at the top of step t of iteration 0's stage, whose rows they are

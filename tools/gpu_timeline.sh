@@ -4,12 +4,13 @@
 # usage: gpurun -- bash tools/gpu_timeline.sh <tag> "<config envs steps>;..." [ENV=... ...]
 cd "$(dirname "$0")/.."
 R=$PWD; TAG=$1; SPECS=$2; shift 2
+EXTRA_ENV=("$@")  # (kept here: `set -- $spec` below replaces the positional parameters)
 mkdir -p gpurun_out; export TMPDIR=/tmp
 IFS=';' read -r -a SP <<< "$SPECS"
 for spec in "${SP[@]}"; do
   set -- $spec
   n=${TAG}_$1e$2
-  (cd /tmp && env "${@:4}" TDMPC2_BENCH_EXACT_STEPS=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_$n -o t -- python $R/bench.py --config $1 --envs $2 --steps $3 --warmup 1 --skip-cpu-baseline --skip-extra-configs --skip-traffic > /dev/null 2>&1)
+  (cd /tmp && env "${EXTRA_ENV[@]}" TDMPC2_BENCH_EXACT_STEPS=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/prof_$n -o t -- python $R/bench.py --config $1 --envs $2 --steps $3 --warmup 1 --skip-cpu-baseline --skip-extra-configs --skip-traffic > /dev/null 2>&1)
   KT=$(find gpurun_out/prof_$n -name "*kernel_trace.csv" | head -1)
   python - "$KT" gpurun_out/${n}_timeline.csv <<'PY'
 import csv, sys
