@@ -141,16 +141,7 @@ __device__ __forceinline__ void gm_issue(char *slot_w, char *slot_a, const char 
     pa += 4096;
 }
 
-// Where a phase's six DMA requests are issued: behind MFMAs 12, 14, .. 22 -- one request per two MFMAs of the phase's second half -- and
-// not all six in front of the first MFMA (the 8 waves' 48 requests right behind the barrier held the MFMAs behind them back: the 317M
-// plan + 2.3 %, four 48M plans + 1.8 %, same bits; in front of the first six MFMAs, beside the LDS reads: - 2.5 %; every fourth MFMA of the
-// whole phase + 1.3 %; the last six + 1.4 %: profiles/r6zu_/r6zv_issue_placement_ab.txt).  -DGM_SPREAD_ISSUE=0: the old placement (A/B).
-#ifndef GM_SPREAD_ISSUE
-#define GM_SPREAD_ISSUE 1
-#endif
-__host__ __device__ constexpr int gm_req_at(int k) {  // the request that goes out behind MFMA k of a phase (-1: none)
-    return GM_SPREAD_ISSUE == 1 ? ((k >= 12 && k % 2 == 0) ? (k - 12) / 2 : -1) : -1;
-}
+// (where in a phase the six requests go out: gm_req_at, tile_order.h)
 // request I (0..3: W, 4..5: A) of the same slab on its own (GM_SPREAD_ISSUE: one request between two MFMAs of the phase's second half)
 template <int I>
 __device__ __forceinline__ void gm_issue1(char *slot_w, char *slot_a, const char *&pw, const char *&pa, unsigned voff) {

@@ -112,17 +112,7 @@ __device__ __forceinline__ void gw_read(GwFrags &f, const unsigned (&la)[GW_NB],
 // One phase.  PH = s mod GW_U (ring slot of slab s = PH % NS, of slab s + 1 = (PH + 1) % NS; register set of slab s = PH & 1).
 // STEADY: slab s + NS exists (its DMA is issued here) and so does slab s + 1; otherwise the flags say (vmc: requests that may
 // stay in flight at the top of the phase).
-// Where a phase's four DMA requests are issued: behind MFMAs 12, 15, 18, 21 (the phase's second half), not all four in front of the
-// first MFMA -- 8 waves x 4 requests right behind the barrier held the MFMAs behind them back.  Same bits; 48M model at 30 plans + 1.7 %,
-// 317M at 8 plans + 2.2 % (in front of the first four MFMAs, beside the LDS reads: + 1.2 / + 1.4 %; every sixth MFMA of the whole phase:
-// 0; 13, 16, 19, 22: the same as this; the last four: + 1.8 / + 1.8 %: profiles/r6zu_/r6zv_issue_placement_ab.txt).
-// -DGW_SPREAD_ISSUE=0: the old placement (A/B).
-#ifndef GW_SPREAD_ISSUE
-#define GW_SPREAD_ISSUE 1
-#endif
-__host__ __device__ constexpr int gw_req_at(int k) {  // the request that goes out behind MFMA k of a phase (-1: none)
-    return GW_SPREAD_ISSUE == 1 ? ((k >= 12 && k % 3 == 0) ? (k - 12) / 3 : -1) : -1;
-}
+// (where in a phase the four requests go out: gw_req_at, tile_order.h)
 template <int PH, bool STEADY>
 __device__ __forceinline__ void gw_phase(f32x16 (&acc)[2][4], GwFrags (&fr)[2], const unsigned (&la)[GW_NB], const unsigned (&lw)[GW_NB],
                                          char *ring_w, const char *&pa, const char *&pw, unsigned voff, bool issue, bool next, int vmc) {

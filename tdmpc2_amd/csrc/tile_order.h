@@ -188,3 +188,31 @@ __host__ __device__ inline bool gemm_w_tile(int b, int nrowblk, int ncolblk, int
     }
     return true;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Issue placement inside a phase of the two LDS-DMA ring GEMMs (24 MFMAs per wave and phase in both): which of the wave's requests goes
+// out behind MFMA k.  tests/test_ring_schedule.py checks that every request of a phase goes out exactly once and none behind the last MFMA
+// (the counted waits of the schedules above assume GW_REQ / GM_REQ requests per phase, whatever their position in it).
+constexpr int RING_MFMAS_PER_PHASE = 24;
+constexpr int GW_REQ = 4;
+// Where a phase's four DMA requests are issued: behind MFMAs 12, 15, 18, 21 (the phase's second half), not all four in front of the
+// first MFMA -- 8 waves x 4 requests right behind the barrier held the MFMAs behind them back.  Same bits; 48M model at 30 plans + 1.7 %,
+// 317M at 8 plans + 2.2 % (in front of the first four MFMAs, beside the LDS reads: + 1.2 / + 1.4 %; every sixth MFMA of the whole phase:
+// 0; 13, 16, 19, 22: the same as this; the last four: + 1.8 / + 1.8 %: profiles/r6zu_/r6zv_issue_placement_ab.txt).
+// -DGW_SPREAD_ISSUE=0: the old placement (A/B).
+#ifndef GW_SPREAD_ISSUE
+#define GW_SPREAD_ISSUE 1
+#endif
+__host__ __device__ constexpr int gw_req_at(int k) {  // the request that goes out behind MFMA k of a phase (-1: none)
+    return GW_SPREAD_ISSUE == 1 ? ((k >= 12 && k < RING_MFMAS_PER_PHASE - 1 && k % 3 == 0) ? (k - 12) / 3 : -1) : -1;
+}
+// Where a phase's six DMA requests are issued: behind MFMAs 12, 14, .. 22 -- one request per two MFMAs of the phase's second half -- and
+// not all six in front of the first MFMA (the 8 waves' 48 requests right behind the barrier held the MFMAs behind them back: the 317M
+// plan + 2.3 %, four 48M plans + 1.8 %, same bits; in front of the first six MFMAs, beside the LDS reads: - 2.5 %; every fourth MFMA of the
+// whole phase + 1.3 %; the last six + 1.4 %: profiles/r6zu_/r6zv_issue_placement_ab.txt).  -DGM_SPREAD_ISSUE=0: the old placement (A/B).
+#ifndef GM_SPREAD_ISSUE
+#define GM_SPREAD_ISSUE 1
+#endif
+__host__ __device__ constexpr int gm_req_at(int k) {  // the request that goes out behind MFMA k of a phase (-1: none)
+    return GM_SPREAD_ISSUE == 1 ? ((k >= 12 && k < RING_MFMAS_PER_PHASE - 1 && k % 2 == 0) ? (k - 12) / 2 : -1) : -1;
+}

@@ -186,6 +186,10 @@ extern "C" void tail_step(int ss, int nk, int ns, int *out) {
     const GmTailStep t = gm_tail_step(ss, nk, ns);
     out[0] = t.issue; out[1] = t.next; out[2] = t.vmc;
 }
+extern "C" int mfmas_per_phase() { return RING_MFMAS_PER_PHASE; }
+extern "C" int gw_requests() { return GW_REQ; }
+extern "C" int gm_request_behind(int k) { return gm_req_at(k); }
+extern "C" int gw_request_behind(int k) { return gw_req_at(k); }
 """
 
 
@@ -381,3 +385,29 @@ def test_kloop_every_fragment_lands_before_its_mfmas(klib, nk):
 def test_kloop_counted_waits_are_tight(klib, nk):
     with pytest.raises(AssertionError, match="used before their loads have landed"):
         kloop_replay(klib, nk, slack=1)
+
+
+@pytest.mark.parametrize("kernel", ["g_gemm_m", "g_gemm_w"])
+def test_every_dma_request_of_a_phase_goes_out_exactly_once_between_its_mfmas(mlib, kernel):
+    """Round 6: the ring GEMMs issue a phase's LDS-DMA requests BETWEEN its MFMAs (tile_order.h: gm_req_at / gw_req_at -- request r behind
+    MFMA k) instead of all of them behind the barrier.  The counted waits replayed above assume GM_REQ / GW_REQ requests per phase and
+    wave: every request index must come up exactly once, in order, behind an MFMA that has a successor in the phase -- and the kernel
+    source must carry a hook behind each of those MFMAs (a table entry without a hook would silently drop a request: the next phase's
+    vmcnt would then wait for a slab that was never asked for... or not wait for one that was)."""
+    n = mlib.mfmas_per_phase()
+    req, at, fname, hook, mf = ((mlib.req(), mlib.gm_request_behind, "layered_mid.cuh", "GM_AT", "gm_phase") if kernel == "g_gemm_m"
+                                else (mlib.gw_requests(), mlib.gw_request_behind, "layered_wide.cuh", "GW_AT", "gw_phase"))
+    placed = [(k, at(k)) for k in range(n) if at(k) >= 0]
+    assert [r for _, r in placed] == list(range(req)), placed   # each request once, in request order (the last one advances the pointers)
+    assert all(k < n - 1 for k, _ in placed)                      # never behind the phase's last MFMA (no hook there)
+    assert at(n - 1) < 0 and at(n) < 0
+    src = open(os.path.join(CSRC, fname)).read()
+    body = src[src.index(f"__device__ __forceinline__ void {mf}("):]
+    body = body[:body.index("\n}\n")]
+    assert body.count("GW_MFMA(") == n, body.count("GW_MFMA(")   # the phase's MFMAs, written out
+    hooks = [int(m) for m in re.findall(hook + r"\((\d+)\)", body)]
+    assert hooks == list(range(n - 1)), hooks                    # a hook behind every MFMA but the last, in order
+    # and the hook is followed by the next MFMA, i.e. sits between two MFMAs
+    for k in range(n - 1):
+        i = body.index(f"{hook}({k})")
+        assert "GW_MFMA(" in body[i:], k
