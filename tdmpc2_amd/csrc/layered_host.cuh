@@ -699,6 +699,8 @@ int lay_estimate_value(tdmpc2_plan *h, hipStream_t st, int E, const float *z0, c
     int rc;
     if (mid_ok(h, rows_p))  // few rows (single plans): K-part tiles + row kernels on one stream (layered_mid.cuh)
         return lay_estimate_value_m(h, st, E, z0, act_mask, disc_pow, actions, pi_eps, pi_eps_estride, qidx, seed, call, iter, value, trace, n_off, n_sub);
+    if (L.pifold)  // lay_run decided with the same predicate that this call computes the policy-prior rows' actions: never reached
+        return fail(TDMPC2_ERR_STATE, "policy-prior rows were left to a stage that does not compute them");
     if ((rc = lay_arrive_reset(h, st))) return rc;
     // X <- [z0 | .] for every sample row, G <- 0, TERM <- 0.  With the shared z0 products (lay_cvec) nothing reads the z columns
     // before the first dynamics step has written z_1 there (the t = 0 GEMMs contract the action columns only), G is
